@@ -1,0 +1,74 @@
+"""Load a golden case produced by tools/make_goldens.py (test infrastructure)."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from golden_weights import make_state
+from nnr_amd.synth import BATCH_FIELDS
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+ALL_CASES = ['tiny_CNE_SUE', 'tiny_CNE_SUE_scaled', 'tiny_MHSA_MHSA', 'tiny_CNN_ATT',
+             'tiny_CNE_SUE_stable', 'full_CNE_SUE_g1p0', 'full_CNE_SUE_g1p6', 'full_CNE_SUE_g1p0_stable',
+             'full_MHSA_MHSA_g1p0', 'full_CNN_ATT_g1p0']
+
+
+def _parse(v):
+    if v in ('True', 'False'):
+        return v == 'True'
+    for cast in (int, float):
+        try:
+            return cast(v)
+        except ValueError:
+            pass
+    return v
+
+
+class GoldenCase:
+    def __init__(self, tag):
+        self.tag = tag
+        self.z = np.load(os.path.join(GOLDEN_DIR, tag + '.npz'))
+        self.meta = {k: _parse(v) for k, v in zip(self.z['meta_keys'], self.z['meta_vals'])}
+        self.config = SimpleNamespace(**self.meta)
+        self.full_arrays = bool(self.meta['full_arrays'])
+
+    def batch(self, device='cpu'):
+        return [torch.from_numpy(self.z['in/' + k].copy()).to(device) for k in BATCH_FIELDS]
+
+    def param_names(self):
+        pre = 'gradnorm/'
+        return [k[len(pre):] for k in self.z.files if k.startswith(pre)]
+
+    def initial_state(self, shapes):
+        """{name: np.ndarray} initial parameters (stored for reference-initialised cases, regenerated otherwise)."""
+        if self.meta['gain'] < 0:
+            return {k: self.z['param0/' + k] for k in shapes}
+        return make_state(shapes, self.meta['seed'], self.meta['gain'])
+
+    def word_table(self):
+        t = self.z['word_table']
+        return None if t.size == 0 else torch.from_numpy(t.copy())
+
+    def load_into(self, model):
+        shapes = {k: tuple(p.shape) for k, p in model.named_parameters()}
+        assert sorted(shapes) == sorted(self.param_names()), 'parameter names differ from the reference'
+        st = self.initial_state(shapes)
+        with torch.no_grad():
+            for k, p in model.named_parameters():
+                assert tuple(st[k].shape) == tuple(p.shape), k
+                p.copy_(torch.from_numpy(np.ascontiguousarray(st[k])).to(p.device))
+
+    def expect(self, key):
+        return self.z[key]
+
+    def expect_param(self, step, name, actual):
+        """Compare a parameter after `step` Adam steps (full array or its first 64 elements)."""
+        e = self.z['param%d/%s' % (step, name)]
+        a = actual.detach().cpu().numpy()
+        return e, (a if self.full_arrays else a.reshape(-1)[:64])
+
+    def expect_grad(self, name, actual):
+        e = self.z['grad/' + name]
+        a = actual.detach().cpu().numpy()
+        return e, (a if self.full_arrays else a.reshape(-1)[:64])

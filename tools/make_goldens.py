@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own model.py on CPU.
+
+Runs only in the build container (needs /root/reference); nothing of the reference travels:
+the fixtures hold inputs and expected outputs (arrays) only.  Accommodations, none of which
+touch the arithmetic:
+  * torch_scatter (third-party, absent) -> tools/ref_shims/torch_scatter.py (pure torch composite);
+  * config.Config() cannot be built without a GPU/dataset -> a SimpleNamespace with the same attributes;
+  * NewsEncoder.__init__ unpickles the word table from CWD -> a synthetic table is written to a temp CWD.
+
+Usage:  python tools/make_goldens.py            (rewrites every fixture)
+"""
+import os
+import pickle
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = '/root/reference'
+sys.path.insert(0, os.path.join(ROOT, 'tools', 'ref_shims'))
+sys.path.insert(0, REF)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+from golden_weights import make_state          # noqa: E402
+from nnr_amd.synth import SynthSpec, SynthCorpus, BATCH_FIELDS, to_torch   # noqa: E402
+from oracle.nnr_oracle import default_config   # noqa: E402  (attribute bag only; no oracle arithmetic used here)
+
+OUT = os.path.join(ROOT, 'tests', 'golden')
+
+
+def build_reference_model(cfg, word_table):
+    import model as ref_model                   # /root/reference/model.py
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        name = 'word_embedding-%d-%d-%s-%d-%d-%s.pkl' % (cfg.word_threshold, cfg.word_embedding_dim, cfg.tokenizer,
+                                                         cfg.max_title_length, cfg.max_abstract_length, cfg.dataset)
+        with open(name, 'wb') as f:
+            pickle.dump(torch.from_numpy(word_table), f)
+        try:
+            m = ref_model.Model(cfg)
+        finally:
+            os.chdir(cwd)
+    m.initialize()
+    return m
+
+
+class stable_sort_patch:
+    """Version-skew accommodation for the *_stable fixtures: the reference pins torch 1.12.1, whose CPU
+    torch.sort is a stable sort; this container's torch 2.10 uses an unstable std::sort for n > 16.  The
+    tie order is observable (newsEncoders.py:112-115,128-129 pair the two streams by sorted rank), so the
+    *_stable fixtures run the reference with torch.sort forced stable, i.e. as under its pinned torch.
+    The unsuffixed fixtures run the reference untouched."""
+
+    def __enter__(self):
+        self.orig = torch.sort
+        orig = self.orig
+
+        def sort(input, dim=-1, descending=False, stable=False, **kw):
+            return orig(input, dim=dim, descending=descending, stable=True, **kw)
+        torch.sort = sort
+
+    def __exit__(self, *a):
+        torch.sort = self.orig
+
+
+def run_case(tag, cfg, spec, batch_size, seed, mode, gain=None, full_arrays=True, adam_steps=3):
+    """mode: 'train' (dropout_rate must be 0) or 'eval' (for MHSA-user's hard-wired F.dropout)."""
+    torch.manual_seed(seed)
+    corpus = SynthCorpus(spec)
+    batch = corpus.batch(batch_size, np.random.default_rng(seed + 100))
+    rngw = np.random.default_rng(seed + 7)
+    table = (rngw.standard_normal((cfg.vocabulary_size, cfg.word_embedding_dim)) * 0.3).astype(np.float32)
+    table[0] = 0
+    m = build_reference_model(cfg, table)
+    shapes = {k: tuple(v.shape) for k, v in m.named_parameters()}
+    if gain is not None:                        # deterministic, regenerable weights
+        st = make_state(shapes, seed, gain)
+        with torch.no_grad():
+            for k, p in m.named_parameters():
+                p.copy_(torch.from_numpy(st[k]))
+    m.train() if mode == 'train' else m.eval()
+    params0 = {k: p.detach().clone().numpy() for k, p in m.named_parameters()}
+
+    rec = {}
+    m.news_encoder.register_forward_hook(lambda mod, i, o: rec.setdefault('reps', []).append(o.detach().clone().numpy()))
+    m.user_encoder.register_forward_hook(lambda mod, i, o: rec.__setitem__('user_rep', o.detach().clone().numpy()))
+
+    opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=cfg.lr, weight_decay=cfg.weight_decay)
+    out = {}
+    for step in range(adam_steps):
+        inp = to_torch(batch)                   # fresh copies: the model mutates masks in place
+        logits = m(*inp)
+        loss = (-torch.log_softmax(logits, dim=1).select(dim=1, index=0)).mean()   # trainer.py:64-66
+        opt.zero_grad()
+        loss.backward()
+        if step == 0:
+            out['logits'] = logits.detach().numpy().copy()
+            out['loss'] = np.float32(float(loss))
+            out['cand_rep'] = rec['reps'][0]
+            out['hist_rep'] = rec['reps'][1]
+            out['user_rep'] = rec['user_rep']
+            grads = {k: p.grad.detach().clone().numpy() for k, p in m.named_parameters()}
+            out['mutated_news_title_mask'] = inp[16].numpy().copy()
+            out['mutated_user_history_category_mask'] = inp[11].numpy().copy()
+        total_norm = torch.nn.utils.clip_grad_norm_(m.parameters(), cfg.gradient_clip_norm)
+        if step == 0:
+            out['grad_total_norm'] = np.float32(float(total_norm))
+        opt.step()
+        out['loss_step%d' % step] = np.float32(float(loss))
+        if step in (0, adam_steps - 1):
+            for k, p in m.named_parameters():
+                a = p.detach().numpy()
+                out['param%d/%s' % (step + 1, k)] = a.copy() if full_arrays else a.reshape(-1)[:64].copy()
+    for k, g in grads.items():
+        out['gradnorm/' + k] = np.float32(np.linalg.norm(g.astype(np.float64)))
+        out['grad/' + k] = g if full_arrays else g.reshape(-1)[:64].copy()
+    for k in BATCH_FIELDS:
+        out['in/' + k] = batch[k]
+    out['word_table'] = table if gain is None else np.zeros(0, np.float32)
+    if gain is None:
+        for k, v in params0.items():
+            out['param0/' + k] = v
+    meta = dict(vars(cfg))
+    meta.update(tie_order='stable' if tag.endswith('_stable') else 'torch', case=tag, mode=mode, seed=seed, gain=-1.0 if gain is None else gain, batch_size=batch_size,
+                full_arrays=full_arrays, adam_steps=adam_steps)
+    out['meta_keys'] = np.array(sorted(meta), dtype=object).astype(str)
+    out['meta_vals'] = np.array([str(meta[k]) for k in sorted(meta)], dtype=object).astype(str)
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, tag + '.npz'), **out)
+    print('%-28s logits[0]=%s loss=%.6f |g|=%.4f' % (tag, np.array2string(out['logits'][0], precision=4), out['loss'],
+                                                     out['grad_total_norm']))
+
+
+def tiny_cfg(news, user, **kw):
+    return default_config(news_encoder=news, user_encoder=user, dataset='small', vocabulary_size=64, word_embedding_dim=16,
+                          hidden_dim=8, attention_dim=8, max_history_num=6, max_title_length=5, max_abstract_length=9,
+                          category_num=3, subCategory_num=7, category_embedding_dim=4, subCategory_embedding_dim=4,
+                          negative_sample_num=2, head_num=2, head_dim=4, cnn_kernel_num=12, gcn_layer_num=2,
+                          dropout_rate=0.0, lr=1e-2, user_num=4, **kw)
+
+
+def tiny_spec(cfg, seed):
+    return SynthSpec(vocabulary_size=cfg.vocabulary_size, category_num=cfg.category_num, subCategory_num=cfg.subCategory_num,
+                     max_title_length=cfg.max_title_length, max_abstract_length=cfg.max_abstract_length,
+                     max_history_num=cfg.max_history_num, negative_sample_num=cfg.negative_sample_num, news_pool=40,
+                     title_len_mean=3.0, content_len_mean=5.0, empty_content_frac=0.2, empty_history_frac=0.2, seed=seed)
+
+
+def full_cfg(news, user, V):
+    return default_config(news_encoder=news, user_encoder=user, dataset='200k', vocabulary_size=V, dropout_rate=0.0,
+                          gcn_layer_num=4, lr=1e-3)
+
+
+def full_spec(cfg, seed):
+    return SynthSpec(vocabulary_size=cfg.vocabulary_size, news_pool=300, seed=seed)
+
+
+def main():
+    torch.set_num_threads(8)
+    # tiny dims, reference's own initialisation, every array stored
+    for news, user, mode in (('CNE', 'SUE', 'train'), ('MHSA', 'MHSA', 'eval'), ('CNN', 'ATT', 'train')):
+        cfg = tiny_cfg(news, user)
+        run_case('tiny_%s_%s' % (news, user), cfg, tiny_spec(cfg, 3), batch_size=3, seed=11, mode=mode)
+    # tiny dims, larger weights (logits O(1-10)), still every array stored
+    cfg = tiny_cfg('CNE', 'SUE')
+    run_case('tiny_CNE_SUE_scaled', cfg, tiny_spec(cfg, 5), batch_size=4, seed=13, mode='train', gain=2.5)
+    with stable_sort_patch():
+        cfg = tiny_cfg('CNE', 'SUE')
+        run_case('tiny_CNE_SUE_stable', cfg, tiny_spec(cfg, 3), batch_size=8, seed=19, mode='train', gain=2.0)
+        cfg = full_cfg('CNE', 'SUE', V=400)
+        run_case('full_CNE_SUE_g1p0_stable', cfg, full_spec(cfg, 9), batch_size=2, seed=17, mode='train', gain=1.0,
+                 full_arrays=False)
+    # full model dims at B=2: regenerable weights, outputs + gradient norms + 64-element slices
+    for news, user, mode, gain in (('CNE', 'SUE', 'train', 1.0), ('CNE', 'SUE', 'train', 1.6),
+                                   ('MHSA', 'MHSA', 'eval', 1.0), ('CNN', 'ATT', 'train', 1.0)):
+        cfg = full_cfg(news, user, V=400)
+        tag = 'full_%s_%s_g%s' % (news, user, str(gain).replace('.', 'p'))
+        run_case(tag, cfg, full_spec(cfg, 9), batch_size=2, seed=17, mode=mode, gain=gain, full_arrays=False)
+
+
+if __name__ == '__main__':
+    main()
