@@ -1,0 +1,188 @@
+/* libnnr_hip.so -- C-ABI of the MI355X-native NNR training hot path (gfx950 only).
+ *
+ * The reference (Veason-silverbullet/NNR) is pure Python; the native work on its hot path happens inside
+ * third-party libraries that its modules call: ATen/cuDNN behind nn.LSTM / nn.Embedding / nn.Linear / bmm /
+ * softmax, torch_scatter 2.0.9, and NCCL.  Each entry point below replaces
+ * one such call site; the citation is the reference file:line whose arithmetic it implements.
+ *
+ * Conventions: extern "C"; plain pointers and sizes; every buffer is a caller-allocated
+ * DEVICE pointer (the host side uses PyTorch's caching allocator purely as a memory manager); row-major,
+ * contiguous unless a leading dimension is passed; kernels are enqueued on the caller's stream and never
+ * synchronise with the host (token counts that depend on the data stay in device memory); returns NNR_OK or a
+ * negative error code, never throws.  fp32 everywhere (the parity bar is 1e-4 fp32 on logits/loss).
+ */
+#ifndef NNR_HIP_H
+#define NNR_HIP_H
+#include <stdint.h>
+#include <hip/hip_runtime_api.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NNR_OK 0
+#define NNR_ERR_ARG (-1)
+#define NNR_ERR_LAUNCH (-2)
+#define NNR_ERR_UNSUPPORTED (-3)
+
+int nnr_version(void);
+
+/* ------------------------------------------------------------------------------------------------ GEMM
+ * C[M,N] = epilogue(alpha * A_op[M,K] . B_op[K,N]).  Replaces every nn.Linear / torch.bmm on the path
+ * (newsEncoders.py:122-123 input projection inside nn.LSTM, :128-129 title_H/title_M; layers.py:168 affine1,
+ * :197 K/Q, :286 bmm(graph, x) and W; userEncoders.py:85-91) and their autograd backward GEMMs.
+ *   trans_a = 0: A is [M,K], K contiguous (lda).        trans_a = 1: A is [K,M], M contiguous.
+ *   trans_b = 0: B is [N,K], K contiguous (nn.Linear weight layout).   trans_b = 1: B is [K,N], N contiguous.
+ *   Supported pairs: (0,0) forward, (0,1) data-gradient, (1,1) weight-gradient.
+ * Epilogue order per element: x = alpha*acc; += bias[n]; += rowvec[map[m]][n]; act; aux_out = x; *= mul[m][n];
+ * += resid[m][n]; dropout (drop_target 3); rowdot += rowdot_w[n]*x; store / accumulate / atomicAdd to C row c_idx[m].
+ */
+typedef struct nnr_gemm_args {
+  const float* A;
+  const float* B;
+  float* C;                 /* may be NULL when only rowdot_out / aux_out are wanted */
+  int M, N, K;
+  int lda, ldb, ldc;
+  int trans_a, trans_b;
+  const int* dyn_dev;       /* device int32: actual extent of the token dimension (<= the static one) */
+  int dyn_dim;              /* 0 none, 1: bounds M, 2: bounds K */
+  const int* a_idx;         /* trans_a=0: A row m is read from A[a_idx[m]] (negative: zero row); embedding gather */
+  const int* b_idx;         /* trans_b=1: B k-row is read from B[b_idx[k]] (negative: zero row) */
+  int drop_target;          /* 0 none; 1 gathered-A element (m,k); 2 gathered-B element (k,n); 3 C element (m,n);
+                               4 scattered atomic C element (m,n).  Element id = row * drop_cols + col. */
+  float drop_p;
+  uint32_t drop_seed;
+  int drop_cols;
+  float alpha;
+  const float* bias;        /* [N] */
+  const float* rowvec;      /* [*, ldrv] */
+  int ldrv;
+  const int* rowvec_map;    /* [M] or NULL */
+  int act;                  /* 0 none, 1 relu, 2 tanh, 3 sigmoid */
+  float* aux_out;           /* [M, ldaux]: value right after the activation */
+  int ldaux;
+  const float* mul;         /* [M, ldmul] */
+  int ldmul;
+  const float* resid;       /* [M, ldres] */
+  int ldres;
+  int accumulate;           /* C += result (non-atomic) */
+  int atomic;               /* atomicAdd into C (implied by split_k > 1) */
+  const int* c_idx;         /* [M]: destination row of C for row m (negative: skip) */
+  int split_k;              /* > 1: reduction split over blockIdx.z, atomicAdd into a pre-zeroed C */
+  const float* rowdot_w;    /* [N]; needs N <= 208 */
+  float* rowdot_out;        /* [M] */
+  int batch;                /* > 1: blockIdx.z batches with the strides below */
+  long strideA, strideB, strideC, stride_aux, stride_res;
+  int tile;                 /* 0 auto, 1: 256x80, 2: 64x80, 3: 128x208 */
+  /* filled by the library */
+  uint32_t drop_thresh;
+  float drop_scale;
+} nnr_gemm_args;
+
+int nnr_gemm_f32(const nnr_gemm_args* args, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------ sequence planner
+ * Replaces newsEncoders.py:106-120 (mask[:,0]=1 in place, lengths, torch.sort x2, index_select, pack_padded_sequence and
+ * its sorted_length.cpu() host sync).  perm_in (optional, [n]): sorted position -> original row, when the caller wants a
+ * specific tie order (e.g. the installed torch's unstable CPU sort); NULL = stable descending order computed on device.
+ * Outputs: len_out[n], order[n], rank[n], slen[n], bs[L], off[L+1] (off[L] = #valid tokens, used as dyn_dev by the GEMMs),
+ * row_seq[n*L], tok[n*L] (token id per packed row; NULL to skip), prev_f[n*L], prev_r[n*L]. */
+int nnr_seq_plan(uint8_t* mask, const int* ids, int n, int L, const int* perm_in, int* len_out, int* order, int* rank, int* slen,
+                 int* bs, int* off, int* row_seq, int* tok, int* prev_f, int* prev_r, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------ Bi-LSTM
+ * Replaces nn.LSTM(bidirectional) on a PackedSequence (newsEncoders.py:66-67, 119-127) and its backward.
+ * Gate columns are kept in "p-order": p = (unit/16)*64 + gate*16 + unit%16, padded to NP = ceil(H/16)*64 per direction. */
+int nnr_lstm_dims(int H, int* UB, int* HP, int* NP);
+/* w_ihp [2*NP, E], b_p [2*NP] (= b_ih + b_hh), wf [2*UB*4*UB*256], wb [2*UB*(NP/16)*256] */
+int nnr_lstm_pack_weights(const float* w_ih_f, const float* w_hh_f, const float* b_ih_f, const float* b_hh_f, const float* w_ih_r,
+                          const float* w_hh_r, const float* b_ih_r, const float* b_hh_r, int H, int E, float* w_ihp, float* b_p,
+                          float* wf, float* wb, hipStream_t stream);
+/* dw_ihp [2*NP, E], db_p [2*NP], dw_hhp [2, NP, H] -> gradients in nn.LSTM's parameter layout (overwritten) */
+int nnr_lstm_unpack_grads(const float* dw_ihp, const float* db_p, const float* dw_hhp, int H, int E, float* dw_ih_f, float* dw_hh_f,
+                          float* db_ih_f, float* db_hh_f, float* dw_ih_r, float* dw_hh_r, float* db_ih_r, float* db_hh_r,
+                          hipStream_t stream);
+typedef struct nnr_lstm_problem {
+  const int* bs; const int* off; const int* slen; const int* prev_f; const int* prev_r;   /* from nnr_seq_plan */
+  int n, L;
+  float* gates;       /* [rows, 2*NP]  fwd: in = x.W_ihp^T + b_p, out = activated gates; bwd: in = gates, out = d(pre-activations) */
+  float* cell;        /* [rows, 2*HP]  c_t */
+  float* hout;        /* [rows, 2*H]   h_t = [fwd | rev] */
+  float* cn;          /* [n, 2*H]      final cell states in sorted order */
+  const float* wf;    /* forward fragment-layout W_hh */
+  const float* wb;    /* backward fragment-layout W_hh */
+  const float* dh;    /* bwd: dL/dH [rows, 2*H] */
+  const float* dcn;   /* bwd: dL/dc_n [n, 2*H] or NULL */
+} nnr_lstm_problem;
+/* up to 2 problems (title + content streams) run in ONE launch */
+int nnr_lstm_fwd(const nnr_lstm_problem* probs, int nprob, int H, hipStream_t stream);
+int nnr_lstm_bwd(const nnr_lstm_problem* probs, int nprob, int H, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------ attention pooling
+ * softmax(mask(score)) . x : the tails of `Attention` (layers.py:169-175) and `ScaledDotProduct_CandidateAttention`
+ * (layers.py:197-203), forward and backward; see pool.hip for the layouts. */
+typedef struct nnr_pool_args {
+  const float* x; int ldx; int D; int n; int L;
+  int packed;                                /* 1: time-major packed rows (off/slen/order), 0: dense [n, L, D] */
+  const int* off; const int* slen; const int* order;
+  const uint8_t* mask; int mask_div;         /* dense only: mask[(s / mask_div) * L + t] */
+  const float* score;                        /* given scores (per row) ... */
+  const float* v; int ldv; float scale;      /* ... or score = scale * <x, v[out index]> */
+  float* alpha;
+  float* out; int ldo; const float* add_in; int ldadd;     /* out = pooled (+ add_in) */
+  const float* dout; int lddo; const float* dout2; int lddo2;   /* backward: upstream = dout (+ dout2) */
+  float* dx; int lddx; int dx_accumulate;
+  float* dscore;
+  float* dv; int lddv;
+} nnr_pool_args;
+int nnr_attn_pool_fwd(const nnr_pool_args* a, hipStream_t stream);
+int nnr_attn_pool_bwd(const nnr_pool_args* a, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------ elementwise / reductions */
+int nnr_gate_bwd(const float* dHt, const float* H, const float* G, float* dH, float* dpre, const int* rows_dev, int rows, int cols,
+                 hipStream_t stream);                                            /* newsEncoders.py:128-131 backward */
+int nnr_packed_seq_sum(const float* x, int D, const int* off, const int* slen, int n, float* out, hipStream_t stream);
+int nnr_tanh_score_bwd(float* th, const float* ds, const float* w2, float* dw2, const int* rows_dev, int rows, int A,
+                       hipStream_t stream);                                      /* layers.py:168-169 backward */
+int nnr_colsum(const float* x, int ld, const int* rows_dev, int rows, int N, float* out_accum, hipStream_t stream);
+int nnr_small_embed_fwd(const float* table, const int* idx, int n, int dim, float* out, int ldo, float p, uint32_t seed,
+                        hipStream_t stream);                                     /* newsEncoders.py:51-53 */
+int nnr_small_embed_bwd(const int* idx, int n, int dim, const float* dout, int lddo, float* dtable_accum, float p, uint32_t seed,
+                        hipStream_t stream);
+int nnr_add(float* y, const float* x, long n, float alpha, hipStream_t stream);
+int nnr_add2d(float* y, int ldy, const float* x, int ldx, int rows, int cols, float alpha, int accumulate, hipStream_t stream);
+int nnr_dropout(const float* x, float* y, long n, float p, uint32_t seed, hipStream_t stream);
+int nnr_relu_bwd(const float* dy, const float* y, float* dx, long n, hipStream_t stream);
+int nnr_relu_drop_bwd(const float* dy, const float* r, float* ds, float* dx, long n, float p, uint32_t seed, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------ SUE (userEncoders.py:68-98) */
+int nnr_sue_x0_fwd(const float* hist, const float* proxy, float* x0, int B, int Hn, int Kc, int D, float p, uint32_t seed,
+                   hipStream_t stream);                                          /* :80 */
+int nnr_sue_x0_bwd(const float* dx0, float* dhist, float* dproxy_accum, int B, int Hn, int Kc, int D, float p, uint32_t seed,
+                   hipStream_t stream);
+int nnr_sue_slice_fwd(const float* gcn, const float* x0, float* gfeat, int B, int Hn, int G, int D, hipStream_t stream);   /* :81-82 */
+int nnr_sue_slice_bwd(const float* dgfeat, float* dpad, int B, int Hn, int G, int D, hipStream_t stream);
+/* torch_scatter.scatter_softmax + scatter_sum (userEncoders.py:85-89): kf [B,Hn,A], qc [B,N,A], g [B,Hn,D], cidx int64 [B,Hn]
+ * -> alpha [B,N,Hn], feat [B,N,C,D] */
+int nnr_sue_intra_fwd(const float* kf, const float* qc, const float* g, const long* cidx, int B, int N, int Hn, int C, int A, int D,
+                      float* alpha, float* feat, hipStream_t stream);
+int nnr_sue_intra_bwd(const float* kf, const float* qc, const float* g, const long* cidx, const float* alpha, const float* dfeat, int B,
+                      int N, int Hn, int C, int A, int D, float* dg, float* dkf, float* dqc, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------ click predictor, loss, optimiser */
+int nnr_logits_loss_fwd(const float* user, const float* cand, int B, int N, int D, float* logits, float* loss, float* dlogits,
+                        hipStream_t stream);                                     /* model.py:126-127, trainer.py:64-66 */
+int nnr_logits_fwd(const float* user, const float* cand, int B, int N, int D, float* logits, hipStream_t stream);   /* model.py:127 */
+int nnr_nls_loss(const float* logits, int B, int N, float* loss, float* dlogits, hipStream_t stream);               /* trainer.py:64-66 */
+int nnr_logits_bwd(const float* dlogits, const float* user, const float* cand, int B, int N, int D, float* duser, float* dcand,
+                   int dcand_accumulate, hipStream_t stream);
+int nnr_sumsq(const float* g, long n, float* out_zeroed, hipStream_t stream);
+/* clip_grad_norm_(max_norm = clip) + torch.optim.Adam step on one flat buffer (trainer.py:118-120); grads are scaled by
+ * grad_scale first (1/world_size after the RCCL sum all-reduce). */
+int nnr_clip_adam(float* p, const float* g, float* m, float* v, long n, const float* sumsq, float grad_scale, float clip, float lr,
+                  float beta1, float beta2, float eps, float weight_decay, int step, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,78 @@
+"""ctypes binding of libnnr_hip.so (include/nnr_hip.h).  No torch types cross the boundary: only raw device
+pointers, sizes and the HIP stream handle.  The product path has NO fallback: if the library is missing or a call
+fails, an exception is raised."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libnnr_hip.so')
+_lib = None
+
+vp, ci, cf, cu32, cl = C.c_void_p, C.c_int, C.c_float, C.c_uint32, C.c_long
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [('A', vp), ('B', vp), ('C', vp), ('M', ci), ('N', ci), ('K', ci), ('lda', ci), ('ldb', ci), ('ldc', ci),
+                ('trans_a', ci), ('trans_b', ci), ('dyn_dev', vp), ('dyn_dim', ci), ('a_idx', vp), ('b_idx', vp),
+                ('drop_target', ci), ('drop_p', cf), ('drop_seed', cu32), ('drop_cols', ci), ('alpha', cf), ('bias', vp),
+                ('rowvec', vp), ('ldrv', ci), ('rowvec_map', vp), ('act', ci), ('aux_out', vp), ('ldaux', ci), ('mul', vp),
+                ('ldmul', ci), ('resid', vp), ('ldres', ci), ('accumulate', ci), ('atomic', ci), ('c_idx', vp),
+                ('split_k', ci), ('rowdot_w', vp), ('rowdot_out', vp), ('batch', ci), ('strideA', cl), ('strideB', cl),
+                ('strideC', cl), ('stride_aux', cl), ('stride_res', cl), ('tile', ci), ('drop_thresh', cu32),
+                ('drop_scale', cf)]
+
+
+class LstmProblem(C.Structure):
+    _fields_ = [('bs', vp), ('off', vp), ('slen', vp), ('prev_f', vp), ('prev_r', vp), ('n', ci), ('L', ci), ('gates', vp),
+                ('cell', vp), ('hout', vp), ('cn', vp), ('wf', vp), ('wb', vp), ('dh', vp), ('dcn', vp)]
+
+
+class PoolArgs(C.Structure):
+    _fields_ = [('x', vp), ('ldx', ci), ('D', ci), ('n', ci), ('L', ci), ('packed', ci), ('off', vp), ('slen', vp),
+                ('order', vp), ('mask', vp), ('mask_div', ci), ('score', vp), ('v', vp), ('ldv', ci), ('scale', cf),
+                ('alpha', vp), ('out', vp), ('ldo', ci), ('add_in', vp), ('ldadd', ci), ('dout', vp), ('lddo', ci),
+                ('dout2', vp), ('lddo2', ci), ('dx', vp), ('lddx', ci), ('dx_accumulate', ci), ('dscore', vp), ('dv', vp),
+                ('lddv', ci)]
+
+
+# every symbol include/nnr_hip.h declares (tests check the .so exports all of them)
+SYMBOLS = [
+    'nnr_version', 'nnr_gemm_f32', 'nnr_seq_plan', 'nnr_lstm_dims', 'nnr_lstm_pack_weights', 'nnr_lstm_unpack_grads',
+    'nnr_lstm_fwd', 'nnr_lstm_bwd', 'nnr_attn_pool_fwd', 'nnr_attn_pool_bwd', 'nnr_gate_bwd', 'nnr_packed_seq_sum',
+    'nnr_tanh_score_bwd', 'nnr_colsum', 'nnr_small_embed_fwd', 'nnr_small_embed_bwd', 'nnr_add', 'nnr_add2d', 'nnr_dropout',
+    'nnr_relu_bwd', 'nnr_relu_drop_bwd', 'nnr_sue_x0_fwd', 'nnr_sue_x0_bwd', 'nnr_sue_slice_fwd', 'nnr_sue_slice_bwd',
+    'nnr_sue_intra_fwd', 'nnr_sue_intra_bwd', 'nnr_logits_loss_fwd', 'nnr_logits_fwd', 'nnr_nls_loss', 'nnr_logits_bwd', 'nnr_sumsq', 'nnr_clip_adam',
+]
+
+
+class NnrHipError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile libnnr_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    if force:
+        bdir = os.path.join(_HERE, 'csrc', 'build')
+        if os.path.isdir(bdir):
+            for f in os.listdir(bdir):
+                os.remove(os.path.join(bdir, f))
+    subprocess.check_call(['bash', os.path.join(_HERE, 'csrc', 'build.sh')])
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NnrHipError('libnnr_hip.so not found at %s -- run `python -c "import __graft_entry__ as g; g.build()"` '
+                              '(there is no CPU / PyTorch fallback on the product path)' % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        for s in SYMBOLS:
+            getattr(_lib, s).restype = ci
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise NnrHipError('%s failed with code %d' % (what, rc))

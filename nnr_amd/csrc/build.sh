@@ -1,0 +1,18 @@
+#!/bin/bash
+# Build libnnr_hip.so for gfx950 (MI355X) in-tree.  hipcc cross-compiles without a GPU.
+set -e
+cd "$(dirname "$0")"
+OUT=../libnnr_hip.so
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-pass-failed"
+mkdir -p build
+pids=()
+for f in gemm seq_plan lstm pool misc mhsa; do
+  [ -f $f.hip ] || continue
+  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ ../../include/nnr_hip.h -nt build/$f.o ]; then
+    hipcc $FLAGS -c $f.hip -o build/$f.o &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait $p; done
+hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT build/*.o
+echo "built $(realpath $OUT)"

@@ -1,0 +1,51 @@
+// Shared device helpers for libnnr_hip (gfx950 / CDNA4 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/nnr_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define NNR_CHECK_LAUNCH()                                   \
+  do {                                                       \
+    hipError_t e_ = hipGetLastError();                       \
+    if (e_ != hipSuccess) return NNR_ERR_LAUNCH;             \
+  } while (0)
+
+// ---------------------------------------------------------------- counter-based dropout
+// keep(idx) is a pure function of (seed, idx): forward and backward recompute the same mask,
+// nothing is stored.  lowbias32 finaliser (two rounds) -- statistical quality is ample for dropout.
+__device__ __forceinline__ uint32_t nnr_hash32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ bool nnr_keep(uint32_t seed, uint64_t idx, uint32_t thresh) {
+  uint32_t h = nnr_hash32((uint32_t)idx ^ nnr_hash32((uint32_t)(idx >> 32) + seed));
+  return h >= thresh;   // P(keep) = 1 - thresh / 2^32
+}
+static inline uint32_t nnr_drop_thresh(float p) {
+  if (p <= 0.f) return 0u;
+  double t = (double)p * 4294967296.0;
+  if (t > 4294967295.0) t = 4294967295.0;
+  return (uint32_t)t;
+}
+
+// ---------------------------------------------------------------- wave-level reductions (64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// sum over the 16 lanes that share (lane >> 4)
+__device__ __forceinline__ float group16_sum(float v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }

@@ -1,0 +1,351 @@
+// fp32 GEMM for the NNR hot path on gfx950:  C[M,N] = epilogue( A_op[M,K] . B_op[K,N] )
+//
+// * v_mfma_f32_16x16x4_f32 (exact fp32, bitwise an fmaf chain) -- 157 TFLOP/s roofline.
+// * Workgroup = 4 waves; wave w owns rows [w*16*TM, (w+1)*16*TM) x all 16*TN columns of the block tile.
+// * BK = 16 per stage; global -> registers -> LDS double buffer, one barrier per stage.
+// * K-contiguous operands ("weights" [N,K], activations [M,K]) live in LDS as [row][16] with an XOR swizzle
+//   on the 16-byte chunk so a fragment is ONE conflict-free ds_read_b128 feeding 4 MFMAs;
+//   K-major operands ([K,M] / [K,N], used by the backward GEMMs) live as [16][R+4] and are read with
+//   conflict-free ds_read_b32.
+// * blockIdx -> tile mapping is XCD-aware: the 8 XCDs each walk a contiguous range of tiles, column blocks
+//   fastest, so the A row-panel of a tile row stays in ONE XCD's L2 while its column blocks run.
+// * Row gather on A (embedding rows feeding the LSTM input projection) / on B's k-rows (backward weight
+//   gradient), counter-based dropout recomputed in the loaders, row scatter with f32 atomics in the epilogue
+//   (embedding gradient), split-K with atomics for the token-reduction GEMMs, dynamic token count read from
+//   device memory (no host sync).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ int swz(int r16) {  // chunk XOR for row r (0..15) of a 16-row block
+  // f(r>>2) = {0,3,2,1}: makes the four ds_read_b128 lane groups hit 16 distinct 16-B slots
+  return (4 - (r16 >> 2)) & 3;
+}
+
+template <int TM, int TN, bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_kernel(nnr_gemm_args g) {
+  constexpr int BM = 64 * TM, BN = 16 * TN;
+  constexpr int A_LD = BM + 4, B_LD = BN + 4;
+  constexpr int A_SZ = TA ? 16 * A_LD : BM * 16;
+  constexpr int B_SZ = TB ? 16 * B_LD : BN * 16;
+  constexpr int NBL = (BN * 4 + 255) / 256;  // B float4 loads per thread
+  __shared__ __attribute__((aligned(16))) float lds[2 * (A_SZ + B_SZ)];
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int r = lane & 15, kk = lane >> 4;
+
+  // ---- dynamic extents
+  int M = g.M, K = g.K;
+  if (g.dyn_dim == 1) M = min(M, *g.dyn_dev);
+  if (g.dyn_dim == 2) K = min(K, *g.dyn_dev);
+  const int N = g.N;
+
+  // ---- XCD-aware tile id
+  const int nbm = (g.M + BM - 1) / BM, nbn = (N + BN - 1) / BN;
+  const int nblk = nbm * nbn;
+  int v;
+  {
+    const int b = blockIdx.x, q = nblk >> 3, rem = nblk & 7, x = b & 7, slot = b >> 3;
+    v = x * q + min(x, rem) + slot;
+  }
+  const int bm = v / nbn, bn = v - bm * nbn;
+  const int m0 = bm * BM, n0 = bn * BN;
+  if (m0 >= M) return;
+
+  // ---- batch / split-K
+  const float* __restrict__ A = g.A;
+  const float* __restrict__ B = g.B;
+  float* __restrict__ C = g.C;
+  int kbeg = 0, kend = K;
+  const int z = blockIdx.z;
+  if (g.split_k > 1) {
+    const int ktiles = (K + 15) >> 4;
+    const int per = (ktiles + g.split_k - 1) / g.split_k;
+    kbeg = z * per * 16;
+    kend = min(K, kbeg + per * 16);
+    if (kbeg >= kend) return;
+  } else if (g.batch > 1) {
+    A += (long)z * g.strideA;
+    B += (long)z * g.strideB;
+    C += (long)z * g.strideC;
+  }
+  const bool vecA = ((g.lda & 3) == 0) && ((((uintptr_t)A) & 15) == 0);
+  const bool vecB = ((g.ldb & 3) == 0) && ((((uintptr_t)B) & 15) == 0);
+  const uint32_t dthr = g.drop_thresh;
+  const float dscale = g.drop_scale;
+
+  // ---- per-thread load coordinates that do not change over k
+  long a_src[TM];   // TA=false: source row offset (elements) or -1
+  if (!TA) {
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int f = tid + 256 * j, row = f >> 2, gm = m0 + row;
+      long s = -1;
+      if (gm < M) {
+        int src = g.a_idx ? g.a_idx[gm] : gm;
+        if (src >= 0) s = (long)src * g.lda;
+      }
+      a_src[j] = s;
+    }
+  }
+
+  f32x4 ra[TM];
+  f32x4 rb[NBL];
+
+  auto load_tiles = [&](int k0) {
+    // ---------------- A
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      f32x4 val = {0.f, 0.f, 0.f, 0.f};
+      const int f = tid + 256 * j;
+      if (!TA) {
+        const int kq = f & 3, k = k0 + 4 * kq;
+        if (a_src[j] >= 0 && k < kend) {
+          const float* p = A + a_src[j] + k;
+          if (vecA && k + 3 < kend) {
+            val = *reinterpret_cast<const f32x4*>(p);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (k + e < kend) val[e] = p[e];
+          }
+          if (g.drop_target == 1) {
+            const int gm = m0 + (f >> 2);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              val[e] = nnr_keep(g.drop_seed, (uint64_t)gm * g.drop_cols + (k + e), dthr) ? val[e] * dscale : 0.f;
+          }
+        }
+      } else {
+        const int kr = f / (BM / 4), mq = f - kr * (BM / 4);
+        const int gk = k0 + kr, gm = m0 + 4 * mq;
+        if (gk < kend && gm < M) {
+          const float* p = A + (long)gk * g.lda + gm;
+          if (vecA && gm + 3 < M) {
+            val = *reinterpret_cast<const f32x4*>(p);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (gm + e < M) val[e] = p[e];
+          }
+        }
+      }
+      ra[j] = val;
+    }
+    // ---------------- B
+#pragma unroll
+    for (int j = 0; j < NBL; ++j) {
+      f32x4 val = {0.f, 0.f, 0.f, 0.f};
+      const int f = tid + 256 * j;
+      if (f < BN * 4) {
+        if (!TB) {
+          const int row = f >> 2, kq = f & 3, gn = n0 + row, k = k0 + 4 * kq;
+          if (gn < N && k < kend) {
+            const float* p = B + (long)gn * g.ldb + k;
+            if (vecB && k + 3 < kend) {
+              val = *reinterpret_cast<const f32x4*>(p);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) if (k + e < kend) val[e] = p[e];
+            }
+          }
+        } else {
+          const int kr = f / (BN / 4), nq = f - kr * (BN / 4);
+          const int gk = k0 + kr, gn = n0 + 4 * nq;
+          if (gk < kend && gn < N) {
+            int src = g.b_idx ? g.b_idx[gk] : gk;
+            if (src >= 0) {
+              const float* p = B + (long)src * g.ldb + gn;
+              if (vecB && gn + 3 < N) {
+                val = *reinterpret_cast<const f32x4*>(p);
+              } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (gn + e < N) val[e] = p[e];
+              }
+              if (g.drop_target == 2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                  val[e] = nnr_keep(g.drop_seed, (uint64_t)gk * g.drop_cols + (gn + e), dthr) ? val[e] * dscale : 0.f;
+              }
+            }
+          }
+        }
+      }
+      rb[j] = val;
+    }
+  };
+
+  auto store_tiles = [&](int buf) {
+    float* As = lds + buf * (A_SZ + B_SZ);
+    float* Bs = As + A_SZ;
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int f = tid + 256 * j;
+      if (!TA) {
+        const int row = f >> 2, kq = f & 3;
+        *reinterpret_cast<f32x4*>(&As[row * 16 + 4 * (kq ^ swz(row & 15))]) = ra[j];
+      } else {
+        const int kr = f / (BM / 4), mq = f - kr * (BM / 4);
+        *reinterpret_cast<f32x4*>(&As[kr * A_LD + 4 * mq]) = ra[j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NBL; ++j) {
+      const int f = tid + 256 * j;
+      if (f < BN * 4) {
+        if (!TB) {
+          const int row = f >> 2, kq = f & 3;
+          *reinterpret_cast<f32x4*>(&Bs[row * 16 + 4 * (kq ^ swz(row & 15))]) = rb[j];
+        } else {
+          const int kr = f / (BN / 4), nq = f - kr * (BN / 4);
+          *reinterpret_cast<f32x4*>(&Bs[kr * B_LD + 4 * nq]) = rb[j];
+        }
+      }
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int m = 0; m < TM; ++m)
+#pragma unroll
+    for (int n = 0; n < TN; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  load_tiles(kbeg);
+  store_tiles(0);
+  __syncthreads();
+
+  int buf = 0;
+  for (int k0 = kbeg; k0 < kend; k0 += 16) {
+    const bool more = (k0 + 16) < kend;
+    if (more) load_tiles(k0 + 16);
+
+    const float* As = lds + buf * (A_SZ + B_SZ);
+    const float* Bs = As + A_SZ;
+    f32x4 af[TM], bf[TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m) {
+      if (!TA) {
+        af[m] = *reinterpret_cast<const f32x4*>(&As[((w * TM + m) * 16 + r) * 16 + 4 * (kk ^ swz(r))]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[m][i] = As[(4 * kk + i) * A_LD + (w * TM + m) * 16 + r];
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < TN; ++n) {
+      if (!TB) {
+        bf[n] = *reinterpret_cast<const f32x4*>(&Bs[(n * 16 + r) * 16 + 4 * (kk ^ swz(r))]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bf[n][i] = Bs[(4 * kk + i) * B_LD + n * 16 + r];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][i], bf[n][i], acc[m][n], 0, 0, 0);
+
+    if (more) store_tiles(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // ---------------------------------------------------------------- epilogue
+  const bool use_atomic = g.atomic || g.split_k > 1;
+  float* aux = g.aux_out;
+  const float* res = g.resid;
+  const float* mulp = g.mul;
+  if (g.batch > 1 && g.split_k <= 1) {
+    if (aux) aux += (long)z * g.stride_aux;
+    if (res) res += (long)z * g.stride_res;
+  }
+#pragma unroll
+  for (int m = 0; m < TM; ++m) {
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int row = m0 + (w * TM + m) * 16 + kk * 4 + reg;
+      const bool rok = row < M;
+      int crow = row;
+      if (rok && g.c_idx) crow = g.c_idx[row];
+      const int rvrow = (rok && g.rowvec) ? (g.rowvec_map ? g.rowvec_map[row] : row) : 0;
+      float dot = 0.f;
+#pragma unroll
+      for (int n = 0; n < TN; ++n) {
+        const int col = n0 + n * 16 + r;
+        if (rok && col < N && crow >= 0) {
+          float x = acc[m][n][reg] * g.alpha;
+          if (g.bias) x += g.bias[col];
+          if (g.rowvec) x += g.rowvec[(long)rvrow * g.ldrv + col];
+          if (g.act == 1) x = fmaxf(x, 0.f);
+          else if (g.act == 2) x = tanhf(x);
+          else if (g.act == 3) x = sigmoidf_(x);
+          if (aux) aux[(long)row * g.ldaux + col] = x;
+          if (mulp) x *= mulp[(long)row * g.ldmul + col];
+          if (res) x += res[(long)row * g.ldres + col];
+          if (g.drop_target == 3)
+            x = nnr_keep(g.drop_seed, (uint64_t)(row + (long)z * g.M) * g.drop_cols + col, dthr) ? x * dscale : 0.f;
+          if (g.rowdot_w) dot += g.rowdot_w[col] * x;
+          if (C) {
+            float* cp = C + (long)crow * g.ldc + col;
+            if (use_atomic) {
+              if (g.drop_target == 4)   // scatter of d(dropout(emb)) : mask keyed by the token row
+                x = nnr_keep(g.drop_seed, (uint64_t)row * g.drop_cols + col, dthr) ? x * dscale : 0.f;
+              atomicAdd(cp, x);
+            } else {
+              if (g.accumulate) x += *cp;
+              *cp = x;
+            }
+          }
+        }
+      }
+      if (g.rowdot_w) {
+        dot = group16_sum(dot);
+        if (rok && r == 0) g.rowdot_out[row] = dot;
+      }
+    }
+  }
+}
+
+template <int TM, int TN>
+int launch_cfg(const nnr_gemm_args& g, hipStream_t s) {
+  constexpr int BM = 64 * TM, BN = 16 * TN;
+  const int nbm = (g.M + BM - 1) / BM, nbn = (g.N + BN - 1) / BN;
+  if (g.rowdot_w && nbn != 1) return NNR_ERR_ARG;
+  dim3 grid(nbm * nbn, 1, g.split_k > 1 ? g.split_k : (g.batch > 1 ? g.batch : 1));
+  dim3 block(256);
+  if (!g.trans_a && !g.trans_b) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, false>), grid, block, 0, s, g);
+  else if (!g.trans_a && g.trans_b) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, true>), grid, block, 0, s, g);
+  else if (g.trans_a && g.trans_b) hipLaunchKernelGGL((gemm_kernel<TM, TN, true, true>), grid, block, 0, s, g);
+  else return NNR_ERR_ARG;   // (A^T, B[N,K]) never occurs on this path
+  NNR_CHECK_LAUNCH();
+  return NNR_OK;
+}
+
+}  // namespace
+
+extern "C" int nnr_gemm_f32(const nnr_gemm_args* a, hipStream_t stream) {
+  if (!a || !a->A || !a->B) return NNR_ERR_ARG;
+  if (!a->C && !a->rowdot_out && !a->aux_out) return NNR_ERR_ARG;
+  if (a->M <= 0 || a->N <= 0 || a->K <= 0) return NNR_OK;
+  nnr_gemm_args g = *a;
+  g.drop_thresh = nnr_drop_thresh(g.drop_target ? g.drop_p : 0.f);
+  g.drop_scale = (g.drop_target && g.drop_p > 0.f) ? 1.f / (1.f - g.drop_p) : 1.f;
+  if (g.drop_thresh == 0u) g.drop_target = 0;
+  if (g.split_k > 1 && (g.bias || g.rowvec || g.act || g.aux_out || g.mul || g.resid || g.batch > 1 || g.rowdot_w))
+    return NNR_ERR_ARG;
+  if ((g.a_idx && g.trans_a) || (g.b_idx && !g.trans_b)) return NNR_ERR_ARG;
+  if ((g.dyn_dim != 0) != (g.dyn_dev != nullptr)) return NNR_ERR_ARG;
+  int tile = g.tile;
+  if (tile == 0) {
+    if (g.rowdot_w) tile = 3;
+    else if (g.M <= 1024) tile = 2;
+    else tile = 1;
+  }
+  switch (tile) {
+    case 1: return launch_cfg<4, 5>(g, stream);    // 256 x 80
+    case 2: return launch_cfg<1, 5>(g, stream);    //  64 x 80
+    case 3: return launch_cfg<2, 13>(g, stream);   // 128 x 208 (whole rows in one wave: fused row-dot)
+    default: return NNR_ERR_ARG;
+  }
+}

@@ -1,0 +1,417 @@
+// Bi-LSTM recurrence for CNE (replaces nn.LSTM on a PackedSequence, newsEncoders.py:119-127, and its autograd
+// backward) on gfx950.
+//
+// Decomposition.  The input projection X.W_ih^T + b for ALL valid tokens of both directions is one big GEMM
+// (gemm.hip, with the embedding-row gather fused into its A loader); what remains is the strictly sequential part
+//     z_t = xw_t + h_{t-1}.W_hh^T ;  c_t = s(f)c_{t-1} + s(i)tanh(g) ;  h_t = s(o)tanh(c_t).
+// One workgroup owns a tile of 16 length-sorted sequences of one direction for ALL their time steps: no
+// inter-workgroup synchronisation exists anywhere.  Sorted tiles have near-equal lengths, so a workgroup runs exactly
+// max(len) steps -- padded positions are never computed (PackedSequence semantics for free).  Tile 0 holds the longest
+// sequences and is dispatched first (LPT order).
+//
+// Per step the workgroup needs h_{t-1}[16, H] . W_hh^T[H, 4H] on the matrix cores (v_mfma_f32_16x16x4_f32, exact fp32).
+// W_hh (640 KB / direction at H=200) cannot live in one CU's LDS, so it is streamed from L2 every step in a
+// pre-swizzled FRAGMENT layout (each wave-load is one contiguous 1 KiB of exactly the B operands it needs), while the
+// tiny A operand h_{t-1} sits in LDS (XOR-swizzled: one conflict-free ds_read_b128 feeds 4 MFMAs).
+// Gate columns are re-ordered [unit-block][gate][16 units] ("p-order") so a lane finds i,f,g,o of the SAME
+// (sequence, unit) in its own four accumulators: the cell update is lane-local, no shuffles, no LDS round trip.
+// The xw buffer is overwritten in place with the activated gates (saved for backward).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ int swz16(int r16) { return (4 - (r16 >> 2)) & 3; }
+// LDS offset (floats) of element (row r, column u) in a K-contiguous [16][ld] tile, ld % 16 == 0
+__device__ __forceinline__ int lds_off(int r, int u, int ld) {
+  return r * ld + (u & ~15) + 4 * (((u >> 2) & 3) ^ swz16(r)) + (u & 3);
+}
+
+struct LstmProblem {
+  // plan
+  const int* bs; const int* off; const int* slen; const int* prev_f; const int* prev_r;
+  int n, L;
+  // buffers
+  float* gates;        // [rows, 2*NP]  in: xw (pre-activation, p-order)   out: activated gates   (bwd: in gates, out dgates)
+  float* cell;         // [rows, 2*HP]
+  float* hout;         // [rows, 2*H]
+  float* cn;           // [n, 2*H]   final cell states, sorted order
+  const float* wfrag;  // fwd: Wf [2][UB][4][KG][64][4] ; bwd: Wb [2][UB][NP/16][64][4]
+  const float* dh;     // bwd: upstream dL/dH [rows, 2*H]
+  const float* dcn;    // bwd: upstream dL/dc_n [n, 2*H] (sorted order) or null
+};
+struct LstmArgs { LstmProblem p[2]; int nprob; int H; };
+
+// ------------------------------------------------------------------------------------------------ forward
+template <int UB>
+__global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmArgs a) {
+  constexpr int HP = UB * 16, NP = UB * 64, KG = UB, OWN = (UB + 3) / 4;
+  const LstmProblem& P = a.p[blockIdx.z];
+  const int H = a.H;
+  const int s0 = blockIdx.x * 16;
+  if (s0 >= P.n) return;
+  const int d = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, kk = lane >> 4;
+  __shared__ __attribute__((aligned(16))) float hbuf[2][16 * HP];
+  for (int i = tid; i < 2 * 16 * HP; i += 256) (&hbuf[0][0])[i] = 0.f;
+  const int tmax = P.slen[s0];
+  float c[OWN][4];
+#pragma unroll
+  for (int o = 0; o < OWN; ++o)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) c[o][e] = 0.f;
+  __syncthreads();
+
+  const int ldg = 2 * NP, ldc = 2 * HP, ldh = 2 * H;
+  int cur = 0;
+  for (int step = 0; step < tmax; ++step) {
+    const int t = d ? (tmax - 1 - step) : step;
+    const int nact = min(16, P.bs[t] - s0);
+    const long row0 = (long)P.off[t] + s0;
+    const float* hc = hbuf[cur];
+    float* hn = hbuf[cur ^ 1];
+#pragma unroll
+    for (int o = 0; o < OWN; ++o) {
+      const int ub = w + 4 * o;
+      if (ub < UB) {
+        // xw loads for this unit block (consumed after the MFMA loop -> latency hidden)
+        float x[4][4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int row = kk * 4 + e;
+            x[g][e] = (row < nact) ? P.gates[(row0 + row) * ldg + d * NP + ub * 64 + g * 16 + r] : 0.f;
+          }
+        f32x4 acc[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4* wf = reinterpret_cast<const f32x4*>(P.wfrag) + ((long)(d * UB + ub) * 4 * KG) * 64 + lane;
+        f32x4 bcur[4], bnxt[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bcur[g] = wf[(g * KG + 0) * 64];
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg) {
+          if (kg + 1 < KG) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bnxt[g] = wf[(g * KG + kg + 1) * 64];
+          }
+          const f32x4 af = *reinterpret_cast<const f32x4*>(&hc[r * HP + kg * 16 + 4 * (kk ^ swz16(r))]);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bcur[g][i], acc[g], 0, 0, 0);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) bcur[g] = bnxt[g];
+        }
+        // lane-local cell update: lane holds (row = kk*4+e, unit = ub*16 + r)
+        const int unit = ub * 16 + r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int row = kk * 4 + e;
+          if (row < nact) {
+            const float gi = sigmoidf_(acc[0][e] + x[0][e]);
+            const float gf = sigmoidf_(acc[1][e] + x[1][e]);
+            const float gg = tanhf(acc[2][e] + x[2][e]);
+            const float go = sigmoidf_(acc[3][e] + x[3][e]);
+            const float cn = gf * c[o][e] + gi * gg;
+            const float hv = go * tanhf(cn);
+            c[o][e] = cn;
+            float* gp = P.gates + (row0 + row) * ldg + d * NP + ub * 64 + r;
+            gp[0] = gi; gp[16] = gf; gp[32] = gg; gp[48] = go;
+            P.cell[(row0 + row) * ldc + d * HP + unit] = cn;
+            if (unit < H) P.hout[(row0 + row) * ldh + d * H + unit] = hv;
+            hn[lds_off(row, unit, HP)] = hv;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  // final cell state (forward: after t = len-1, reverse: after t = 0) -- rows keep c once they go inactive
+#pragma unroll
+  for (int o = 0; o < OWN; ++o) {
+    const int ub = w + 4 * o, unit = ub * 16 + r;
+    if (ub < UB && unit < H) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int s = s0 + kk * 4 + e;
+        if (s < P.n) P.cn[(long)s * ldh + d * H + unit] = c[o][e];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+// Per step: (1) lane-local gate gradients from the saved activations -> dgates tile in LDS (+ global, in place over
+// the saved gates);  (2) dh_{prev} = dgates[16, 4H] . W_hh on the matrix cores, W_hh streamed from L2 in fragment
+// layout; dh_prev / dc_prev stay in registers in the same lane that needs them next step.
+template <int UB>
+__global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmArgs a) {
+  constexpr int HP = UB * 16, NP = UB * 64, KGB = NP / 16, OWN = (UB + 3) / 4;
+  const LstmProblem& P = a.p[blockIdx.z];
+  const int H = a.H;
+  const int s0 = blockIdx.x * 16;
+  if (s0 >= P.n) return;
+  const int d = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, kk = lane >> 4;
+  __shared__ __attribute__((aligned(16))) float dg[16 * NP];
+  const int tmax = P.slen[s0];
+  const int* prev = d ? P.prev_r : P.prev_f;
+  int mylen[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int s = s0 + kk * 4 + e;
+    mylen[e] = (s < P.n) ? P.slen[s] : 0;
+  }
+  float dhr[OWN][4], dcr[OWN][4];
+#pragma unroll
+  for (int o = 0; o < OWN; ++o)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { dhr[o][e] = 0.f; dcr[o][e] = 0.f; }
+
+  const int ldg = 2 * NP, ldc = 2 * HP, ldh = 2 * H;
+  for (int step = 0; step < tmax; ++step) {
+    const int t = d ? step : (tmax - 1 - step);          // reverse of the forward pass's order
+    const int nact = min(16, P.bs[t] - s0);
+    const long row0 = (long)P.off[t] + s0;
+    // ---- (1) gate gradients
+#pragma unroll
+    for (int o = 0; o < OWN; ++o) {
+      const int ub = w + 4 * o;
+      if (ub < UB) {
+        const int unit = ub * 16 + r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int row = kk * 4 + e;
+          float di = 0.f, df = 0.f, dgg = 0.f, dov = 0.f;
+          if (row < nact) {
+            const long grow = row0 + row;
+            float* gp = P.gates + grow * ldg + d * NP + ub * 64 + r;
+            const float gi = gp[0], gf = gp[16], gg = gp[32], go = gp[48];
+            const float ct = P.cell[grow * ldc + d * HP + unit];
+            const int pr = prev[grow];
+            const float cp = (pr >= 0) ? P.cell[(long)pr * ldc + d * HP + unit] : 0.f;
+            float dh = dhr[o][e];
+            if (unit < H) dh += P.dh[grow * ldh + d * H + unit];
+            float dc = dcr[o][e];
+            // first step of this row's backward = last step of its forward: add dL/dc_n
+            const bool last_fwd_step = d ? (t == 0) : (t == mylen[e] - 1);
+            if (last_fwd_step && P.dcn && unit < H) dc += P.dcn[(long)(s0 + row) * ldh + d * H + unit];
+            const float tc = tanhf(ct);
+            dov = dh * tc * go * (1.f - go);
+            dc += dh * go * (1.f - tc * tc);
+            di = dc * gg * gi * (1.f - gi);
+            df = dc * cp * gf * (1.f - gf);
+            dgg = dc * gi * (1.f - gg * gg);
+            dcr[o][e] = dc * gf;
+            gp[0] = di; gp[16] = df; gp[32] = dgg; gp[48] = dov;
+          }
+          const int pc = ub * 64 + r;
+          dg[lds_off(row, pc, NP)] = di;
+          dg[lds_off(row, pc + 16, NP)] = df;
+          dg[lds_off(row, pc + 32, NP)] = dgg;
+          dg[lds_off(row, pc + 48, NP)] = dov;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- (2) dh_prev[16, HP] = dgates[16, NP] . W_hh (p-order rows)
+    {
+      f32x4 acc[OWN];
+#pragma unroll
+      for (int o = 0; o < OWN; ++o) acc[o] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const f32x4* wb = reinterpret_cast<const f32x4*>(P.wfrag) + (long)d * UB * KGB * 64 + lane;
+      f32x4 bcur[OWN], bnxt[OWN];
+#pragma unroll
+      for (int o = 0; o < OWN; ++o) {
+        const int ub = w + 4 * o;
+        bcur[o] = (ub < UB) ? wb[((long)ub * KGB + 0) * 64] : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll 4
+      for (int kg = 0; kg < KGB; ++kg) {
+        if (kg + 1 < KGB) {
+#pragma unroll
+          for (int o = 0; o < OWN; ++o) {
+            const int ub = w + 4 * o;
+            if (ub < UB) bnxt[o] = wb[((long)ub * KGB + kg + 1) * 64];
+          }
+        }
+        const f32x4 af = *reinterpret_cast<const f32x4*>(&dg[r * NP + kg * 16 + 4 * (kk ^ swz16(r))]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int o = 0; o < OWN; ++o)
+            if (w + 4 * o < UB) acc[o] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bcur[o][i], acc[o], 0, 0, 0);
+#pragma unroll
+        for (int o = 0; o < OWN; ++o) bcur[o] = bnxt[o];
+      }
+#pragma unroll
+      for (int o = 0; o < OWN; ++o)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dhr[o][e] = acc[o][e];
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ weight (un)packing
+__global__ void lstm_pack_kernel(const float* __restrict__ w_ih_f, const float* __restrict__ w_hh_f,
+                                 const float* __restrict__ b_ih_f, const float* __restrict__ b_hh_f,
+                                 const float* __restrict__ w_ih_r, const float* __restrict__ w_hh_r,
+                                 const float* __restrict__ b_ih_r, const float* __restrict__ b_hh_r, int H, int E, int UB,
+                                 float* __restrict__ w_ihp, float* __restrict__ b_p, float* __restrict__ wf,
+                                 float* __restrict__ wb) {
+  const int NP = UB * 64, KG = UB, KGB = NP / 16;
+  const long n_ihp = (long)2 * NP * E, n_b = 2 * NP, n_wf = (long)2 * UB * 4 * KG * 256, n_wb = (long)2 * UB * KGB * 256;
+  const long total = n_ihp + n_b + n_wf + n_wb;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    long i = idx;
+    if (i < n_ihp) {                       // w_ihp[d*NP + p][e]
+      const int e = i % E; const int dp = i / E; const int d = dp / NP, p = dp % NP;
+      const int ub = p / 64, g = (p % 64) / 16, u = p % 16, unit = ub * 16 + u;
+      const float* src = d ? w_ih_r : w_ih_f;
+      w_ihp[i] = (unit < H) ? src[(long)(g * H + unit) * E + e] : 0.f;
+      continue;
+    }
+    i -= n_ihp;
+    if (i < n_b) {
+      const int d = i / NP, p = i % NP;
+      const int ub = p / 64, g = (p % 64) / 16, u = p % 16, unit = ub * 16 + u;
+      const float* bi = d ? b_ih_r : b_ih_f; const float* bh = d ? b_hh_r : b_hh_f;
+      b_p[i] = (unit < H) ? bi[g * H + unit] + bh[g * H + unit] : 0.f;
+      continue;
+    }
+    i -= n_b;
+    if (i < n_wf) {                        // wf[d][ub][g][kg][lane][ii] = w_hh[g*H + ub*16 + (lane&15)][16kg + 4(lane>>4) + ii]
+      const int ii = i & 3, lane = (i >> 2) & 63; long q = i >> 8;
+      const int kg = q % KG; q /= KG; const int g = q % 4; q /= 4; const int ub = q % UB; const int d = q / UB;
+      const int unit = ub * 16 + (lane & 15), k = 16 * kg + 4 * (lane >> 4) + ii;
+      const float* src = d ? w_hh_r : w_hh_f;
+      wf[i] = (unit < H && k < H) ? src[(long)(g * H + unit) * H + k] : 0.f;
+      continue;
+    }
+    i -= n_wf;
+    {                                      // wb[d][ubn][kg][lane][ii] = w_hh[row(p)][ubn*16 + (lane&15)],  p = 16kg + 4(lane>>4) + ii
+      const int ii = i & 3, lane = (i >> 2) & 63; long q = i >> 8;
+      const int kg = q % KGB; q /= KGB; const int ubn = q % UB; const int d = q / UB;
+      const int p = 16 * kg + 4 * (lane >> 4) + ii;
+      const int ub = p / 64, g = (p % 64) / 16, u = p % 16, unit = ub * 16 + u, col = ubn * 16 + (lane & 15);
+      const float* src = d ? w_hh_r : w_hh_f;
+      wb[i] = (unit < H && col < H) ? src[(long)(g * H + unit) * H + col] : 0.f;
+    }
+  }
+}
+
+// dW_ihp [2*NP, E], db_p [2*NP], dW_hhp [2][NP][H]  ->  reference-layout gradients (overwrite)
+__global__ void lstm_unpack_kernel(const float* __restrict__ dw_ihp, const float* __restrict__ db_p,
+                                   const float* __restrict__ dw_hhp, int H, int E, int UB, float* __restrict__ dw_ih_f,
+                                   float* __restrict__ dw_hh_f, float* __restrict__ db_ih_f, float* __restrict__ db_hh_f,
+                                   float* __restrict__ dw_ih_r, float* __restrict__ dw_hh_r, float* __restrict__ db_ih_r,
+                                   float* __restrict__ db_hh_r) {
+  const int NP = UB * 64;
+  const long n_ih = (long)2 * 4 * H * E, n_hh = (long)2 * 4 * H * H, n_b = 2 * 4 * H;
+  const long total = n_ih + n_hh + n_b;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    long i = idx;
+    if (i < n_ih) {
+      const int e = i % E; long q = i / E; const int row = q % (4 * H); const int d = q / (4 * H);
+      const int g = row / H, unit = row % H, p = (unit / 16) * 64 + g * 16 + (unit % 16);
+      (d ? dw_ih_r : dw_ih_f)[(long)row * E + e] = dw_ihp[(long)(d * NP + p) * E + e];
+      continue;
+    }
+    i -= n_ih;
+    if (i < n_hh) {
+      const int k = i % H; long q = i / H; const int row = q % (4 * H); const int d = q / (4 * H);
+      const int g = row / H, unit = row % H, p = (unit / 16) * 64 + g * 16 + (unit % 16);
+      (d ? dw_hh_r : dw_hh_f)[(long)row * H + k] = dw_hhp[((long)d * NP + p) * H + k];
+      continue;
+    }
+    i -= n_hh;
+    {
+      const int row = i % (4 * H), d = i / (4 * H);
+      const int g = row / H, unit = row % H, p = (unit / 16) * 64 + g * 16 + (unit % 16);
+      const float v = db_p[d * NP + p];
+      (d ? db_ih_r : db_ih_f)[row] = v;
+      (d ? db_hh_r : db_hh_f)[row] = v;
+    }
+  }
+}
+
+template <int UB>
+int launch_rec(const LstmArgs& a, bool backward, int max_tiles, hipStream_t s) {
+  dim3 grid(max_tiles, 2, a.nprob), block(256);
+  if (backward) hipLaunchKernelGGL((lstm_bwd_kernel<UB>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((lstm_fwd_kernel<UB>), grid, block, 0, s, a);
+  NNR_CHECK_LAUNCH();
+  return NNR_OK;
+}
+
+}  // namespace
+
+extern "C" int nnr_lstm_dims(int H, int* UB, int* HP, int* NP) {
+  const int ub = (H + 15) / 16;
+  if (UB) *UB = ub;
+  if (HP) *HP = ub * 16;
+  if (NP) *NP = ub * 64;
+  return (ub == 1 || ub == 2 || ub == 13) ? NNR_OK : NNR_ERR_UNSUPPORTED;
+}
+
+extern "C" int nnr_lstm_pack_weights(const float* w_ih_f, const float* w_hh_f, const float* b_ih_f, const float* b_hh_f,
+                                     const float* w_ih_r, const float* w_hh_r, const float* b_ih_r, const float* b_hh_r,
+                                     int H, int E, float* w_ihp, float* b_p, float* wf, float* wb, hipStream_t stream) {
+  int UB;
+  if (nnr_lstm_dims(H, &UB, nullptr, nullptr) != NNR_OK) return NNR_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(lstm_pack_kernel, dim3(1024), dim3(256), 0, stream, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r,
+                     b_ih_r, b_hh_r, H, E, UB, w_ihp, b_p, wf, wb);
+  NNR_CHECK_LAUNCH();
+  return NNR_OK;
+}
+
+extern "C" int nnr_lstm_unpack_grads(const float* dw_ihp, const float* db_p, const float* dw_hhp, int H, int E,
+                                     float* dw_ih_f, float* dw_hh_f, float* db_ih_f, float* db_hh_f, float* dw_ih_r,
+                                     float* dw_hh_r, float* db_ih_r, float* db_hh_r, hipStream_t stream) {
+  int UB;
+  if (nnr_lstm_dims(H, &UB, nullptr, nullptr) != NNR_OK) return NNR_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(lstm_unpack_kernel, dim3(1024), dim3(256), 0, stream, dw_ihp, db_p, dw_hhp, H, E, UB, dw_ih_f,
+                     dw_hh_f, db_ih_f, db_hh_f, dw_ih_r, dw_hh_r, db_ih_r, db_hh_r);
+  NNR_CHECK_LAUNCH();
+  return NNR_OK;
+}
+
+static int lstm_run(const nnr_lstm_problem* probs, int nprob, int H, bool backward, hipStream_t stream) {
+  if (!probs || nprob < 1 || nprob > 2) return NNR_ERR_ARG;
+  int UB;
+  if (nnr_lstm_dims(H, &UB, nullptr, nullptr) != NNR_OK) return NNR_ERR_UNSUPPORTED;
+  LstmArgs a;
+  a.nprob = nprob;
+  a.H = H;
+  int max_tiles = 0;
+  for (int i = 0; i < nprob; ++i) {
+    const nnr_lstm_problem& q = probs[i];
+    LstmProblem& p = a.p[i];
+    p.bs = q.bs; p.off = q.off; p.slen = q.slen; p.prev_f = q.prev_f; p.prev_r = q.prev_r;
+    p.n = q.n; p.L = q.L;
+    p.gates = q.gates; p.cell = q.cell; p.hout = q.hout; p.cn = q.cn;
+    p.wfrag = backward ? q.wb : q.wf;
+    p.dh = q.dh; p.dcn = q.dcn;
+    if (!p.bs || !p.off || !p.slen || !p.gates || !p.cell || !p.wfrag || p.n <= 0) return NNR_ERR_ARG;
+    if (backward ? (!p.dh || !p.prev_f || !p.prev_r) : (!p.hout || !p.cn)) return NNR_ERR_ARG;
+    max_tiles = max(max_tiles, (p.n + 15) / 16);
+  }
+  if (nprob == 1) a.p[1] = a.p[0];
+  switch (UB) {
+    case 1: return launch_rec<1>(a, backward, max_tiles, stream);
+    case 2: return launch_rec<2>(a, backward, max_tiles, stream);
+    case 13: return launch_rec<13>(a, backward, max_tiles, stream);
+  }
+  return NNR_ERR_UNSUPPORTED;
+}
+
+extern "C" int nnr_lstm_fwd(const nnr_lstm_problem* probs, int nprob, int H, hipStream_t stream) {
+  return lstm_run(probs, nprob, H, false, stream);
+}
+extern "C" int nnr_lstm_bwd(const nnr_lstm_problem* probs, int nprob, int H, hipStream_t stream) {
+  return lstm_run(probs, nprob, H, true, stream);
+}

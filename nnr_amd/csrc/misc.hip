@@ -1,0 +1,487 @@
+// HBM-bound elementwise / reduction kernels of the hot path (all float4-vectorised where the layout allows,
+// grid capped at 2048 workgroups with grid-stride loops).
+#include "common.h"
+
+namespace {
+
+constexpr int EW_BLOCKS = 2048;
+__host__ __device__ inline int ew_grid(long n, int per_block) {
+  long b = (n + per_block - 1) / per_block;
+  return (int)(b < 1 ? 1 : (b > EW_BLOCKS ? EW_BLOCKS : b));
+}
+__device__ __forceinline__ int dyn_rows(const int* dev, int rows) { return dev ? min(rows, *dev) : rows; }
+
+// ---- cross-selective gate backward (newsEncoders.py:128-131):  Ht = H * G, G = sigmoid(pre)
+//      dH = dHt * G ;  dpre = dHt * H * G * (1 - G)
+__global__ void gate_bwd_kernel(const float* __restrict__ dHt, const float* __restrict__ H, const float* __restrict__ G,
+                                float* __restrict__ dH, float* __restrict__ dpre, const int* rows_dev, int rows, int cols) {
+  const long n4 = (long)dyn_rows(rows_dev, rows) * cols / 4;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const f32x4 d = reinterpret_cast<const f32x4*>(dHt)[i], h = reinterpret_cast<const f32x4*>(H)[i],
+                g = reinterpret_cast<const f32x4*>(G)[i];
+    reinterpret_cast<f32x4*>(dH)[i] = d * g;
+    reinterpret_cast<f32x4*>(dpre)[i] = d * h * g * (1.f - g);
+  }
+}
+
+// ---- out[s, :] = sum_{t < slen[s]} x[off[t] + s, :]   (one wave per sequence)
+__global__ __launch_bounds__(256) void packed_seq_sum_kernel(const float* __restrict__ x, int D, const int* __restrict__ off,
+                                                             const int* __restrict__ slen, int n, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63, s = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s >= n) return;
+  const int len = slen[s], nv = D >> 2;
+  for (int c0 = 0; c0 < nv; c0 += 64) {
+    const int c = c0 + lane;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (c < nv)
+      for (int t = 0; t < len; ++t) acc += *reinterpret_cast<const f32x4*>(x + ((long)off[t] + s) * D + 4 * c);
+    if (c < nv) *reinterpret_cast<f32x4*>(out + (long)s * D + 4 * c) = acc;
+  }
+}
+
+// ---- additive-attention score backward (layers.py:168-169): th = tanh(pre) saved; s = w2 . th
+//      dpre = ds * w2 * (1 - th^2)  (in place over th) ;  dw2[a] += sum_rows ds * th
+__global__ __launch_bounds__(256) void tanh_score_bwd_kernel(float* __restrict__ th, const float* __restrict__ ds,
+                                                             const float* __restrict__ w2, float* __restrict__ dw2,
+                                                             const int* rows_dev, int rows, int A, int rows_per_block) {
+  const int R = dyn_rows(rows_dev, rows);
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(R, r0 + rows_per_block);
+  for (int a = threadIdx.x; a < A; a += blockDim.x) {
+    const float w = w2[a];
+    float acc = 0.f;
+    for (int row = r0; row < r1; ++row) {
+      const float d = ds[row];
+      const float t = th[(long)row * A + a];
+      acc += d * t;
+      th[(long)row * A + a] = d * w * (1.f - t * t);
+    }
+    if (r0 < r1) atomicAdd(&dw2[a], acc);
+  }
+}
+
+// ---- out[c] += sum_rows x[row, c]   (bias gradients)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int ld, const int* rows_dev, int rows, int N,
+                                                     float* __restrict__ out, int rows_per_block) {
+  const int R = dyn_rows(rows_dev, rows);
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(R, r0 + rows_per_block);
+  if (r0 >= r1) return;
+  for (int c = blockIdx.y * blockDim.x + threadIdx.x; c < N; c += gridDim.y * blockDim.x) {
+    float acc = 0.f;
+    for (int row = r0; row < r1; ++row) acc += x[(long)row * ld + c];
+    atomicAdd(&out[c], acc);
+  }
+}
+
+// ---- small embedding tables (category / subCategory, newsEncoders.py:51-53): out[i, :dim] = drop(table[idx[i]])
+__global__ void small_embed_kernel(const float* __restrict__ table, const int* __restrict__ idx, int n, int dim,
+                                   float* __restrict__ out, int ldo, float* __restrict__ dtable,
+                                   const float* __restrict__ dout, int lddo, uint32_t seed, uint32_t thr, float scale) {
+  const long total = (long)n * dim;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int row = i / dim, c = i - (long)row * dim;
+    const float m = nnr_keep(seed, (uint64_t)i, thr) ? scale : 0.f;
+    if (out) out[(long)row * ldo + c] = table[(long)idx[row] * dim + c] * m;
+    if (dtable) atomicAdd(&dtable[(long)idx[row] * dim + c], dout[(long)row * lddo + c] * m);
+  }
+}
+
+// ---- generic y (op)= x
+__global__ void add_kernel(float* __restrict__ y, const float* __restrict__ x, long n, float alpha) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] += alpha * x[i];
+}
+__global__ void add2d_kernel(float* __restrict__ y, int ldy, const float* __restrict__ x, int ldx, int rows, int cols,
+                             float alpha, int accumulate) {
+  const long total = (long)rows * cols;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int r = i / cols, c = i - (long)r * cols;
+    const float v = alpha * x[(long)r * ldx + c];
+    float* p = y + (long)r * ldy + c;
+    *p = accumulate ? *p + v : v;
+  }
+}
+
+// ---- SUE graph input (userEncoders.py:80): X0[b, :Hn] = hist[b] ; X0[b, Hn + k] = dropout_(proxy[k])  (mask per sample)
+//      backward: dhist = dX0[:, :Hn] ; dproxy[k] += sum_b mask * dX0[b, Hn + k]
+__global__ void sue_x0_kernel(const float* __restrict__ hist, const float* __restrict__ proxy, float* __restrict__ x0, int B,
+                              int Hn, int Kc, int D, const float* __restrict__ dx0, float* __restrict__ dhist,
+                              float* __restrict__ dproxy, uint32_t seed, uint32_t thr, float scale) {
+  const int G = Hn + Kc;
+  const long total = (long)B * G * D;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = i % D; const long q = i / D; const int j = q % G; const int b = q / G;
+    if (j < Hn) {
+      if (x0) x0[i] = hist[((long)b * Hn + j) * D + c];
+      if (dhist) dhist[((long)b * Hn + j) * D + c] = dx0[i];
+    } else {
+      const int k = j - Hn;
+      const float m = nnr_keep(seed, (uint64_t)((long)b * Kc + k) * D + c, thr) ? scale : 0.f;
+      if (x0) x0[i] = proxy[(long)k * D + c] * m;
+      if (dproxy) atomicAdd(&dproxy[(long)k * D + c], dx0[i] * m);
+    }
+  }
+}
+
+// ---- gfeat[b, j, :] = gcn[b, j, :] + x0[b, j, :], j < Hn (userEncoders.py:81-82); backward scatters dgfeat back
+//      into the padded [B, G, D] gradient (proxy rows get zero) -- used for both addends.
+__global__ void sue_slice_kernel(const float* __restrict__ gcn, const float* __restrict__ x0, float* __restrict__ gfeat,
+                                 const float* __restrict__ dgfeat, float* __restrict__ dpad, int B, int Hn, int G, int D) {
+  const long total = (long)B * G * D;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = i % D; const long q = i / D; const int j = q % G; const int b = q / G;
+    if (gfeat) { if (j < Hn) gfeat[((long)b * Hn + j) * D + c] = gcn[i] + x0[i]; }
+    if (dpad) dpad[i] = (j < Hn) ? dgfeat[((long)b * Hn + j) * D + c] : 0.f;
+  }
+}
+
+// ---- backward of  y = dropout(relu(z) + x)  given r = relu(z):  dym = mask(dy) ; ds = dym * (r > 0) ; dx = dym
+__global__ void relu_drop_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ r, float* __restrict__ ds,
+                                     float* __restrict__ dx, long n, int cols, uint32_t seed, uint32_t thr, float scale) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float m = nnr_keep(seed, (uint64_t)i, thr) ? scale : 0.f;
+    const float g = dy[i] * m;
+    ds[i] = (r[i] > 0.f) ? g : 0.f;
+    if (dx) dx[i] = g;
+  }
+}
+
+// ---- standalone dropout  y = mask(x)   (same mask forward / backward)
+__global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long n, uint32_t seed, uint32_t thr,
+                               float scale) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    y[i] = nnr_keep(seed, (uint64_t)i, thr) ? x[i] * scale : 0.f;
+}
+
+// ---- relu backward in place-free form: dx = dy * (y > 0)
+__global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    dx[i] = (y[i] > 0.f) ? dy[i] : 0.f;
+}
+
+// ---- SUE intra-cluster attention (userEncoders.py:85-89; replaces torch_scatter.scatter_softmax / scatter_sum).
+// One workgroup per (sample b, candidate n).  scores over the Hn history items, softmax WITHIN each cluster id
+// (segments held in LDS), cluster-wise weighted sum of the [Hn, D] features -> [C, D]; empty clusters give 0.
+constexpr int SUE_MAXH = 64, SUE_MAXC = 32;
+__global__ __launch_bounds__(256) void sue_intra_fwd_kernel(const float* __restrict__ kf, const float* __restrict__ qc,
+                                                            const float* __restrict__ g, const long* __restrict__ cidx,
+                                                            int N, int Hn, int C, int A, int D, float inv_scale,
+                                                            float* __restrict__ alpha, float* __restrict__ feat) {
+  __shared__ float sc[SUE_MAXH], al[SUE_MAXH], cmax[SUE_MAXC], csum[SUE_MAXC];
+  __shared__ int cid[SUE_MAXH];
+  const int bn = blockIdx.x, b = bn / N;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  for (int j = tid; j < Hn; j += 256) cid[j] = (int)cidx[(long)b * Hn + j];
+  const float* q = qc + (long)bn * A;
+  for (int j = w; j < Hn; j += 4) {
+    const float* k = kf + ((long)b * Hn + j) * A;
+    float p = 0.f;
+    for (int x = lane; x < A; x += 64) p += k[x] * q[x];
+    p = wave_sum(p);
+    if (lane == 0) sc[j] = p * inv_scale;
+  }
+  __syncthreads();
+  if (tid < C) {
+    float m = -INFINITY;
+    for (int j = 0; j < Hn; ++j) if (cid[j] == tid) m = fmaxf(m, sc[j]);
+    float s = 0.f;
+    for (int j = 0; j < Hn; ++j) if (cid[j] == tid) s += expf(sc[j] - m);
+    cmax[tid] = m; csum[tid] = s;
+  }
+  __syncthreads();
+  for (int j = tid; j < Hn; j += 256) {
+    const float v = expf(sc[j] - cmax[cid[j]]) / csum[cid[j]];
+    al[j] = v;
+    alpha[(long)bn * Hn + j] = v;
+  }
+  __syncthreads();
+  const float* gb = g + (long)b * Hn * D;
+  float* fo = feat + (long)bn * C * D;
+  for (int col = tid; col < D; col += 256) {
+    for (int c = 0; c < C; ++c) {
+      float acc = 0.f;
+      for (int j = 0; j < Hn; ++j) if (cid[j] == c) acc += al[j] * gb[(long)j * D + col];
+      fo[(long)c * D + col] = acc;
+    }
+  }
+}
+
+// backward, one workgroup per sample b (loops the N candidates so dg needs no atomics)
+__global__ __launch_bounds__(256) void sue_intra_bwd_kernel(const float* __restrict__ kf, const float* __restrict__ qc,
+                                                            const float* __restrict__ g, const long* __restrict__ cidx,
+                                                            const float* __restrict__ alpha, const float* __restrict__ dfeat,
+                                                            int N, int Hn, int C, int A, int D, float inv_scale,
+                                                            float* __restrict__ dg, float* __restrict__ dkf,
+                                                            float* __restrict__ dqc) {
+  __shared__ float al[SUE_MAXH], da[SUE_MAXH], dsn[8][SUE_MAXH], csum[SUE_MAXC];
+  __shared__ int cid[SUE_MAXH];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  for (int j = tid; j < Hn; j += 256) cid[j] = (int)cidx[(long)b * Hn + j];
+  const float* gb = g + (long)b * Hn * D;
+  __syncthreads();
+  for (int n = 0; n < N; ++n) {
+    const long bn = (long)b * N + n;
+    const float* df = dfeat + bn * C * D;
+    for (int j = tid; j < Hn; j += 256) al[j] = alpha[bn * Hn + j];
+    // dalpha_j = <dfeat[cid_j], g_j>
+    for (int j = w; j < Hn; j += 4) {
+      const float* dr = df + (long)cid[j] * D;
+      const float* gr = gb + (long)j * D;
+      float p = 0.f;
+      for (int x = lane; x < D; x += 64) p += dr[x] * gr[x];
+      p = wave_sum(p);
+      if (lane == 0) da[j] = p;
+    }
+    __syncthreads();
+    if (tid < C) {
+      float s = 0.f;
+      for (int j = 0; j < Hn; ++j) if (cid[j] == tid) s += al[j] * da[j];
+      csum[tid] = s;
+    }
+    __syncthreads();
+    for (int j = tid; j < Hn; j += 256) dsn[n][j] = al[j] * (da[j] - csum[cid[j]]) * inv_scale;
+    // dg[b, j, :] (+)= alpha_j * dfeat[cid_j, :]
+    for (int col = tid; col < D; col += 256)
+      for (int j = 0; j < Hn; ++j) {
+        const float v = al[j] * df[(long)cid[j] * D + col];
+        float* p = dg + ((long)b * Hn + j) * D + col;
+        *p = (n == 0) ? v : *p + v;
+      }
+    __syncthreads();
+  }
+  // dkf[b, j, :] = sum_n ds[n][j] * qc[b, n, :] ;  dqc[b, n, :] = sum_j ds[n][j] * kf[b, j, :]
+  for (int x = tid; x < A; x += 256) {
+    for (int j = 0; j < Hn; ++j) {
+      float acc = 0.f;
+      for (int n = 0; n < N; ++n) acc += dsn[n][j] * qc[((long)b * N + n) * A + x];
+      dkf[((long)b * Hn + j) * A + x] = acc;
+    }
+    for (int n = 0; n < N; ++n) {
+      float acc = 0.f;
+      for (int j = 0; j < Hn; ++j) acc += dsn[n][j] * kf[((long)b * Hn + j) * A + x];
+      dqc[((long)b * N + n) * A + x] = acc;
+    }
+  }
+}
+
+// ---- click predictor + loss (model.py:126-127, trainer.py:64-66), one workgroup for the whole (tiny) batch tail.
+// logits[b, n] = <user[b, n], cand[b, n]> ; loss = mean_b( -log_softmax(logits[b])[0] )
+// dlogits[b, n] = (softmax(logits[b])[n] - [n == 0]) * loss_scale / B   (loss_scale = 1, or 1 for DP: grads are averaged later)
+__global__ __launch_bounds__(256) void logits_kernel(const float* __restrict__ user, const float* __restrict__ cand, int BN, int D,
+                                                     float* __restrict__ logits) {
+  const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= BN) return;
+  float p = 0.f;
+  for (int x = lane; x < D; x += 64) p += user[(long)i * D + x] * cand[(long)i * D + x];
+  p = wave_sum(p);
+  if (lane == 0) logits[i] = p;
+}
+__global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ logits, int B, int N, float* __restrict__ loss,
+                                                   float* __restrict__ dlogits) {
+  __shared__ float part[256];
+  float acc = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const float* l = logits + (long)b * N;
+    float m = -INFINITY;
+    for (int n = 0; n < N; ++n) m = fmaxf(m, l[n]);
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s += expf(l[n] - m);
+    const float lse = m + logf(s);
+    acc += lse - l[0];
+    if (dlogits)
+      for (int n = 0; n < N; ++n) dlogits[(long)b * N + n] = (expf(l[n] - lse) - (n == 0 ? 1.f : 0.f)) / (float)B;
+  }
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *loss = part[0] / (float)B;
+}
+// duser = dlogit * cand ; dcand (+)= dlogit * user
+__global__ void logits_bwd_kernel(const float* __restrict__ dlogits, const float* __restrict__ user, const float* __restrict__ cand,
+                                  long BN, int D, float* __restrict__ duser, float* __restrict__ dcand, int dcand_acc) {
+  const long total = BN * D;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const float d = dlogits[i / D];
+    duser[i] = d * cand[i];
+    const float v = d * user[i];
+    dcand[i] = dcand_acc ? dcand[i] + v : v;
+  }
+}
+
+// ---- optimiser (trainer.py:118-120): global L2 norm -> clip coefficient -> Adam (torch.optim.Adam defaults), one flat buffer
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ out) {
+  __shared__ float part[4];
+  float acc = 0.f;
+  const long n4 = n >> 2;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(g)[i];
+    acc += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = g[(n4 << 2) + threadIdx.x]; acc += v * v; }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+}
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            long n, const float* __restrict__ sumsq, float grad_scale, float clip, float lr, float b1, float b2,
+                            float eps, float wd, float bc1, float bc2_sqrt) {
+  // clip_grad_norm_: coef = clip / (norm + 1e-6), applied only when < 1 (torch clamps the coefficient to 1)
+  float coef = grad_scale;
+  if (clip > 0.f) {
+    const float norm = sqrtf(*sumsq) * grad_scale;
+    const float c = clip / (norm + 1e-6f);
+    if (c < 1.f) coef *= c;
+  }
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float gi = g[i] * coef;
+    if (wd != 0.f) gi += wd * p[i];
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] -= (lr / bc1) * (mi / denom);
+  }
+}
+
+}  // namespace
+
+#define EW_LAUNCH(kern, n, ...)                                                             \
+  do {                                                                                      \
+    hipLaunchKernelGGL(kern, dim3(ew_grid((n), 256)), dim3(256), 0, stream, __VA_ARGS__);   \
+    NNR_CHECK_LAUNCH();                                                                     \
+    return NNR_OK;                                                                          \
+  } while (0)
+
+extern "C" int nnr_version(void) { return 1; }
+
+extern "C" int nnr_gate_bwd(const float* dHt, const float* H, const float* G, float* dH, float* dpre, const int* rows_dev,
+                            int rows, int cols, hipStream_t stream) {
+  if (cols & 3) return NNR_ERR_UNSUPPORTED;
+  EW_LAUNCH(gate_bwd_kernel, (long)rows * cols / 4, dHt, H, G, dH, dpre, rows_dev, rows, cols);
+}
+
+extern "C" int nnr_packed_seq_sum(const float* x, int D, const int* off, const int* slen, int n, float* out, hipStream_t stream) {
+  if (D & 3) return NNR_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(packed_seq_sum_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, x, D, off, slen, n, out);
+  NNR_CHECK_LAUNCH();
+  return NNR_OK;
+}
+
+extern "C" int nnr_tanh_score_bwd(float* th, const float* ds, const float* w2, float* dw2, const int* rows_dev, int rows, int A,
+                                  hipStream_t stream) {
+  const int rpb = 64;
+  hipLaunchKernelGGL(tanh_score_bwd_kernel, dim3((rows + rpb - 1) / rpb), dim3(256), 0, stream, th, ds, w2, dw2, rows_dev, rows, A, rpb);
+  NNR_CHECK_LAUNCH();
+  return NNR_OK;
+}
+
+extern "C" int nnr_colsum(const float* x, int ld, const int* rows_dev, int rows, int N, float* out, hipStream_t stream) {
+  if (rows <= 0 || N <= 0) return NNR_OK;
+  const int rpb = 128;
+  hipLaunchKernelGGL(colsum_kernel, dim3((rows + rpb - 1) / rpb, (N + 255) / 256), dim3(256), 0, stream, x, ld, rows_dev, rows, N, out, rpb);
+  NNR_CHECK_LAUNCH();
+  return NNR_OK;
+}
+
+extern "C" int nnr_small_embed_fwd(const float* table, const int* idx, int n, int dim, float* out, int ldo, float p, uint32_t seed,
+                                   hipStream_t stream) {
+  const float sc = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  EW_LAUNCH(small_embed_kernel, (long)n * dim, table, idx, n, dim, out, ldo, (float*)nullptr, (const float*)nullptr, 0, seed,
+            nnr_drop_thresh(p), sc);
+}
+extern "C" int nnr_small_embed_bwd(const int* idx, int n, int dim, const float* dout, int lddo, float* dtable, float p, uint32_t seed,
+                                   hipStream_t stream) {
+  const float sc = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  EW_LAUNCH(small_embed_kernel, (long)n * dim, (const float*)nullptr, idx, n, dim, (float*)nullptr, 0, dtable, dout, lddo, seed,
+            nnr_drop_thresh(p), sc);
+}
+
+extern "C" int nnr_add(float* y, const float* x, long n, float alpha, hipStream_t stream) { EW_LAUNCH(add_kernel, n, y, x, n, alpha); }
+extern "C" int nnr_add2d(float* y, int ldy, const float* x, int ldx, int rows, int cols, float alpha, int accumulate,
+                         hipStream_t stream) {
+  EW_LAUNCH(add2d_kernel, (long)rows * cols, y, ldy, x, ldx, rows, cols, alpha, accumulate);
+}
+
+extern "C" int nnr_sue_x0_fwd(const float* hist, const float* proxy, float* x0, int B, int Hn, int Kc, int D, float p, uint32_t seed,
+                              hipStream_t stream) {
+  const float sc = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  EW_LAUNCH(sue_x0_kernel, (long)B * (Hn + Kc) * D, hist, proxy, x0, B, Hn, Kc, D, (const float*)nullptr, (float*)nullptr,
+            (float*)nullptr, seed, nnr_drop_thresh(p), sc);
+}
+extern "C" int nnr_sue_x0_bwd(const float* dx0, float* dhist, float* dproxy, int B, int Hn, int Kc, int D, float p, uint32_t seed,
+                              hipStream_t stream) {
+  const float sc = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  EW_LAUNCH(sue_x0_kernel, (long)B * (Hn + Kc) * D, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, B, Hn, Kc, D, dx0,
+            dhist, dproxy, seed, nnr_drop_thresh(p), sc);
+}
+extern "C" int nnr_sue_slice_fwd(const float* gcn, const float* x0, float* gfeat, int B, int Hn, int G, int D, hipStream_t stream) {
+  EW_LAUNCH(sue_slice_kernel, (long)B * G * D, gcn, x0, gfeat, (const float*)nullptr, (float*)nullptr, B, Hn, G, D);
+}
+extern "C" int nnr_sue_slice_bwd(const float* dgfeat, float* dpad, int B, int Hn, int G, int D, hipStream_t stream) {
+  EW_LAUNCH(sue_slice_kernel, (long)B * G * D, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, dgfeat, dpad, B, Hn, G, D);
+}
+
+extern "C" int nnr_relu_drop_bwd(const float* dy, const float* r, float* ds, float* dx, long n, float p, uint32_t seed,
+                                 hipStream_t stream) {
+  const float sc = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  EW_LAUNCH(relu_drop_bwd_kernel, n, dy, r, ds, dx, n, 0, seed, nnr_drop_thresh(p), sc);
+}
+extern "C" int nnr_dropout(const float* x, float* y, long n, float p, uint32_t seed, hipStream_t stream) {
+  const float sc = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  EW_LAUNCH(dropout_kernel, n, x, y, n, seed, nnr_drop_thresh(p), sc);
+}
+extern "C" int nnr_relu_bwd(const float* dy, const float* y, float* dx, long n, hipStream_t stream) {
+  EW_LAUNCH(relu_bwd_kernel, n, dy, y, dx, n);
+}
+
+extern "C" int nnr_sue_intra_fwd(const float* kf, const float* qc, const float* g, const long* cidx, int B, int N, int Hn, int C, int A,
+                                 int D, float* alpha, float* feat, hipStream_t stream) {
+  if (Hn > SUE_MAXH || C > SUE_MAXC) return NNR_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(sue_intra_fwd_kernel, dim3(B * N), dim3(256), 0, stream, kf, qc, g, cidx, N, Hn, C, A, D, 1.f / sqrtf((float)A),
+                     alpha, feat);
+  NNR_CHECK_LAUNCH();
+  return NNR_OK;
+}
+extern "C" int nnr_sue_intra_bwd(const float* kf, const float* qc, const float* g, const long* cidx, const float* alpha,
+                                 const float* dfeat, int B, int N, int Hn, int C, int A, int D, float* dg, float* dkf, float* dqc,
+                                 hipStream_t stream) {
+  if (Hn > SUE_MAXH || C > SUE_MAXC || N > 8) return NNR_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(sue_intra_bwd_kernel, dim3(B), dim3(256), 0, stream, kf, qc, g, cidx, alpha, dfeat, N, Hn, C, A, D,
+                     1.f / sqrtf((float)A), dg, dkf, dqc);
+  NNR_CHECK_LAUNCH();
+  return NNR_OK;
+}
+
+extern "C" int nnr_logits_loss_fwd(const float* user, const float* cand, int B, int N, int D, float* logits, float* loss, float* dlogits,
+                                   hipStream_t stream) {
+  hipLaunchKernelGGL(logits_kernel, dim3((B * N + 3) / 4), dim3(256), 0, stream, user, cand, B * N, D, logits);
+  NNR_CHECK_LAUNCH();
+  hipLaunchKernelGGL(loss_kernel, dim3(1), dim3(256), 0, stream, logits, B, N, loss, dlogits);
+  NNR_CHECK_LAUNCH();
+  return NNR_OK;
+}
+extern "C" int nnr_logits_fwd(const float* user, const float* cand, int B, int N, int D, float* logits, hipStream_t stream) {
+  hipLaunchKernelGGL(logits_kernel, dim3((B * N + 3) / 4), dim3(256), 0, stream, user, cand, B * N, D, logits);
+  NNR_CHECK_LAUNCH();
+  return NNR_OK;
+}
+extern "C" int nnr_nls_loss(const float* logits, int B, int N, float* loss, float* dlogits, hipStream_t stream) {
+  hipLaunchKernelGGL(loss_kernel, dim3(1), dim3(256), 0, stream, logits, B, N, loss, dlogits);
+  NNR_CHECK_LAUNCH();
+  return NNR_OK;
+}
+extern "C" int nnr_logits_bwd(const float* dlogits, const float* user, const float* cand, int B, int N, int D, float* duser, float* dcand,
+                              int dcand_accumulate, hipStream_t stream) {
+  EW_LAUNCH(logits_bwd_kernel, (long)B * N * D, dlogits, user, cand, (long)B * N, D, duser, dcand, dcand_accumulate);
+}
+
+extern "C" int nnr_sumsq(const float* g, long n, float* out_zeroed, hipStream_t stream) { EW_LAUNCH(sumsq_kernel, n / 4 + 1, g, n, out_zeroed); }
+
+extern "C" int nnr_clip_adam(float* p, const float* g, float* m, float* v, long n, const float* sumsq, float grad_scale, float clip,
+                             float lr, float beta1, float beta2, float eps, float weight_decay, int step, hipStream_t stream) {
+  const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+  const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+  EW_LAUNCH(adam_kernel, n, p, g, m, v, n, sumsq, grad_scale, clip, lr, beta1, beta2, eps, weight_decay, bc1, bc2s);
+}

@@ -1,0 +1,256 @@
+// Masked-softmax attention pooling, one wave (64 lanes) per sequence / group; wave-shuffle softmax.
+// Replaces the softmax + bmm(alpha, feature) tails of `Attention` (layers.py:169-175) and
+// `ScaledDotProduct_CandidateAttention` (layers.py:197-203) and their backward.
+//
+//   layout PACKED : item (s, t) lives at row off[t] + s of x (time-major packed, see seq_plan.hip), t < slen[s];
+//                   outputs / query vectors are indexed by order[s] (the caller's news order).
+//   layout DENSE  : item (s, t) lives at row s*L + t, optional mask[(s / mask_div)*L + t] (0 -> score = -1e9, exactly
+//                   as masked_fill(mask == 0, -1e9) in the reference); outputs indexed by s.
+//   score GIVEN   : score[row] precomputed (additive attention: w2 . tanh(W1 x + b1), fused into the GEMM epilogue).
+//   score DOT     : score = scale * <x[row], v[oidx]>   with v = K^T (Q q + b_Q)  -- the algebraic form of
+//                   (K x).(Q q) that turns the [tokens, F] x [F, A] projection of every token into one GEMV per news.
+#include "common.h"
+
+namespace {
+
+constexpr int MAXT = 2;   // positions per lane: supports L <= 128 (the selects below assume exactly 2)
+constexpr int MAXV = 4;   // float4 per lane:   supports D <= 1024
+
+struct PoolArgs {
+  const float* x; int ldx; int D; int n; int L;
+  int packed;
+  const int* off; const int* slen; const int* order;
+  const uint8_t* mask; int mask_div;
+  const float* score;            // GIVEN
+  const float* v; int ldv; float scale;   // DOT
+  float* alpha;                  // [rows] (PACKED: packed row; DENSE: s*L+t)
+  float* out; int ldo; const float* add_in; int ldadd;
+  // backward
+  const float* dout; int lddo; const float* dout2; int lddo2;
+  float* dx; int lddx; int dx_accumulate;
+  float* dscore;
+  float* dv; int lddv;
+};
+
+__device__ __forceinline__ long item_row(const PoolArgs& a, int s, int t) {
+  return a.packed ? (long)a.off[t] + s : (long)s * a.L + t;
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void pool_kernel(PoolArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s >= a.n) return;
+  const int len = a.packed ? a.slen[s] : a.L;
+  const int oidx = a.packed ? a.order[s] : s;
+  const int nv = (a.D + 3) >> 2;           // float4 per row (D % 4 == 0 required)
+  const bool dot = a.v != nullptr;
+
+  f32x4 q[MAXV];                           // DOT: query vector v ; BWD: dout
+  if (dot) {
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+      const int c = lane + 64 * j;
+      q[j] = (c < nv) ? *reinterpret_cast<const f32x4*>(a.v + (long)oidx * a.ldv + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+
+  if (!BWD) {
+    // ---- scores
+    float sc[MAXT];
+#pragma unroll
+    for (int k = 0; k < MAXT; ++k) sc[k] = -INFINITY;
+    if (dot) {
+      for (int t = 0; t < len; ++t) {
+        const float* xr = a.x + item_row(a, s, t) * a.ldx;
+        float p = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXV; ++j) {
+          const int c = lane + 64 * j;
+          if (c < nv) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + 4 * c);
+            p += xv[0] * q[j][0] + xv[1] * q[j][1] + xv[2] * q[j][2] + xv[3] * q[j][3];
+          }
+        }
+        p = wave_sum(p) * a.scale;
+        if ((t & 63) == lane) { if (t < 64) sc[0] = p; else sc[1] = p; }
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < MAXT; ++k) {
+        const int t = lane + 64 * k;
+        if (t < len) sc[k] = a.score[item_row(a, s, t)];
+      }
+    }
+    if (a.mask) {
+#pragma unroll
+      for (int k = 0; k < MAXT; ++k) {
+        const int t = lane + 64 * k;
+        if (t < len && !a.mask[(long)(s / a.mask_div) * a.L + t]) sc[k] = -1e9f;
+      }
+    }
+    // ---- softmax over t < len
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < MAXT; ++k) m = fmaxf(m, sc[k]);
+    m = wave_max(m);
+    float e[MAXT], sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXT; ++k) {
+      const int t = lane + 64 * k;
+      e[k] = (t < len) ? expf(sc[k] - m) : 0.f;
+      sum += e[k];
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int k = 0; k < MAXT; ++k) {
+      const int t = lane + 64 * k;
+      e[k] *= inv;
+      if (t < len && a.alpha) a.alpha[item_row(a, s, t)] = e[k];
+    }
+    // ---- weighted sum
+    f32x4 acc[MAXV];
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < len; ++t) {
+      const float al = __shfl(t < 64 ? e[0] : e[1], t & 63, 64);
+      const float* xr = a.x + item_row(a, s, t) * a.ldx;
+#pragma unroll
+      for (int j = 0; j < MAXV; ++j) {
+        const int c = lane + 64 * j;
+        if (c < nv) {
+          const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + 4 * c);
+          acc[j] += al * xv;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+      const int c = lane + 64 * j;
+      if (c < nv) {
+        f32x4 o = acc[j];
+        if (a.add_in) o += *reinterpret_cast<const f32x4*>(a.add_in + (long)oidx * a.ldadd + 4 * c);
+        *reinterpret_cast<f32x4*>(a.out + (long)oidx * a.ldo + 4 * c) = o;
+      }
+    }
+  } else {
+    // ---------------------------------------------------------------- backward
+    f32x4 go[MAXV];
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+      const int c = lane + 64 * j;
+      go[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (c < nv) {
+        go[j] = *reinterpret_cast<const f32x4*>(a.dout + (long)oidx * a.lddo + 4 * c);
+        if (a.dout2) go[j] += *reinterpret_cast<const f32x4*>(a.dout2 + (long)oidx * a.lddo2 + 4 * c);
+      }
+    }
+    float al[MAXT], da[MAXT];
+#pragma unroll
+    for (int k = 0; k < MAXT; ++k) {
+      const int t = lane + 64 * k;
+      al[k] = (t < len) ? a.alpha[item_row(a, s, t)] : 0.f;
+      da[k] = 0.f;
+    }
+    // dalpha_t = <dout, x_t>
+    for (int t = 0; t < len; ++t) {
+      const float* xr = a.x + item_row(a, s, t) * a.ldx;
+      float p = 0.f;
+#pragma unroll
+      for (int j = 0; j < MAXV; ++j) {
+        const int c = lane + 64 * j;
+        if (c < nv) {
+          const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + 4 * c);
+          p += xv[0] * go[j][0] + xv[1] * go[j][1] + xv[2] * go[j][2] + xv[3] * go[j][3];
+        }
+      }
+      p = wave_sum(p);
+      if ((t & 63) == lane) { if (t < 64) da[0] = p; else da[1] = p; }
+    }
+    float dsum = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXT; ++k) dsum += al[k] * da[k];
+    dsum = wave_sum(dsum);
+    float ds[MAXT];
+#pragma unroll
+    for (int k = 0; k < MAXT; ++k) {
+      const int t = lane + 64 * k;
+      ds[k] = al[k] * (da[k] - dsum);          // d loss / d score_t (masked items have alpha = 0 -> 0)
+      if (t < len && a.dscore) a.dscore[item_row(a, s, t)] = ds[k];
+    }
+    f32x4 dvacc[MAXV];
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) dvacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < len; ++t) {
+      const float alt = __shfl(t < 64 ? al[0] : al[1], t & 63, 64);
+      const float dst = __shfl(t < 64 ? ds[0] : ds[1], t & 63, 64) * a.scale;
+      const long row = item_row(a, s, t);
+      const float* xr = a.x + row * a.ldx;
+#pragma unroll
+      for (int j = 0; j < MAXV; ++j) {
+        const int c = lane + 64 * j;
+        if (c < nv) {
+          f32x4 g = alt * go[j];
+          if (dot) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + 4 * c);
+            g += dst * q[j];
+            dvacc[j] += dst * xv;
+          }
+          if (a.dx) {
+            f32x4* dp = reinterpret_cast<f32x4*>(a.dx + row * a.lddx + 4 * c);
+            if (a.dx_accumulate) g += *dp;
+            *dp = g;
+          }
+        }
+      }
+    }
+    if (dot && a.dv) {
+#pragma unroll
+      for (int j = 0; j < MAXV; ++j) {
+        const int c = lane + 64 * j;
+        if (c < nv) *reinterpret_cast<f32x4*>(a.dv + (long)oidx * a.lddv + 4 * c) = dvacc[j];
+      }
+    }
+  }
+}
+
+}  // namespace
+
+static int pool_check(const nnr_pool_args* p) {
+  if (!p || !p->x || p->n <= 0) return NNR_ERR_ARG;
+  if ((p->D & 3) || p->D > 4 * 64 * MAXV || (p->ldx & 3)) return NNR_ERR_UNSUPPORTED;
+  if (p->L > 64 * MAXT) return NNR_ERR_UNSUPPORTED;
+  if (p->packed && (!p->off || !p->slen || !p->order)) return NNR_ERR_ARG;
+  if (!p->v && !p->score && !p->alpha) return NNR_ERR_ARG;
+  return NNR_OK;
+}
+
+static PoolArgs to_args(const nnr_pool_args* p) {
+  PoolArgs a;
+  a.x = p->x; a.ldx = p->ldx; a.D = p->D; a.n = p->n; a.L = p->L; a.packed = p->packed;
+  a.off = p->off; a.slen = p->slen; a.order = p->order; a.mask = p->mask; a.mask_div = p->mask_div > 0 ? p->mask_div : 1;
+  a.score = p->score; a.v = p->v; a.ldv = p->ldv; a.scale = p->v ? p->scale : 1.f;
+  a.alpha = p->alpha; a.out = p->out; a.ldo = p->ldo; a.add_in = p->add_in; a.ldadd = p->ldadd;
+  a.dout = p->dout; a.lddo = p->lddo; a.dout2 = p->dout2; a.lddo2 = p->lddo2;
+  a.dx = p->dx; a.lddx = p->lddx; a.dx_accumulate = p->dx_accumulate; a.dscore = p->dscore; a.dv = p->dv; a.lddv = p->lddv;
+  return a;
+}
+
+extern "C" int nnr_attn_pool_fwd(const nnr_pool_args* p, hipStream_t stream) {
+  int rc = pool_check(p);
+  if (rc != NNR_OK) return rc;
+  if (!p->out || (!p->v && !p->score)) return NNR_ERR_ARG;
+  hipLaunchKernelGGL((pool_kernel<false>), dim3((p->n + 3) / 4), dim3(256), 0, stream, to_args(p));
+  NNR_CHECK_LAUNCH();
+  return NNR_OK;
+}
+
+extern "C" int nnr_attn_pool_bwd(const nnr_pool_args* p, hipStream_t stream) {
+  int rc = pool_check(p);
+  if (rc != NNR_OK) return rc;
+  if (!p->dout || !p->alpha) return NNR_ERR_ARG;
+  hipLaunchKernelGGL((pool_kernel<true>), dim3((p->n + 3) / 4), dim3(256), 0, stream, to_args(p));
+  NNR_CHECK_LAUNCH();
+  return NNR_OK;
+}

@@ -1,0 +1,167 @@
+"""Layer classes of the hot path with the reference's names, constructor signatures and parameter names
+(layers.py of the reference), so checkpoints / state_dicts are interchangeable.  Inside CNE / SUE the encoders drive
+the HIP kernels directly from these parameter holders; the standalone `forward`s (dense [n, L, F] inputs, used by the
+MHSA / ATT / CNN encoders) are autograd Functions over the same kernels."""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+def grad_of(p):
+    """`p.grad`, created zero-filled on first use.  The hand-written backward passes ACCUMULATE into it (the news
+    encoder runs twice per step), exactly like autograd's AccumulateGrad; the trainer zeroes the flat gradient buffer."""
+    if p.grad is None:
+        p.grad = torch.zeros_like(p)
+    return p.grad
+
+
+class LSTMParams(nn.Module):
+    """Parameter holder with nn.LSTM(bidirectional=True, num_layers=1) names/shapes/default init (newsEncoders.py:66-67)."""
+
+    def __init__(self, input_dim, hidden_dim):
+        super().__init__()
+        self.input_dim, self.hidden_dim = input_dim, hidden_dim
+        k = 1.0 / math.sqrt(hidden_dim)
+        for sfx in ('', '_reverse'):
+            for name, shape in (('weight_ih_l0', (4 * hidden_dim, input_dim)), ('weight_hh_l0', (4 * hidden_dim, hidden_dim)),
+                                ('bias_ih_l0', (4 * hidden_dim,)), ('bias_hh_l0', (4 * hidden_dim,))):
+                self.register_parameter(name + sfx, nn.Parameter(torch.empty(shape).uniform_(-k, k)))
+
+    def param_list(self):
+        return [self.weight_ih_l0, self.weight_hh_l0, self.bias_ih_l0, self.bias_hh_l0,
+                self.weight_ih_l0_reverse, self.weight_hh_l0_reverse, self.bias_ih_l0_reverse, self.bias_hh_l0_reverse]
+
+
+# ------------------------------------------------------------------------------------------------ additive attention
+class _AttentionFn(torch.autograd.Function):
+    """layers.py:167-175 on a dense [n, L, F] feature: GEMM with fused tanh.w2 row-dot, then the wave-softmax pool."""
+
+    @staticmethod
+    def forward(ctx, feature, mod, mask):
+        n, Lx, F = feature.shape
+        A = mod.affine1.weight.shape[0]
+        x = feature.contiguous().view(n * Lx, F)
+        f32 = dict(device=x.device, dtype=torch.float32)
+        th = torch.empty((n * Lx, A), **f32)
+        score = torch.empty(n * Lx, **f32)
+        ops.gemm(x, mod.affine1.weight, None, M=n * Lx, N=A, K=F, lda=F, ldb=F, bias=mod.affine1.bias, act=ops.ACT_TANH, aux_out=th,
+                 ldaux=A, rowdot_w=mod.affine2.weight, rowdot_out=score, tile=3)
+        alpha = torch.empty(n * Lx, **f32)
+        out = torch.empty((n, F), **f32)
+        ops.pool_fwd(x=x, ldx=F, D=F, n=n, Lx=Lx, mask=mask, score=score, alpha=alpha, out=out, ldo=F)
+        ctx.mod, ctx.mask, ctx.saved = mod, mask, (x, th, alpha, n, Lx, F, A)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        mod = ctx.mod
+        x, th, alpha, n, Lx, F, A = ctx.saved
+        f32 = dict(device=x.device, dtype=torch.float32)
+        dx = torch.empty((n * Lx, F), **f32)
+        ds = torch.empty(n * Lx, **f32)
+        ops.pool_bwd(x=x, ldx=F, D=F, n=n, Lx=Lx, mask=ctx.mask, alpha=alpha, dout=dout.contiguous(), lddo=F, dx=dx, lddx=F, dscore=ds)
+        ops.tanh_score_bwd(th, ds, mod.affine2.weight, grad_of(mod.affine2.weight), None, A)
+        ops.gemm(th, mod.affine1.weight, dx, M=n * Lx, N=F, K=A, lda=A, ldb=F, ldc=F, trans_b=True, accumulate=True)
+        ops.linear_bwd_weight(th, x, grad_of(mod.affine1.weight))
+        ops.bias_grad(th, grad_of(mod.affine1.bias))
+        return dx.view(n, Lx, F), None, None
+
+
+class Attention(nn.Module):
+    """layers.py:151-175."""
+
+    def __init__(self, feature_dim: int, attention_dim: int):
+        super().__init__()
+        self.affine1 = nn.Linear(feature_dim, attention_dim, bias=True)
+        self.affine2 = nn.Linear(attention_dim, 1, bias=False)
+
+    def initialize(self):
+        nn.init.xavier_uniform_(self.affine1.weight, gain=nn.init.calculate_gain('tanh'))
+        nn.init.zeros_(self.affine1.bias)
+        nn.init.xavier_uniform_(self.affine2.weight)
+
+    def forward(self, feature, mask=None):
+        return _AttentionFn.apply(feature, self, mask)
+
+
+class ScaledDotProduct_CandidateAttention(nn.Module):
+    """layers.py:178-203 (parameter holder; CNE and SUE evaluate it in its GEMV form, see their pipelines)."""
+
+    def __init__(self, feature_dim: int, query_dim: int, attention_dim: int):
+        super().__init__()
+        self.K = nn.Linear(feature_dim, attention_dim, bias=False)
+        self.Q = nn.Linear(query_dim, attention_dim, bias=True)
+        self.attention_scalar = math.sqrt(float(attention_dim))
+
+    def initialize(self):
+        nn.init.xavier_uniform_(self.K.weight)
+        nn.init.xavier_uniform_(self.Q.weight)
+        nn.init.zeros_(self.Q.bias)
+
+
+class MultiHeadAttention(nn.Module):
+    """layers.py:102-148 (parameter holder + forward over the MFMA attention kernel, see news_encoders.MHSA)."""
+
+    def __init__(self, h: int, d_model: int, len_q: int, len_k: int, d_k: int, d_v: int):
+        super().__init__()
+        self.h, self.d_model, self.len_q, self.len_k, self.d_k, self.d_v = h, d_model, len_q, len_k, d_k, d_v
+        self.out_dim = h * d_v
+        self.attention_scalar = math.sqrt(float(d_k))
+        self.W_Q = nn.Linear(d_model, h * d_k, bias=True)
+        self.W_K = nn.Linear(d_model, h * d_k, bias=True)
+        self.W_V = nn.Linear(d_model, h * d_v, bias=True)
+
+    def initialize(self):
+        nn.init.xavier_uniform_(self.W_Q.weight)
+        nn.init.zeros_(self.W_Q.bias)
+        nn.init.xavier_uniform_(self.W_K.weight)
+        nn.init.zeros_(self.W_K.bias)
+        nn.init.xavier_uniform_(self.W_V.weight)
+        nn.init.zeros_(self.W_V.bias)
+
+
+class Conv1D(nn.Module):
+    """layers.py:7-44, 'naive' branch (the only one the in-scope CNN encoder uses)."""
+
+    def __init__(self, cnn_method: str, in_channels: int, cnn_kernel_num: int, cnn_window_size: int):
+        super().__init__()
+        assert cnn_method == 'naive', 'only cnn_method=naive is on the hot path (SURVEY.md section 2, row 5)'
+        self.cnn_method = cnn_method
+        self.conv = nn.Conv1d(in_channels=in_channels, out_channels=cnn_kernel_num, kernel_size=cnn_window_size,
+                              padding=(cnn_window_size - 1) // 2)
+
+
+class GCNLayer(nn.Module):
+    """layers.py:265-292 (parameter holder; SUE's pipeline evaluates relu(A (X W^T) + b) + X)."""
+
+    def __init__(self, in_dim, out_dim, residual=False, layer_norm=False):
+        super().__init__()
+        if layer_norm:
+            raise NotImplementedError('--gcn_layer_norm is off on the BASELINE configs; not implemented on the HIP path')
+        if residual and in_dim != out_dim:
+            raise Exception('To facilitate residual connection, in_dim must equal to out_dim')
+        self.residual = residual
+        self.W = nn.Linear(in_dim, out_dim, bias=True)
+
+    def initialize(self):
+        nn.init.xavier_uniform_(self.W.weight, gain=nn.init.calculate_gain('relu'))
+        nn.init.zeros_(self.W.bias)
+
+
+class GCN(nn.Module):
+    """layers.py:294-323."""
+
+    def __init__(self, in_dim, out_dim, hidden_dim=0, num_layers=1, dropout=0.1, residual=False, layer_norm=False):
+        super().__init__()
+        assert in_dim == out_dim and (num_layers == 1 or hidden_dim == in_dim)
+        self.num_layers = num_layers
+        self.dropout_rate = float(dropout)
+        self.residual = residual
+        self.gcn_layers = nn.ModuleList([GCNLayer(in_dim, in_dim, residual=residual, layer_norm=layer_norm) for _ in range(num_layers)])
+
+    def initialize(self):
+        for gcn_layer in self.gcn_layers:
+            gcn_layer.initialize()

@@ -1,0 +1,97 @@
+"""`Model(news_encoder, user_encoder, click_predictor)` -- the reference's plugin hub (model.py:10-133) for the
+in-scope encoders, dispatching on the same `--news_encoder / --user_encoder` strings; forward takes the same 21
+positional tensors (trainer.py:105-106) and returns logits [batch, 1 + negative_sample_num]."""
+import torch
+import torch.nn as nn
+
+from . import ops
+from . import news_encoders as newsEncoders
+from . import user_encoders as userEncoders
+
+
+class _DotProductFn(torch.autograd.Function):
+    """logits = (user_representation * news_representation).sum(dim=2)   (model.py:126-127)"""
+
+    @staticmethod
+    def forward(ctx, user, cand):
+        B, N, D = cand.shape
+        user, cand = user.contiguous(), cand.contiguous()
+        logits = torch.empty((B, N), device=cand.device, dtype=torch.float32)
+        ops.logits_fwd(user, cand, B, N, D, logits)
+        ctx.save_for_backward(user, cand)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        user, cand = ctx.saved_tensors
+        B, N, D = cand.shape
+        duser, dcand = torch.empty_like(user), torch.empty_like(cand)
+        ops.logits_bwd(dlogits.contiguous(), user, cand, B, N, D, duser, dcand)
+        return duser, dcand
+
+
+class _NegLogSoftmaxFn(torch.autograd.Function):
+    """loss = (-log_softmax(logits, dim=1)[:, 0]).mean()   (trainer.py:64-66); the gradient is produced in the same pass."""
+
+    @staticmethod
+    def forward(ctx, logits):
+        B, N = logits.shape
+        logits = logits.contiguous()
+        loss = torch.empty((), device=logits.device, dtype=torch.float32)
+        dlogits = torch.empty_like(logits)
+        ops.nls_loss(logits, B, N, loss, dlogits)
+        ctx.save_for_backward(dlogits)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (dlogits,) = ctx.saved_tensors
+        return dlogits * dloss
+
+
+def negative_log_softmax(logits):
+    return _NegLogSoftmaxFn.apply(logits)
+
+
+class Model(nn.Module):
+    def __init__(self, config, word_table=None):
+        super().__init__()
+        if config.news_encoder == 'CNE':
+            self.news_encoder = newsEncoders.CNE(config, word_table)
+        elif config.news_encoder == 'CNN':
+            self.news_encoder = newsEncoders.CNN(config, word_table)
+        elif config.news_encoder == 'MHSA':
+            self.news_encoder = newsEncoders.MHSA(config, word_table)
+        else:
+            raise Exception(config.news_encoder + ' is not on the MI355X hot path (in scope: CNE, CNN, MHSA; SURVEY.md section 8a)')
+        if config.user_encoder == 'SUE':
+            self.user_encoder = userEncoders.SUE(self.news_encoder, config)
+        elif config.user_encoder == 'MHSA':
+            self.user_encoder = userEncoders.MHSA(self.news_encoder, config)
+        elif config.user_encoder == 'ATT':
+            self.user_encoder = userEncoders.ATT(self.news_encoder, config)
+        else:
+            raise Exception(config.user_encoder + ' is not on the MI355X hot path (in scope: SUE, MHSA, ATT; SURVEY.md section 8a)')
+        self.model_name = config.news_encoder + '-' + config.user_encoder
+        self.news_embedding_dim = self.news_encoder.news_embedding_dim
+        self.use_user_embedding = False
+        if config.click_predictor != 'dot_product':
+            raise Exception('click_predictor=%s is out of scope (dot_product only, model.py:126-127)' % config.click_predictor)
+        self.click_predictor = config.click_predictor
+
+    def initialize(self):
+        self.news_encoder.initialize()
+        self.user_encoder.initialize()
+
+    def forward(self, user_ID, user_category, user_subCategory, user_title_text, user_title_mask, user_title_entity, user_content_text,
+                user_content_mask, user_content_entity, user_history_mask, user_history_graph, user_history_category_mask,
+                user_history_category_indices, news_category, news_subCategory, news_title_text, news_title_mask, news_title_entity,
+                news_content_text, news_content_mask, news_content_entity):
+        user_embedding = None
+        news_representation = self.news_encoder(news_title_text, news_title_mask, news_title_entity, news_content_text, news_content_mask,
+                                                news_content_entity, news_category, news_subCategory, user_embedding)
+        user_representation = self.user_encoder(user_title_text, user_title_mask, user_title_entity, user_content_text, user_content_mask,
+                                                user_content_entity, user_category, user_subCategory, user_history_mask,
+                                                user_history_graph, user_history_category_mask, user_history_category_indices,
+                                                user_embedding, news_representation)
+        return _DotProductFn.apply(user_representation, news_representation)

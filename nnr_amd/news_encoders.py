@@ -1,0 +1,284 @@
+"""News encoders of the hot path -- same class names, constructor signatures, parameter names and forward
+signatures as the reference's newsEncoders.py, computed by the HIP kernels of libnnr_hip.so.
+
+CNE (newsEncoders.py:57-141) pipeline per token stream (title L=32 / content L=128), all on packed valid tokens only:
+  seq_plan  -> [embedding-row gather + dropout + x.W_ih^T + b]  (one GEMM, gather fused in the A loader)
+            -> persistent Bi-LSTM recurrence (both streams, both directions, ONE launch)
+            -> cross-selective gate  H * sigmoid(H.W_H^T + M(c_other))   (GEMM epilogue)
+            -> additive self attention (GEMM with fused tanh.w2 row-dot) -> wave-softmax pool
+            -> cross attention  score = <H~_t, K^T(Q q + b)> / sqrt(A)   (GEMV form) -> pool
+            -> feature fusion with category / subCategory rows.
+The backward pass is written by hand against the same kernels (no autograd graph inside the encoder); parameter
+gradients are accumulated straight into `param.grad`.
+
+Tie order (see oracle/nnr_oracle.py:length_order): the reference sorts each stream by length with an unstable sort and
+gates the title at title-rank r with the content memory at content-rank r.  Because this implementation keeps each stream
+in its own sorted order end to end, that pairing is reproduced by construction; `tie_order` only selects how equal lengths
+are ordered: 'stable' (device-side, no host sync; = torch 1.12.1 CPU behaviour) or 'torch' (ask the installed torch on the
+host, exactly as the reference's CPU path would -- costs a device->host sync, used for bit-parity tests)."""
+import math
+import os
+import pickle
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .layers import Attention, ScaledDotProduct_CandidateAttention, MultiHeadAttention, Conv1D, LSTMParams, grad_of
+
+_SITE = dict(title=1, content=2, cat=3, sub=4)
+
+
+class NewsEncoder(nn.Module):
+    """newsEncoders.py:11-54."""
+
+    def __init__(self, config, word_table=None):
+        super().__init__()
+        self.word_embedding_dim = config.word_embedding_dim
+        self.word_embedding = nn.Embedding(num_embeddings=config.vocabulary_size, embedding_dim=self.word_embedding_dim)
+        fname = 'word_embedding-' + str(config.word_threshold) + '-' + str(config.word_embedding_dim) + '-' + config.tokenizer + '-' + \
+                str(config.max_title_length) + '-' + str(config.max_abstract_length) + '-' + config.dataset + '.pkl'
+        if word_table is None and os.path.exists(fname):            # the reference's behaviour (newsEncoders.py:16-17)
+            with open(fname, 'rb') as f:
+                word_table = pickle.load(f)
+        if word_table is not None:
+            self.word_embedding.weight.data.copy_(word_table)
+        self.category_embedding = nn.Embedding(num_embeddings=config.category_num, embedding_dim=config.category_embedding_dim)
+        self.subCategory_embedding = nn.Embedding(num_embeddings=config.subCategory_num, embedding_dim=config.subCategory_embedding_dim)
+        self.dropout_rate = float(config.dropout_rate)
+        self.auxiliary_loss = None
+        self._seed_base = int(getattr(config, 'seed', 0)) * 7919 + 17
+        self._calls = 0
+
+    def _next_seed(self):
+        self._calls += 1
+        return (self._seed_base + 104729 * self._calls) & 0x7FFFFFFF
+
+    def initialize(self):
+        nn.init.uniform_(self.category_embedding.weight, -0.1, 0.1)
+        nn.init.uniform_(self.subCategory_embedding.weight, -0.1, 0.1)
+        with torch.no_grad():
+            self.subCategory_embedding.weight[0].zero_()
+
+    def forward(self, title_text, title_mask, title_entity, content_text, content_mask, content_entity, category, subCategory, user_embedding):
+        raise Exception('Function forward must be implemented at sub-class')
+
+
+def _i32(t):
+    return t if t.dtype == torch.int32 else t.to(torch.int32)
+
+
+# ================================================================================================== CNE
+class _CNEFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, mod, title_text, title_mask, content_text, content_mask, category, subCategory):
+        rep, saved = cne_forward(mod, title_text, title_mask, content_text, content_mask, category, subCategory)
+        ctx.mod, ctx.saved = mod, saved
+        return rep
+
+    @staticmethod
+    def backward(ctx, drep):
+        cne_backward(ctx.mod, ctx.saved, drep.contiguous())
+        ctx.saved = None
+        return (None,) * 8
+
+
+def cne_forward(mod, title_text, title_mask, content_text, content_mask, category, subCategory):
+    B, N = title_text.shape[:2]
+    n = B * N
+    dev = title_text.device
+    H, E, A = mod.hidden_dim, mod.word_embedding_dim, mod.attention_dim
+    H2 = 2 * H
+    D = mod.news_embedding_dim
+    f32 = dict(device=dev, dtype=torch.float32)
+    p = mod.dropout_rate if mod.training else 0.0
+    seed = mod._next_seed()
+    emb = mod.word_embedding.weight
+
+    streams = []
+    for name, ids, mask, Lx, lstm, Hlin, Mlin, satt, catt in (
+            ('title', title_text, title_mask, mod.max_title_length, mod.title_lstm, mod.title_H, mod.title_M,
+             mod.title_self_attention, mod.title_cross_attention),
+            ('content', content_text, content_mask, mod.max_content_length, mod.content_lstm, mod.content_H, mod.content_M,
+             mod.content_self_attention, mod.content_cross_attention)):
+        ids2 = _i32(ids).reshape(n, Lx).contiguous()
+        mask2 = mask.view(n, Lx)                        # a view: the in-place mask[:,0]=1 must reach the caller's tensor
+        perm = None
+        if mod.tie_order == 'torch':
+            lens = mask2.sum(dim=1).long() + (~mask2[:, 0]).long()      # lengths after the mask[:,0]=1 fix
+            perm = torch.sort(lens.cpu(), descending=True)[1].to(torch.int32).to(dev)
+        plan = ops.SeqPlan(mask2, ids2, perm)
+        w = ops.LstmPacked(lstm.param_list(), H, E)
+        cap = plan.cap
+        st = dict(name=name, L=Lx, plan=plan, w=w, lstm=lstm, Hlin=Hlin, Mlin=Mlin, satt=satt, catt=catt, seed=seed + _SITE[name])
+        st['gates'] = torch.empty((cap, 2 * w.NP), **f32)
+        ops.gemm(emb, w.w_ihp, st['gates'], M=cap, N=2 * w.NP, K=E, lda=E, ldb=E, ldc=2 * w.NP, a_idx=plan.tok, dyn=plan.total,
+                 dyn_dim=1, bias=w.b_p, drop=(1, p, st['seed'], E))
+        st['cell'] = torch.empty((cap, 2 * w.HP), **f32)
+        st['hout'] = torch.empty((cap, H2), **f32)
+        st['cn'] = torch.empty((n, H2), **f32)
+        streams.append(st)
+    t_, c_ = streams
+    ops.lstm_fwd([c_, t_], H)                            # content first: longest tiles are dispatched first
+
+    for st, other in ((t_, c_), (c_, t_)):
+        plan, cap = st['plan'], st['plan'].cap
+        # title_M(sorted_content_m): both indexed by sorted RANK (newsEncoders.py:128-129)
+        st['mproj'] = ops.linear_fwd(other['cn'], st['Mlin'].weight, st['Mlin'].bias)
+        st['G'] = torch.empty((cap, H2), **f32)
+        st['Ht'] = torch.empty((cap, H2), **f32)
+        ops.gemm(st['hout'], st['Hlin'].weight, st['Ht'], M=cap, N=H2, K=H2, lda=H2, ldb=H2, ldc=H2, dyn=plan.total, dyn_dim=1,
+                 rowvec=st['mproj'], ldrv=H2, rowvec_map=plan.row_seq, act=ops.ACT_SIGMOID, aux_out=st['G'], ldaux=H2,
+                 mul=st['hout'], ldmul=H2)
+        st['th'] = torch.empty((cap, A), **f32)
+        st['score'] = torch.empty(cap, **f32)
+        sa = st['satt']
+        ops.gemm(st['Ht'], sa.affine1.weight, None, M=cap, N=A, K=H2, lda=H2, ldb=H2, dyn=plan.total, dyn_dim=1,
+                 bias=sa.affine1.bias, act=ops.ACT_TANH, aux_out=st['th'], ldaux=A, rowdot_w=sa.affine2.weight,
+                 rowdot_out=st['score'], tile=3)
+        st['alpha_s'] = torch.empty(cap, **f32)
+        st['selfv'] = torch.empty((n, H2), **f32)
+        ops.pool_fwd(x=st['Ht'], ldx=H2, D=H2, n=n, Lx=st['L'], plan=plan, score=st['score'], alpha=st['alpha_s'],
+                     out=st['selfv'], ldo=H2)
+
+    rep = torch.empty((n, D), **f32)
+    for st, other, col0 in ((t_, c_, 0), (c_, t_, H2)):
+        plan, ca = st['plan'], st['catt']
+        st['qv'] = ops.linear_fwd(other['selfv'], ca.Q.weight, ca.Q.bias)                    # [n, A]
+        st['v'] = torch.empty((n, H2), **f32)
+        ops.gemm(st['qv'], ca.K.weight, st['v'], M=n, N=H2, K=A, lda=A, ldb=H2, ldc=H2, trans_b=True)   # K^T (Q q + b)
+        st['alpha_c'] = torch.empty(plan.cap, **f32)
+        ops.pool_fwd(x=st['Ht'], ldx=H2, D=H2, n=n, Lx=st['L'], plan=plan, v=st['v'], ldv=H2, scale=1.0 / math.sqrt(A),
+                     alpha=st['alpha_c'], out=rep[:, col0:], ldo=D, add_in=st['selfv'], ldadd=H2)
+    cat = _i32(category).reshape(n).contiguous()
+    sub = _i32(subCategory).reshape(n).contiguous()
+    cd, sd = mod.category_embedding.weight.shape[1], mod.subCategory_embedding.weight.shape[1]
+    ops.small_embed_fwd(mod.category_embedding.weight, cat, rep[:, 2 * H2:], D, p, seed + _SITE['cat'])
+    ops.small_embed_fwd(mod.subCategory_embedding.weight, sub, rep[:, 2 * H2 + cd:], D, p, seed + _SITE['sub'])
+    saved = dict(streams=streams, n=n, B=B, N=N, p=p, seed=seed, cat=cat, sub=sub, cd=cd, sd=sd)
+    for st in streams:                                   # not needed by backward
+        st.pop('score'); st.pop('mproj')
+    return rep.view(B, N, D), saved
+
+
+def cne_backward(mod, sv, drep):
+    t_, c_ = sv['streams']
+    n, p, seed = sv['n'], sv['p'], sv['seed']
+    H, E, A = mod.hidden_dim, mod.word_embedding_dim, mod.attention_dim
+    H2 = 2 * H
+    D = mod.news_embedding_dim
+    dev = drep.device
+    f32 = dict(device=dev, dtype=torch.float32)
+    drep = drep.reshape(n, D)
+    emb = mod.word_embedding.weight
+
+    ops.small_embed_bwd(sv['cat'], sv['cd'], drep[:, 2 * H2:], D, grad_of(mod.category_embedding.weight), p, seed + _SITE['cat'])
+    ops.small_embed_bwd(sv['sub'], sv['sd'], drep[:, 2 * H2 + sv['cd']:], D, grad_of(mod.subCategory_embedding.weight), p, seed + _SITE['sub'])
+
+    # ---- cross attention pools: dHt (overwrite), dv -> K / Q params and the gradient of the OTHER stream's self vector
+    for st, other, col0 in ((t_, c_, 0), (c_, t_, H2)):
+        plan, ca, cap = st['plan'], st['catt'], st['plan'].cap
+        st['dHt'] = torch.empty((cap, H2), **f32)
+        dv = torch.empty((n, H2), **f32)
+        ops.pool_bwd(x=st['Ht'], ldx=H2, D=H2, n=n, Lx=st['L'], plan=plan, v=st['v'], ldv=H2, scale=1.0 / math.sqrt(A),
+                     alpha=st['alpha_c'], dout=drep[:, col0:], lddo=D, dx=st['dHt'], lddx=H2, dv=dv, lddv=H2)
+        dqv = torch.empty((n, A), **f32)
+        ops.gemm(dv, ca.K.weight, dqv, M=n, N=A, K=H2, lda=H2, ldb=H2, ldc=A)                 # dqv = dv . K^T
+        ops.linear_bwd_weight(st['qv'], dv, grad_of(ca.K.weight))                             # dK[A,H2] += qv^T dv
+        ops.linear_bwd_weight(dqv, other['selfv'], grad_of(ca.Q.weight))
+        ops.bias_grad(dqv, grad_of(ca.Q.bias))
+        other['dself_x'] = ops.linear_bwd_data(dqv, ca.Q.weight)                              # grad of other.selfv via the query
+
+    # ---- self attention pools, additive score, gate
+    for st, other, col0 in ((t_, c_, 0), (c_, t_, H2)):
+        plan, sa, cap = st['plan'], st['satt'], st['plan'].cap
+        ds = torch.empty(cap, **f32)
+        ops.pool_bwd(x=st['Ht'], ldx=H2, D=H2, n=n, Lx=st['L'], plan=plan, score=None, alpha=st['alpha_s'],
+                     dout=drep[:, col0:], lddo=D, dout2=st['dself_x'], lddo2=H2, dx=st['dHt'], lddx=H2, dx_accumulate=True, dscore=ds)
+        th = st['th']
+        ops.tanh_score_bwd(th, ds, sa.affine2.weight, grad_of(sa.affine2.weight), plan, A)    # th := dpre
+        ops.gemm(th, sa.affine1.weight, st['dHt'], M=cap, N=H2, K=A, lda=A, ldb=H2, ldc=H2, trans_b=True, accumulate=True,
+                 dyn=plan.total, dyn_dim=1)
+        ops.linear_bwd_weight(th, st['Ht'], grad_of(sa.affine1.weight), dyn=plan.total)
+        ops.bias_grad(th, grad_of(sa.affine1.bias), dyn=plan.total)
+        # gate: Ht = hout * G
+        st['dH'] = torch.empty((cap, H2), **f32)
+        dpre = st['Ht']                                   # reuse: Ht is dead after the GEMM above
+        ops.gate_bwd(st['dHt'], st['hout'], st['G'], st['dH'], dpre, plan, H2)
+        ops.gemm(dpre, st['Hlin'].weight, st['dH'], M=cap, N=H2, K=H2, lda=H2, ldb=H2, ldc=H2, trans_b=True, accumulate=True,
+                 dyn=plan.total, dyn_dim=1)
+        ops.linear_bwd_weight(dpre, st['hout'], grad_of(st['Hlin'].weight), dyn=plan.total)
+        dP = torch.empty((n, H2), **f32)                  # d mproj[rank]
+        ops.packed_seq_sum(dpre, H2, plan, dP)
+        ops.linear_bwd_weight(dP, other['cn'], grad_of(st['Mlin'].weight))
+        ops.bias_grad(dP, grad_of(st['Mlin'].bias))
+        other['dcn'] = ops.linear_bwd_data(dP, st['Mlin'].weight)                             # [n, H2], rank-indexed
+        st['dHt'] = None
+
+    # ---- recurrence backward (both streams, one launch), then the token-reduction GEMMs
+    for st in (t_, c_):
+        st['dh'] = st['dH']
+    ops.lstm_bwd([c_, t_], H)
+    for st in (t_, c_):
+        plan, w, cap = st['plan'], st['w'], st['plan'].cap
+        dg = st['gates']                                  # now d(pre-activation gates), p-order
+        NP = w.NP
+        dw_ihp = torch.zeros((2 * NP, E), **f32)
+        db_p = torch.zeros(2 * NP, **f32)
+        dw_hhp = torch.zeros((2, NP, H), **f32)
+        ops.gemm(dg, emb, dw_ihp, M=2 * NP, N=E, K=cap, lda=2 * NP, ldb=E, ldc=E, trans_a=True, trans_b=True, b_idx=plan.tok,
+                 drop=(2, p, st['seed'], E), split_k=ops.split_for(2 * NP, E, cap), atomic=True, dyn=plan.total, dyn_dim=2)
+        ops.bias_grad(dg, db_p, dyn=plan.total, rows=cap)
+        for d, prev in ((0, plan.prev_f), (1, plan.prev_r)):
+            ops.gemm(dg[:, d * NP:], st['hout'][:, d * H:], dw_hhp[d], M=NP, N=H, K=cap, lda=2 * NP, ldb=H2, ldc=H, trans_a=True,
+                     trans_b=True, b_idx=prev, split_k=ops.split_for(NP, H, cap), atomic=True, dyn=plan.total, dyn_dim=2)
+        ops.lstm_unpack_grads(dw_ihp, db_p, dw_hhp, H, E, [grad_of(q) for q in st['lstm'].param_list()])
+        # d(embedding rows): dX = dgates . W_ihp, scattered (atomic) into the table gradient through the dropout mask
+        ops.gemm(dg, w.w_ihp, grad_of(emb), M=cap, N=E, K=2 * NP, lda=2 * NP, ldb=E, ldc=E, trans_b=True, c_idx=plan.tok, atomic=True,
+                 drop=(4, p, st['seed'], E), dyn=plan.total, dyn_dim=1)
+
+
+class CNE(NewsEncoder):
+    """newsEncoders.py:57-141."""
+
+    def __init__(self, config, word_table=None):
+        super().__init__(config, word_table)
+        self.max_title_length = config.max_title_length
+        self.max_content_length = config.max_abstract_length
+        self.hidden_dim = config.hidden_dim
+        self.attention_dim = config.attention_dim
+        self.news_embedding_dim = config.hidden_dim * 4 + config.category_embedding_dim + config.subCategory_embedding_dim
+        self.tie_order = getattr(config, 'tie_order', 'stable')
+        h2 = self.hidden_dim * 2
+        self.title_lstm = LSTMParams(self.word_embedding_dim, self.hidden_dim)
+        self.content_lstm = LSTMParams(self.word_embedding_dim, self.hidden_dim)
+        self.title_H = nn.Linear(h2, h2, bias=False)
+        self.title_M = nn.Linear(h2, h2, bias=True)
+        self.content_H = nn.Linear(h2, h2, bias=False)
+        self.content_M = nn.Linear(h2, h2, bias=True)
+        self.title_self_attention = Attention(h2, config.attention_dim)
+        self.content_self_attention = Attention(h2, config.attention_dim)
+        self.title_cross_attention = ScaledDotProduct_CandidateAttention(h2, h2, config.attention_dim)
+        self.content_cross_attention = ScaledDotProduct_CandidateAttention(h2, h2, config.attention_dim)
+
+    def initialize(self):
+        super().initialize()
+        for lstm in (self.title_lstm, self.content_lstm):
+            for parameter in lstm.parameters():
+                if len(parameter.size()) >= 2:
+                    nn.init.orthogonal_(parameter.data)
+                else:
+                    nn.init.zeros_(parameter.data)
+        gain = nn.init.calculate_gain('sigmoid')
+        for lin in (self.title_H, self.title_M, self.content_H, self.content_M):
+            nn.init.xavier_uniform_(lin.weight, gain=gain)
+        nn.init.zeros_(self.title_M.bias)
+        nn.init.zeros_(self.content_M.bias)
+        self.title_self_attention.initialize()
+        self.content_self_attention.initialize()
+        self.title_cross_attention.initialize()
+        self.content_cross_attention.initialize()
+
+    def forward(self, title_text, title_mask, title_entity, content_text, content_mask, content_entity, category, subCategory, user_embedding):
+        # title_entity / content_entity / user_embedding are accepted and ignored, as in the reference (newsEncoders.py:102-141)
+        return _CNEFunction.apply(self.word_embedding.weight, self, title_text, title_mask, content_text, content_mask, category, subCategory)

@@ -1,0 +1,308 @@
+"""Thin Python wrappers over the C-ABI (one function per entry point of include/nnr_hip.h).
+Tensors are only used as (device pointer, size) carriers; views are fine as long as the leading dimension is passed."""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib as L
+
+ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise L.NnrHipError('nnr_amd ops need device tensors (no CPU fallback on the product path)')
+    return C.c_void_p(t.data_ptr())
+
+
+def _s():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def split_for(m, n, k, tile_m=256, tile_n=80, target_blocks=768, kmin=256):
+    """split-K factor for the token-reduction (weight-gradient) GEMMs: enough blocks to fill 256 CUs x ~3."""
+    tiles = max(1, ((m + tile_m - 1) // tile_m) * ((n + tile_n - 1) // tile_n))
+    return int(max(1, min((k + kmin - 1) // kmin, (target_blocks + tiles - 1) // tiles)))
+
+
+def gemm(A, B, C_=None, *, M, N, K, lda, ldb, ldc=0, trans_a=False, trans_b=False, dyn=None, dyn_dim=0, a_idx=None, b_idx=None,
+         drop=None, alpha=1.0, bias=None, rowvec=None, ldrv=0, rowvec_map=None, act=0, aux_out=None, ldaux=0, mul=None, ldmul=0,
+         resid=None, ldres=0, accumulate=False, atomic=False, c_idx=None, split_k=1, rowdot_w=None, rowdot_out=None, batch=1,
+         strideA=0, strideB=0, strideC=0, stride_aux=0, stride_res=0, tile=0):
+    g = L.GemmArgs()
+    g.A, g.B, g.C = _p(A), _p(B), _p(C_)
+    g.M, g.N, g.K, g.lda, g.ldb, g.ldc = M, N, K, lda, ldb, ldc
+    g.trans_a, g.trans_b = int(trans_a), int(trans_b)
+    g.dyn_dev, g.dyn_dim = _p(dyn), (dyn_dim if dyn is not None else 0)
+    g.a_idx, g.b_idx = _p(a_idx), _p(b_idx)
+    if drop is not None and drop[1] > 0.0:
+        g.drop_target, g.drop_p, g.drop_seed, g.drop_cols = drop[0], float(drop[1]), int(drop[2]) & 0xFFFFFFFF, int(drop[3])
+    g.alpha = float(alpha)
+    g.bias, g.rowvec, g.ldrv, g.rowvec_map = _p(bias), _p(rowvec), ldrv, _p(rowvec_map)
+    g.act = act
+    g.aux_out, g.ldaux, g.mul, g.ldmul, g.resid, g.ldres = _p(aux_out), ldaux, _p(mul), ldmul, _p(resid), ldres
+    g.accumulate, g.atomic, g.c_idx, g.split_k = int(accumulate), int(atomic), _p(c_idx), int(split_k)
+    g.rowdot_w, g.rowdot_out = _p(rowdot_w), _p(rowdot_out)
+    g.batch, g.strideA, g.strideB, g.strideC, g.stride_aux, g.stride_res = batch, strideA, strideB, strideC, stride_aux, stride_res
+    g.tile = tile
+    L.check(L.lib().nnr_gemm_f32(C.byref(g), _s()), 'nnr_gemm_f32')
+
+
+def linear_fwd(x, w, bias=None, out=None, act=0, **kw):
+    """out[M,N] = act(x[M,K] . w[N,K]^T + bias) for contiguous 2-D x."""
+    M, K = x.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty((M, N), device=x.device, dtype=torch.float32)
+    gemm(x, w, out, M=M, N=N, K=K, lda=x.stride(0), ldb=w.stride(0), ldc=out.stride(0), bias=bias, act=act, **kw)
+    return out
+
+
+def linear_bwd_data(dy, w, out=None, accumulate=False, **kw):
+    """dx[M,K] (+)= dy[M,N] . w[N,K]"""
+    M, N = dy.shape
+    K = w.shape[1]
+    if out is None:
+        out = torch.empty((M, K), device=dy.device, dtype=torch.float32)
+    gemm(dy, w, out, M=M, N=K, K=N, lda=dy.stride(0), ldb=w.stride(0), ldc=out.stride(0), trans_b=True, accumulate=accumulate, **kw)
+    return out
+
+
+def linear_bwd_weight(dy, x, dw, dyn=None, rows=None, **kw):
+    """dw[N,K] += dy[rows,N]^T . x[rows,K]   (split-K atomics; dw must already hold the running gradient)"""
+    R = dy.shape[0] if rows is None else rows
+    N, K = dw.shape
+    gemm(dy, x, dw, M=N, N=K, K=R, lda=dy.stride(0), ldb=x.stride(0), ldc=dw.stride(0), trans_a=True, trans_b=True,
+         split_k=split_for(N, K, R), atomic=True, dyn=dyn, dyn_dim=2, **kw)
+
+
+def bias_grad(dy, db, dyn=None, rows=None):
+    R = dy.shape[0] if rows is None else rows
+    L.check(L.lib().nnr_colsum(_p(dy), dy.stride(0), _p(dyn), R, db.numel(), _p(db), _s()), 'nnr_colsum')
+
+
+# ---------------------------------------------------------------------------------------------- planner / LSTM
+class SeqPlan:
+    """Device-resident plan of one token stream (see csrc/seq_plan.hip)."""
+
+    def __init__(self, mask, ids, perm=None):
+        n, Lx = mask.shape
+        dev = mask.device
+        self.n, self.L = n, Lx
+        i32 = dict(device=dev, dtype=torch.int32)
+        self.len = torch.empty(n, **i32)
+        self.order = torch.empty(n, **i32)
+        self.rank = torch.empty(n, **i32)
+        self.slen = torch.empty(n, **i32)
+        self.bs = torch.empty(Lx, **i32)
+        self.off = torch.empty(Lx + 1, **i32)
+        self.row_seq = torch.empty(n * Lx, **i32)
+        self.tok = torch.empty(n * Lx, **i32) if ids is not None else None
+        self.prev_f = torch.empty(n * Lx, **i32)
+        self.prev_r = torch.empty(n * Lx, **i32)
+        self.total = self.off[Lx:]                 # device int32 view: number of valid tokens
+        self.cap = n * Lx
+        m8 = mask.view(torch.uint8) if mask.dtype == torch.bool else mask
+        assert m8.is_contiguous() and (ids is None or (ids.is_contiguous() and ids.dtype == torch.int32))
+        L.check(L.lib().nnr_seq_plan(_p(m8), _p(ids), n, Lx, _p(perm), _p(self.len), _p(self.order), _p(self.rank), _p(self.slen),
+                                     _p(self.bs), _p(self.off), _p(self.row_seq), _p(self.tok), _p(self.prev_f), _p(self.prev_r),
+                                     _s()), 'nnr_seq_plan')
+
+
+def lstm_dims(H):
+    ub, hp, np_ = C.c_int(), C.c_int(), C.c_int()
+    L.check(L.lib().nnr_lstm_dims(H, C.byref(ub), C.byref(hp), C.byref(np_)), 'nnr_lstm_dims(H=%d)' % H)
+    return ub.value, hp.value, np_.value
+
+
+class LstmPacked:
+    """nn.LSTM parameters re-laid out for the recurrent kernels (csrc/lstm.hip)."""
+
+    def __init__(self, p, H, E):
+        ub, hp, np_ = lstm_dims(H)
+        dev = p[0].device
+        f = dict(device=dev, dtype=torch.float32)
+        self.UB, self.HP, self.NP, self.H, self.E = ub, hp, np_, H, E
+        self.w_ihp = torch.empty((2 * np_, E), **f)
+        self.b_p = torch.empty(2 * np_, **f)
+        self.wf = torch.empty(2 * ub * 4 * ub * 256, **f)
+        self.wb = torch.empty(2 * ub * (np_ // 16) * 256, **f)
+        L.check(L.lib().nnr_lstm_pack_weights(*[_p(t) for t in p], H, E, _p(self.w_ihp), _p(self.b_p), _p(self.wf), _p(self.wb), _s()),
+                'nnr_lstm_pack_weights')
+
+
+def lstm_unpack_grads(dw_ihp, db_p, dw_hhp, H, E, grads):
+    """grads: 8 tensors in nn.LSTM order (w_ih, w_hh, b_ih, b_hh, then *_reverse); accumulated into."""
+    tmp = [torch.empty_like(g) for g in grads]
+    order = [tmp[0], tmp[1], tmp[2], tmp[3], tmp[4], tmp[5], tmp[6], tmp[7]]
+    L.check(L.lib().nnr_lstm_unpack_grads(_p(dw_ihp), _p(db_p), _p(dw_hhp), H, E, *[_p(t) for t in order], _s()),
+            'nnr_lstm_unpack_grads')
+    for g, t in zip(grads, tmp):
+        add_(g, t)
+
+
+def _lstm_probs(items):
+    arr = (L.LstmProblem * len(items))()
+    for a, it in zip(arr, items):
+        pl = it['plan']
+        a.bs, a.off, a.slen, a.prev_f, a.prev_r = _p(pl.bs), _p(pl.off), _p(pl.slen), _p(pl.prev_f), _p(pl.prev_r)
+        a.n, a.L = pl.n, pl.L
+        a.gates, a.cell, a.hout, a.cn = _p(it['gates']), _p(it['cell']), _p(it.get('hout')), _p(it.get('cn'))
+        a.wf, a.wb = _p(it['w'].wf), _p(it['w'].wb)
+        a.dh, a.dcn = _p(it.get('dh')), _p(it.get('dcn'))
+    return arr
+
+
+def lstm_fwd(items, H):
+    arr = _lstm_probs(items)
+    L.check(L.lib().nnr_lstm_fwd(arr, len(items), H, _s()), 'nnr_lstm_fwd')
+
+
+def lstm_bwd(items, H):
+    arr = _lstm_probs(items)
+    L.check(L.lib().nnr_lstm_bwd(arr, len(items), H, _s()), 'nnr_lstm_bwd')
+
+
+# ---------------------------------------------------------------------------------------------- pooling
+def _pool_args(x, ldx, D, n, Lx, plan=None, mask=None, mask_div=1, score=None, v=None, ldv=0, scale=1.0, alpha=None, out=None,
+               ldo=0, add_in=None, ldadd=0, dout=None, lddo=0, dout2=None, lddo2=0, dx=None, lddx=0, dx_accumulate=False,
+               dscore=None, dv=None, lddv=0):
+    a = L.PoolArgs()
+    a.x, a.ldx, a.D, a.n, a.L = _p(x), ldx, D, n, Lx
+    a.packed = int(plan is not None)
+    if plan is not None:
+        a.off, a.slen, a.order = _p(plan.off), _p(plan.slen), _p(plan.order)
+    if mask is not None:
+        a.mask = _p(mask.view(torch.uint8) if mask.dtype == torch.bool else mask)
+    a.mask_div = mask_div
+    a.score, a.v, a.ldv, a.scale, a.alpha = _p(score), _p(v), ldv, float(scale), _p(alpha)
+    a.out, a.ldo, a.add_in, a.ldadd = _p(out), ldo, _p(add_in), ldadd
+    a.dout, a.lddo, a.dout2, a.lddo2 = _p(dout), lddo, _p(dout2), lddo2
+    a.dx, a.lddx, a.dx_accumulate, a.dscore, a.dv, a.lddv = _p(dx), lddx, int(dx_accumulate), _p(dscore), _p(dv), lddv
+    return a
+
+
+def pool_fwd(**kw):
+    L.check(L.lib().nnr_attn_pool_fwd(C.byref(_pool_args(**kw)), _s()), 'nnr_attn_pool_fwd')
+
+
+def pool_bwd(**kw):
+    L.check(L.lib().nnr_attn_pool_bwd(C.byref(_pool_args(**kw)), _s()), 'nnr_attn_pool_bwd')
+
+
+# ---------------------------------------------------------------------------------------------- elementwise
+def add_(y, x, alpha=1.0):
+    assert y.is_contiguous() and x.is_contiguous() and y.numel() == x.numel()
+    L.check(L.lib().nnr_add(_p(y), _p(x), C.c_long(y.numel()), C.c_float(alpha), _s()), 'nnr_add')
+    return y
+
+
+def add2d(y, ldy, x, ldx, rows, cols, alpha=1.0, accumulate=False):
+    L.check(L.lib().nnr_add2d(_p(y), ldy, _p(x), ldx, rows, cols, C.c_float(alpha), int(accumulate), _s()), 'nnr_add2d')
+
+
+def gate_bwd(dHt, H, G, dH, dpre, plan, cols):
+    L.check(L.lib().nnr_gate_bwd(_p(dHt), _p(H), _p(G), _p(dH), _p(dpre), _p(plan.total), plan.cap, cols, _s()), 'nnr_gate_bwd')
+
+
+def packed_seq_sum(x, D, plan, out):
+    L.check(L.lib().nnr_packed_seq_sum(_p(x), D, _p(plan.off), _p(plan.slen), plan.n, _p(out), _s()), 'nnr_packed_seq_sum')
+
+
+def tanh_score_bwd(th, ds, w2, dw2, plan, A):
+    L.check(L.lib().nnr_tanh_score_bwd(_p(th), _p(ds), _p(w2), _p(dw2), _p(plan.total) if plan is not None else None,
+                                       plan.cap if plan is not None else th.shape[0], A, _s()), 'nnr_tanh_score_bwd')
+
+
+def small_embed_fwd(table, idx, out_view, ldo, p, seed):
+    n, dim = idx.numel(), table.shape[1]
+    L.check(L.lib().nnr_small_embed_fwd(_p(table), _p(idx), n, dim, _p(out_view), ldo, C.c_float(p), C.c_uint32(seed & 0xFFFFFFFF), _s()),
+            'nnr_small_embed_fwd')
+
+
+def small_embed_bwd(idx, dim, dout_view, lddo, dtable, p, seed):
+    L.check(L.lib().nnr_small_embed_bwd(_p(idx), idx.numel(), dim, _p(dout_view), lddo, _p(dtable), C.c_float(p),
+                                        C.c_uint32(seed & 0xFFFFFFFF), _s()), 'nnr_small_embed_bwd')
+
+
+def dropout(x, p, seed, out=None):
+    if out is None:
+        out = torch.empty_like(x)
+    L.check(L.lib().nnr_dropout(_p(x), _p(out), C.c_long(x.numel()), C.c_float(p), C.c_uint32(seed & 0xFFFFFFFF), _s()), 'nnr_dropout')
+    return out
+
+
+def relu_bwd(dy, y, dx=None):
+    if dx is None:
+        dx = torch.empty_like(dy)
+    L.check(L.lib().nnr_relu_bwd(_p(dy), _p(y), _p(dx), C.c_long(dy.numel()), _s()), 'nnr_relu_bwd')
+    return dx
+
+
+def relu_drop_bwd(dy, r, ds, dx, p, seed):
+    L.check(L.lib().nnr_relu_drop_bwd(_p(dy), _p(r), _p(ds), _p(dx), C.c_long(dy.numel()), C.c_float(p), C.c_uint32(seed & 0xFFFFFFFF),
+                                      _s()), 'nnr_relu_drop_bwd')
+
+
+# ---------------------------------------------------------------------------------------------- SUE / loss / optimiser
+def sue_x0_fwd(hist, proxy, x0, B, Hn, Kc, D, p, seed):
+    L.check(L.lib().nnr_sue_x0_fwd(_p(hist), _p(proxy), _p(x0), B, Hn, Kc, D, C.c_float(p), C.c_uint32(seed & 0xFFFFFFFF), _s()), 'nnr_sue_x0_fwd')
+
+
+def sue_x0_bwd(dx0, dhist, dproxy, B, Hn, Kc, D, p, seed):
+    L.check(L.lib().nnr_sue_x0_bwd(_p(dx0), _p(dhist), _p(dproxy), B, Hn, Kc, D, C.c_float(p), C.c_uint32(seed & 0xFFFFFFFF), _s()), 'nnr_sue_x0_bwd')
+
+
+def sue_slice_fwd(gcn, x0, gfeat, B, Hn, G, D):
+    L.check(L.lib().nnr_sue_slice_fwd(_p(gcn), _p(x0), _p(gfeat), B, Hn, G, D, _s()), 'nnr_sue_slice_fwd')
+
+
+def sue_slice_bwd(dgfeat, dpad, B, Hn, G, D):
+    L.check(L.lib().nnr_sue_slice_bwd(_p(dgfeat), _p(dpad), B, Hn, G, D, _s()), 'nnr_sue_slice_bwd')
+
+
+def sue_intra_fwd(kf, qc, g, cidx, B, N, Hn, Cn, A, D, alpha, feat):
+    L.check(L.lib().nnr_sue_intra_fwd(_p(kf), _p(qc), _p(g), _p(cidx), B, N, Hn, Cn, A, D, _p(alpha), _p(feat), _s()), 'nnr_sue_intra_fwd')
+
+
+def sue_intra_bwd(kf, qc, g, cidx, alpha, dfeat, B, N, Hn, Cn, A, D, dg, dkf, dqc):
+    L.check(L.lib().nnr_sue_intra_bwd(_p(kf), _p(qc), _p(g), _p(cidx), _p(alpha), _p(dfeat), B, N, Hn, Cn, A, D, _p(dg), _p(dkf), _p(dqc),
+                                      _s()), 'nnr_sue_intra_bwd')
+
+
+def logits_loss_fwd(user, cand, B, N, D, logits, loss, dlogits):
+    L.check(L.lib().nnr_logits_loss_fwd(_p(user), _p(cand), B, N, D, _p(logits), _p(loss), _p(dlogits), _s()), 'nnr_logits_loss_fwd')
+
+
+def logits_fwd(user, cand, B, N, D, logits):
+    L.check(L.lib().nnr_logits_fwd(_p(user), _p(cand), B, N, D, _p(logits), _s()), 'nnr_logits_fwd')
+
+
+def nls_loss(logits, B, N, loss, dlogits):
+    L.check(L.lib().nnr_nls_loss(_p(logits), B, N, _p(loss), _p(dlogits), _s()), 'nnr_nls_loss')
+
+
+def logits_bwd(dlogits, user, cand, B, N, D, duser, dcand, accumulate=False):
+    L.check(L.lib().nnr_logits_bwd(_p(dlogits), _p(user), _p(cand), B, N, D, _p(duser), _p(dcand), int(accumulate), _s()), 'nnr_logits_bwd')
+
+
+def sumsq(g, out_zeroed):
+    L.check(L.lib().nnr_sumsq(_p(g), C.c_long(g.numel()), _p(out_zeroed), _s()), 'nnr_sumsq')
+
+
+def clip_adam(p, g, m, v, sumsq_buf, grad_scale, clip, lr, beta1, beta2, eps, wd, step):
+    L.check(L.lib().nnr_clip_adam(_p(p), _p(g), _p(m), _p(v), C.c_long(p.numel()), _p(sumsq_buf), C.c_float(grad_scale), C.c_float(clip),
+                                  C.c_float(lr), C.c_float(beta1), C.c_float(beta2), C.c_float(eps), C.c_float(wd), int(step), _s()),
+            'nnr_clip_adam')
+
+
+def mhsa_fwd(qkv, mask, n, Lq, heads, dh, out, prob):
+    L.check(L.lib().nnr_mhsa_fwd(_p(qkv), _p(mask.view(torch.uint8) if mask is not None and mask.dtype == torch.bool else mask), n, Lq,
+                                 heads, dh, C.c_float(1.0 / math.sqrt(dh)), _p(out), _p(prob), _s()), 'nnr_mhsa_fwd')
+
+
+def mhsa_bwd(qkv, prob, dout, n, Lq, heads, dh, dqkv):
+    L.check(L.lib().nnr_mhsa_bwd(_p(qkv), _p(prob), _p(dout), n, Lq, heads, dh, C.c_float(1.0 / math.sqrt(dh)), _p(dqkv), _s()), 'nnr_mhsa_bwd')

@@ -1,0 +1,213 @@
+"""User encoders of the hot path (reference: userEncoders.py) on the HIP kernels.
+
+SUE (userEncoders.py:42-98):
+  X0 = [history news reps ; dropout_(proxy nodes)]                                   (sue_x0 kernel)
+  L x { X <- dropout(relu(A (X W^T) + b) + X) }   -- the dense GEMM first, then the per-user 68x68 aggregate as a batched
+                                                     GEMM whose epilogue applies bias / relu / residual / dropout
+  gfeat = (GCN(X0) + X0)[:, :50]
+  intra-cluster attention: torch_scatter's scatter_softmax / scatter_sum -> sue_intra kernel (segmented LDS reduction;
+  the key projection is evaluated once per history item, not on the N-times expanded tensor -- identical math)
+  F <- dropout(relu(F W_c^T + b_c) + F)  (GEMM epilogue) ; inter-cluster ScaledDotProduct attention in GEMV form + pool.
+Backward is hand-written against the same kernels; parameter gradients accumulate into `param.grad`."""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .layers import Attention, ScaledDotProduct_CandidateAttention, MultiHeadAttention, GCN, grad_of
+from .news_encoders import NewsEncoder
+
+
+class UserEncoder(nn.Module):
+    """userEncoders.py:12-39: holds a reference to the SAME news-encoder instance (:16)."""
+
+    def __init__(self, news_encoder: NewsEncoder, config):
+        super().__init__()
+        self.news_embedding_dim = news_encoder.news_embedding_dim
+        self.news_encoder = news_encoder
+        self.auxiliary_loss = None
+        self._seed_base = int(getattr(config, 'seed', 0)) * 104723 + 29
+        self._calls = 0
+
+    def _next_seed(self):
+        self._calls += 1
+        return (self._seed_base + 15485863 * self._calls) & 0x7FFFFFFF
+
+    def forward(self, user_title_text, user_title_mask, user_title_entity, user_content_text, user_content_mask, user_content_entity,
+                user_category, user_subCategory, user_history_mask, user_history_graph, user_history_category_mask,
+                user_history_category_indices, user_embedding, candidate_news_representation):
+        raise Exception('Function forward must be implemented at sub-class')
+
+
+class _SUEFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, hist, cand, mod, graph, cmask, cidx):
+        out, saved = sue_forward(mod, hist.contiguous(), cand.contiguous(), graph, cmask, cidx)
+        ctx.mod, ctx.saved = mod, saved
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dhist, dcand = sue_backward(ctx.mod, ctx.saved, dout.contiguous())
+        ctx.saved = None
+        return dhist, dcand, None, None, None, None
+
+
+def sue_forward(mod, hist, cand, graph, cmask, cidx):
+    B, Hn, D = hist.shape
+    N = cand.shape[1]
+    Kc = mod.proxy_node_embedding.shape[0]
+    G, Cn, A = Hn + Kc, Kc + 1, mod.attention_dim
+    dev = hist.device
+    f32 = dict(device=dev, dtype=torch.float32)
+    p = mod.dropout_rate if mod.training else 0.0
+    seed = mod._next_seed()
+    sv = dict(B=B, Hn=Hn, D=D, N=N, Kc=Kc, G=G, Cn=Cn, A=A, p=p, seed=seed, hist=hist, cand=cand, cidx=cidx, cmask=cmask,
+              graph=graph)
+    x0 = torch.empty((B, G, D), **f32)
+    ops.sue_x0_fwd(hist, mod.proxy_node_embedding, x0, B, Hn, Kc, D, p, seed + 1)
+    # ---- GCN
+    Lg = mod.gcn.num_layers
+    xs, rs = [x0], []
+    x = x0
+    for l, layer in enumerate(mod.gcn.gcn_layers):
+        z = ops.linear_fwd(x.view(B * G, D), layer.W.weight)                       # X W^T  (bias goes after the aggregate)
+        y = torch.empty((B, G, D), **f32)
+        r = torch.empty((B, G, D), **f32)
+        pl = (mod.gcn.dropout_rate if mod.training else 0.0) if l + 1 < Lg else 0.0
+        ops.gemm(graph, z, y, M=G, N=D, K=G, lda=G, ldb=D, ldc=D, trans_b=True, bias=layer.W.bias, act=ops.ACT_RELU, aux_out=r,
+                 ldaux=D, resid=x if mod.gcn.residual else None, ldres=D, drop=(3, pl, seed + 10 + l, D), batch=B, strideA=G * G,
+                 strideB=G * D, strideC=G * D, stride_aux=G * D, stride_res=G * D, tile=2)
+        xs.append(y)
+        rs.append(r)
+        x = y
+    sv['xs'], sv['rs'] = xs, rs
+    gfeat = torch.empty((B, Hn, D), **f32)
+    ops.sue_slice_fwd(x, x0, gfeat, B, Hn, G, D)
+    # ---- intra-cluster attention
+    cand2 = cand.view(B * N, D)
+    kf = ops.linear_fwd(gfeat.view(B * Hn, D), mod.intraCluster_K.weight)                                # [B*Hn, A]
+    qc = ops.linear_fwd(cand2, mod.intraCluster_Q.weight, mod.intraCluster_Q.bias)                       # [B*N, A]
+    alpha_i = torch.empty((B, N, Hn), **f32)
+    feat = torch.empty((B * N * Cn, D), **f32)
+    ops.sue_intra_fwd(kf, qc, gfeat, cidx, B, N, Hn, Cn, A, D, alpha_i, feat)
+    # ---- cluster feature affine: dropout(relu(W F + b) + F)
+    rc = torch.empty((B * N * Cn, D), **f32)
+    f2 = torch.empty((B * N * Cn, D), **f32)
+    ops.gemm(feat, mod.clusterFeatureAffine.weight, f2, M=B * N * Cn, N=D, K=D, lda=D, ldb=D, ldc=D, bias=mod.clusterFeatureAffine.bias,
+             act=ops.ACT_RELU, aux_out=rc, ldaux=D, resid=feat, ldres=D, drop=(3, p, seed + 2, D))
+    # ---- inter-cluster attention (layers.py:196-203) in GEMV form
+    ia = mod.interClusterAttention
+    qv = ops.linear_fwd(cand2, ia.Q.weight, ia.Q.bias)                                                   # [B*N, A]
+    v = torch.empty((B * N, D), **f32)
+    ops.gemm(qv, ia.K.weight, v, M=B * N, N=D, K=A, lda=A, ldb=D, ldc=D, trans_b=True)
+    alpha_o = torch.empty(B * N * Cn, **f32)
+    out = torch.empty((B * N, D), **f32)
+    ops.pool_fwd(x=f2, ldx=D, D=D, n=B * N, Lx=Cn, mask=cmask, mask_div=N, v=v, ldv=D, scale=1.0 / math.sqrt(A), alpha=alpha_o, out=out,
+                 ldo=D)
+    sv.update(gfeat=gfeat, kf=kf, qc=qc, alpha_i=alpha_i, feat=feat, rc=rc, f2=f2, qv=qv, v=v, alpha_o=alpha_o)
+    return out.view(B, N, D), sv
+
+
+def sue_backward(mod, sv, dout):
+    B, Hn, D, N, Kc, G, Cn, A, p, seed = (sv[k] for k in ('B', 'Hn', 'D', 'N', 'Kc', 'G', 'Cn', 'A', 'p', 'seed'))
+    dev = dout.device
+    f32 = dict(device=dev, dtype=torch.float32)
+    cand2 = sv['cand'].view(B * N, D)
+    dout = dout.view(B * N, D)
+    ia = mod.interClusterAttention
+    # ---- inter-cluster pool
+    df2 = torch.empty((B * N * Cn, D), **f32)
+    dv = torch.empty((B * N, D), **f32)
+    ops.pool_bwd(x=sv['f2'], ldx=D, D=D, n=B * N, Lx=Cn, mask=sv['cmask'], mask_div=N, v=sv['v'], ldv=D, scale=1.0 / math.sqrt(A),
+                 alpha=sv['alpha_o'], dout=dout, lddo=D, dx=df2, lddx=D, dv=dv, lddv=D)
+    dqv = torch.empty((B * N, A), **f32)
+    ops.gemm(dv, ia.K.weight, dqv, M=B * N, N=A, K=D, lda=D, ldb=D, ldc=A)
+    ops.linear_bwd_weight(sv['qv'], dv, grad_of(ia.K.weight))
+    ops.linear_bwd_weight(dqv, cand2, grad_of(ia.Q.weight))
+    ops.bias_grad(dqv, grad_of(ia.Q.bias))
+    dcand = ops.linear_bwd_data(dqv, ia.Q.weight)                                                        # [B*N, D]
+    # ---- cluster affine
+    dS = torch.empty((B * N * Cn, D), **f32)
+    dfeat = torch.empty((B * N * Cn, D), **f32)
+    ops.relu_drop_bwd(df2, sv['rc'], dS, dfeat, p, seed + 2)
+    ops.linear_bwd_data(dS, mod.clusterFeatureAffine.weight, out=dfeat, accumulate=True)
+    ops.linear_bwd_weight(dS, sv['feat'], grad_of(mod.clusterFeatureAffine.weight))
+    ops.bias_grad(dS, grad_of(mod.clusterFeatureAffine.bias))
+    # ---- intra-cluster attention
+    dg = torch.empty((B, Hn, D), **f32)
+    dkf = torch.empty((B * Hn, A), **f32)
+    dqc = torch.empty((B * N, A), **f32)
+    ops.sue_intra_bwd(sv['kf'], sv['qc'], sv['gfeat'], sv['cidx'], sv['alpha_i'], dfeat, B, N, Hn, Cn, A, D, dg, dkf, dqc)
+    ops.linear_bwd_data(dkf, mod.intraCluster_K.weight, out=dg.view(B * Hn, D), accumulate=True)
+    ops.linear_bwd_weight(dkf, sv['gfeat'].view(B * Hn, D), grad_of(mod.intraCluster_K.weight))
+    ops.linear_bwd_data(dqc, mod.intraCluster_Q.weight, out=dcand, accumulate=True)
+    ops.linear_bwd_weight(dqc, cand2, grad_of(mod.intraCluster_Q.weight))
+    ops.bias_grad(dqc, grad_of(mod.intraCluster_Q.bias))
+    # ---- GCN (+ outer residual)
+    dpad = torch.empty((B, G, D), **f32)
+    ops.sue_slice_bwd(dg, dpad, B, Hn, G, D)
+    Lg = mod.gcn.num_layers
+    dy = dpad
+    graph = sv['graph']
+    for l in range(Lg - 1, -1, -1):
+        layer = mod.gcn.gcn_layers[l]
+        pl = (mod.gcn.dropout_rate if mod.training else 0.0) if l + 1 < Lg else 0.0
+        dS = torch.empty((B, G, D), **f32)
+        dx = torch.empty((B, G, D), **f32)
+        ops.relu_drop_bwd(dy, sv['rs'][l], dS, dx, pl, seed + 10 + l)        # dx = masked dy (residual branch)
+        if not mod.gcn.residual:
+            dx.zero_()
+        ops.bias_grad(dS.view(B * G, D), grad_of(layer.W.bias))
+        dz = torch.empty((B, G, D), **f32)                                   # dZ_b = A_b^T dS_b
+        ops.gemm(graph, dS, dz, M=G, N=D, K=G, lda=G, ldb=D, ldc=D, trans_a=True, trans_b=True, batch=B, strideA=G * G, strideB=G * D,
+                 strideC=G * D, tile=2)
+        ops.linear_bwd_data(dz.view(B * G, D), layer.W.weight, out=dx.view(B * G, D), accumulate=True)
+        ops.linear_bwd_weight(dz.view(B * G, D), sv['xs'][l].view(B * G, D), grad_of(layer.W.weight))
+        dy = dx
+    ops.add_(dy, dpad)                                                       # gcn(X0) + X0
+    dhist = torch.empty((B, Hn, D), **f32)
+    ops.sue_x0_bwd(dy, dhist, grad_of(mod.proxy_node_embedding), B, Hn, Kc, D, p, seed + 1)
+    return dhist, dcand.view(B, N, D)
+
+
+class SUE(UserEncoder):
+    """userEncoders.py:42-98."""
+
+    def __init__(self, news_encoder: NewsEncoder, config):
+        super().__init__(news_encoder, config)
+        self.attention_dim = max(config.attention_dim, self.news_embedding_dim // 4)
+        self.proxy_node_embedding = nn.Parameter(torch.zeros([config.category_num, self.news_embedding_dim]))
+        self.gcn = GCN(in_dim=self.news_embedding_dim, out_dim=self.news_embedding_dim, hidden_dim=self.news_embedding_dim,
+                       num_layers=config.gcn_layer_num, dropout=config.dropout_rate / 2, residual=not config.no_gcn_residual,
+                       layer_norm=config.gcn_layer_norm)
+        self.intraCluster_K = nn.Linear(self.news_embedding_dim, self.attention_dim, bias=False)
+        self.intraCluster_Q = nn.Linear(self.news_embedding_dim, self.attention_dim, bias=True)
+        self.clusterFeatureAffine = nn.Linear(self.news_embedding_dim, self.news_embedding_dim, bias=True)
+        self.interClusterAttention = ScaledDotProduct_CandidateAttention(self.news_embedding_dim, self.news_embedding_dim, self.attention_dim)
+        self.dropout_rate = float(config.dropout_rate)
+        self.category_num = config.category_num + 1     # extra one category index for padding news
+        self.max_history_num = config.max_history_num
+        self.attention_scalar = math.sqrt(float(self.attention_dim))
+
+    def initialize(self):
+        self.gcn.initialize()
+        nn.init.zeros_(self.proxy_node_embedding)
+        nn.init.xavier_uniform_(self.intraCluster_K.weight)
+        nn.init.xavier_uniform_(self.intraCluster_Q.weight)
+        nn.init.zeros_(self.intraCluster_Q.bias)
+        nn.init.xavier_uniform_(self.clusterFeatureAffine.weight, gain=nn.init.calculate_gain('relu'))
+        nn.init.zeros_(self.clusterFeatureAffine.bias)
+        self.interClusterAttention.initialize()
+
+    def forward(self, user_title_text, user_title_mask, user_title_entity, user_content_text, user_content_mask, user_content_entity,
+                user_category, user_subCategory, user_history_mask, user_history_graph, user_history_category_mask,
+                user_history_category_indices, user_embedding, candidate_news_representation):
+        user_history_category_mask[:, -1] = 1            # in place on the caller's tensor (userEncoders.py:73)
+        history_embedding = self.news_encoder(user_title_text, user_title_mask, user_title_entity, user_content_text, user_content_mask,
+                                              user_content_entity, user_category, user_subCategory, user_embedding)
+        graph = user_history_graph.contiguous()
+        cidx = user_history_category_indices.contiguous()
+        assert cidx.dtype == torch.int64 and graph.dtype == torch.float32
+        return _SUEFunction.apply(history_embedding, candidate_news_representation, self, graph, user_history_category_mask, cidx)

@@ -1,0 +1,424 @@
+"""GPU parity of the individual C-ABI entry points against fp64 CPU references (run with -m gpu on the MI355X box)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device('cuda:0')
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).float()
+
+
+def close(actual, expect, tol=2e-5, what=''):
+    a = actual.detach().double().cpu()
+    e = expect.detach().double().cpu()
+    scale = max(1.0, float(e.abs().max()))
+    err = float((a - e).abs().max())
+    assert err <= tol * scale, '%s: max err %.3e (scale %.3e)' % (what, err, scale)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+def test_gemm_nt_bias_relu_and_unaligned():
+    from nnr_amd import ops
+    for (M, N, K, seed) in ((300, 225, 900, 1), (130, 900, 225, 2), (2000, 400, 300, 3), (70, 37, 50, 4)):
+        x, w, b = rnd(M, K, seed=seed), rnd(N, K, seed=seed + 10), rnd(N, seed=seed + 20)
+        out = ops.linear_fwd(x.to(dev()), w.to(dev()), b.to(dev()), act=ops.ACT_RELU)
+        close(out, torch.relu(x.double() @ w.double().t() + b.double()), what='NT %s' % ((M, N, K),))
+
+
+def test_gemm_nn_accumulate_and_tn_splitk_dyn():
+    from nnr_amd import ops
+    dy, w = rnd(300, 225, seed=1), rnd(225, 900, seed=2)
+    base = rnd(300, 900, seed=3)
+    out = base.to(dev()).clone()
+    ops.linear_bwd_data(dy.to(dev()), w.to(dev()), out=out, accumulate=True)
+    close(out, base.double() + dy.double() @ w.double(), what='NN accumulate')
+    R, used = 5000, 3777
+    dy, x = rnd(R, 832, seed=4), rnd(R, 300, seed=5)
+    dw = torch.zeros(832, 300, device=dev())
+    dyn = torch.tensor([used], dtype=torch.int32, device=dev())
+    ops.linear_bwd_weight(dy.to(dev()), x.to(dev()), dw, dyn=dyn)
+    close(dw, dy[:used].double().t() @ x[:used].double(), tol=5e-5, what='TN split-K dyn')
+
+
+def test_gemm_gather_rowdot_gate_batched():
+    from nnr_amd import ops
+    d = dev()
+    # gather + dyn M + bias (LSTM input projection shape)
+    V, E, NP2, cap, used = 1000, 300, 1664, 5000, 4321
+    emb, w, b = rnd(V, E, seed=1), rnd(NP2, E, seed=2, scale=0.1), rnd(NP2, seed=3)
+    idx = torch.randint(0, V, (cap,), generator=torch.Generator().manual_seed(4)).int()
+    idx[17] = -1
+    out = torch.full((cap, NP2), 7.0, device=d)
+    dyn = torch.tensor([used], dtype=torch.int32, device=d)
+    ops.gemm(emb.to(d), w.to(d), out, M=cap, N=NP2, K=E, lda=E, ldb=E, ldc=NP2, a_idx=idx.to(d), dyn=dyn, dyn_dim=1, bias=b.to(d))
+    x = emb[idx.clamp_min(0).long()].double()
+    x[17] = 0
+    ref = x @ w.double().t() + b.double()
+    close(out[:used], ref[:used], what='gather GEMM')
+    assert float((out[used:] - 7.0).abs().max()) == 0.0, 'rows past the dynamic extent must not be written'
+    # fused tanh . w2 row-dot (tile 3)
+    M, F, A = 1000, 400, 200
+    x, w1, b1, w2 = rnd(M, F, seed=5), rnd(A, F, seed=6, scale=0.05), rnd(A, seed=7, scale=0.1), rnd(1, A, seed=8)
+    th = torch.empty(M, A, device=d)
+    sc = torch.empty(M, device=d)
+    ops.gemm(x.to(d), w1.to(d), None, M=M, N=A, K=F, lda=F, ldb=F, bias=b1.to(d), act=ops.ACT_TANH, aux_out=th, ldaux=A,
+             rowdot_w=w2.to(d), rowdot_out=sc, tile=3)
+    tref = torch.tanh(x.double() @ w1.double().t() + b1.double())
+    close(th, tref, what='tanh aux')
+    close(sc, tref @ w2.double()[0], what='rowdot')
+    # gate epilogue: h * sigmoid(h W^T + P[map])
+    M, F, n = 900, 400, 40
+    h, w, P = rnd(M, F, seed=9), rnd(F, F, seed=10, scale=0.05), rnd(n, F, seed=11)
+    rmap = torch.randint(0, n, (M,), generator=torch.Generator().manual_seed(12)).int()
+    G = torch.empty(M, F, device=d)
+    Ht = torch.empty(M, F, device=d)
+    hd = h.to(d)
+    ops.gemm(hd, w.to(d), Ht, M=M, N=F, K=F, lda=F, ldb=F, ldc=F, rowvec=P.to(d), ldrv=F, rowvec_map=rmap.to(d), act=ops.ACT_SIGMOID,
+             aux_out=G, ldaux=F, mul=hd, ldmul=F)
+    gref = torch.sigmoid(h.double() @ w.double().t() + P.double()[rmap.long()])
+    close(G, gref, what='gate G')
+    close(Ht, gref * h.double(), what='gate Ht')
+    # batched 68x68 aggregate with bias / relu / residual
+    Bt, Gn, D = 5, 68, 900
+    graph, z, bias, xres = rnd(Bt, Gn, Gn, seed=13, scale=0.2), rnd(Bt, Gn, D, seed=14), rnd(D, seed=15), rnd(Bt, Gn, D, seed=16)
+    y = torch.empty(Bt, Gn, D, device=d)
+    r = torch.empty(Bt, Gn, D, device=d)
+    ops.gemm(graph.to(d), z.to(d), y, M=Gn, N=D, K=Gn, lda=Gn, ldb=D, ldc=D, trans_b=True, bias=bias.to(d), act=ops.ACT_RELU, aux_out=r,
+             ldaux=D, resid=xres.to(d), ldres=D, batch=Bt, strideA=Gn * Gn, strideB=Gn * D, strideC=Gn * D, stride_aux=Gn * D,
+             stride_res=Gn * D, tile=2)
+    rref = torch.relu(torch.einsum('bij,bjd->bid', graph.double(), z.double()) + bias.double())
+    close(r, rref, what='batched relu aux')
+    close(y, rref + xres.double(), what='batched + residual')
+    # A^T (graph transpose) batched
+    dz = torch.empty(Bt, Gn, D, device=d)
+    ops.gemm(graph.to(d), z.to(d), dz, M=Gn, N=D, K=Gn, lda=Gn, ldb=D, ldc=D, trans_a=True, trans_b=True, batch=Bt, strideA=Gn * Gn,
+             strideB=Gn * D, strideC=Gn * D, tile=2)
+    close(dz, torch.einsum('bij,bid->bjd', graph.double(), z.double()), what='batched A^T')
+
+
+def test_gemm_dropout_masks_are_consistent():
+    """The same (seed, row, col) mask must be seen by the forward gather (target 1), the weight-gradient B loader
+    (target 2) and the scatter epilogue (target 4)."""
+    from nnr_amd import ops
+    d = dev()
+    V, E, R, p, seed = 50, 300, 700, 0.3, 1234
+    emb = (rnd(V, E, seed=1).abs() + 0.5).to(d)
+    idx = torch.randint(0, V, (R,), generator=torch.Generator().manual_seed(2)).int().to(d)
+    eye = torch.eye(E, device=d)
+    xd = torch.empty(R, E, device=d)
+    ops.gemm(emb, eye, xd, M=R, N=E, K=E, lda=E, ldb=E, ldc=E, a_idx=idx, drop=(1, p, seed, E))       # = dropout(emb[idx])
+    x = emb[idx.long()]
+    keep = xd != 0
+    frac = float(keep.float().mean())
+    assert abs(frac - (1 - p)) < 0.02, frac
+    close(xd, torch.where(keep, x / (1 - p), torch.zeros_like(x)), what='dropout scale')
+    dy = rnd(R, 64, seed=3).to(d)
+    dw = torch.zeros(64, E, device=d)
+    ops.gemm(dy, emb, dw, M=64, N=E, K=R, lda=64, ldb=E, ldc=E, trans_a=True, trans_b=True, b_idx=idx, drop=(2, p, seed, E), split_k=4,
+             atomic=True)
+    close(dw, dy.double().t().cpu() @ xd.double().cpu(), tol=5e-5, what='target-2 mask')
+    dtab = torch.zeros(V, E, device=d)
+    ones = torch.ones(R, E, device=d)
+    ops.gemm(ones, eye, dtab, M=R, N=E, K=E, lda=E, ldb=E, ldc=E, trans_b=True, c_idx=idx, atomic=True, drop=(4, p, seed, E))
+    ref = torch.zeros(V, E, dtype=torch.float64)
+    ref.index_add_(0, idx.long().cpu(), keep.double().cpu() / (1 - p))
+    close(dtab, ref, what='target-4 scatter mask')
+
+
+# ------------------------------------------------------------------------------------------------ planner + LSTM
+def _lengths(n, Lx, seed):
+    g = torch.Generator().manual_seed(seed)
+    l = torch.randint(1, Lx + 1, (n,), generator=g)
+    l[0] = Lx
+    l[1] = 1
+    return l
+
+
+def test_seq_plan_matches_stable_sort():
+    from nnr_amd import ops
+    n, Lx = 333, 32
+    lens = _lengths(n, Lx, 5)
+    mask = torch.arange(Lx)[None, :] < lens[:, None]
+    mask[7] = False            # an all-false row: position 0 must be forced on (newsEncoders.py:108)
+    lens[7] = 1
+    ids = torch.randint(2, 1000, (n, Lx), generator=torch.Generator().manual_seed(6)).int() * mask.int()
+    md = mask.clone().to(dev())
+    plan = ops.SeqPlan(md, ids.to(dev()))
+    order = torch.argsort(lens, descending=True, stable=True)
+    assert bool(md[7, 0]) and int(md.sum()) == int(lens.sum())
+    assert torch.equal(plan.order.cpu().long(), order)
+    assert torch.equal(plan.slen.cpu().long(), lens[order])
+    bs = torch.tensor([(lens > t).sum() for t in range(Lx)])
+    assert torch.equal(plan.bs.cpu().long(), bs)
+    off = torch.cat([torch.zeros(1, dtype=torch.long), bs.cumsum(0)])
+    assert torch.equal(plan.off.cpu().long(), off)
+    tok, rs, pf, pr = plan.tok.cpu(), plan.row_seq.cpu(), plan.prev_f.cpu(), plan.prev_r.cpu()
+    for s in (0, 1, 50, n - 1):
+        i = int(order[s])
+        for t in range(int(lens[i])):
+            row = int(off[t]) + s
+            assert int(tok[row]) == int(ids[i, t]) and int(rs[row]) == s
+            assert int(pf[row]) == (int(off[t - 1]) + s if t > 0 else -1)
+            assert int(pr[row]) == (int(off[t + 1]) + s if t + 1 < int(lens[i]) else -1)
+    # caller-supplied order
+    perm = torch.sort(lens, descending=True)[1].int()
+    plan2 = ops.SeqPlan(mask.clone().to(dev()), ids.to(dev()), perm.to(dev()))
+    assert torch.equal(plan2.order.cpu(), perm)
+
+
+@pytest.mark.parametrize('n,Lx,E,H', [(37, 12, 16, 8), (100, 32, 300, 200), (45, 128, 300, 200)])
+def test_bilstm_forward_backward_matches_oracle(n, Lx, E, H):
+    from nnr_amd import ops
+    from nnr_amd.layers import LSTMParams
+    from oracle.nnr_oracle import BiLSTM
+    d = dev()
+    torch.manual_seed(n)
+    lens = _lengths(n, Lx, n)
+    mask = torch.arange(Lx)[None, :] < lens[:, None]
+    x = rnd(n, Lx, E, seed=1, scale=0.5)
+    ref = BiLSTM(E, H).double()
+    with torch.no_grad():
+        for q in ref.parameters():
+            q.mul_(1.5)
+    holder = LSTMParams(E, H)
+    holder.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    holder = holder.to(d)
+    # reference forward / backward in fp64
+    xr = x.double().requires_grad_(True)
+    Hr, cr = ref(xr, lens)
+    dH = rnd(n, Lx, 2 * H, seed=2) * mask[:, :, None]
+    dc = rnd(n, 2 * H, seed=3)
+    ((Hr * dH.double()).sum() + (cr * dc.double()).sum()).backward()
+    # HIP path: table = flattened x, ids = arange
+    ids = torch.arange(n * Lx, dtype=torch.int32).view(n, Lx)
+    plan = ops.SeqPlan(mask.clone().to(d), ids.to(d))
+    w = ops.LstmPacked(holder.param_list(), H, E)
+    table = x.view(n * Lx, E).to(d)
+    cap = plan.cap
+    f32 = dict(device=d, dtype=torch.float32)
+    st = dict(plan=plan, w=w, gates=torch.empty((cap, 2 * w.NP), **f32), cell=torch.empty((cap, 2 * w.HP), **f32),
+              hout=torch.zeros((cap, 2 * H), **f32), cn=torch.empty((n, 2 * H), **f32))
+    ops.gemm(table, w.w_ihp, st['gates'], M=cap, N=2 * w.NP, K=E, lda=E, ldb=E, ldc=2 * w.NP, a_idx=plan.tok, dyn=plan.total, dyn_dim=1,
+             bias=w.b_p)
+    ops.lstm_fwd([st], H)
+    off, rank, order = plan.off.cpu().long(), plan.rank.cpu().long(), plan.order.cpu().long()
+    rows = (off[:Lx][None, :] + rank[:, None])                      # packed row of (i, t)
+    hout = st['hout'].cpu()
+    got = torch.where(mask[:, :, None], hout[rows.clamp_max(cap - 1)], torch.zeros(1))
+    close(got, Hr, what='LSTM H')
+    close(st['cn'].cpu()[rank], cr, what='LSTM c_n')
+    # backward
+    dh_packed = torch.zeros((cap, 2 * H))
+    dh_packed[rows[mask]] = dH[mask]
+    st['dh'] = dh_packed.to(d)
+    st['dcn'] = dc[order].contiguous().to(d)
+    ops.lstm_bwd([st], H)
+    dg = st['gates']
+    NP = w.NP
+    dw_ihp = torch.zeros((2 * NP, E), **f32)
+    db_p = torch.zeros(2 * NP, **f32)
+    dw_hhp = torch.zeros((2, NP, H), **f32)
+    ops.gemm(dg, table, dw_ihp, M=2 * NP, N=E, K=cap, lda=2 * NP, ldb=E, ldc=E, trans_a=True, trans_b=True, b_idx=plan.tok,
+             split_k=ops.split_for(2 * NP, E, cap), atomic=True, dyn=plan.total, dyn_dim=2)
+    ops.bias_grad(dg, db_p, dyn=plan.total, rows=cap)
+    for dd, prev in ((0, plan.prev_f), (1, plan.prev_r)):
+        ops.gemm(dg[:, dd * NP:], st['hout'][:, dd * H:], dw_hhp[dd], M=NP, N=H, K=cap, lda=2 * NP, ldb=2 * H, ldc=H, trans_a=True,
+                 trans_b=True, b_idx=prev, split_k=ops.split_for(NP, H, cap), atomic=True, dyn=plan.total, dyn_dim=2)
+    grads = [torch.zeros_like(q) for q in holder.param_list()]
+    ops.lstm_unpack_grads(dw_ihp, db_p, dw_hhp, H, E, grads)
+    names = ['weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0']
+    names = names + [k + '_reverse' for k in names]
+    for k, g in zip(names, grads):
+        close(g, getattr(ref, k).grad, tol=1e-4, what='LSTM d' + k)
+    dtab = torch.zeros((n * Lx, E), **f32)
+    ops.gemm(dg, w.w_ihp, dtab, M=cap, N=E, K=2 * NP, lda=2 * NP, ldb=E, ldc=E, trans_b=True, c_idx=plan.tok, atomic=True, dyn=plan.total,
+             dyn_dim=1)
+    close(dtab.view(n, Lx, E), xr.grad, tol=1e-4, what='LSTM dX')
+
+
+# ------------------------------------------------------------------------------------------------ pools
+def _softmax_pool_ref(x, score, mask):
+    s = score if mask is None else torch.where(mask, score, torch.full_like(score, -1e9))
+    a = torch.softmax(s, dim=1)
+    return torch.einsum('nl,nld->nd', a, x), a
+
+
+@pytest.mark.parametrize('dot', [False, True])
+def test_pool_packed_forward_backward(dot):
+    from nnr_amd import ops
+    d = dev()
+    n, Lx, D = 50, 128, 400
+    lens = _lengths(n, Lx, 3)
+    mask = torch.arange(Lx)[None, :] < lens[:, None]
+    plan = ops.SeqPlan(mask.clone().to(d), None)
+    off, rank = plan.off.cpu().long(), plan.rank.cpu().long()
+    rows = off[:Lx][None, :] + rank[:, None]
+    cap = plan.cap
+    x = rnd(n, Lx, D, seed=1)
+    xp = torch.zeros(cap, D)
+    xp[rows[mask]] = x[mask]
+    v = rnd(n, D, seed=2, scale=0.2)
+    sc = rnd(n, Lx, seed=3)
+    add_in = rnd(n, D, seed=4)
+    scale = 0.37
+    xr = x.double().requires_grad_(True)
+    vr = v.double().requires_grad_(True)
+    scr = sc.double().requires_grad_(True)
+    score = scale * torch.einsum('nld,nd->nl', xr, vr) if dot else scr
+    out_ref, a_ref = _softmax_pool_ref(xr, score, mask)
+    dout = rnd(n, D, seed=5)
+    dout2 = rnd(n, D, seed=6)
+    (out_ref * (dout + dout2).double()).sum().backward()
+    f32 = dict(device=d, dtype=torch.float32)
+    xd = xp.to(d)
+    alpha = torch.zeros(cap, **f32)
+    out = torch.empty(n, D, **f32)
+    kw = dict(x=xd, ldx=D, D=D, n=n, Lx=Lx, plan=plan, alpha=alpha)
+    if dot:
+        kw.update(v=v.to(d), ldv=D, scale=scale)
+    else:
+        scp = torch.zeros(cap)
+        scp[rows[mask]] = sc[mask]
+        kw.update(score=scp.to(d))
+    ops.pool_fwd(out=out, ldo=D, add_in=add_in.to(d), ldadd=D, **kw)
+    close(out, out_ref + add_in.double(), what='pool out')
+    dx = torch.full((cap, D), 0.5, **f32)
+    dscore = torch.zeros(cap, **f32)
+    dv = torch.empty(n, D, **f32)
+    kw.pop('score', None)
+    ops.pool_bwd(dout=dout.to(d), lddo=D, dout2=dout2.to(d), lddo2=D, dx=dx, lddx=D, dx_accumulate=True, dscore=dscore,
+                 dv=dv if dot else None, lddv=D, **kw)
+    got = torch.zeros(n, Lx, D, dtype=torch.float64)
+    got[mask] = dx.cpu().double()[rows[mask]] - 0.5
+    close(got, xr.grad, what='pool dx')
+    if dot:
+        close(dv, vr.grad, what='pool dv')
+    else:
+        gs = torch.zeros(n, Lx, dtype=torch.float64)
+        gs[mask] = dscore.cpu().double()[rows[mask]]
+        close(gs, scr.grad, what='pool dscore')
+
+
+def test_pool_dense_masked_dot():
+    from nnr_amd import ops
+    d = dev()
+    Bn, N, Cn, D = 6, 5, 19, 900
+    n = Bn * N
+    x = rnd(n, Cn, D, seed=1)
+    v = rnd(n, D, seed=2, scale=0.1)
+    cmask = torch.rand(Bn, Cn, generator=torch.Generator().manual_seed(3)) < 0.4
+    cmask[:, -1] = True
+    m_full = cmask[:, None, :].expand(Bn, N, Cn).reshape(n, Cn)
+    scale = 1 / 15.0
+    xr, vr = x.double().requires_grad_(True), v.double().requires_grad_(True)
+    out_ref, _ = _softmax_pool_ref(xr, scale * torch.einsum('nld,nd->nl', xr, vr), m_full)
+    dout = rnd(n, D, seed=4)
+    (out_ref * dout.double()).sum().backward()
+    f32 = dict(device=d, dtype=torch.float32)
+    alpha = torch.empty(n * Cn, **f32)
+    out = torch.empty(n, D, **f32)
+    kw = dict(x=x.to(d), ldx=D, D=D, n=n, Lx=Cn, mask=cmask.to(d), mask_div=N, v=v.to(d), ldv=D, scale=scale, alpha=alpha)
+    ops.pool_fwd(out=out, ldo=D, **kw)
+    close(out, out_ref, what='dense pool out')
+    dx = torch.empty(n * Cn, D, **f32)
+    dv = torch.empty(n, D, **f32)
+    ops.pool_bwd(dout=dout.to(d), lddo=D, dx=dx, lddx=D, dv=dv, lddv=D, **kw)
+    close(dx.view(n, Cn, D), xr.grad, what='dense pool dx')
+    close(dv, vr.grad, what='dense pool dv')
+
+
+# ------------------------------------------------------------------------------------------------ SUE intra-cluster, misc
+def test_sue_intra_cluster_matches_scatter_semantics():
+    from nnr_amd import ops
+    d = dev()
+    Bn, N, Hn, Cn, A, D = 7, 5, 50, 19, 225, 900
+    kf, qc, g = rnd(Bn, Hn, A, seed=1, scale=0.3), rnd(Bn, N, A, seed=2), rnd(Bn, Hn, D, seed=3)
+    cidx = torch.randint(0, Cn, (Bn, Hn), generator=torch.Generator().manual_seed(4))
+    cidx[0] = Cn - 1
+    kr, qr, gr = (t.double().requires_grad_(True) for t in (kf, qc, g))
+    s = torch.einsum('bja,bna->bnj', kr, qr) / math.sqrt(A)
+    feat_ref = torch.zeros(Bn, N, Cn, D, dtype=torch.float64)
+    alpha_ref = torch.zeros(Bn, N, Hn, dtype=torch.float64)
+    for b in range(Bn):                                  # explicit per-cluster loops = torch_scatter's definition
+        for c in range(Cn):
+            sel = (cidx[b] == c).nonzero().flatten()
+            if sel.numel():
+                a = torch.softmax(s[b][:, sel], dim=1)
+                alpha_ref[b][:, sel] = a
+                feat_ref[b, :, c] = a @ gr[b, sel]
+    dfeat = rnd(Bn, N, Cn, D, seed=5)
+    (feat_ref * dfeat.double()).sum().backward()
+    f32 = dict(device=d, dtype=torch.float32)
+    alpha = torch.empty(Bn, N, Hn, **f32)
+    feat = torch.empty(Bn * N * Cn, D, **f32)
+    kd, qd, gd, cd = kf.to(d), qc.to(d), g.to(d), cidx.to(d)
+    ops.sue_intra_fwd(kd, qd, gd, cd, Bn, N, Hn, Cn, A, D, alpha, feat)
+    close(alpha, alpha_ref, what='intra alpha')
+    close(feat.view(Bn, N, Cn, D), feat_ref, what='intra feat')
+    dg, dk, dq = torch.empty(Bn, Hn, D, **f32), torch.empty(Bn * Hn, A, **f32), torch.empty(Bn * N, A, **f32)
+    ops.sue_intra_bwd(kd, qd, gd, cd, alpha, dfeat.to(d).view(-1, D), Bn, N, Hn, Cn, A, D, dg, dk, dq)
+    close(dg, gr.grad, what='intra dg')
+    close(dk.view(Bn, Hn, A), kr.grad, what='intra dkf')
+    close(dq.view(Bn, N, A), qr.grad, what='intra dqc')
+
+
+def test_elementwise_and_optimizer():
+    from nnr_amd import ops
+    d = dev()
+    f32 = dict(device=d, dtype=torch.float32)
+    # loss / logits
+    Bn, N, D = 9, 5, 900
+    user, cand = rnd(Bn, N, D, seed=1, scale=0.1), rnd(Bn, N, D, seed=2, scale=0.3)
+    ur, cr = user.double().requires_grad_(True), cand.double().requires_grad_(True)
+    lg = (ur * cr).sum(2)
+    loss_ref = -(torch.log_softmax(lg, 1)[:, 0]).mean()
+    loss_ref.backward()
+    logits, loss, dl = torch.empty(Bn, N, **f32), torch.empty((), **f32), torch.empty(Bn, N, **f32)
+    ud, cd = user.to(d), cand.to(d)
+    ops.logits_fwd(ud, cd, Bn, N, D, logits)
+    ops.nls_loss(logits, Bn, N, loss, dl)
+    close(logits, lg, what='logits')
+    close(loss, loss_ref, tol=2e-6, what='loss')
+    du, dc = torch.empty_like(ud), torch.empty_like(cd)
+    ops.logits_bwd(dl, ud, cd, Bn, N, D, du, dc)
+    close(du, ur.grad, what='duser')
+    close(dc, cr.grad, what='dcand')
+    # clip + Adam vs torch.optim.Adam on a flat buffer, 3 steps
+    P = 100003
+    p0, gs = rnd(P, seed=3), [rnd(P, seed=10 + i, scale=0.05 * (i + 1)) for i in range(3)]
+    pr = torch.nn.Parameter(p0.double().clone())
+    opt = torch.optim.Adam([pr], lr=1e-3)
+    p, m, v, ss = p0.to(d).clone(), torch.zeros(P, **f32), torch.zeros(P, **f32), torch.zeros(1, **f32)
+    for i, g in enumerate(gs):
+        pr.grad = (g.double() / 2).clone()               # grads averaged over world_size=2
+        torch.nn.utils.clip_grad_norm_([pr], 4.0)
+        opt.step()
+        ss.zero_()
+        ops.sumsq(g.to(d), ss)
+        ops.clip_adam(p, g.to(d), m, v, ss, 0.5, 4.0, 1e-3, 0.9, 0.999, 1e-8, 0.0, i + 1)
+    close(p, pr.data, tol=2e-6, what='clip+Adam')
+    # colsum / small embedding / gate backward
+    x = rnd(1000, 400, seed=20)
+    out = torch.zeros(400, **f32)
+    dyn = torch.tensor([777], dtype=torch.int32, device=d)
+    ops.bias_grad(x.to(d), out, dyn=dyn)
+    close(out, x[:777].double().sum(0), what='colsum')
+    table = rnd(18, 50, seed=21)
+    idx = torch.randint(0, 18, (320,), generator=torch.Generator().manual_seed(22)).int()
+    rep = torch.zeros(320, 900, **f32)
+    ops.small_embed_fwd(table.to(d), idx.to(d), rep[:, 800:], 900, 0.0, 1)
+    close(rep[:, 800:850], table[idx.long()], what='small embed')
+    dt = torch.zeros(18, 50, **f32)
+    drep = rnd(320, 900, seed=23)
+    ops.small_embed_bwd(idx.to(d), 50, drep.to(d)[:, 800:], 900, dt, 0.0, 1)
+    ref = torch.zeros(18, 50, dtype=torch.float64).index_add_(0, idx.long(), drep[:, 800:850].double())
+    close(dt, ref, what='small embed bwd')
