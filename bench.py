@@ -1,0 +1,147 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the hot path: training impressions/sec, CNE+SUE on MIND-200k-shaped synthetic data, global
+batch 64 (BASELINE.json), one process per GPU.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+One "step" = one optimizer step of trainer.py:105-120 (forward, loss, backward, [RCCL all-reduce of the flat gradient],
+clip_grad_norm_(4), Adam) on one batch that is already resident in HBM; dropout is ON (0.2, the reference's 200k
+setting).  The reference's --batch_size is the GLOBAL batch (per-rank = batch_size // world_size, trainer.py:218), so
+the default is strong scaling at global batch 64; --per_gpu_batch B switches to weak scaling (B per GPU).
+
+Prints ONE JSON line (rank 0) with the throughput, the roofline of the dominant kernel measured live with HIP events
+on the launch stream, and a CPU baseline (the oracle, timed on this box's host cores on a bounded sample)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_TFLOPS = 157.3          # MI355X_MICROARCH.md: fp32 vector = fp32 MFMA peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--news_encoder', default='CNE')
+    ap.add_argument('--user_encoder', default='SUE')
+    ap.add_argument('--batch_size', type=int, default=64, help='GLOBAL batch (reference semantics)')
+    ap.add_argument('--per_gpu_batch', type=int, default=0, help='>0: weak scaling with this many impressions per GPU')
+    ap.add_argument('--vocabulary_size', type=int, default=60000)
+    ap.add_argument('--dense', action='store_true', help='all titles/abstracts at full length (worst-case roofline variant)')
+    ap.add_argument('--no_cpu_baseline', action='store_true')
+    ap.add_argument('--cpu_baseline_batch', type=int, default=8)
+    ap.add_argument('--cpu_baseline_steps', type=int, default=2)
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, spec, batch_size, steps):
+    """Time the CPU oracle (oracle/nnr_oracle.py, pinned against the reference by tests/golden) on this box's host cores."""
+    from nnr_amd.synth import SynthCorpus, to_torch
+    from oracle import nnr_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    model = O.Model(cfg)
+    model.initialize()
+    model.train()
+    opt = O.make_optimizer(model, cfg)
+    corpus = SynthCorpus(spec)
+    rng = np.random.default_rng(11)
+    batches = [to_torch(corpus.batch(batch_size, rng)) for _ in range(steps + 1)]
+    O.train_step(model, opt, batches[0], cfg.gradient_clip_norm)          # warm-up
+    t0 = time.perf_counter()
+    for b in batches[1:]:
+        O.train_step(model, opt, b, cfg.gradient_clip_norm)
+    dt = time.perf_counter() - t0
+    return dict(value=round(steps * batch_size / dt, 4), unit='impressions/s', cores=cores, kind='port',
+                sample='%d optimizer steps of the same workload at batch %d (%.1f s of CPU work), torch %s CPU ops, %d threads' %
+                       (steps, batch_size, dt, torch.__version__, cores))
+
+
+def main():
+    a = parse()
+    from nnr_amd import dp, ops
+    from nnr_amd.config import make_config
+    from nnr_amd.model import Model
+    from nnr_amd.synth import SynthSpec, SynthCorpus, to_torch
+    from nnr_amd.trainer import Trainer
+    from nnr_amd import profile as prof
+
+    rank, local, world = dp.init_from_env('nccl' if a.gpus > 1 else None)
+    assert world == a.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % a.gpus
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    weak = a.per_gpu_batch > 0
+    per_gpu = a.per_gpu_batch if weak else a.batch_size // world
+    global_batch = per_gpu * world
+    cfg = make_config(['--news_encoder=' + a.news_encoder, '--user_encoder=' + a.user_encoder, '--dataset=200k',
+                       '--batch_size=%d' % global_batch, '--world_size=%d' % world],
+                      corpus_sizes=dict(vocabulary_size=a.vocabulary_size))
+    spec = SynthSpec(vocabulary_size=cfg.vocabulary_size, dense=a.dense)
+
+    torch.manual_seed(cfg.seed)
+    table = torch.randn(cfg.vocabulary_size, cfg.word_embedding_dim) * 0.3
+    table[0] = 0
+    model = Model(cfg, table)
+    model.initialize()
+    model = model.to(dev).train()
+    trainer = Trainer(model, cfg)
+
+    corpus = SynthCorpus(spec)
+    rng = np.random.default_rng(100 + rank)
+    nb = min(8, a.steps + a.warmup)
+    batches = [to_torch(corpus.batch(per_gpu, rng), dev) for _ in range(nb)]
+
+    def fresh(i):          # masks are mutated in place by the model; mutation is idempotent, so batches can be reused
+        return batches[i % nb]
+
+    for i in range(a.warmup):
+        trainer.train_step(fresh(i))
+    dp.barrier()
+    torch.cuda.synchronize()
+    prof.enable()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        trainer.train_step(fresh(a.warmup + i))
+    dp.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof.disable()
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tmax)
+    roof = prof.roofline(PEAK_F32_TFLOPS)
+
+    if rank == 0:
+        out = {
+            'metric': 'training impressions/sec on MIND-200k (CNE+SUE, bs=64)' if (a.news_encoder, a.user_encoder) == ('CNE', 'SUE')
+                      else 'training impressions/sec (%s+%s)' % (a.news_encoder, a.user_encoder),
+            'value': round(a.steps * global_batch / dt, 2), 'unit': 'impressions/s', 'n_gpus': world, 'steps': a.steps,
+            'warmup': a.warmup, 'ms_per_step': round(1000 * dt / a.steps, 3), 'higher_is_better': True,
+            'scaling': 'weak' if weak else 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': '%s+%s train step, MIND-200k-shaped synthetic batches, dropout %.2f, gcn_layer_num %d%s' %
+                                   (a.news_encoder, a.user_encoder, cfg.dropout_rate, cfg.gcn_layer_num, ', dense lengths' if a.dense else ''),
+                       'global_batch': global_batch, 'per_gpu_batch': per_gpu, 'parallelism': 'dp%d' % world,
+                       'synth': {k: v for k, v in spec.describe().items() if k in ('vocabulary_size', 'title_len_mean', 'content_len_mean', 'news_pool', 'dense')}},
+            'roofline': roof,
+        }
+        if not a.no_cpu_baseline and world == 1:
+            out['cpu_baseline'] = cpu_baseline(cfg, spec, a.cpu_baseline_batch, a.cpu_baseline_steps)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -92,7 +92,7 @@ int nnr_seq_plan(uint8_t* mask, const int* ids, int n, int L, const int* perm_in
 
 /* ------------------------------------------------------------------------------------------------ Bi-LSTM
  * Replaces nn.LSTM(bidirectional) on a PackedSequence (newsEncoders.py:66-67, 119-127) and its backward.
- * Gate columns are kept in "p-order": p = (unit/16)*64 + gate*16 + unit%16, padded to NP = ceil(H/16)*64 per direction. */
+ * Gate columns are kept in "p-order": p = (unit/16)*64 + (unit%16)*4 + gate, padded to NP = ceil(H/16)*64 per direction. */
 int nnr_lstm_dims(int H, int* UB, int* HP, int* NP);
 /* w_ihp [2*NP, E], b_p [2*NP] (= b_ih + b_hh), wf [2*UB*4*UB*256], wb [2*UB*(NP/16)*256] */
 int nnr_lstm_pack_weights(const float* w_ih_f, const float* w_hh_f, const float* b_ih_f, const float* b_hh_f, const float* w_ih_r,

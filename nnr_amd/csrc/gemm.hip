@@ -29,7 +29,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(nnr_gemm_args g) {
   constexpr int A_SZ = TA ? 16 * A_LD : BM * 16;
   constexpr int B_SZ = TB ? 16 * B_LD : BN * 16;
   constexpr int NBL = (BN * 4 + 255) / 256;  // B float4 loads per thread
-  __shared__ __attribute__((aligned(16))) float lds[2 * (A_SZ + B_SZ)];
+  constexpr int E_LD = BN + 4;                // epilogue staging: 64 rows x BN (+pad) per pass
+  constexpr int LDS_FLOATS = (2 * (A_SZ + B_SZ) > 64 * E_LD) ? 2 * (A_SZ + B_SZ) : 64 * E_LD;
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int r = lane & 15, kk = lane >> 4;
@@ -40,9 +42,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(nnr_gemm_args g) {
   if (g.dyn_dim == 2) K = min(K, *g.dyn_dev);
   const int N = g.N;
 
-  // ---- XCD-aware tile id
-  const int nbm = (g.M + BM - 1) / BM, nbn = (N + BN - 1) / BN;
+  // ---- XCD-aware tile id over the LIVE tiles only (with a device-side M most of the static grid is empty; the
+  //      remap must spread the live row-panels over all 8 XCDs, not pack them onto the first ones)
+  const int nbm = (M + BM - 1) / BM, nbn = (N + BN - 1) / BN;
   const int nblk = nbm * nbn;
+  if ((int)blockIdx.x >= nblk) return;
   int v;
   {
     const int b = blockIdx.x, q = nblk >> 3, rem = nblk & 7, x = b & 7, slot = b >> 3;
@@ -50,7 +54,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(nnr_gemm_args g) {
   }
   const int bm = v / nbn, bn = v - bm * nbn;
   const int m0 = bm * BM, n0 = bn * BN;
-  if (m0 >= M) return;
 
   // ---- batch / split-K
   const float* __restrict__ A = g.A;
@@ -252,6 +255,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(nnr_gemm_args g) {
   }
 
   // ---------------------------------------------------------------- epilogue
+  // Accumulators go through LDS in TM passes of 64 rows (tiny fully-unrolled store loop: the MFMA registers are only
+  // ever indexed statically), then a rolled, runtime-flagged loop applies the epilogue with consecutive lanes on
+  // consecutive columns: every global access (C, aux, mul, resid, atomics) is a contiguous 256-B wave access.
   const bool use_atomic = g.atomic || g.split_k > 1;
   float* aux = g.aux_out;
   const float* res = g.resid;
@@ -260,48 +266,68 @@ __global__ __launch_bounds__(256) void gemm_kernel(nnr_gemm_args g) {
     if (aux) aux += (long)z * g.stride_aux;
     if (res) res += (long)z * g.stride_res;
   }
+  float* stage = lds;
 #pragma unroll
   for (int m = 0; m < TM; ++m) {
+    if (m > 0) __syncthreads();
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int row = m0 + (w * TM + m) * 16 + kk * 4 + reg;
-      const bool rok = row < M;
-      int crow = row;
-      if (rok && g.c_idx) crow = g.c_idx[row];
-      const int rvrow = (rok && g.rowvec) ? (g.rowvec_map ? g.rowvec_map[row] : row) : 0;
-      float dot = 0.f;
+    for (int n = 0; n < TN; ++n)
 #pragma unroll
-      for (int n = 0; n < TN; ++n) {
-        const int col = n0 + n * 16 + r;
-        if (rok && col < N && crow >= 0) {
-          float x = acc[m][n][reg] * g.alpha;
-          if (g.bias) x += g.bias[col];
-          if (g.rowvec) x += g.rowvec[(long)rvrow * g.ldrv + col];
-          if (g.act == 1) x = fmaxf(x, 0.f);
-          else if (g.act == 2) x = tanhf(x);
-          else if (g.act == 3) x = sigmoidf_(x);
-          if (aux) aux[(long)row * g.ldaux + col] = x;
-          if (mulp) x *= mulp[(long)row * g.ldmul + col];
-          if (res) x += res[(long)row * g.ldres + col];
-          if (g.drop_target == 3)
-            x = nnr_keep(g.drop_seed, (uint64_t)(row + (long)z * g.M) * g.drop_cols + col, dthr) ? x * dscale : 0.f;
-          if (g.rowdot_w) dot += g.rowdot_w[col] * x;
-          if (C) {
-            float* cp = C + (long)crow * g.ldc + col;
-            if (use_atomic) {
-              if (g.drop_target == 4)   // scatter of d(dropout(emb)) : mask keyed by the token row
-                x = nnr_keep(g.drop_seed, (uint64_t)row * g.drop_cols + col, dthr) ? x * dscale : 0.f;
-              atomicAdd(cp, x);
-            } else {
-              if (g.accumulate) x += *cp;
-              *cp = x;
+      for (int reg = 0; reg < 4; ++reg) stage[(w * 16 + kk * 4 + reg) * E_LD + n * 16 + r] = acc[m][n][reg];
+    __syncthreads();
+    if (g.rowdot_w) {
+      // one wave per row: lanes stride the columns, wave-reduce the w2-weighted sum (needs the whole row in this tile)
+      for (int lr = w; lr < 64; lr += 4) {
+        const int row = m0 + (lr >> 4) * (TM * 16) + m * 16 + (lr & 15);
+        float dot = 0.f;
+        if (row < M) {
+          for (int c = lane; c < BN; c += 64) {
+            const int col = n0 + c;
+            if (col < N) {
+              float x = stage[lr * E_LD + c] * g.alpha;
+              if (g.bias) x += g.bias[col];
+              if (g.act == 1) x = fmaxf(x, 0.f);
+              else if (g.act == 2) x = tanhf(x);
+              else if (g.act == 3) x = sigmoidf_(x);
+              if (aux) aux[(long)row * g.ldaux + col] = x;
+              dot += g.rowdot_w[col] * x;
+              if (C) C[(long)row * g.ldc + col] = x;
             }
           }
         }
+        dot = wave_sum(dot);
+        if (row < M && lane == 0) g.rowdot_out[row] = dot;
       }
-      if (g.rowdot_w) {
-        dot = group16_sum(dot);
-        if (rok && r == 0) g.rowdot_out[row] = dot;
+    } else {
+      for (int idx = tid; idx < 64 * BN; idx += 256) {
+        const int lr = idx / BN, c = idx - lr * BN;
+        const int row = m0 + (lr >> 4) * (TM * 16) + m * 16 + (lr & 15);
+        const int col = n0 + c;
+        if (row >= M || col >= N) continue;
+        int crow = row;
+        if (g.c_idx) { crow = g.c_idx[row]; if (crow < 0) continue; }
+        float x = stage[lr * E_LD + c] * g.alpha;
+        if (g.bias) x += g.bias[col];
+        if (g.rowvec) x += g.rowvec[(long)(g.rowvec_map ? g.rowvec_map[row] : row) * g.ldrv + col];
+        if (g.act == 1) x = fmaxf(x, 0.f);
+        else if (g.act == 2) x = tanhf(x);
+        else if (g.act == 3) x = sigmoidf_(x);
+        if (aux) aux[(long)row * g.ldaux + col] = x;
+        if (mulp) x *= mulp[(long)row * g.ldmul + col];
+        if (res) x += res[(long)row * g.ldres + col];
+        if (g.drop_target == 3)
+          x = nnr_keep(g.drop_seed, (uint64_t)(row + (long)z * g.M) * g.drop_cols + col, dthr) ? x * dscale : 0.f;
+        if (C) {
+          float* cp = C + (long)crow * g.ldc + col;
+          if (use_atomic) {
+            if (g.drop_target == 4)   // scatter of d(dropout(emb)) : mask keyed by the token row
+              x = nnr_keep(g.drop_seed, (uint64_t)row * g.drop_cols + col, dthr) ? x * dscale : 0.f;
+            atomicAdd(cp, x);
+          } else {
+            if (g.accumulate) x += *cp;
+            *cp = x;
+          }
+        }
       }
     }
   }

@@ -13,8 +13,11 @@
 // W_hh (640 KB / direction at H=200) cannot live in one CU's LDS, so it is streamed from L2 every step in a
 // pre-swizzled FRAGMENT layout (each wave-load is one contiguous 1 KiB of exactly the B operands it needs), while the
 // tiny A operand h_{t-1} sits in LDS (XOR-swizzled: one conflict-free ds_read_b128 feeds 4 MFMAs).
-// Gate columns are re-ordered [unit-block][gate][16 units] ("p-order") so a lane finds i,f,g,o of the SAME
-// (sequence, unit) in its own four accumulators: the cell update is lane-local, no shuffles, no LDS round trip.
+// Gate columns are re-ordered [unit-block][unit][gate] ("p-order": p = (unit/16)*64 + (unit%16)*4 + gate) so a lane finds
+// i,f,g,o of the SAME (sequence, unit) in its own four accumulators AND as one contiguous float4 in memory: the cell
+// update is lane-local (no shuffles, no LDS round trip) and every gate access is a 16-byte load/store, 256 B per 16 lanes.
+// Streaming buffers (gates / cell / h) are accessed non-temporally so the four W_hh fragment arrays stay L2-resident, and
+// waves raise their priority with the tile's length: the longest tile is the critical path of the whole launch.
 // The xw buffer is overwritten in place with the activated gates (saved for backward).
 #include "common.h"
 
@@ -24,6 +27,13 @@ __device__ __forceinline__ int swz16(int r16) { return (4 - (r16 >> 2)) & 3; }
 // LDS offset (floats) of element (row r, column u) in a K-contiguous [16][ld] tile, ld % 16 == 0
 __device__ __forceinline__ int lds_off(int r, int u, int ld) {
   return r * ld + (u & ~15) + 4 * (((u >> 2) & 3) ^ swz16(r)) + (u & 3);
+}
+
+// Longer tiles = longer dependent chains: give their waves the matrix pipe first (priority beats age in the arbiter).
+__device__ __forceinline__ void set_prio_by_length(int tmax) {
+  if (tmax >= 96) __builtin_amdgcn_s_setprio(3);
+  else if (tmax >= 64) __builtin_amdgcn_s_setprio(2);
+  else if (tmax >= 32) __builtin_amdgcn_s_setprio(1);
 }
 
 struct LstmProblem {
@@ -43,8 +53,9 @@ struct LstmArgs { LstmProblem p[2]; int nprob; int H; };
 
 // ------------------------------------------------------------------------------------------------ forward
 template <int UB>
-__global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmArgs a) {
-  constexpr int HP = UB * 16, NP = UB * 64, KG = UB, OWN = (UB + 3) / 4;
+__global__ __launch_bounds__((UB > 4 ? 16 : 4) * 64) void lstm_fwd_kernel(LstmArgs a) {
+  constexpr int NW = UB > 4 ? 16 : 4, NT = NW * 64;      // one 16-unit block per wave when the hidden size is large
+  constexpr int HP = UB * 16, NP = UB * 64, KG = UB, OWN = (UB + NW - 1) / NW;
   const LstmProblem& P = a.p[blockIdx.z];
   const int H = a.H;
   const int s0 = blockIdx.x * 16;
@@ -52,8 +63,9 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmArgs a) {
   const int d = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, kk = lane >> 4;
   __shared__ __attribute__((aligned(16))) float hbuf[2][16 * HP];
-  for (int i = tid; i < 2 * 16 * HP; i += 256) (&hbuf[0][0])[i] = 0.f;
+  for (int i = tid; i < 2 * 16 * HP; i += NT) (&hbuf[0][0])[i] = 0.f;
   const int tmax = P.slen[s0];
+  set_prio_by_length(tmax);
   float c[OWN][4];
 #pragma unroll
   for (int o = 0; o < OWN; ++o)
@@ -71,17 +83,16 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmArgs a) {
     float* hn = hbuf[cur ^ 1];
 #pragma unroll
     for (int o = 0; o < OWN; ++o) {
-      const int ub = w + 4 * o;
+      const int ub = w + NW * o;
       if (ub < UB) {
-        // xw loads for this unit block (consumed after the MFMA loop -> latency hidden)
-        float x[4][4];
+        // xw (i,f,g,o of this lane's unit) for 4 rows: consumed after the MFMA loop -> latency hidden
+        f32x4 x[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int row = kk * 4 + e;
-            x[g][e] = (row < nact) ? P.gates[(row0 + row) * ldg + d * NP + ub * 64 + g * 16 + r] : 0.f;
-          }
+        for (int e = 0; e < 4; ++e) {
+          const int row = kk * 4 + e;
+          x[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (row < nact) x[e] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(P.gates + (row0 + row) * ldg + d * NP + ub * 64 + r * 4));
+        }
         f32x4 acc[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -110,16 +121,15 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmArgs a) {
         for (int e = 0; e < 4; ++e) {
           const int row = kk * 4 + e;
           if (row < nact) {
-            const float gi = sigmoidf_(acc[0][e] + x[0][e]);
-            const float gf = sigmoidf_(acc[1][e] + x[1][e]);
-            const float gg = tanhf(acc[2][e] + x[2][e]);
-            const float go = sigmoidf_(acc[3][e] + x[3][e]);
+            const float gi = sigmoidf_(acc[0][e] + x[e][0]);
+            const float gf = sigmoidf_(acc[1][e] + x[e][1]);
+            const float gg = tanhf(acc[2][e] + x[e][2]);
+            const float go = sigmoidf_(acc[3][e] + x[e][3]);
             const float cn = gf * c[o][e] + gi * gg;
             const float hv = go * tanhf(cn);
             c[o][e] = cn;
-            float* gp = P.gates + (row0 + row) * ldg + d * NP + ub * 64 + r;
-            gp[0] = gi; gp[16] = gf; gp[32] = gg; gp[48] = go;
-            P.cell[(row0 + row) * ldc + d * HP + unit] = cn;
+            __builtin_nontemporal_store(f32x4{gi, gf, gg, go}, reinterpret_cast<f32x4*>(P.gates + (row0 + row) * ldg + d * NP + ub * 64 + r * 4));
+            __builtin_nontemporal_store(cn, P.cell + (row0 + row) * ldc + d * HP + unit);
             if (unit < H) P.hout[(row0 + row) * ldh + d * H + unit] = hv;
             hn[lds_off(row, unit, HP)] = hv;
           }
@@ -132,7 +142,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmArgs a) {
   // final cell state (forward: after t = len-1, reverse: after t = 0) -- rows keep c once they go inactive
 #pragma unroll
   for (int o = 0; o < OWN; ++o) {
-    const int ub = w + 4 * o, unit = ub * 16 + r;
+    const int ub = w + NW * o, unit = ub * 16 + r;
     if (ub < UB && unit < H) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -148,8 +158,9 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmArgs a) {
 // the saved gates);  (2) dh_{prev} = dgates[16, 4H] . W_hh on the matrix cores, W_hh streamed from L2 in fragment
 // layout; dh_prev / dc_prev stay in registers in the same lane that needs them next step.
 template <int UB>
-__global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmArgs a) {
-  constexpr int HP = UB * 16, NP = UB * 64, KGB = NP / 16, OWN = (UB + 3) / 4;
+__global__ __launch_bounds__((UB > 4 ? 16 : 4) * 64) void lstm_bwd_kernel(LstmArgs a) {
+  constexpr int NW = UB > 4 ? 16 : 4;
+  constexpr int HP = UB * 16, NP = UB * 64, KGB = NP / 16, OWN = (UB + NW - 1) / NW;
   const LstmProblem& P = a.p[blockIdx.z];
   const int H = a.H;
   const int s0 = blockIdx.x * 16;
@@ -158,7 +169,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, kk = lane >> 4;
   __shared__ __attribute__((aligned(16))) float dg[16 * NP];
   const int tmax = P.slen[s0];
-  const int* prev = d ? P.prev_r : P.prev_f;
+  set_prio_by_length(tmax);
   int mylen[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -172,6 +183,40 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmArgs a) {
     for (int e = 0; e < 4; ++e) { dhr[o][e] = 0.f; dcr[o][e] = 0.f; }
 
   const int ldg = 2 * NP, ldc = 2 * HP, ldh = 2 * H;
+  // software-pipelined inputs of the gate-gradient phase (loaded one step ahead, under the MFMA phase)
+  f32x4 in_g[OWN][4];
+  float in_ct[OWN][4], in_cp[OWN][4], in_dh[OWN][4];
+  auto load_inputs = [&](int step) {
+    const int t = d ? step : (tmax - 1 - step);
+    const int nact = min(16, P.bs[t] - s0);
+    const long row0 = (long)P.off[t] + s0;
+    // previous step of the FORWARD recurrence: t-1 (forward dir) / t+1 (reverse dir, if inside the sequence)
+    const int tp = d ? t + 1 : t - 1;
+    const long prow0 = (tp >= 0 && tp < P.L) ? (long)P.off[tp] + s0 : 0;
+#pragma unroll
+    for (int o = 0; o < OWN; ++o) {
+      const int ub = w + NW * o;
+      if (ub < UB) {
+        const int unit = ub * 16 + r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int row = kk * 4 + e;
+          in_g[o][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+          in_ct[o][e] = 0.f; in_cp[o][e] = 0.f; in_dh[o][e] = 0.f;
+          if (row < nact) {
+            const long grow = row0 + row;
+            in_g[o][e] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(P.gates + grow * ldg + d * NP + ub * 64 + r * 4));
+            in_ct[o][e] = __builtin_nontemporal_load(P.cell + grow * ldc + d * HP + unit);
+            const bool has_prev = d ? (t + 1 < mylen[e]) : (t > 0);
+            if (has_prev) in_cp[o][e] = __builtin_nontemporal_load(P.cell + (prow0 + row) * ldc + d * HP + unit);
+            if (unit < H) in_dh[o][e] = __builtin_nontemporal_load(P.dh + grow * ldh + d * H + unit);
+          }
+        }
+      }
+    }
+  };
+  load_inputs(0);
+
   for (int step = 0; step < tmax; ++step) {
     const int t = d ? step : (tmax - 1 - step);          // reverse of the forward pass's order
     const int nact = min(16, P.bs[t] - s0);
@@ -179,44 +224,37 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmArgs a) {
     // ---- (1) gate gradients
 #pragma unroll
     for (int o = 0; o < OWN; ++o) {
-      const int ub = w + 4 * o;
+      const int ub = w + NW * o;
       if (ub < UB) {
         const int unit = ub * 16 + r;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int row = kk * 4 + e;
-          float di = 0.f, df = 0.f, dgg = 0.f, dov = 0.f;
+          f32x4 dgv = {0.f, 0.f, 0.f, 0.f};
           if (row < nact) {
             const long grow = row0 + row;
-            float* gp = P.gates + grow * ldg + d * NP + ub * 64 + r;
-            const float gi = gp[0], gf = gp[16], gg = gp[32], go = gp[48];
-            const float ct = P.cell[grow * ldc + d * HP + unit];
-            const int pr = prev[grow];
-            const float cp = (pr >= 0) ? P.cell[(long)pr * ldc + d * HP + unit] : 0.f;
-            float dh = dhr[o][e];
-            if (unit < H) dh += P.dh[grow * ldh + d * H + unit];
+            const float gi = in_g[o][e][0], gf = in_g[o][e][1], gg = in_g[o][e][2], go = in_g[o][e][3];
+            const float ct = in_ct[o][e], cp = in_cp[o][e];
+            const float dh = dhr[o][e] + in_dh[o][e];
             float dc = dcr[o][e];
             // first step of this row's backward = last step of its forward: add dL/dc_n
             const bool last_fwd_step = d ? (t == 0) : (t == mylen[e] - 1);
             if (last_fwd_step && P.dcn && unit < H) dc += P.dcn[(long)(s0 + row) * ldh + d * H + unit];
             const float tc = tanhf(ct);
-            dov = dh * tc * go * (1.f - go);
+            dgv[3] = dh * tc * go * (1.f - go);
             dc += dh * go * (1.f - tc * tc);
-            di = dc * gg * gi * (1.f - gi);
-            df = dc * cp * gf * (1.f - gf);
-            dgg = dc * gi * (1.f - gg * gg);
+            dgv[0] = dc * gg * gi * (1.f - gi);
+            dgv[1] = dc * cp * gf * (1.f - gf);
+            dgv[2] = dc * gi * (1.f - gg * gg);
             dcr[o][e] = dc * gf;
-            gp[0] = di; gp[16] = df; gp[32] = dgg; gp[48] = dov;
+            __builtin_nontemporal_store(dgv, reinterpret_cast<f32x4*>(P.gates + grow * ldg + d * NP + ub * 64 + r * 4));
           }
-          const int pc = ub * 64 + r;
-          dg[lds_off(row, pc, NP)] = di;
-          dg[lds_off(row, pc + 16, NP)] = df;
-          dg[lds_off(row, pc + 32, NP)] = dgg;
-          dg[lds_off(row, pc + 48, NP)] = dov;
+          *reinterpret_cast<f32x4*>(&dg[lds_off(row, ub * 64 + r * 4, NP)]) = dgv;
         }
       }
     }
     __syncthreads();
+    if (step + 1 < tmax) load_inputs(step + 1);
     // ---- (2) dh_prev[16, HP] = dgates[16, NP] . W_hh (p-order rows)
     {
       f32x4 acc[OWN];
@@ -226,15 +264,16 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmArgs a) {
       f32x4 bcur[OWN], bnxt[OWN];
 #pragma unroll
       for (int o = 0; o < OWN; ++o) {
-        const int ub = w + 4 * o;
+        const int ub = w + NW * o;
         bcur[o] = (ub < UB) ? wb[((long)ub * KGB + 0) * 64] : f32x4{0.f, 0.f, 0.f, 0.f};
+        bnxt[o] = bcur[o];
       }
-#pragma unroll 4
+#pragma unroll 2
       for (int kg = 0; kg < KGB; ++kg) {
         if (kg + 1 < KGB) {
 #pragma unroll
           for (int o = 0; o < OWN; ++o) {
-            const int ub = w + 4 * o;
+            const int ub = w + NW * o;
             if (ub < UB) bnxt[o] = wb[((long)ub * KGB + kg + 1) * 64];
           }
         }
@@ -243,7 +282,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmArgs a) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int o = 0; o < OWN; ++o)
-            if (w + 4 * o < UB) acc[o] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bcur[o][i], acc[o], 0, 0, 0);
+            if (w + NW * o < UB) acc[o] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bcur[o][i], acc[o], 0, 0, 0);
 #pragma unroll
         for (int o = 0; o < OWN; ++o) bcur[o] = bnxt[o];
       }
@@ -270,7 +309,7 @@ __global__ void lstm_pack_kernel(const float* __restrict__ w_ih_f, const float* 
     long i = idx;
     if (i < n_ihp) {                       // w_ihp[d*NP + p][e]
       const int e = i % E; const int dp = i / E; const int d = dp / NP, p = dp % NP;
-      const int ub = p / 64, g = (p % 64) / 16, u = p % 16, unit = ub * 16 + u;
+      const int ub = p / 64, u = (p % 64) / 4, g = p % 4, unit = ub * 16 + u;
       const float* src = d ? w_ih_r : w_ih_f;
       w_ihp[i] = (unit < H) ? src[(long)(g * H + unit) * E + e] : 0.f;
       continue;
@@ -278,7 +317,7 @@ __global__ void lstm_pack_kernel(const float* __restrict__ w_ih_f, const float* 
     i -= n_ihp;
     if (i < n_b) {
       const int d = i / NP, p = i % NP;
-      const int ub = p / 64, g = (p % 64) / 16, u = p % 16, unit = ub * 16 + u;
+      const int ub = p / 64, u = (p % 64) / 4, g = p % 4, unit = ub * 16 + u;
       const float* bi = d ? b_ih_r : b_ih_f; const float* bh = d ? b_hh_r : b_hh_f;
       b_p[i] = (unit < H) ? bi[g * H + unit] + bh[g * H + unit] : 0.f;
       continue;
@@ -297,7 +336,7 @@ __global__ void lstm_pack_kernel(const float* __restrict__ w_ih_f, const float* 
       const int ii = i & 3, lane = (i >> 2) & 63; long q = i >> 8;
       const int kg = q % KGB; q /= KGB; const int ubn = q % UB; const int d = q / UB;
       const int p = 16 * kg + 4 * (lane >> 4) + ii;
-      const int ub = p / 64, g = (p % 64) / 16, u = p % 16, unit = ub * 16 + u, col = ubn * 16 + (lane & 15);
+      const int ub = p / 64, u = (p % 64) / 4, g = p % 4, unit = ub * 16 + u, col = ubn * 16 + (lane & 15);
       const float* src = d ? w_hh_r : w_hh_f;
       wb[i] = (unit < H && col < H) ? src[(long)(g * H + unit) * H + col] : 0.f;
     }
@@ -317,21 +356,21 @@ __global__ void lstm_unpack_kernel(const float* __restrict__ dw_ihp, const float
     long i = idx;
     if (i < n_ih) {
       const int e = i % E; long q = i / E; const int row = q % (4 * H); const int d = q / (4 * H);
-      const int g = row / H, unit = row % H, p = (unit / 16) * 64 + g * 16 + (unit % 16);
+      const int g = row / H, unit = row % H, p = (unit / 16) * 64 + (unit % 16) * 4 + g;
       (d ? dw_ih_r : dw_ih_f)[(long)row * E + e] = dw_ihp[(long)(d * NP + p) * E + e];
       continue;
     }
     i -= n_ih;
     if (i < n_hh) {
       const int k = i % H; long q = i / H; const int row = q % (4 * H); const int d = q / (4 * H);
-      const int g = row / H, unit = row % H, p = (unit / 16) * 64 + g * 16 + (unit % 16);
+      const int g = row / H, unit = row % H, p = (unit / 16) * 64 + (unit % 16) * 4 + g;
       (d ? dw_hh_r : dw_hh_f)[(long)row * H + k] = dw_hhp[((long)d * NP + p) * H + k];
       continue;
     }
     i -= n_hh;
     {
       const int row = i % (4 * H), d = i / (4 * H);
-      const int g = row / H, unit = row % H, p = (unit / 16) * 64 + g * 16 + (unit % 16);
+      const int g = row / H, unit = row % H, p = (unit / 16) * 64 + (unit % 16) * 4 + g;
       const float v = db_p[d * NP + p];
       (d ? db_ih_r : db_ih_f)[row] = v;
       (d ? db_hh_r : db_hh_f)[row] = v;
@@ -341,7 +380,7 @@ __global__ void lstm_unpack_kernel(const float* __restrict__ dw_ihp, const float
 
 template <int UB>
 int launch_rec(const LstmArgs& a, bool backward, int max_tiles, hipStream_t s) {
-  dim3 grid(max_tiles, 2, a.nprob), block(256);
+  dim3 grid(max_tiles, 2, a.nprob), block((UB > 4 ? 16 : 4) * 64);
   if (backward) hipLaunchKernelGGL((lstm_bwd_kernel<UB>), grid, block, 0, s, a);
   else hipLaunchKernelGGL((lstm_fwd_kernel<UB>), grid, block, 0, s, a);
   NNR_CHECK_LAUNCH();

@@ -6,6 +6,7 @@ import math
 import torch
 
 from . import _lib as L
+from . import profile as _prof
 
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
 
@@ -48,7 +49,20 @@ def gemm(A, B, C_=None, *, M, N, K, lda, ldb, ldc=0, trans_a=False, trans_b=Fals
     g.rowdot_w, g.rowdot_out = _p(rowdot_w), _p(rowdot_out)
     g.batch, g.strideA, g.strideB, g.strideC, g.stride_aux, g.stride_res = batch, strideA, strideB, strideC, stride_aux, stride_res
     g.tile = tile
-    L.check(L.lib().nnr_gemm_f32(C.byref(g), _s()), 'nnr_gemm_f32')
+    if not _prof.active():
+        L.check(L.lib().nnr_gemm_f32(C.byref(g), _s()), 'nnr_gemm_f32')
+        return
+    t = tile if tile else (3 if rowdot_w is not None else (2 if M <= 1024 else 1))
+    fam = 'gemm_%s_%s' % ('tn' if trans_a else ('nn' if trans_b else 'nt'), {1: '256x80', 2: '64x80', 3: '128x208'}[t])
+
+    def flops(M=M, N=N, K=K, dyn=dyn, dyn_dim=dyn_dim, batch=batch):
+        m, k = M, K
+        if dyn is not None:
+            d = int(dyn.item())
+            m, k = (min(M, d), K) if dyn_dim == 1 else (M, min(K, d))
+        return 2.0 * m * N * k * max(1, batch)
+    with _prof.span(fam, flops):
+        L.check(L.lib().nnr_gemm_f32(C.byref(g), _s()), 'nnr_gemm_f32')
 
 
 def linear_fwd(x, w, bias=None, out=None, act=0, **kw):
@@ -156,14 +170,21 @@ def _lstm_probs(items):
     return arr
 
 
+def _lstm_flops(items, H):
+    totals = [it['plan'].total for it in items]
+    return lambda: sum(float(t.item()) for t in totals) * 2 * (2.0 * H * 4 * H)     # tokens x 2 directions x [1,H]x[H,4H]
+
+
 def lstm_fwd(items, H):
     arr = _lstm_probs(items)
-    L.check(L.lib().nnr_lstm_fwd(arr, len(items), H, _s()), 'nnr_lstm_fwd')
+    with _prof.span('lstm_fwd', _lstm_flops(items, H)):
+        L.check(L.lib().nnr_lstm_fwd(arr, len(items), H, _s()), 'nnr_lstm_fwd')
 
 
 def lstm_bwd(items, H):
     arr = _lstm_probs(items)
-    L.check(L.lib().nnr_lstm_bwd(arr, len(items), H, _s()), 'nnr_lstm_bwd')
+    with _prof.span('lstm_bwd', _lstm_flops(items, H)):
+        L.check(L.lib().nnr_lstm_bwd(arr, len(items), H, _s()), 'nnr_lstm_bwd')
 
 
 # ---------------------------------------------------------------------------------------------- pooling

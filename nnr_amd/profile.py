@@ -1,0 +1,80 @@
+"""Live per-kernel-family timing for bench.py: HIP events recorded on the launch stream around each instrumented
+launch (the kernels run on torch's current stream, so torch.cuda.Event sees them), plus the ALGORITHMIC FLOPs of the
+launch (true dims, not the padded tile dims; data-dependent token counts are read back from device memory after the
+timed region).  Families map 1:1 to kernel symbols, so the rocprofv3 --kernel-trace --stats averages under profiles/
+can be compared directly."""
+import torch
+
+_on = False
+_records = []          # (family, start, end, flops_fn)
+
+KERNEL_OF = {
+    'gemm_nt_256x80': 'gemm_kernel<4, 5, false, false>', 'gemm_nn_256x80': 'gemm_kernel<4, 5, false, true>',
+    'gemm_tn_256x80': 'gemm_kernel<4, 5, true, true>', 'gemm_nt_64x80': 'gemm_kernel<1, 5, false, false>',
+    'gemm_nn_64x80': 'gemm_kernel<1, 5, false, true>', 'gemm_tn_64x80': 'gemm_kernel<1, 5, true, true>',
+    'gemm_nt_128x208': 'gemm_kernel<2, 13, false, false>', 'lstm_fwd': 'lstm_fwd_kernel<13>', 'lstm_bwd': 'lstm_bwd_kernel<13>',
+}
+
+
+def enable():
+    global _on
+    _on = True
+    _records.clear()
+
+
+def disable():
+    global _on
+    _on = False
+
+
+def active():
+    return _on
+
+
+class span:
+    """with profile.span(family, flops_fn): <launch>"""
+
+    def __init__(self, family, flops_fn):
+        self.family, self.flops_fn = family, flops_fn
+
+    def __enter__(self):
+        if _on:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+        return self
+
+    def __exit__(self, *a):
+        if _on:
+            self.e.record()
+            _records.append((self.family, self.s, self.e, self.flops_fn))
+        return False
+
+
+def summary():
+    torch.cuda.synchronize()
+    fam = {}
+    for family, s, e, fn in _records:
+        d = fam.setdefault(family, dict(ms=0.0, flops=0.0, launches=0))
+        d['ms'] += s.elapsed_time(e)
+        d['flops'] += float(fn())
+        d['launches'] += 1
+    return fam
+
+
+def roofline(peak_tflops):
+    fam = summary()
+    if not fam:
+        return None
+    total_ms = sum(d['ms'] for d in fam.values())
+    name = max(fam, key=lambda k: fam[k]['ms'])
+    d = fam[name]
+    ach = d['flops'] / (d['ms'] * 1e-3) / 1e12 if d['ms'] > 0 else 0.0
+    return {
+        'bound': 'mfma', 'achieved': round(ach, 3), 'peak': peak_tflops, 'unit': 'TFLOP/s', 'frac': round(ach / peak_tflops, 4),
+        'traffic': None, 'kernel': KERNEL_OF.get(name, name), 'launches': d['launches'],
+        'avg_launch_us': round(1000 * d['ms'] / max(1, d['launches']), 2),
+        'share_of_instrumented_time': round(d['ms'] / total_ms, 3),
+        'families': {k: {'ms': round(v['ms'], 3), 'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2) if v['ms'] > 0 else 0.0,
+                         'launches': v['launches']} for k, v in sorted(fam.items(), key=lambda kv: -kv[1]['ms'])},
+    }
