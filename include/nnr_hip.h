@@ -65,7 +65,7 @@ typedef struct nnr_gemm_args {
   int ldmul;
   const float* resid;       /* [M, ldres] */
   int ldres;
-  int accumulate;           /* C += result (non-atomic) */
+  int accumulate;           /* 1: C += result (after the epilogue); 2: add the old C BEFORE bias/activation (k-split convs) */
   int atomic;               /* atomicAdd into C (implied by split_k > 1) */
   const int* c_idx;         /* [M]: destination row of C for row m (negative: skip) */
   int split_k;              /* > 1: reduction split over blockIdx.z, atomicAdd into a pre-zeroed C */
@@ -149,11 +149,26 @@ int nnr_small_embed_fwd(const float* table, const int* idx, int n, int dim, floa
                         hipStream_t stream);                                     /* newsEncoders.py:51-53 */
 int nnr_small_embed_bwd(const int* idx, int n, int dim, const float* dout, int lddo, float* dtable_accum, float p, uint32_t seed,
                         hipStream_t stream);
+/* nn.Embedding forward / backward for a dense id tensor (newsEncoders.py:117-118, 163, 193) with the in-place dropout fused:
+ * out[row,:] = dropout(table[idx[row],:]) (negative idx: zero row); dtable[idx[row],:] += mask * dout[row,:] (f32 atomics). */
+int nnr_embed_gather(const float* table, const int* idx, long n, int dim, float* out, float p, uint32_t seed, hipStream_t stream);
+int nnr_embed_scatter(const float* dout, const int* idx, long n, int dim, float* dtable_accum, float p, uint32_t seed,
+                      hipStream_t stream);
+int nnr_transpose2d(const float* in, float* out, long rows, int cols, int accumulate, hipStream_t stream);
 int nnr_add(float* y, const float* x, long n, float alpha, hipStream_t stream);
 int nnr_add2d(float* y, int ldy, const float* x, int ldx, int rows, int cols, float alpha, int accumulate, hipStream_t stream);
 int nnr_dropout(const float* x, float* y, long n, float p, uint32_t seed, hipStream_t stream);
 int nnr_relu_bwd(const float* dy, const float* y, float* dx, long n, hipStream_t stream);
 int nnr_relu_drop_bwd(const float* dy, const float* r, float* ds, float* dx, long n, float p, uint32_t seed, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------ multi-head self-attention core
+ * MultiHeadAttention.forward after the W_Q/W_K/W_V projections (layers.py:137-147) on v_mfma_f32_32x32x2_f32:
+ * qkv [n*Lq, 3*heads*dh] = [Q | K | V] (head h at columns h*dh), key mask [n, Lq] (0 -> -1e9) or NULL, scale = 1/sqrt(dh);
+ * out [n*Lq, heads*dh]; prob [n*heads, NB*NB*1024] (NB = 1 for Lq <= 32, 2 for Lq <= 64) saved for backward. */
+int nnr_mhsa_fwd(const float* qkv, const uint8_t* mask, int n, int Lq, int heads, int dh, float scale, float* out, float* prob,
+                 hipStream_t stream);
+int nnr_mhsa_bwd(const float* qkv, const uint8_t* mask, const float* prob, const float* dout, int n, int Lq, int heads, int dh,
+                 float scale, float* dqkv, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------ SUE (userEncoders.py:68-98) */
 int nnr_sue_x0_fwd(const float* hist, const float* proxy, float* x0, int B, int Hn, int Kc, int D, float p, uint32_t seed,

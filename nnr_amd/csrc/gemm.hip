@@ -307,6 +307,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(nnr_gemm_args g) {
         int crow = row;
         if (g.c_idx) { crow = g.c_idx[row]; if (crow < 0) continue; }
         float x = stage[lr * E_LD + c] * g.alpha;
+        if (g.accumulate == 2) x += C[(long)crow * g.ldc + col];      // running sum BEFORE bias / activation
         if (g.bias) x += g.bias[col];
         if (g.rowvec) x += g.rowvec[(long)(g.rowvec_map ? g.rowvec_map[row] : row) * g.ldrv + col];
         if (g.act == 1) x = fmaxf(x, 0.f);
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(nnr_gemm_args g) {
               x = nnr_keep(g.drop_seed, (uint64_t)row * g.drop_cols + col, dthr) ? x * dscale : 0.f;
             atomicAdd(cp, x);
           } else {
-            if (g.accumulate) x += *cp;
+            if (g.accumulate == 1) x += *cp;
             *cp = x;
           }
         }

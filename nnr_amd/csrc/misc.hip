@@ -85,6 +85,52 @@ __global__ void small_embed_kernel(const float* __restrict__ table, const int* _
   }
 }
 
+
+// ---- embedding-row gather (nn.Embedding forward, newsEncoders.py:117-118,163,193) with fused dropout.
+// One wave per row: the index is wave-uniform, the row is read as contiguous 16-byte lanes (a 300-float row = 75 float4 =
+// two fully coalesced 1 KiB / 176 B wave accesses).  Pure HBM/L2 streaming: out bytes written once, table rows read once.
+__global__ __launch_bounds__(256) void embed_gather_kernel(const float* __restrict__ table, const int* __restrict__ idx, long n,
+                                                           int dim, float* __restrict__ out, uint32_t seed, uint32_t thr, float scale) {
+  const int lane = threadIdx.x & 63;
+  const int nv = dim >> 2;
+  for (long row = blockIdx.x * 4L + (threadIdx.x >> 6); row < n; row += gridDim.x * 4L) {
+    const int src = idx[row];
+    const f32x4* tp = reinterpret_cast<const f32x4*>(table + (long)src * dim);
+    f32x4* op = reinterpret_cast<f32x4*>(out + row * dim);
+    for (int c = lane; c < nv; c += 64) {
+      f32x4 v = (src >= 0) ? tp[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (thr) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = nnr_keep(seed, (uint64_t)row * dim + 4 * c + e, thr) ? v[e] * scale : 0.f;
+      }
+      __builtin_nontemporal_store(v, op + c);
+    }
+  }
+}
+// backward: dtable[idx[row], :] += mask * dout[row, :]  -- f32 atomics, each wave-instruction = 256 contiguous bytes of one row
+__global__ __launch_bounds__(256) void embed_scatter_kernel(const float* __restrict__ dout, const int* __restrict__ idx, long n, int dim,
+                                                            float* __restrict__ dtable, uint32_t seed, uint32_t thr, float scale) {
+  const int lane = threadIdx.x & 63;
+  for (long row = blockIdx.x * 4L + (threadIdx.x >> 6); row < n; row += gridDim.x * 4L) {
+    const int dst = idx[row];
+    if (dst < 0) continue;
+    for (int c = lane; c < dim; c += 64) {
+      float v = dout[row * dim + c];
+      if (thr) v = nnr_keep(seed, (uint64_t)row * dim + c, thr) ? v * scale : 0.f;
+      atomicAdd(&dtable[(long)dst * dim + c], v);
+    }
+  }
+}
+// ---- out[c, r] = in[r, c]  (weight re-layouts, e.g. Conv1d [C_out*C_in, k] -> [k, C_out*C_in])
+__global__ void transpose2d_kernel(const float* __restrict__ in, float* __restrict__ out, long rows, int cols, int accumulate) {
+  const long total = rows * cols;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long c = i / rows, r = i - c * rows;             // consecutive threads -> consecutive r : coalesced writes
+    const float v = in[r * cols + c];
+    out[i] = accumulate ? out[i] + v : v;
+  }
+}
+
 // ---- generic y (op)= x
 __global__ void add_kernel(float* __restrict__ y, const float* __restrict__ x, long n, float alpha) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] += alpha * x[i];
@@ -396,6 +442,24 @@ extern "C" int nnr_small_embed_bwd(const int* idx, int n, int dim, const float* 
   const float sc = p > 0.f ? 1.f / (1.f - p) : 1.f;
   EW_LAUNCH(small_embed_kernel, (long)n * dim, (const float*)nullptr, idx, n, dim, (float*)nullptr, 0, dtable, dout, lddo, seed,
             nnr_drop_thresh(p), sc);
+}
+
+
+extern "C" int nnr_embed_gather(const float* table, const int* idx, long n, int dim, float* out, float p, uint32_t seed, hipStream_t stream) {
+  if (dim & 3) return NNR_ERR_UNSUPPORTED;
+  const float sc = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  hipLaunchKernelGGL(embed_gather_kernel, dim3(ew_grid(n, 4)), dim3(256), 0, stream, table, idx, n, dim, out, seed, nnr_drop_thresh(p), sc);
+  NNR_CHECK_LAUNCH();
+  return NNR_OK;
+}
+extern "C" int nnr_embed_scatter(const float* dout, const int* idx, long n, int dim, float* dtable, float p, uint32_t seed, hipStream_t stream) {
+  const float sc = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  hipLaunchKernelGGL(embed_scatter_kernel, dim3(ew_grid(n, 4)), dim3(256), 0, stream, dout, idx, n, dim, dtable, seed, nnr_drop_thresh(p), sc);
+  NNR_CHECK_LAUNCH();
+  return NNR_OK;
+}
+extern "C" int nnr_transpose2d(const float* in, float* out, long rows, int cols, int accumulate, hipStream_t stream) {
+  EW_LAUNCH(transpose2d_kernel, rows * cols, in, out, rows, cols, accumulate);
 }
 
 extern "C" int nnr_add(float* y, const float* x, long n, float alpha, hipStream_t stream) { EW_LAUNCH(add_kernel, n, y, x, n, alpha); }

@@ -1,0 +1,212 @@
+"""Autograd building blocks over the C-ABI for the MHSA / CNN / ATT encoders (dense [n, L, F] layouts).
+Parameter gradients are accumulated straight into `param.grad` (see layers.grad_of); the Functions return gradients
+only for activations."""
+import math
+
+import torch
+
+from . import ops
+from .layers import grad_of
+
+
+class EmbedDropFn(torch.autograd.Function):
+    """dropout(word_embedding(ids))  -- nn.Embedding + in-place Dropout (newsEncoders.py:163,193)."""
+
+    @staticmethod
+    def forward(ctx, table, ids, p, seed):
+        idx = ids.reshape(-1)
+        idx = (idx if idx.dtype == torch.int32 else idx.to(torch.int32)).contiguous()
+        out = ops.embed_gather(table, idx, p, seed)
+        ctx.table, ctx.idx, ctx.p, ctx.seed = table, idx, p, seed
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        ops.embed_scatter(dout.contiguous(), ctx.idx, grad_of(ctx.table), ctx.p, ctx.seed)
+        return None, None, None, None
+
+
+class LinearFn(torch.autograd.Function):
+    """y = dropout(act(x W^T + b)) for 2-D contiguous x;  act in {none, relu};  dropout mask keyed by the output element."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act, p, seed):
+        x = x.contiguous()
+        M, K = x.shape
+        N = weight.shape[0]
+        y = torch.empty((M, N), device=x.device, dtype=torch.float32)
+        r = torch.empty((M, N), device=x.device, dtype=torch.float32) if (act == ops.ACT_RELU) else None
+        ops.gemm(x, weight, y, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias, act=act, aux_out=r, ldaux=N, drop=(3, p, seed, N))
+        ctx.x, ctx.weight, ctx.bias, ctx.r, ctx.act, ctx.p, ctx.seed = x, weight, bias, r, act, p, seed
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        if ctx.act == ops.ACT_RELU or ctx.p > 0:
+            dz = torch.empty_like(dy)
+            r = ctx.r if ctx.r is not None else torch.ones_like(dy)
+            ops.relu_drop_bwd(dy, r, dz, None, ctx.p, ctx.seed)
+        else:
+            dz = dy
+        dx = ops.linear_bwd_data(dz, ctx.weight)
+        ops.linear_bwd_weight(dz, ctx.x, grad_of(ctx.weight))
+        if ctx.bias is not None:
+            ops.bias_grad(dz, grad_of(ctx.bias))
+        return dx, None, None, None, None, None
+
+
+class QKVFn(torch.autograd.Function):
+    """[Q | K | V] = x W_{Q,K,V}^T + b  into one [M, 3*h*d] buffer (layers.py:134-136)."""
+
+    @staticmethod
+    def forward(ctx, x, mha):
+        x = x.contiguous()
+        M, K = x.shape
+        HD = mha.W_Q.weight.shape[0]
+        qkv = torch.empty((M, 3 * HD), device=x.device, dtype=torch.float32)
+        for s, lin in enumerate((mha.W_Q, mha.W_K, mha.W_V)):
+            ops.gemm(x, lin.weight, qkv[:, s * HD:], M=M, N=HD, K=K, lda=K, ldb=K, ldc=3 * HD, bias=lin.bias)
+        ctx.x, ctx.mha, ctx.HD = x, mha, HD
+        return qkv
+
+    @staticmethod
+    def backward(ctx, dqkv):
+        dqkv = dqkv.contiguous()
+        x, mha, HD = ctx.x, ctx.mha, ctx.HD
+        M, K = x.shape
+        dx = torch.empty_like(x)
+        for s, lin in enumerate((mha.W_Q, mha.W_K, mha.W_V)):
+            d = dqkv[:, s * HD:]
+            ops.gemm(d, lin.weight, dx, M=M, N=K, K=HD, lda=3 * HD, ldb=K, ldc=K, trans_b=True, accumulate=(s > 0))
+            ops.gemm(d, x, grad_of(lin.weight), M=HD, N=K, K=M, lda=3 * HD, ldb=K, ldc=K, trans_a=True, trans_b=True,
+                     split_k=ops.split_for(HD, K, M), atomic=True)
+            ops.bias_grad(d, grad_of(lin.bias), rows=M)
+        return dx, None
+
+
+class MhsaCoreFn(torch.autograd.Function):
+    """softmax(mask(Q K^T / sqrt(d_k))) V per head on the MFMA kernel (layers.py:137-147)."""
+
+    @staticmethod
+    def forward(ctx, qkv, mask, n, Lq, heads, dh):
+        qkv = qkv.contiguous()
+        out = torch.empty((n * Lq, heads * dh), device=qkv.device, dtype=torch.float32)
+        prob = torch.empty(ops.mhsa_prob_size(n, Lq, heads), device=qkv.device, dtype=torch.float32)
+        ops.mhsa_fwd(qkv, mask, n, Lq, heads, dh, out, prob)
+        ctx.qkv, ctx.prob, ctx.mask, ctx.dims = qkv, prob, mask, (n, Lq, heads, dh)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        n, Lq, heads, dh = ctx.dims
+        dqkv = torch.empty_like(ctx.qkv)
+        ops.mhsa_bwd(ctx.qkv, ctx.mask, ctx.prob, dout.contiguous(), n, Lq, heads, dh, dqkv)
+        return dqkv, None, None, None, None, None
+
+
+class DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        ctx.p, ctx.seed = p, seed
+        return ops.dropout(x.contiguous(), p, seed)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.dropout(dy.contiguous(), ctx.p, ctx.seed), None, None
+
+
+class Conv1dReluFn(torch.autograd.Function):
+    """relu(Conv1d(E -> C, kernel k, 'same' padding)) over [n, L, E] (layers.py:33-35) as k shifted GEMMs:
+    y[(i,t), :] = sum_dt x[(i, t+dt), :] . W[:, :, dt]^T  (rows outside [0, L) read as zero through the row-gather index)."""
+
+    @staticmethod
+    def forward(ctx, x, conv, n, Lx):
+        x = x.contiguous()
+        E = x.shape[1]
+        Cn, _, k = conv.weight.shape
+        pad = (k - 1) // 2
+        dev = x.device
+        wt = torch.empty((k, Cn, E), device=dev, dtype=torch.float32)              # [k][C][E]  (Conv1d stores [C][E][k])
+        ops.transpose2d(conv.weight, wt, Cn * E, k)
+        t = torch.arange(Lx, device=dev, dtype=torch.int32)
+        base = (torch.arange(n, device=dev, dtype=torch.int32) * Lx)[:, None]
+        idxs = []
+        for j in range(k):
+            tt = t + (j - pad)
+            idxs.append(torch.where((tt >= 0) & (tt < Lx), base + tt[None, :], torch.full_like(base + tt[None, :], -1)).reshape(-1).contiguous())
+        M = n * Lx
+        y = torch.empty((M, Cn), device=dev, dtype=torch.float32)
+        for j in range(k):
+            last = j == k - 1
+            ops.gemm(x, wt[j], y, M=M, N=Cn, K=E, lda=E, ldb=E, ldc=Cn, a_idx=idxs[j], accumulate=(2 if j > 0 else 0),
+                     bias=conv.bias if last else None, act=ops.ACT_RELU if last else 0)
+        ctx.x, ctx.conv, ctx.wt, ctx.idxs, ctx.y, ctx.dims = x, conv, wt, idxs, y, (n, Lx, E, Cn, k)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, Lx, E, Cn, k = ctx.dims
+        M = n * Lx
+        dz = ops.relu_bwd(dy.contiguous(), ctx.y)
+        dx = torch.zeros_like(ctx.x)
+        dwt = torch.zeros_like(ctx.wt)
+        for j in range(k):
+            # dx[(i, t+dt)] += dz[(i,t)] . W_dt : scattered to the shifted row (a bijection on valid rows -> plain accumulate)
+            ops.gemm(dz, ctx.wt[j], dx, M=M, N=E, K=Cn, lda=Cn, ldb=E, ldc=E, trans_b=True, c_idx=ctx.idxs[j], accumulate=True)
+            ops.gemm(dz, ctx.x, dwt[j], M=Cn, N=E, K=M, lda=Cn, ldb=E, ldc=E, trans_a=True, trans_b=True, b_idx=ctx.idxs[j],
+                     split_k=ops.split_for(Cn, E, M), atomic=True)
+        ops.transpose2d(dwt, grad_of(ctx.conv.weight), k, Cn * E, accumulate=True)
+        ops.bias_grad(dz, grad_of(ctx.conv.bias))
+        return dx, None, None, None
+
+
+class FuseFn(torch.autograd.Function):
+    """feature_fusion (newsEncoders.py:50-54): [rep | dropout(category row) | dropout(subCategory row)]."""
+
+    @staticmethod
+    def forward(ctx, rep, enc, category, subCategory, p, seed):
+        n, F = rep.shape
+        cd, sd = enc.category_embedding.weight.shape[1], enc.subCategory_embedding.weight.shape[1]
+        D = F + cd + sd
+        out = torch.empty((n, D), device=rep.device, dtype=torch.float32)
+        ops.add2d(out, D, rep.contiguous(), F, n, F)
+        cat = category.reshape(n).to(torch.int32).contiguous()
+        sub = subCategory.reshape(n).to(torch.int32).contiguous()
+        ops.small_embed_fwd(enc.category_embedding.weight, cat, out[:, F:], D, p, seed + 3)
+        ops.small_embed_fwd(enc.subCategory_embedding.weight, sub, out[:, F + cd:], D, p, seed + 4)
+        ctx.enc, ctx.cat, ctx.sub, ctx.dims, ctx.p, ctx.seed = enc, cat, sub, (n, F, cd, sd, D), p, seed
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        n, F, cd, sd, D = ctx.dims
+        dout = dout.contiguous()
+        ops.small_embed_bwd(ctx.cat, cd, dout[:, F:], D, grad_of(ctx.enc.category_embedding.weight), ctx.p, ctx.seed + 3)
+        ops.small_embed_bwd(ctx.sub, sd, dout[:, F + cd:], D, grad_of(ctx.enc.subCategory_embedding.weight), ctx.p, ctx.seed + 4)
+        drep = torch.empty((n, F), device=dout.device, dtype=torch.float32)
+        ops.add2d(drep, F, dout, D, n, F)
+        return drep, None, None, None, None, None
+
+
+class ExpandFn(torch.autograd.Function):
+    """[B, D] -> [B, N, D] (repeat / expand over the candidates, userEncoders.py:172,190); backward sums over N."""
+
+    @staticmethod
+    def forward(ctx, x, N):
+        B, D = x.shape
+        out = torch.empty((B, N, D), device=x.device, dtype=torch.float32)
+        x = x.contiguous()
+        for j in range(N):
+            ops.add2d(out[:, j], N * D, x, D, B, D)
+        ctx.N = N
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, N, D = dout.shape
+        dout = dout.contiguous()
+        dx = torch.empty((B, D), device=dout.device, dtype=torch.float32)
+        for j in range(N):
+            ops.add2d(dx, D, dout[:, j], N * D, B, D, accumulate=(j > 0))
+        return dx, None

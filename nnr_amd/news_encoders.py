@@ -282,3 +282,68 @@ class CNE(NewsEncoder):
     def forward(self, title_text, title_mask, title_entity, content_text, content_mask, content_entity, category, subCategory, user_embedding):
         # title_entity / content_entity / user_embedding are accepted and ignored, as in the reference (newsEncoders.py:102-141)
         return _CNEFunction.apply(self.word_embedding.weight, self, title_text, title_mask, content_text, content_mask, category, subCategory)
+
+
+# ================================================================================================== MHSA / CNN
+class MHSA(NewsEncoder):
+    """newsEncoders.py:173-200: title only; embedding gather -> QKV GEMMs -> MFMA attention core -> dropout ->
+    additive attention pool -> feature fusion."""
+
+    def __init__(self, config, word_table=None):
+        super().__init__(config, word_table)
+        self.max_sentence_length = config.max_title_length
+        self.head_num, self.head_dim = config.head_num, config.head_dim
+        self.feature_dim = config.head_num * config.head_dim
+        self.multiheadAttention = MultiHeadAttention(config.head_num, config.word_embedding_dim, config.max_title_length,
+                                                     config.max_title_length, config.head_dim, config.head_dim)
+        self.attention = Attention(config.head_num * config.head_dim, config.attention_dim)
+        self.news_embedding_dim = config.head_num * config.head_dim + config.category_embedding_dim + config.subCategory_embedding_dim
+
+    def initialize(self):
+        super().initialize()
+        self.multiheadAttention.initialize()
+        self.attention.initialize()
+
+    def forward(self, title_text, title_mask, title_entity, content_text, content_mask, content_entity, category, subCategory, user_embedding):
+        from . import functional as Fn
+        B, N = title_text.shape[:2]
+        n, Lx = B * N, self.max_sentence_length
+        p = self.dropout_rate if self.training else 0.0
+        seed = self._next_seed()
+        mask = title_mask.view(n, Lx)
+        w = Fn.EmbedDropFn.apply(self.word_embedding.weight, title_text, p, seed + 1)                       # [n*L, E]
+        qkv = Fn.QKVFn.apply(w, self.multiheadAttention)
+        c = Fn.MhsaCoreFn.apply(qkv, mask, n, Lx, self.head_num, self.head_dim)                             # [n*L, h*d]
+        c = Fn.DropoutFn.apply(c, p, seed + 2)
+        rep = self.attention(c.view(n, Lx, self.feature_dim), mask)                                         # [n, h*d]
+        return Fn.FuseFn.apply(rep, self, category, subCategory, p, seed).view(B, N, self.news_embedding_dim)
+
+
+class CNN(NewsEncoder):
+    """newsEncoders.py:144-170: title only; embedding gather -> Conv1d(k=3)+ReLU as shifted GEMMs -> dropout_ ->
+    additive attention pool -> feature fusion."""
+
+    def __init__(self, config, word_table=None):
+        super().__init__(config, word_table)
+        self.max_sentence_length = config.max_title_length
+        self.cnn_kernel_num = config.cnn_kernel_num
+        self.conv = Conv1D(config.cnn_method, config.word_embedding_dim, config.cnn_kernel_num, config.cnn_window_size)
+        self.attention = Attention(config.cnn_kernel_num, config.attention_dim)
+        self.news_embedding_dim = config.cnn_kernel_num + config.category_embedding_dim + config.subCategory_embedding_dim
+
+    def initialize(self):
+        super().initialize()
+        self.attention.initialize()
+
+    def forward(self, title_text, title_mask, title_entity, content_text, content_mask, content_entity, category, subCategory, user_embedding):
+        from . import functional as Fn
+        B, N = title_text.shape[:2]
+        n, Lx = B * N, self.max_sentence_length
+        p = self.dropout_rate if self.training else 0.0
+        seed = self._next_seed()
+        mask = title_mask.view(n, Lx)
+        w = Fn.EmbedDropFn.apply(self.word_embedding.weight, title_text, p, seed + 1)
+        c = Fn.Conv1dReluFn.apply(w, self.conv.conv, n, Lx)                                                # [n*L, C]
+        c = Fn.DropoutFn.apply(c, p, seed + 2)
+        rep = self.attention(c.view(n, Lx, self.cnn_kernel_num), mask)
+        return Fn.FuseFn.apply(rep, self, category, subCategory, p, seed).view(B, N, self.news_embedding_dim)

@@ -321,9 +321,38 @@ def clip_adam(p, g, m, v, sumsq_buf, grad_scale, clip, lr, beta1, beta2, eps, wd
 
 
 def mhsa_fwd(qkv, mask, n, Lq, heads, dh, out, prob):
-    L.check(L.lib().nnr_mhsa_fwd(_p(qkv), _p(mask.view(torch.uint8) if mask is not None and mask.dtype == torch.bool else mask), n, Lq,
+    if mask is not None and mask.dtype == torch.bool:
+        mask = mask.view(torch.uint8)
+    L.check(L.lib().nnr_mhsa_fwd(_p(qkv), _p(mask), n, Lq,
                                  heads, dh, C.c_float(1.0 / math.sqrt(dh)), _p(out), _p(prob), _s()), 'nnr_mhsa_fwd')
 
 
-def mhsa_bwd(qkv, prob, dout, n, Lq, heads, dh, dqkv):
-    L.check(L.lib().nnr_mhsa_bwd(_p(qkv), _p(prob), _p(dout), n, Lq, heads, dh, C.c_float(1.0 / math.sqrt(dh)), _p(dqkv), _s()), 'nnr_mhsa_bwd')
+def mhsa_bwd(qkv, mask, prob, dout, n, Lq, heads, dh, dqkv):
+    if mask is not None and mask.dtype == torch.bool:
+        mask = mask.view(torch.uint8)
+    L.check(L.lib().nnr_mhsa_bwd(_p(qkv), _p(mask), _p(prob), _p(dout), n, Lq, heads, dh, C.c_float(1.0 / math.sqrt(dh)), _p(dqkv), _s()),
+            'nnr_mhsa_bwd')
+
+
+def mhsa_prob_size(n, Lq, heads):
+    nb = 2 if Lq > 32 else 1
+    return n * heads * nb * nb * 1024
+
+
+def embed_gather(table, idx, p, seed, out=None):
+    n, dim = idx.numel(), table.shape[1]
+    if out is None:
+        out = torch.empty((n, dim), device=table.device, dtype=torch.float32)
+    L.check(L.lib().nnr_embed_gather(_p(table), _p(idx), C.c_long(n), dim, _p(out), C.c_float(p), C.c_uint32(seed & 0xFFFFFFFF), _s()),
+            'nnr_embed_gather')
+    return out
+
+
+def embed_scatter(dout, idx, dtable, p, seed):
+    n, dim = idx.numel(), dtable.shape[1]
+    L.check(L.lib().nnr_embed_scatter(_p(dout), _p(idx), C.c_long(n), dim, _p(dtable), C.c_float(p), C.c_uint32(seed & 0xFFFFFFFF), _s()),
+            'nnr_embed_scatter')
+
+
+def transpose2d(x, out, rows, cols, accumulate=False):
+    L.check(L.lib().nnr_transpose2d(_p(x), _p(out), C.c_long(rows), cols, int(accumulate), _s()), 'nnr_transpose2d')

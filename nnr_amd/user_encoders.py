@@ -211,3 +211,56 @@ class SUE(UserEncoder):
         cidx = user_history_category_indices.contiguous()
         assert cidx.dtype == torch.int64 and graph.dtype == torch.float32
         return _SUEFunction.apply(history_embedding, candidate_news_representation, self, graph, user_history_category_mask, cidx)
+
+
+class MHSA(UserEncoder):
+    """userEncoders.py:151-173.  Note F.dropout's default p = 0.5 (not dropout_rate) at :171 and the UNMASKED pool at :172."""
+
+    def __init__(self, news_encoder: NewsEncoder, config):
+        super().__init__(news_encoder, config)
+        self.head_num, self.head_dim, self.max_history_num = config.head_num, config.head_dim, config.max_history_num
+        self.multiheadAttention = MultiHeadAttention(config.head_num, self.news_embedding_dim, config.max_history_num,
+                                                     config.max_history_num, config.head_dim, config.head_dim)
+        self.affine = nn.Linear(config.head_num * config.head_dim, self.news_embedding_dim, bias=True)
+        self.attention = Attention(self.news_embedding_dim, config.attention_dim)
+
+    def initialize(self):
+        self.multiheadAttention.initialize()
+        nn.init.xavier_uniform_(self.affine.weight, gain=nn.init.calculate_gain('relu'))
+        nn.init.zeros_(self.affine.bias)
+        self.attention.initialize()
+
+    def forward(self, user_title_text, user_title_mask, user_title_entity, user_content_text, user_content_mask, user_content_entity,
+                user_category, user_subCategory, user_history_mask, user_history_graph, user_history_category_mask,
+                user_history_category_indices, user_embedding, candidate_news_representation):
+        from . import functional as Fn
+        news_num = candidate_news_representation.size(1)
+        history_embedding = self.news_encoder(user_title_text, user_title_mask, user_title_entity, user_content_text, user_content_mask,
+                                              user_content_entity, user_category, user_subCategory, user_embedding)
+        B, Hn, D = history_embedding.shape
+        qkv = Fn.QKVFn.apply(history_embedding.reshape(B * Hn, D), self.multiheadAttention)
+        h = Fn.MhsaCoreFn.apply(qkv, user_history_mask.contiguous(), B, Hn, self.head_num, self.head_dim)
+        # relu(dropout(affine(h))) == dropout(relu(affine(h))): the mask scales by a non-negative factor
+        h = Fn.LinearFn.apply(h, self.affine.weight, self.affine.bias, ops.ACT_RELU, 0.5 if self.training else 0.0, self._next_seed())
+        user = self.attention(h.view(B, Hn, D))                                                            # unmasked
+        return Fn.ExpandFn.apply(user, news_num)
+
+
+class ATT(UserEncoder):
+    """userEncoders.py:176-191: unmasked additive attention over the history slots (padded slots participate)."""
+
+    def __init__(self, news_encoder: NewsEncoder, config):
+        super().__init__(news_encoder, config)
+        self.attention = Attention(self.news_embedding_dim, config.attention_dim)
+
+    def initialize(self):
+        self.attention.initialize()
+
+    def forward(self, user_title_text, user_title_mask, user_title_entity, user_content_text, user_content_mask, user_content_entity,
+                user_category, user_subCategory, user_history_mask, user_history_graph, user_history_category_mask,
+                user_history_category_indices, user_embedding, candidate_news_representation):
+        from . import functional as Fn
+        news_num = candidate_news_representation.size(1)
+        history_embedding = self.news_encoder(user_title_text, user_title_mask, user_title_entity, user_content_text, user_content_mask,
+                                              user_content_entity, user_category, user_subCategory, user_embedding)
+        return Fn.ExpandFn.apply(self.attention(history_embedding), news_num)

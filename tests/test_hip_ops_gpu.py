@@ -422,3 +422,52 @@ def test_elementwise_and_optimizer():
     ops.small_embed_bwd(idx.to(d), 50, drep.to(d)[:, 800:], 900, dt, 0.0, 1)
     ref = torch.zeros(18, 50, dtype=torch.float64).index_add_(0, idx.long(), drep[:, 800:850].double())
     close(dt, ref, what='small embed bwd')
+
+
+# ------------------------------------------------------------------------------------------------ MFMA attention core
+@pytest.mark.parametrize('n,Lq,heads,dh', [(7, 32, 20, 20), (5, 50, 20, 20), (3, 5, 2, 4)])
+def test_mhsa_core_forward_backward(n, Lq, heads, dh):
+    from nnr_amd import ops
+    d = dev()
+    HD = heads * dh
+    qkv = rnd(n * Lq, 3 * HD, seed=1, scale=0.7)
+    mask = torch.rand(n, Lq, generator=torch.Generator().manual_seed(2)) < 0.7
+    mask[0] = False                                   # a fully masked sample: softmax must stay finite (uniform over keys)
+    mask[1] = True
+    x = qkv.double().requires_grad_(True)
+    q, k, v = (x[:, s * HD:(s + 1) * HD].reshape(n, Lq, heads, dh) for s in range(3))
+    s_ = torch.einsum('nqhd,nkhd->nhqk', q, k) / math.sqrt(dh)
+    s_ = torch.where(mask[:, None, None, :], s_, torch.full_like(s_, -1e9))
+    ref = torch.einsum('nhqk,nkhd->nqhd', torch.softmax(s_, 3), v).reshape(n * Lq, HD)
+    dout = rnd(n * Lq, HD, seed=3)
+    (ref * dout.double()).sum().backward()
+    out = torch.empty(n * Lq, HD, device=d)
+    prob = torch.empty(ops.mhsa_prob_size(n, Lq, heads), device=d)
+    qd = qkv.to(d)
+    ops.mhsa_fwd(qd, mask.to(d), n, Lq, heads, dh, out, prob)
+    close(out, ref, what='mhsa out')
+    dqkv = torch.full_like(qd, 3.0)
+    ops.mhsa_bwd(qd, mask.to(d), prob, dout.to(d), n, Lq, heads, dh, dqkv)
+    close(dqkv, x.grad, what='mhsa dqkv')
+
+
+def test_embed_gather_scatter_and_transpose():
+    from nnr_amd import ops
+    d = dev()
+    V, E, n = 500, 300, 3000
+    table = rnd(V, E, seed=1)
+    idx = torch.randint(0, V, (n,), generator=torch.Generator().manual_seed(2)).int()
+    out = ops.embed_gather(table.to(d), idx.to(d), 0.0, 1)
+    close(out, table[idx.long()], tol=0, what='gather')
+    dropped = ops.embed_gather(table.to(d), idx.to(d), 0.25, 9)
+    keep = dropped != 0
+    assert abs(float(keep.float().mean()) - 0.75) < 0.01
+    g = rnd(n, E, seed=3)
+    dt = torch.zeros(V, E, device=d)
+    ops.embed_scatter(g.to(d), idx.to(d), dt, 0.25, 9)
+    ref = torch.zeros(V, E, dtype=torch.float64).index_add_(0, idx.long(), (g.double() * keep.cpu().double() / 0.75))
+    close(dt, ref, what='scatter with the same mask')
+    a = rnd(37, 5, seed=4)
+    o = torch.empty(5, 37, device=d)
+    ops.transpose2d(a.to(d), o, 37, 5)
+    close(o, a.t(), tol=0, what='transpose')

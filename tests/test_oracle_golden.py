@@ -38,7 +38,7 @@ def check_params_after_adam(case, model, steps, tight=5e-5):
     for k, p in model.named_parameters():
         e, a = case.expect_param(steps, k, p)
         g = np.abs(case.expect('grad/' + k)).reshape(e.shape)
-        resolved = g > 1e-3 * max(float(g.max()), 1e-30)
+        resolved = g > 0.05 * max(float(g.max()), 1e-30)
         d = np.abs(a - e)
         assert d[resolved].max(initial=0.0) <= tight, k
         assert d.max(initial=0.0) <= steps * lr * 1.01 + tight, k
