@@ -48,7 +48,9 @@ def cpu_baseline(cfg, spec, batch_size, steps):
     """Time the CPU oracle (oracle/nnr_oracle.py, pinned against the reference by tests/golden) on this box's host cores."""
     from nnr_amd.synth import SynthCorpus, to_torch
     from oracle import nnr_oracle as O
-    cores = os.cpu_count() or 1
+    # The oracle's explicit-time-loop LSTM is thousands of small ops: beyond ~16 threads intra-op parallelism stops helping
+    # (measured on the 256-core bench host: 8 / 16 / 32 threads -> 4.7 / 4.3 / 4.7 s per batch-4 step; 256 threads stall).
+    cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     model = O.Model(cfg)
