@@ -73,7 +73,7 @@ typedef struct nnr_gemm_args {
   float* rowdot_out;        /* [M] */
   int batch;                /* > 1: blockIdx.z batches with the strides below */
   long strideA, strideB, strideC, stride_aux, stride_res;
-  int tile;                 /* 0 auto, 1: 256x80, 2: 64x80, 3: 128x208 */
+  int tile;                 /* 0 auto, 1: 256x80, 2: 64x80, 3: 128x208, 4: 128x80 */
   /* filled by the library */
   uint32_t drop_thresh;
   float drop_scale;
@@ -114,7 +114,8 @@ typedef struct nnr_lstm_problem {
   const float* dh;    /* bwd: dL/dH [rows, 2*H] */
   const float* dcn;   /* bwd: dL/dc_n [n, 2*H] or NULL */
 } nnr_lstm_problem;
-/* up to 2 problems (title + content streams) run in ONE launch */
+/* up to 4 problems (title + content streams of the candidate call and of the history call) run in ONE launch: the
+ * recurrence is bound by its longest dependent chain, so independent streams are free to share it */
 int nnr_lstm_fwd(const nnr_lstm_problem* probs, int nprob, int H, hipStream_t stream);
 int nnr_lstm_bwd(const nnr_lstm_problem* probs, int nprob, int H, hipStream_t stream);
 

@@ -366,13 +366,15 @@ extern "C" int nnr_gemm_f32(const nnr_gemm_args* a, hipStream_t stream) {
   int tile = g.tile;
   if (tile == 0) {
     if (g.rowdot_w) tile = 3;
-    else if (g.M <= 1024) tile = 2;
-    else tile = 1;
+    else if (g.M <= 512) tile = 2;
+    else tile = 4;           // 128 x 80: 117 VGPRs -> 4 waves/SIMD, 4 workgroups per CU hide barriers, prologue and epilogue
+                             // (measured 84-96 TF vs 63-79 TF for the 256 x 80 tile on the CNE shapes)
   }
   switch (tile) {
     case 1: return launch_cfg<4, 5>(g, stream);    // 256 x 80
     case 2: return launch_cfg<1, 5>(g, stream);    //  64 x 80
     case 3: return launch_cfg<2, 13>(g, stream);   // 128 x 208 (whole rows in one wave: fused row-dot)
+    case 4: return launch_cfg<2, 5>(g, stream);    // 128 x 80 (4 waves/SIMD: more workgroups in flight per CU)
     default: return NNR_ERR_ARG;
   }
 }

@@ -20,6 +20,7 @@
 // waves raise their priority with the tile's length: the longest tile is the critical path of the whole launch.
 // The xw buffer is overwritten in place with the activated gates (saved for backward).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -49,7 +50,7 @@ struct LstmProblem {
   const float* dh;     // bwd: upstream dL/dH [rows, 2*H]
   const float* dcn;    // bwd: upstream dL/dc_n [n, 2*H] (sorted order) or null
 };
-struct LstmArgs { LstmProblem p[2]; int nprob; int H; };
+struct LstmArgs { LstmProblem p[4]; int nprob; int H; int dbg; };   // dbg: timing-attribution mask (NNR_LSTM_DBG), 0 in production
 
 // ------------------------------------------------------------------------------------------------ forward
 template <int UB>
@@ -75,6 +76,34 @@ __global__ __launch_bounds__((UB > 4 ? 16 : 4) * 64) void lstm_fwd_kernel(LstmAr
 
   const int ldg = 2 * NP, ldc = 2 * HP, ldh = 2 * H;
   int cur = 0;
+  // W_hh fragments are the same every step: the (kg+1) % KG prefetch wraps around, so the first fragments of the NEXT step
+  // are already in flight while this step's cell update and barrier run.  (OWN == 1 for H = 200: one unit block per wave.)
+  f32x4 bcur[OWN][4];
+#pragma unroll
+  for (int o = 0; o < OWN; ++o) {
+    const int ub = w + NW * o;
+    const f32x4* wf = reinterpret_cast<const f32x4*>(P.wfrag) + ((long)(d * UB + (ub < UB ? ub : 0)) * 4 * KG) * 64 + lane;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bcur[o][g] = wf[(g * KG + 0) * 64];
+  }
+  auto load_x = [&](int step, f32x4 (&x)[OWN][4]) {
+    const int t = d ? (tmax - 1 - step) : step;
+    const int nact = min(16, P.bs[t] - s0);
+    const long row0 = (long)P.off[t] + s0;
+#pragma unroll
+    for (int o = 0; o < OWN; ++o) {
+      const int ub = w + NW * o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = kk * 4 + e;
+        x[o][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ub < UB && row < nact)
+          x[o][e] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(P.gates + (row0 + row) * ldg + d * NP + ub * 64 + r * 4));
+      }
+    }
+  };
+  f32x4 x[OWN][4];
+  load_x(0, x);
   for (int step = 0; step < tmax; ++step) {
     const int t = d ? (tmax - 1 - step) : step;
     const int nact = min(16, P.bs[t] - s0);
@@ -85,35 +114,28 @@ __global__ __launch_bounds__((UB > 4 ? 16 : 4) * 64) void lstm_fwd_kernel(LstmAr
     for (int o = 0; o < OWN; ++o) {
       const int ub = w + NW * o;
       if (ub < UB) {
-        // xw (i,f,g,o of this lane's unit) for 4 rows: consumed after the MFMA loop -> latency hidden
-        f32x4 x[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int row = kk * 4 + e;
-          x[e] = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (row < nact) x[e] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(P.gates + (row0 + row) * ldg + d * NP + ub * 64 + r * 4));
-        }
         f32x4 acc[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
         const f32x4* wf = reinterpret_cast<const f32x4*>(P.wfrag) + ((long)(d * UB + ub) * 4 * KG) * 64 + lane;
-        f32x4 bcur[4], bnxt[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) bcur[g] = wf[(g * KG + 0) * 64];
+        f32x4 bnxt[4];
+        if (!(a.dbg & 4))
 #pragma unroll
         for (int kg = 0; kg < KG; ++kg) {
-          if (kg + 1 < KG) {
+          const int kn = (kg + 1 < KG) ? kg + 1 : 0;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) bnxt[g] = wf[(g * KG + kg + 1) * 64];
-          }
+          for (int g = 0; g < 4; ++g) bnxt[g] = wf[(g * KG + kn) * 64];
+          // keep the prefetch where it is: hipcc otherwise sinks these loads next to their first use (one k-group
+          // later), exposing an L2 round trip per fragment on the critical path of the recurrence
+          __builtin_amdgcn_sched_barrier(0);
           const f32x4 af = *reinterpret_cast<const f32x4*>(&hc[r * HP + kg * 16 + 4 * (kk ^ swz16(r))]);
 #pragma unroll
           for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
-              acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bcur[g][i], acc[g], 0, 0, 0);
+              acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bcur[o][g][i], acc[g], 0, 0, 0);
 #pragma unroll
-          for (int g = 0; g < 4; ++g) bcur[g] = bnxt[g];
+          for (int g = 0; g < 4; ++g) bcur[o][g] = bnxt[g];
         }
         // lane-local cell update: lane holds (row = kk*4+e, unit = ub*16 + r)
         const int unit = ub * 16 + r;
@@ -121,22 +143,27 @@ __global__ __launch_bounds__((UB > 4 ? 16 : 4) * 64) void lstm_fwd_kernel(LstmAr
         for (int e = 0; e < 4; ++e) {
           const int row = kk * 4 + e;
           if (row < nact) {
-            const float gi = sigmoidf_(acc[0][e] + x[e][0]);
-            const float gf = sigmoidf_(acc[1][e] + x[e][1]);
-            const float gg = tanhf(acc[2][e] + x[e][2]);
-            const float go = sigmoidf_(acc[3][e] + x[e][3]);
+            const float gi = fast_sigmoid(acc[0][e] + x[o][e][0]);
+            const float gf = fast_sigmoid(acc[1][e] + x[o][e][1]);
+            const float gg = fast_tanh(acc[2][e] + x[o][e][2]);
+            const float go = fast_sigmoid(acc[3][e] + x[o][e][3]);
             const float cn = gf * c[o][e] + gi * gg;
-            const float hv = go * tanhf(cn);
+            const float hv = go * fast_tanh(cn);
             c[o][e] = cn;
-            __builtin_nontemporal_store(f32x4{gi, gf, gg, go}, reinterpret_cast<f32x4*>(P.gates + (row0 + row) * ldg + d * NP + ub * 64 + r * 4));
-            __builtin_nontemporal_store(cn, P.cell + (row0 + row) * ldc + d * HP + unit);
+            if (!(a.dbg & 1)) {
+            // plain (write-back) stores: they retire from the in-order vmcnt queue at L2, so the next step's W_hh
+            // fragment loads do not wait behind an HBM write (non-temporal stores cost +1.4 us per step here)
+            *reinterpret_cast<f32x4*>(P.gates + (row0 + row) * ldg + d * NP + ub * 64 + r * 4) = f32x4{gi, gf, gg, go};
+            P.cell[(row0 + row) * ldc + d * HP + unit] = cn;
             if (unit < H) P.hout[(row0 + row) * ldh + d * H + unit] = hv;
+            }
             hn[lds_off(row, unit, HP)] = hv;
           }
         }
       }
     }
-    __syncthreads();
+    if (step + 1 < tmax && !(a.dbg & 2)) load_x(step + 1, x);       // in flight across the barrier and the next step's MFMA loop
+    if (!(a.dbg & 8)) __syncthreads();
     cur ^= 1;
   }
   // final cell state (forward: after t = len-1, reverse: after t = 0) -- rows keep c once they go inactive
@@ -167,7 +194,8 @@ __global__ __launch_bounds__((UB > 4 ? 16 : 4) * 64) void lstm_bwd_kernel(LstmAr
   if (s0 >= P.n) return;
   const int d = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, kk = lane >> 4;
-  __shared__ __attribute__((aligned(16))) float dg[16 * NP];
+  constexpr int DLD = NP + 16;             // row stride = 4 (mod 16) 16-byte chunks: the swizzle needs it (NP alone is 0 mod 16)
+  __shared__ __attribute__((aligned(16))) float dg[16 * DLD];
   const int tmax = P.slen[s0];
   set_prio_by_length(tmax);
   int mylen[4];
@@ -216,6 +244,17 @@ __global__ __launch_bounds__((UB > 4 ? 16 : 4) * 64) void lstm_bwd_kernel(LstmAr
     }
   };
   load_inputs(0);
+  constexpr int PF = 4;
+  static_assert(KGB % PF == 0, "prefetch ring must divide the fragment count");
+  f32x4 ring[OWN][PF];
+#pragma unroll
+  for (int o = 0; o < OWN; ++o) {
+    const int ub = w + NW * o;
+#pragma unroll
+    for (int j = 0; j < PF; ++j)
+      ring[o][j] = (ub < UB) ? (reinterpret_cast<const f32x4*>(P.wfrag) + (long)d * UB * KGB * 64 + lane)[((long)ub * KGB + j) * 64]
+                             : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
   for (int step = 0; step < tmax; ++step) {
     const int t = d ? step : (tmax - 1 - step);          // reverse of the forward pass's order
@@ -240,16 +279,16 @@ __global__ __launch_bounds__((UB > 4 ? 16 : 4) * 64) void lstm_bwd_kernel(LstmAr
             // first step of this row's backward = last step of its forward: add dL/dc_n
             const bool last_fwd_step = d ? (t == 0) : (t == mylen[e] - 1);
             if (last_fwd_step && P.dcn && unit < H) dc += P.dcn[(long)(s0 + row) * ldh + d * H + unit];
-            const float tc = tanhf(ct);
+            const float tc = fast_tanh(ct);
             dgv[3] = dh * tc * go * (1.f - go);
             dc += dh * go * (1.f - tc * tc);
             dgv[0] = dc * gg * gi * (1.f - gi);
             dgv[1] = dc * cp * gf * (1.f - gf);
             dgv[2] = dc * gi * (1.f - gg * gg);
             dcr[o][e] = dc * gf;
-            __builtin_nontemporal_store(dgv, reinterpret_cast<f32x4*>(P.gates + grow * ldg + d * NP + ub * 64 + r * 4));
+            *reinterpret_cast<f32x4*>(P.gates + grow * ldg + d * NP + ub * 64 + r * 4) = dgv;
           }
-          *reinterpret_cast<f32x4*>(&dg[lds_off(row, ub * 64 + r * 4, NP)]) = dgv;
+          *reinterpret_cast<f32x4*>(&dg[lds_off(row, ub * 64 + r * 4, DLD)]) = dgv;
         }
       }
     }
@@ -261,30 +300,21 @@ __global__ __launch_bounds__((UB > 4 ? 16 : 4) * 64) void lstm_bwd_kernel(LstmAr
 #pragma unroll
       for (int o = 0; o < OWN; ++o) acc[o] = f32x4{0.f, 0.f, 0.f, 0.f};
       const f32x4* wb = reinterpret_cast<const f32x4*>(P.wfrag) + (long)d * UB * KGB * 64 + lane;
-      f32x4 bcur[OWN], bnxt[OWN];
-#pragma unroll
-      for (int o = 0; o < OWN; ++o) {
-        const int ub = w + NW * o;
-        bcur[o] = (ub < UB) ? wb[((long)ub * KGB + 0) * 64] : f32x4{0.f, 0.f, 0.f, 0.f};
-        bnxt[o] = bcur[o];
-      }
-#pragma unroll 2
+      // ring of PF fragments in flight: one fragment feeds only 4 MFMAs (128 cycles) here, far less than an L2 round trip
+#pragma unroll 4
       for (int kg = 0; kg < KGB; ++kg) {
-        if (kg + 1 < KGB) {
+        const int kn = (kg + PF < KGB) ? kg + PF : kg + PF - KGB;     // wraps into the next step
+        const f32x4 af = *reinterpret_cast<const f32x4*>(&dg[r * DLD + kg * 16 + 4 * (kk ^ swz16(r))]);
 #pragma unroll
-          for (int o = 0; o < OWN; ++o) {
-            const int ub = w + NW * o;
-            if (ub < UB) bnxt[o] = wb[((long)ub * KGB + kg + 1) * 64];
+        for (int o = 0; o < OWN; ++o) {
+          if (w + NW * o < UB) {
+            const f32x4 b = ring[o][kg % PF];
+            ring[o][kg % PF] = wb[((long)(w + NW * o) * KGB + kn) * 64];
+            __builtin_amdgcn_sched_barrier(0);      // pin the refill ahead of the MFMAs (see the forward kernel)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[o] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], b[i], acc[o], 0, 0, 0);
           }
         }
-        const f32x4 af = *reinterpret_cast<const f32x4*>(&dg[r * NP + kg * 16 + 4 * (kk ^ swz16(r))]);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int o = 0; o < OWN; ++o)
-            if (w + NW * o < UB) acc[o] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bcur[o][i], acc[o], 0, 0, 0);
-#pragma unroll
-        for (int o = 0; o < OWN; ++o) bcur[o] = bnxt[o];
       }
 #pragma unroll
       for (int o = 0; o < OWN; ++o)
@@ -420,12 +450,13 @@ extern "C" int nnr_lstm_unpack_grads(const float* dw_ihp, const float* db_p, con
 }
 
 static int lstm_run(const nnr_lstm_problem* probs, int nprob, int H, bool backward, hipStream_t stream) {
-  if (!probs || nprob < 1 || nprob > 2) return NNR_ERR_ARG;
+  if (!probs || nprob < 1 || nprob > 4) return NNR_ERR_ARG;
   int UB;
   if (nnr_lstm_dims(H, &UB, nullptr, nullptr) != NNR_OK) return NNR_ERR_UNSUPPORTED;
   LstmArgs a;
   a.nprob = nprob;
   a.H = H;
+  { const char* e = getenv("NNR_LSTM_DBG"); a.dbg = e ? atoi(e) : 0; }
   int max_tiles = 0;
   for (int i = 0; i < nprob; ++i) {
     const nnr_lstm_problem& q = probs[i];
@@ -439,7 +470,7 @@ static int lstm_run(const nnr_lstm_problem* probs, int nprob, int H, bool backwa
     if (backward ? (!p.dh || !p.prev_f || !p.prev_r) : (!p.hout || !p.cn)) return NNR_ERR_ARG;
     max_tiles = max(max_tiles, (p.n + 15) / 16);
   }
-  if (nprob == 1) a.p[1] = a.p[0];
+  for (int i = nprob; i < 4; ++i) a.p[i] = a.p[0];
   switch (UB) {
     case 1: return launch_rec<1>(a, backward, max_tiles, stream);
     case 2: return launch_rec<2>(a, backward, max_tiles, stream);

@@ -10,6 +10,11 @@ import torch.nn as nn
 from . import ops
 
 
+# Bumped by every optimizer step that updates parameters through raw pointers (nnr_amd.trainer): derived weight layouts
+# (e.g. the packed LSTM fragments) are cached against it, together with torch's own version counters.
+PARAM_EPOCH = [0]
+
+
 def grad_of(p):
     """`p.grad`, created zero-filled on first use.  The hand-written backward passes ACCUMULATE into it (the news
     encoder runs twice per step), exactly like autograd's AccumulateGrad; the trainer zeroes the flat gradient buffer."""

@@ -88,10 +88,20 @@ class Model(nn.Module):
                 user_history_category_indices, news_category, news_subCategory, news_title_text, news_title_mask, news_title_entity,
                 news_content_text, news_content_mask, news_content_entity):
         user_embedding = None
-        news_representation = self.news_encoder(news_title_text, news_title_mask, news_title_entity, news_content_text, news_content_mask,
-                                                news_content_entity, news_category, news_subCategory, user_embedding)
-        user_representation = self.user_encoder(user_title_text, user_title_mask, user_title_entity, user_content_text, user_content_mask,
-                                                user_content_entity, user_category, user_subCategory, user_history_mask,
-                                                user_history_graph, user_history_category_mask, user_history_category_indices,
-                                                user_embedding, news_representation)
+        if hasattr(self.news_encoder, 'forward_pair'):
+            # same arithmetic as the two encoder calls of model.py:123-125, issued in lock-step so that launch-latency-bound
+            # stages (the Bi-LSTM recurrences) of the candidate call and of the history call share one launch
+            news_representation, history_embedding = self.news_encoder.forward_pair(
+                (news_title_text, news_title_mask, news_content_text, news_content_mask, news_category, news_subCategory),
+                (user_title_text, user_title_mask, user_content_text, user_content_mask, user_category, user_subCategory))
+            user_representation = self.user_encoder.encode_user(history_embedding, user_history_mask, user_history_graph,
+                                                                user_history_category_mask, user_history_category_indices,
+                                                                news_representation)
+        else:
+            news_representation = self.news_encoder(news_title_text, news_title_mask, news_title_entity, news_content_text, news_content_mask,
+                                                    news_content_entity, news_category, news_subCategory, user_embedding)
+            user_representation = self.user_encoder(user_title_text, user_title_mask, user_title_entity, user_content_text, user_content_mask,
+                                                    user_content_entity, user_category, user_subCategory, user_history_mask,
+                                                    user_history_graph, user_history_category_mask, user_history_category_indices,
+                                                    user_embedding, news_representation)
         return _DotProductFn.apply(user_representation, news_representation)

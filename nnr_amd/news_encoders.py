@@ -24,7 +24,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .layers import Attention, ScaledDotProduct_CandidateAttention, MultiHeadAttention, Conv1D, LSTMParams, grad_of
+from .layers import Attention, ScaledDotProduct_CandidateAttention, MultiHeadAttention, Conv1D, LSTMParams, grad_of, PARAM_EPOCH
 
 _SITE = dict(title=1, content=2, cat=3, sub=4)
 
@@ -69,6 +69,23 @@ def _i32(t):
 
 
 # ================================================================================================== CNE
+class _CNEPairFunction(torch.autograd.Function):
+    """Candidate call + history call of the SAME encoder in lock-step (one recurrence launch forward, one backward)."""
+
+    @staticmethod
+    def forward(ctx, anchor, mod, *tensors):
+        (rep_a, sv_a), (rep_b, sv_b) = cne_forward_many(mod, [tensors[:6], tensors[6:]])
+        ctx.mod, ctx.saved = mod, (sv_a, sv_b)
+        return rep_a, rep_b
+
+    @staticmethod
+    def backward(ctx, drep_a, drep_b):
+        sv_a, sv_b = ctx.saved
+        cne_backward_many(ctx.mod, [(sv_a, drep_a.contiguous()), (sv_b, drep_b.contiguous())])
+        ctx.saved = None
+        return (None,) * 14
+
+
 class _CNEFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, mod, title_text, title_mask, content_text, content_mask, category, subCategory):
@@ -84,12 +101,29 @@ class _CNEFunction(torch.autograd.Function):
 
 
 def cne_forward(mod, title_text, title_mask, content_text, content_mask, category, subCategory):
+    """Single encoder call (plugin API).  Model.forward uses cne_forward_many to share the recurrence launch between the
+    candidate call and the history call."""
+    (rep, saved), = cne_forward_many(mod, [(title_text, title_mask, content_text, content_mask, category, subCategory)])
+    return rep, saved
+
+
+def cne_forward_many(mod, calls):
+    """Run several independent CNE calls in lock-step: everything is per call except the Bi-LSTM recurrence, which is ONE
+    launch over all streams of all calls (it is latency-bound by its longest sequence, not throughput-bound)."""
+    H = mod.hidden_dim
+    pre = [_cne_fwd_pre(mod, *c) for c in calls]
+    items = [st for sv in pre for st in (sv['streams'][1],)] + [st for sv in pre for st in (sv['streams'][0],)]   # content streams first
+    for i in range(0, len(items), 4):
+        ops.lstm_fwd(items[i:i + 4], H)
+    return [_cne_fwd_post(mod, sv) for sv in pre]
+
+
+def _cne_fwd_pre(mod, title_text, title_mask, content_text, content_mask, category, subCategory):
     B, N = title_text.shape[:2]
     n = B * N
     dev = title_text.device
     H, E, A = mod.hidden_dim, mod.word_embedding_dim, mod.attention_dim
     H2 = 2 * H
-    D = mod.news_embedding_dim
     f32 = dict(device=dev, dtype=torch.float32)
     p = mod.dropout_rate if mod.training else 0.0
     seed = mod._next_seed()
@@ -108,7 +142,7 @@ def cne_forward(mod, title_text, title_mask, content_text, content_mask, categor
             lens = mask2.sum(dim=1).long() + (~mask2[:, 0]).long()      # lengths after the mask[:,0]=1 fix
             perm = torch.sort(lens.cpu(), descending=True)[1].to(torch.int32).to(dev)
         plan = ops.SeqPlan(mask2, ids2, perm)
-        w = ops.LstmPacked(lstm.param_list(), H, E)
+        w = mod._packed_weights(name, lstm)
         cap = plan.cap
         st = dict(name=name, L=Lx, plan=plan, w=w, lstm=lstm, Hlin=Hlin, Mlin=Mlin, satt=satt, catt=catt, seed=seed + _SITE[name])
         st['gates'] = torch.empty((cap, 2 * w.NP), **f32)
@@ -118,8 +152,17 @@ def cne_forward(mod, title_text, title_mask, content_text, content_mask, categor
         st['hout'] = torch.empty((cap, H2), **f32)
         st['cn'] = torch.empty((n, H2), **f32)
         streams.append(st)
-    t_, c_ = streams
-    ops.lstm_fwd([c_, t_], H)                            # content first: longest tiles are dispatched first
+    return dict(streams=streams, n=n, B=B, N=N, p=p, seed=seed, category=category, subCategory=subCategory)
+
+
+def _cne_fwd_post(mod, sv):
+    t_, c_ = sv['streams']
+    n, B, N, p, seed = sv['n'], sv['B'], sv['N'], sv['p'], sv['seed']
+    dev = t_['gates'].device
+    H, E, A = mod.hidden_dim, mod.word_embedding_dim, mod.attention_dim
+    H2 = 2 * H
+    D = mod.news_embedding_dim
+    f32 = dict(device=dev, dtype=torch.float32)
 
     for st, other in ((t_, c_), (c_, t_)):
         plan, cap = st['plan'], st['plan'].cap
@@ -150,18 +193,34 @@ def cne_forward(mod, title_text, title_mask, content_text, content_mask, categor
         st['alpha_c'] = torch.empty(plan.cap, **f32)
         ops.pool_fwd(x=st['Ht'], ldx=H2, D=H2, n=n, Lx=st['L'], plan=plan, v=st['v'], ldv=H2, scale=1.0 / math.sqrt(A),
                      alpha=st['alpha_c'], out=rep[:, col0:], ldo=D, add_in=st['selfv'], ldadd=H2)
-    cat = _i32(category).reshape(n).contiguous()
-    sub = _i32(subCategory).reshape(n).contiguous()
+    cat = _i32(sv.pop('category')).reshape(n).contiguous()
+    sub = _i32(sv.pop('subCategory')).reshape(n).contiguous()
     cd, sd = mod.category_embedding.weight.shape[1], mod.subCategory_embedding.weight.shape[1]
     ops.small_embed_fwd(mod.category_embedding.weight, cat, rep[:, 2 * H2:], D, p, seed + _SITE['cat'])
     ops.small_embed_fwd(mod.subCategory_embedding.weight, sub, rep[:, 2 * H2 + cd:], D, p, seed + _SITE['sub'])
-    saved = dict(streams=streams, n=n, B=B, N=N, p=p, seed=seed, cat=cat, sub=sub, cd=cd, sd=sd)
-    for st in streams:                                   # not needed by backward
+    sv.update(cat=cat, sub=sub, cd=cd, sd=sd)
+    for st in sv['streams']:                             # not needed by backward
         st.pop('score'); st.pop('mproj')
-    return rep.view(B, N, D), saved
+    return rep.view(B, N, D), sv
 
 
 def cne_backward(mod, sv, drep):
+    cne_backward_many(mod, [(sv, drep)])
+
+
+def cne_backward_many(mod, pairs):
+    """Backward of cne_forward_many: per-call stages around ONE shared recurrence-backward launch."""
+    H = mod.hidden_dim
+    for sv, drep in pairs:
+        _cne_bwd_pre(mod, sv, drep)
+    items = [sv['streams'][1] for sv, _ in pairs] + [sv['streams'][0] for sv, _ in pairs]
+    for i in range(0, len(items), 4):
+        ops.lstm_bwd(items[i:i + 4], H)
+    for sv, _ in pairs:
+        _cne_bwd_post(mod, sv)
+
+
+def _cne_bwd_pre(mod, sv, drep):
     t_, c_ = sv['streams']
     n, p, seed = sv['n'], sv['p'], sv['seed']
     H, E, A = mod.hidden_dim, mod.word_embedding_dim, mod.attention_dim
@@ -215,10 +274,17 @@ def cne_backward(mod, sv, drep):
         other['dcn'] = ops.linear_bwd_data(dP, st['Mlin'].weight)                             # [n, H2], rank-indexed
         st['dHt'] = None
 
-    # ---- recurrence backward (both streams, one launch), then the token-reduction GEMMs
     for st in (t_, c_):
         st['dh'] = st['dH']
-    ops.lstm_bwd([c_, t_], H)
+
+
+def _cne_bwd_post(mod, sv):
+    t_, c_ = sv['streams']
+    p = sv['p']
+    H, E = mod.hidden_dim, mod.word_embedding_dim
+    H2 = 2 * H
+    f32 = dict(device=t_['gates'].device, dtype=torch.float32)
+    emb = mod.word_embedding.weight
     for st in (t_, c_):
         plan, w, cap = st['plan'], st['w'], st['plan'].cap
         dg = st['gates']                                  # now d(pre-activation gates), p-order
@@ -279,9 +345,26 @@ class CNE(NewsEncoder):
         self.title_cross_attention.initialize()
         self.content_cross_attention.initialize()
 
+    def _packed_weights(self, name, lstm):
+        """nn.LSTM parameters in the recurrent kernels' layouts, re-packed when the parameters change (once per optimizer
+        step: both encoder calls of a step share them)."""
+        cache = self.__dict__.setdefault('_pack_cache', {})
+        key = (PARAM_EPOCH[0],) + tuple((q.data_ptr(), q._version) for q in lstm.param_list())
+        hit = cache.get(name)
+        if hit is None or hit[0] != key:
+            hit = (key, ops.LstmPacked(lstm.param_list(), self.hidden_dim, self.word_embedding_dim))
+            cache[name] = hit
+        return hit[1]
+
     def forward(self, title_text, title_mask, title_entity, content_text, content_mask, content_entity, category, subCategory, user_embedding):
         # title_entity / content_entity / user_embedding are accepted and ignored, as in the reference (newsEncoders.py:102-141)
         return _CNEFunction.apply(self.word_embedding.weight, self, title_text, title_mask, content_text, content_mask, category, subCategory)
+
+    def forward_pair(self, cand, hist):
+        """(candidate call, history call) -> (candidate reps, history reps); same results as two forward() calls, with the
+        two calls' Bi-LSTM recurrences sharing one launch.  cand / hist = (title_text, title_mask, content_text, content_mask,
+        category, subCategory)."""
+        return _CNEPairFunction.apply(self.word_embedding.weight, self, *cand, *hist)
 
 
 # ================================================================================================== MHSA / CNN

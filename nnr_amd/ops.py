@@ -23,7 +23,7 @@ def _s():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def split_for(m, n, k, tile_m=256, tile_n=80, target_blocks=768, kmin=256):
+def split_for(m, n, k, tile_m=128, tile_n=80, target_blocks=2048, kmin=256):
     """split-K factor for the token-reduction (weight-gradient) GEMMs: enough blocks to fill 256 CUs x ~3."""
     tiles = max(1, ((m + tile_m - 1) // tile_m) * ((n + tile_n - 1) // tile_n))
     return int(max(1, min((k + kmin - 1) // kmin, (target_blocks + tiles - 1) // tiles)))
@@ -52,8 +52,8 @@ def gemm(A, B, C_=None, *, M, N, K, lda, ldb, ldc=0, trans_a=False, trans_b=Fals
     if not _prof.active():
         L.check(L.lib().nnr_gemm_f32(C.byref(g), _s()), 'nnr_gemm_f32')
         return
-    t = tile if tile else (3 if rowdot_w is not None else (2 if M <= 1024 else 1))
-    fam = 'gemm_%s_%s' % ('tn' if trans_a else ('nn' if trans_b else 'nt'), {1: '256x80', 2: '64x80', 3: '128x208'}[t])
+    t = tile if tile else (3 if rowdot_w is not None else (2 if M <= 512 else 4))
+    fam = 'gemm_%s_%s' % ('tn' if trans_a else ('nn' if trans_b else 'nt'), {1: '256x80', 2: '64x80', 3: '128x208', 4: '128x80'}[t])
 
     def flops(M=M, N=N, K=K, dyn=dyn, dyn_dim=dyn_dim, batch=batch):
         m, k = M, K

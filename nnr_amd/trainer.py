@@ -6,6 +6,7 @@ import torch
 import torch.nn as nn
 
 from . import dp, ops
+from .layers import PARAM_EPOCH
 from .model import negative_log_softmax
 
 
@@ -65,6 +66,7 @@ class Trainer:
         ops.sumsq(self.flat.grad, self.sumsq)
         ops.clip_adam(self.flat.flat, self.flat.grad, self.m, self.v, self.sumsq, grad_scale, self.gradient_clip_norm, self.lr, 0.9, 0.999,
                       1e-8, self.weight_decay, self.step_count)
+        PARAM_EPOCH[0] += 1           # parameters changed behind torch's back: invalidate cached weight layouts
 
     def grad_total_norm(self, grad_scale=1.0):
         s = torch.zeros(1, device=self.flat.grad.device, dtype=torch.float32)

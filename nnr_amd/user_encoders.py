@@ -204,14 +204,19 @@ class SUE(UserEncoder):
     def forward(self, user_title_text, user_title_mask, user_title_entity, user_content_text, user_content_mask, user_content_entity,
                 user_category, user_subCategory, user_history_mask, user_history_graph, user_history_category_mask,
                 user_history_category_indices, user_embedding, candidate_news_representation):
-        user_history_category_mask[:, -1] = 1            # in place on the caller's tensor (userEncoders.py:73)
         history_embedding = self.news_encoder(user_title_text, user_title_mask, user_title_entity, user_content_text, user_content_mask,
                                               user_content_entity, user_category, user_subCategory, user_embedding)
+        return self.encode_user(history_embedding, user_history_mask, user_history_graph, user_history_category_mask,
+                                user_history_category_indices, candidate_news_representation)
+
+    def encode_user(self, history_embedding, user_history_mask, user_history_graph, user_history_category_mask,
+                    user_history_category_indices, candidate_news_representation):
+        """Everything of forward() after the history news have been encoded (userEncoders.py:73-75, 79-98)."""
+        user_history_category_mask[:, -1] = 1            # in place on the caller's tensor (userEncoders.py:73)
         graph = user_history_graph.contiguous()
         cidx = user_history_category_indices.contiguous()
         assert cidx.dtype == torch.int64 and graph.dtype == torch.float32
         return _SUEFunction.apply(history_embedding, candidate_news_representation, self, graph, user_history_category_mask, cidx)
-
 
 class MHSA(UserEncoder):
     """userEncoders.py:151-173.  Note F.dropout's default p = 0.5 (not dropout_rate) at :171 and the UNMASKED pool at :172."""
@@ -233,10 +238,15 @@ class MHSA(UserEncoder):
     def forward(self, user_title_text, user_title_mask, user_title_entity, user_content_text, user_content_mask, user_content_entity,
                 user_category, user_subCategory, user_history_mask, user_history_graph, user_history_category_mask,
                 user_history_category_indices, user_embedding, candidate_news_representation):
-        from . import functional as Fn
-        news_num = candidate_news_representation.size(1)
         history_embedding = self.news_encoder(user_title_text, user_title_mask, user_title_entity, user_content_text, user_content_mask,
                                               user_content_entity, user_category, user_subCategory, user_embedding)
+        return self.encode_user(history_embedding, user_history_mask, user_history_graph, user_history_category_mask,
+                                user_history_category_indices, candidate_news_representation)
+
+    def encode_user(self, history_embedding, user_history_mask, user_history_graph, user_history_category_mask,
+                    user_history_category_indices, candidate_news_representation):
+        from . import functional as Fn
+        news_num = candidate_news_representation.size(1)
         B, Hn, D = history_embedding.shape
         qkv = Fn.QKVFn.apply(history_embedding.reshape(B * Hn, D), self.multiheadAttention)
         h = Fn.MhsaCoreFn.apply(qkv, user_history_mask.contiguous(), B, Hn, self.head_num, self.head_dim)
@@ -244,7 +254,6 @@ class MHSA(UserEncoder):
         h = Fn.LinearFn.apply(h, self.affine.weight, self.affine.bias, ops.ACT_RELU, 0.5 if self.training else 0.0, self._next_seed())
         user = self.attention(h.view(B, Hn, D))                                                            # unmasked
         return Fn.ExpandFn.apply(user, news_num)
-
 
 class ATT(UserEncoder):
     """userEncoders.py:176-191: unmasked additive attention over the history slots (padded slots participate)."""
@@ -259,8 +268,12 @@ class ATT(UserEncoder):
     def forward(self, user_title_text, user_title_mask, user_title_entity, user_content_text, user_content_mask, user_content_entity,
                 user_category, user_subCategory, user_history_mask, user_history_graph, user_history_category_mask,
                 user_history_category_indices, user_embedding, candidate_news_representation):
-        from . import functional as Fn
-        news_num = candidate_news_representation.size(1)
         history_embedding = self.news_encoder(user_title_text, user_title_mask, user_title_entity, user_content_text, user_content_mask,
                                               user_content_entity, user_category, user_subCategory, user_embedding)
-        return Fn.ExpandFn.apply(self.attention(history_embedding), news_num)
+        return self.encode_user(history_embedding, user_history_mask, user_history_graph, user_history_category_mask,
+                                user_history_category_indices, candidate_news_representation)
+
+    def encode_user(self, history_embedding, user_history_mask, user_history_graph, user_history_category_mask,
+                    user_history_category_indices, candidate_news_representation):
+        from . import functional as Fn
+        return Fn.ExpandFn.apply(self.attention(history_embedding), candidate_news_representation.size(1))

@@ -42,8 +42,25 @@ def test_model_matches_reference_golden(tag):
     trainer = Trainer(model, cfg)
     steps = int(case.meta['adam_steps'])
     rec = {}
-    model.news_encoder.register_forward_hook(lambda m, i, o: rec.setdefault('reps', []).append(o.detach().cpu().numpy()))
-    model.user_encoder.register_forward_hook(lambda m, i, o: rec.__setitem__('user', o.detach().cpu().numpy()))
+    ne = model.news_encoder
+    if hasattr(ne, 'forward_pair'):                   # Model.forward drives CNE through the lock-step pair entry
+        orig_pair = ne.forward_pair
+
+        def recording_pair(c, h):
+            a, b = orig_pair(c, h)
+            rec['reps'] = [a.detach().cpu().numpy(), b.detach().cpu().numpy()]
+            return a, b
+        ne.forward_pair = recording_pair
+    else:
+        ne.register_forward_hook(lambda m, i, o: rec.setdefault('reps', []).append(o.detach().cpu().numpy()))
+    ue = model.user_encoder
+    orig_enc = ue.encode_user
+
+    def recording_enc(*a):
+        o = orig_enc(*a)
+        rec['user'] = o.detach().cpu().numpy()
+        return o
+    ue.encode_user = recording_enc
     report = []
     for s in range(steps):
         batch = case.batch('cuda')
@@ -96,3 +113,19 @@ def test_missing_library_fails_loudly(monkeypatch):
     from nnr_amd import ops, _lib
     with pytest.raises(_lib.NnrHipError):
         ops.add_(torch.zeros(4), torch.zeros(4))
+
+
+@pytest.mark.parametrize('tag', ['tiny_CNE_SUE_stable', 'full_CNE_SUE_g1p0_stable'])
+def test_plugin_calls_equal_lockstep_path(tag):
+    """The reference's plugin surface (news_encoder(...) then user_encoder(...), model.py:123-125) must give exactly what
+    Model.forward's lock-step path gives (same kernels, only the recurrence launches are shared)."""
+    case = GoldenCase(tag)
+    model, cfg = _build(case)
+    b = case.batch('cuda')
+    logits = model(*b).detach()
+    b = case.batch('cuda')
+    (uid, ucat, usub, utt, utm, ute, uct, ucm, uce, uhm, ug, ucmask, ucidx, ncat, nsub, ntt, ntm, nte, nct, ncm, nce) = b
+    cand = model.news_encoder(ntt, ntm, nte, nct, ncm, nce, ncat, nsub, None)
+    user = model.user_encoder(utt, utm, ute, uct, ucm, uce, ucat, usub, uhm, ug, ucmask, ucidx, None, cand)
+    plug = (user * cand).sum(dim=2)
+    assert float((plug - logits).abs().max()) <= 1e-6

@@ -21,7 +21,29 @@ def timeit(fn, iters=10):
     return s.elapsed_time(e) / iters
 
 
+def tiles():
+    M, E, NP2 = 131072, 300, 1664
+    x = torch.randn(M, E, device=d); w = torch.randn(NP2, E, device=d) * 0.05; out = torch.empty(M, NP2, device=d)
+    dg = torch.randn(M, NP2, device=d); dw = torch.zeros(NP2, E, device=d)
+    h = torch.randn(M, 400, device=d); wh = torch.randn(400, 400, device=d); oh = torch.empty(M, 400, device=d)
+    for tile in (1, 4):
+        ms = timeit(lambda: ops.gemm(x, w, out, M=M, N=NP2, K=E, lda=E, ldb=E, ldc=NP2, tile=tile))
+        print('tile %d NT 131072x1664x300  %7.3f ms %6.1f TF' % (tile, ms, 2.0 * M * NP2 * E / ms / 1e9))
+        ms = timeit(lambda: ops.gemm(h, wh, oh, M=M, N=400, K=400, lda=400, ldb=400, ldc=400, tile=tile))
+        print('tile %d NT 131072x400x400   %7.3f ms %6.1f TF' % (tile, ms, 2.0 * M * 400 * 400 / ms / 1e9))
+        m2 = 13000
+        ms = timeit(lambda: ops.gemm(h, wh, oh, M=m2, N=400, K=400, lda=400, ldb=400, ldc=400, tile=tile))
+        print('tile %d NT 13000x400x400    %7.3f ms %6.1f TF' % (tile, ms, 2.0 * m2 * 400 * 400 / ms / 1e9))
+        ms = timeit(lambda: ops.gemm(dg, w, x, M=M, N=E, K=NP2, lda=NP2, ldb=E, ldc=E, trans_b=True, tile=tile))
+        print('tile %d NN 131072x300x1664  %7.3f ms %6.1f TF' % (tile, ms, 2.0 * M * NP2 * E / ms / 1e9))
+        for sk in (14, 28, 56):
+            ms = timeit(lambda: ops.gemm(dg, x, dw, M=NP2, N=E, K=M, lda=NP2, ldb=E, ldc=E, trans_a=True, trans_b=True, split_k=sk, atomic=True, tile=tile))
+            print('tile %d TN 1664x300x131072 split %d %7.3f ms %6.1f TF' % (tile, sk, ms, 2.0 * M * NP2 * E / ms / 1e9))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'tiles':
+        return tiles()
     M, E, NP2, V = 131072, 300, 1664, 60000
     x = torch.randn(M, E, device=d)
     emb = torch.randn(V, E, device=d)
