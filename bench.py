@@ -7,8 +7,14 @@ batch 64 (BASELINE.json), one process per GPU.
 
 One "step" = one optimizer step of trainer.py:105-120 (forward, loss, backward, [RCCL all-reduce of the flat gradient],
 clip_grad_norm_(4), Adam) on one batch that is already resident in HBM; dropout is ON (0.2, the reference's 200k
-setting).  The reference's --batch_size is the GLOBAL batch (per-rank = batch_size // world_size, trainer.py:218), so
-the default is strong scaling at global batch 64; --per_gpu_batch B switches to weak scaling (B per GPU).
+setting).
+
+Scaling mode.  Impressions are independent units sharded over the ranks, so the default is WEAK scaling: every GPU
+processes the headline batch of 64 impressions per step (global batch 64*N) and `value` = impressions of all ranks / time.
+`--global_batch G` instead fixes the GLOBAL batch (the reference's `--batch_size` semantics: per-rank = G // world_size,
+trainer.py:218) = strong scaling; at G=64 on 8 GPUs that is 8 impressions per GPU, a regime bound by the 128-step
+dependent chain of the Bi-LSTM and by launch latency, not by throughput (measured on 1 GPU: 14.8 ms/step at batch 8 vs
+24.8 ms at batch 64).
 
 Prints ONE JSON line (rank 0) with the throughput, the roofline of the dominant kernel measured live with HIP events
 on the launch stream, and a CPU baseline (the oracle, timed on this box's host cores on a bounded sample)."""
@@ -34,8 +40,8 @@ def parse():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--news_encoder', default='CNE')
     ap.add_argument('--user_encoder', default='SUE')
-    ap.add_argument('--batch_size', type=int, default=64, help='GLOBAL batch (reference semantics)')
-    ap.add_argument('--per_gpu_batch', type=int, default=0, help='>0: weak scaling with this many impressions per GPU')
+    ap.add_argument('--batch_size', type=int, default=64, help='impressions per GPU per step (weak scaling, the default)')
+    ap.add_argument('--global_batch', type=int, default=0, help='>0: strong scaling, this GLOBAL batch split over the GPUs')
     ap.add_argument('--vocabulary_size', type=int, default=60000)
     ap.add_argument('--dense', action='store_true', help='all titles/abstracts at full length (worst-case roofline variant)')
     ap.add_argument('--no_cpu_baseline', action='store_true')
@@ -83,8 +89,8 @@ def main():
     assert world == a.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % a.gpus
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    weak = a.per_gpu_batch > 0
-    per_gpu = a.per_gpu_batch if weak else a.batch_size // world
+    weak = a.global_batch <= 0
+    per_gpu = a.batch_size if weak else a.global_batch // world
     global_batch = per_gpu * world
     cfg = make_config(['--news_encoder=' + a.news_encoder, '--user_encoder=' + a.user_encoder, '--dataset=200k',
                        '--batch_size=%d' % global_batch, '--world_size=%d' % world],

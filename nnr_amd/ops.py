@@ -61,6 +61,7 @@ def gemm(A, B, C_=None, *, M, N, K, lda, ldb, ldc=0, trans_a=False, trans_b=Fals
             d = int(dyn.item())
             m, k = (min(M, d), K) if dyn_dim == 1 else (M, min(K, d))
         return 2.0 * m * N * k * max(1, batch)
+    flops.tag = 'M%d N%d K%d%s%s%s' % (M, N, K, ' b%d' % batch if batch > 1 else '', ' sk%d' % split_k if split_k > 1 else '', ' dyn' if dyn is not None else '')
     with _prof.span(fam, flops):
         L.check(L.lib().nnr_gemm_f32(C.byref(g), _s()), 'nnr_gemm_f32')
 

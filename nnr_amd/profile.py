@@ -52,6 +52,19 @@ class span:
         return False
 
 
+def by_shape():
+    """Diagnostic: time and achieved TFLOP/s per (family, shape tag)."""
+    torch.cuda.synchronize()
+    out = {}
+    for family, s, e, fn in _records:
+        tag = getattr(fn, 'tag', '')
+        d = out.setdefault((family, tag), dict(ms=0.0, flops=0.0, launches=0))
+        d['ms'] += s.elapsed_time(e)
+        d['flops'] += float(fn())
+        d['launches'] += 1
+    return out
+
+
 def summary():
     torch.cuda.synchronize()
     fam = {}
