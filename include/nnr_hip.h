@@ -77,6 +77,7 @@ typedef struct nnr_gemm_args {
   /* filled by the library */
   uint32_t drop_thresh;
   float drop_scale;
+  int vec_epi;
 } nnr_gemm_args;
 
 int nnr_gemm_f32(const nnr_gemm_args* args, hipStream_t stream);

@@ -19,14 +19,24 @@ __device__ __forceinline__ uint32_t nnr_hash32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
   return x;
 }
+// One 32-bit hash serves TWO neighbouring elements (16 bits each): keep(idx) tests bits [16*(idx&1), +16) of hash(idx>>1)
+// against a 16-bit threshold, so P(drop) is p rounded to 1/65536 and a float4 of elements costs two hashes.
+__device__ __forceinline__ uint32_t nnr_hash_pair(uint32_t seed, uint64_t pair) {
+  return nnr_hash32((uint32_t)pair ^ nnr_hash32((uint32_t)(pair >> 32) + seed));
+}
 __device__ __forceinline__ bool nnr_keep(uint32_t seed, uint64_t idx, uint32_t thresh) {
-  uint32_t h = nnr_hash32((uint32_t)idx ^ nnr_hash32((uint32_t)(idx >> 32) + seed));
-  return h >= thresh;   // P(keep) = 1 - thresh / 2^32
+  const uint32_t h = nnr_hash_pair(seed, idx >> 1);
+  return ((h >> (16u * (uint32_t)(idx & 1))) & 0xFFFFu) >= thresh;   // P(keep) = 1 - thresh / 65536
+}
+// four consecutive elements starting at an index that is a multiple of 4 (the common float4 case): two hashes
+__device__ __forceinline__ void nnr_keep4(uint32_t seed, uint64_t idx4, uint32_t thresh, bool (&k)[4]) {
+  const uint32_t h0 = nnr_hash_pair(seed, idx4 >> 1), h1 = nnr_hash_pair(seed, (idx4 >> 1) + 1);
+  k[0] = (h0 & 0xFFFFu) >= thresh; k[1] = (h0 >> 16) >= thresh; k[2] = (h1 & 0xFFFFu) >= thresh; k[3] = (h1 >> 16) >= thresh;
 }
 static inline uint32_t nnr_drop_thresh(float p) {
   if (p <= 0.f) return 0u;
-  double t = (double)p * 4294967296.0;
-  if (t > 4294967295.0) t = 4294967295.0;
+  double t = (double)p * 65536.0 + 0.5;
+  if (t > 65535.0) t = 65535.0;
   return (uint32_t)t;
 }
 

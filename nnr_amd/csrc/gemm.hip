@@ -113,9 +113,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(nnr_gemm_args g) {
           }
           if (g.drop_target == 1) {
             const int gm = m0 + (f >> 2);
+            bool kp[4];
+            if ((g.drop_cols & 3) == 0) nnr_keep4(g.drop_seed, (uint64_t)gm * g.drop_cols + k, dthr, kp);
+            else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-              val[e] = nnr_keep(g.drop_seed, (uint64_t)gm * g.drop_cols + (k + e), dthr) ? val[e] * dscale : 0.f;
+              for (int e = 0; e < 4; ++e) kp[e] = nnr_keep(g.drop_seed, (uint64_t)gm * g.drop_cols + (k + e), dthr);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) val[e] = kp[e] ? val[e] * dscale : 0.f;
           }
         }
       } else {
@@ -164,9 +169,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(nnr_gemm_args g) {
                 for (int e = 0; e < 4; ++e) if (gn + e < N) val[e] = p[e];
               }
               if (g.drop_target == 2) {
+                bool kp[4];
+                if ((g.drop_cols & 3) == 0) nnr_keep4(g.drop_seed, (uint64_t)gk * g.drop_cols + gn, dthr, kp);
+                else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                  val[e] = nnr_keep(g.drop_seed, (uint64_t)gk * g.drop_cols + (gn + e), dthr) ? val[e] * dscale : 0.f;
+                  for (int e = 0; e < 4; ++e) kp[e] = nnr_keep(g.drop_seed, (uint64_t)gk * g.drop_cols + (gn + e), dthr);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) val[e] = kp[e] ? val[e] * dscale : 0.f;
               }
             }
           }
@@ -298,6 +308,43 @@ __global__ __launch_bounds__(256) void gemm_kernel(nnr_gemm_args g) {
         dot = wave_sum(dot);
         if (row < M && lane == 0) g.rowdot_out[row] = dot;
       }
+    } else if (g.vec_epi) {
+      // float4 path (all operands 16-B aligned, no scatter / atomics): a wave writes 1 KiB contiguous pieces of C rows
+      constexpr int NV = BN / 4;
+      for (int idx = tid; idx < 64 * NV; idx += 256) {
+        const int lr = idx / NV, c4 = idx - lr * NV;
+        const int row = m0 + (lr >> 4) * (TM * 16) + m * 16 + (lr & 15);
+        const int col = n0 + 4 * c4;
+        if (row >= M || col >= N) continue;
+        f32x4 x = *reinterpret_cast<const f32x4*>(&stage[lr * E_LD + 4 * c4]) * g.alpha;
+        if (g.accumulate == 2) x += *reinterpret_cast<const f32x4*>(C + (long)row * g.ldc + col);
+        if (g.bias) x += *reinterpret_cast<const f32x4*>(g.bias + col);
+        if (g.rowvec) x += *reinterpret_cast<const f32x4*>(g.rowvec + (long)(g.rowvec_map ? g.rowvec_map[row] : row) * g.ldrv + col);
+        if (g.act == 1) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) x[e] = fmaxf(x[e], 0.f);
+        } else if (g.act == 2) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) x[e] = tanhf(x[e]);
+        } else if (g.act == 3) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) x[e] = sigmoidf_(x[e]);
+        }
+        if (aux) *reinterpret_cast<f32x4*>(aux + (long)row * g.ldaux + col) = x;
+        if (mulp) x *= *reinterpret_cast<const f32x4*>(mulp + (long)row * g.ldmul + col);
+        if (res) x += *reinterpret_cast<const f32x4*>(res + (long)row * g.ldres + col);
+        if (g.drop_target == 3) {
+          bool kp[4];
+          nnr_keep4(g.drop_seed, (uint64_t)(row + (long)z * g.M) * g.drop_cols + col, dthr, kp);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) x[e] = kp[e] ? x[e] * dscale : 0.f;
+        }
+        if (C) {
+          f32x4* cp = reinterpret_cast<f32x4*>(C + (long)row * g.ldc + col);
+          if (g.accumulate == 1) x += *cp;
+          *cp = x;
+        }
+      }
     } else {
       for (int idx = tid; idx < 64 * BN; idx += 256) {
         const int lr = idx / BN, c = idx - lr * BN;
@@ -363,6 +410,13 @@ extern "C" int nnr_gemm_f32(const nnr_gemm_args* a, hipStream_t stream) {
     return NNR_ERR_ARG;
   if ((g.a_idx && g.trans_a) || (g.b_idx && !g.trans_b)) return NNR_ERR_ARG;
   if ((g.dyn_dim != 0) != (g.dyn_dev != nullptr)) return NNR_ERR_ARG;
+  {
+    auto ok = [](const void* p, int ld) { return p == nullptr || ((((uintptr_t)p) & 15) == 0 && (ld & 3) == 0); };
+    const bool strides = g.batch <= 1 || (((g.strideC | g.stride_aux | g.stride_res) & 3) == 0);
+    g.vec_epi = (!g.c_idx && !g.atomic && g.split_k <= 1 && !g.rowdot_w && (g.N & 3) == 0 && ok(g.C, g.ldc) && ok(g.bias, 0) &&
+                 ok(g.rowvec, g.ldrv) && ok(g.aux_out, g.ldaux) && ok(g.mul, g.ldmul) && ok(g.resid, g.ldres) && strides &&
+                 (g.drop_target != 3 || (g.drop_cols & 3) == 0)) ? 1 : 0;
+  }
   int tile = g.tile;
   if (tile == 0) {
     if (g.rowdot_w) tile = 3;

@@ -100,8 +100,10 @@ __global__ __launch_bounds__(256) void embed_gather_kernel(const float* __restri
     for (int c = lane; c < nv; c += 64) {
       f32x4 v = (src >= 0) ? tp[c] : f32x4{0.f, 0.f, 0.f, 0.f};
       if (thr) {
+        bool kp[4];
+        nnr_keep4(seed, (uint64_t)row * dim + 4 * c, thr, kp);       // dim % 4 == 0 is checked by the launcher
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = nnr_keep(seed, (uint64_t)row * dim + 4 * c + e, thr) ? v[e] * scale : 0.f;
+        for (int e = 0; e < 4; ++e) v[e] = kp[e] ? v[e] * scale : 0.f;
       }
       __builtin_nontemporal_store(v, op + c);
     }
