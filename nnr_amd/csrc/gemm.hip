@@ -17,18 +17,22 @@
 
 namespace {
 
+template <int BK>
 __device__ __forceinline__ int swz(int r16) {  // chunk XOR for row r (0..15) of a 16-row block
-  // f(r>>2) = {0,3,2,1}: makes the four ds_read_b128 lane groups hit 16 distinct 16-B slots
-  return (4 - (r16 >> 2)) & 3;
+  // BK=16 (4 chunks / row): f(r>>2) = {0,3,2,1};  BK=32 (8 chunks / row): (r>>1)&7.
+  // Either makes the four ds_read_b128 lane groups hit 16 distinct 16-B slots (brute-force checked).
+  return BK == 16 ? ((4 - (r16 >> 2)) & 3) : ((r16 >> 1) & 7);
 }
 
-template <int TM, int TN, bool TA, bool TB>
+template <int TM, int TN, bool TA, bool TB, int BK>
 __global__ __launch_bounds__(256) void gemm_kernel(nnr_gemm_args g) {
   constexpr int BM = 64 * TM, BN = 16 * TN;
   constexpr int A_LD = BM + 4, B_LD = BN + 4;
-  constexpr int A_SZ = TA ? 16 * A_LD : BM * 16;
-  constexpr int B_SZ = TB ? 16 * B_LD : BN * 16;
-  constexpr int NBL = (BN * 4 + 255) / 256;  // B float4 loads per thread
+  constexpr int KQ = BK / 4, NKG = BK / 16;      // 16-byte chunks per K-contiguous row; 16-wide k-groups per stage
+  constexpr int A_SZ = TA ? BK * A_LD : BM * BK;
+  constexpr int B_SZ = TB ? BK * B_LD : BN * BK;
+  constexpr int NAL = BM * KQ / 256;             // A float4 loads per thread
+  constexpr int NBL = (BN * KQ + 255) / 256;     // B float4 loads per thread
   constexpr int E_LD = BN + 4;                // epilogue staging: 64 rows x BN (+pad) per pass
   constexpr int LDS_FLOATS = (2 * (A_SZ + B_SZ) > 64 * E_LD) ? 2 * (A_SZ + B_SZ) : 64 * E_LD;
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
@@ -62,10 +66,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(nnr_gemm_args g) {
   int kbeg = 0, kend = K;
   const int z = blockIdx.z;
   if (g.split_k > 1) {
-    const int ktiles = (K + 15) >> 4;
+    const int ktiles = (K + BK - 1) / BK;
     const int per = (ktiles + g.split_k - 1) / g.split_k;
-    kbeg = z * per * 16;
-    kend = min(K, kbeg + per * 16);
+    kbeg = z * per * BK;
+    kend = min(K, kbeg + per * BK);
     if (kbeg >= kend) return;
   } else if (g.batch > 1) {
     A += (long)z * g.strideA;
@@ -78,11 +82,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(nnr_gemm_args g) {
   const float dscale = g.drop_scale;
 
   // ---- per-thread load coordinates that do not change over k
-  long a_src[TM];   // TA=false: source row offset (elements) or -1
+  long a_src[NAL];   // TA=false: source row offset (elements) or -1
   if (!TA) {
 #pragma unroll
-    for (int j = 0; j < TM; ++j) {
-      const int f = tid + 256 * j, row = f >> 2, gm = m0 + row;
+    for (int j = 0; j < NAL; ++j) {
+      const int f = tid + 256 * j, row = f / KQ, gm = m0 + row;
       long s = -1;
       if (gm < M) {
         int src = g.a_idx ? g.a_idx[gm] : gm;
@@ -92,17 +96,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(nnr_gemm_args g) {
     }
   }
 
-  f32x4 ra[TM];
+  f32x4 ra[NAL];
   f32x4 rb[NBL];
 
   auto load_tiles = [&](int k0) {
     // ---------------- A
 #pragma unroll
-    for (int j = 0; j < TM; ++j) {
+    for (int j = 0; j < NAL; ++j) {
       f32x4 val = {0.f, 0.f, 0.f, 0.f};
       const int f = tid + 256 * j;
       if (!TA) {
-        const int kq = f & 3, k = k0 + 4 * kq;
+        const int kq = f % KQ, k = k0 + 4 * kq;
         if (a_src[j] >= 0 && k < kend) {
           const float* p = A + a_src[j] + k;
           if (vecA && k + 3 < kend) {
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(nnr_gemm_args g) {
             for (int e = 0; e < 4; ++e) if (k + e < kend) val[e] = p[e];
           }
           if (g.drop_target == 1) {
-            const int gm = m0 + (f >> 2);
+            const int gm = m0 + f / KQ;
             bool kp[4];
             if ((g.drop_cols & 3) == 0) nnr_keep4(g.drop_seed, (uint64_t)gm * g.drop_cols + k, dthr, kp);
             else {
@@ -143,9 +147,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(nnr_gemm_args g) {
     for (int j = 0; j < NBL; ++j) {
       f32x4 val = {0.f, 0.f, 0.f, 0.f};
       const int f = tid + 256 * j;
-      if (f < BN * 4) {
+      if (f < BN * KQ || TB) {
         if (!TB) {
-          const int row = f >> 2, kq = f & 3, gn = n0 + row, k = k0 + 4 * kq;
+          const int row = f / KQ, kq = f % KQ, gn = n0 + row, k = k0 + 4 * kq;
           if (gn < N && k < kend) {
             const float* p = B + (long)gn * g.ldb + k;
             if (vecB && k + 3 < kend) {
@@ -158,7 +162,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(nnr_gemm_args g) {
         } else {
           const int kr = f / (BN / 4), nq = f - kr * (BN / 4);
           const int gk = k0 + kr, gn = n0 + 4 * nq;
-          if (gk < kend && gn < N) {
+          if (kr < BK && gk < kend && gn < N) {
             int src = g.b_idx ? g.b_idx[gk] : gk;
             if (src >= 0) {
               const float* p = B + (long)src * g.ldb + gn;
@@ -190,11 +194,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(nnr_gemm_args g) {
     float* As = lds + buf * (A_SZ + B_SZ);
     float* Bs = As + A_SZ;
 #pragma unroll
-    for (int j = 0; j < TM; ++j) {
+    for (int j = 0; j < NAL; ++j) {
       const int f = tid + 256 * j;
       if (!TA) {
-        const int row = f >> 2, kq = f & 3;
-        *reinterpret_cast<f32x4*>(&As[row * 16 + 4 * (kq ^ swz(row & 15))]) = ra[j];
+        const int row = f / KQ, kq = f % KQ;
+        *reinterpret_cast<f32x4*>(&As[row * BK + 4 * (kq ^ swz<BK>(row & 15))]) = ra[j];
       } else {
         const int kr = f / (BM / 4), mq = f - kr * (BM / 4);
         *reinterpret_cast<f32x4*>(&As[kr * A_LD + 4 * mq]) = ra[j];
@@ -203,13 +207,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(nnr_gemm_args g) {
 #pragma unroll
     for (int j = 0; j < NBL; ++j) {
       const int f = tid + 256 * j;
-      if (f < BN * 4) {
+      if (f < BN * KQ || TB) {
         if (!TB) {
-          const int row = f >> 2, kq = f & 3;
-          *reinterpret_cast<f32x4*>(&Bs[row * 16 + 4 * (kq ^ swz(row & 15))]) = rb[j];
+          const int row = f / KQ, kq = f % KQ;
+          *reinterpret_cast<f32x4*>(&Bs[row * BK + 4 * (kq ^ swz<BK>(row & 15))]) = rb[j];
         } else {
           const int kr = f / (BN / 4), nq = f - kr * (BN / 4);
-          *reinterpret_cast<f32x4*>(&Bs[kr * B_LD + 4 * nq]) = rb[j];
+          if (kr < BK) *reinterpret_cast<f32x4*>(&Bs[kr * B_LD + 4 * nq]) = rb[j];
         }
       }
     }
@@ -226,38 +230,41 @@ __global__ __launch_bounds__(256) void gemm_kernel(nnr_gemm_args g) {
   __syncthreads();
 
   int buf = 0;
-  for (int k0 = kbeg; k0 < kend; k0 += 16) {
-    const bool more = (k0 + 16) < kend;
-    if (more) load_tiles(k0 + 16);
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    const bool more = (k0 + BK) < kend;
+    if (more) load_tiles(k0 + BK);
 
     const float* As = lds + buf * (A_SZ + B_SZ);
     const float* Bs = As + A_SZ;
-    f32x4 af[TM], bf[TN];
 #pragma unroll
-    for (int m = 0; m < TM; ++m) {
-      if (!TA) {
-        af[m] = *reinterpret_cast<const f32x4*>(&As[((w * TM + m) * 16 + r) * 16 + 4 * (kk ^ swz(r))]);
-      } else {
+    for (int kg2 = 0; kg2 < NKG; ++kg2) {
+      f32x4 af[TM], bf[TN];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) af[m][i] = As[(4 * kk + i) * A_LD + (w * TM + m) * 16 + r];
+      for (int m = 0; m < TM; ++m) {
+        if (!TA) {
+          af[m] = *reinterpret_cast<const f32x4*>(&As[((w * TM + m) * 16 + r) * BK + 4 * ((kg2 * 4 + kk) ^ swz<BK>(r))]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) af[m][i] = As[(kg2 * 16 + 4 * kk + i) * A_LD + (w * TM + m) * 16 + r];
+        }
       }
-    }
 #pragma unroll
-    for (int n = 0; n < TN; ++n) {
-      if (!TB) {
-        bf[n] = *reinterpret_cast<const f32x4*>(&Bs[(n * 16 + r) * 16 + 4 * (kk ^ swz(r))]);
-      } else {
+      for (int n = 0; n < TN; ++n) {
+        if (!TB) {
+          bf[n] = *reinterpret_cast<const f32x4*>(&Bs[(n * 16 + r) * BK + 4 * ((kg2 * 4 + kk) ^ swz<BK>(r))]);
+        } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) bf[n][i] = Bs[(4 * kk + i) * B_LD + n * 16 + r];
+          for (int i = 0; i < 4; ++i) bf[n][i] = Bs[(kg2 * 16 + 4 * kk + i) * B_LD + n * 16 + r];
+        }
       }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+          for (int n = 0; n < TN; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][i], bf[n][i], acc[m][n], 0, 0, 0);
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int m = 0; m < TM; ++m)
-#pragma unroll
-        for (int n = 0; n < TN; ++n)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][i], bf[n][i], acc[m][n], 0, 0, 0);
 
     if (more) store_tiles(buf ^ 1);
     __syncthreads();
@@ -381,16 +388,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(nnr_gemm_args g) {
   }
 }
 
-template <int TM, int TN>
+template <int TM, int TN, int BK>
 int launch_cfg(const nnr_gemm_args& g, hipStream_t s) {
   constexpr int BM = 64 * TM, BN = 16 * TN;
   const int nbm = (g.M + BM - 1) / BM, nbn = (g.N + BN - 1) / BN;
   if (g.rowdot_w && nbn != 1) return NNR_ERR_ARG;
   dim3 grid(nbm * nbn, 1, g.split_k > 1 ? g.split_k : (g.batch > 1 ? g.batch : 1));
   dim3 block(256);
-  if (!g.trans_a && !g.trans_b) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, false>), grid, block, 0, s, g);
-  else if (!g.trans_a && g.trans_b) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, true>), grid, block, 0, s, g);
-  else if (g.trans_a && g.trans_b) hipLaunchKernelGGL((gemm_kernel<TM, TN, true, true>), grid, block, 0, s, g);
+  if (!g.trans_a && !g.trans_b) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, false, BK>), grid, block, 0, s, g);
+  else if (!g.trans_a && g.trans_b) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, true, BK>), grid, block, 0, s, g);
+  else if (g.trans_a && g.trans_b) hipLaunchKernelGGL((gemm_kernel<TM, TN, true, true, BK>), grid, block, 0, s, g);
   else return NNR_ERR_ARG;   // (A^T, B[N,K]) never occurs on this path
   NNR_CHECK_LAUNCH();
   return NNR_OK;
@@ -421,14 +428,16 @@ extern "C" int nnr_gemm_f32(const nnr_gemm_args* a, hipStream_t stream) {
   if (tile == 0) {
     if (g.rowdot_w) tile = 3;
     else if (g.M <= 512) tile = 2;
+    else if (!g.trans_a && !g.trans_b) tile = 5;   // NT: BK = 32 measured +7 % (97.7 vs 90.9 TF); the K-major operands of NN / TN lose with it
     else tile = 4;           // 128 x 80: 117 VGPRs -> 4 waves/SIMD, 4 workgroups per CU hide barriers, prologue and epilogue
                              // (measured 84-96 TF vs 63-79 TF for the 256 x 80 tile on the CNE shapes)
   }
   switch (tile) {
-    case 1: return launch_cfg<4, 5>(g, stream);    // 256 x 80
-    case 2: return launch_cfg<1, 5>(g, stream);    //  64 x 80
-    case 3: return launch_cfg<2, 13>(g, stream);   // 128 x 208 (whole rows in one wave: fused row-dot)
-    case 4: return launch_cfg<2, 5>(g, stream);    // 128 x 80 (4 waves/SIMD: more workgroups in flight per CU)
+    case 1: return launch_cfg<4, 5, 16>(g, stream);    // 256 x 80
+    case 2: return launch_cfg<1, 5, 16>(g, stream);    //  64 x 80
+    case 3: return launch_cfg<2, 13, 16>(g, stream);   // 128 x 208 (whole rows in one wave: fused row-dot)
+    case 4: return launch_cfg<2, 5, 16>(g, stream);    // 128 x 80 (4 waves/SIMD: more workgroups in flight per CU)
+    case 5: return launch_cfg<2, 5, 32>(g, stream);   // 128 x 80, BK = 32: half the barriers per FLOP, 3 workgroups per CU
     default: return NNR_ERR_ARG;
   }
 }

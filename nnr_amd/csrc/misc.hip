@@ -109,19 +109,46 @@ __global__ __launch_bounds__(256) void embed_gather_kernel(const float* __restri
     }
   }
 }
-// backward: dtable[idx[row], :] += mask * dout[row, :]  -- f32 atomics, each wave-instruction = 256 contiguous bytes of one row
+// backward: dtable[idx[row], :] += mask * dout[row, :]  -- f32 atomics, each wave-instruction = 256 contiguous bytes of one row.
+// Dense id tensors are mostly <PAD> (id 0) past each title's length, and atomics into ONE row run ~14x slower than spread
+// ones (MI355X_MICROARCH.md, global float atomics): rows with the block's hot id (0) are pre-reduced in registers / LDS and
+// leave the block as a single atomic row.
 __global__ __launch_bounds__(256) void embed_scatter_kernel(const float* __restrict__ dout, const int* __restrict__ idx, long n, int dim,
                                                             float* __restrict__ dtable, uint32_t seed, uint32_t thr, float scale) {
-  const int lane = threadIdx.x & 63;
-  for (long row = blockIdx.x * 4L + (threadIdx.x >> 6); row < n; row += gridDim.x * 4L) {
+  constexpr int MAXC = 8;                      // columns per lane: dim <= 512
+  __shared__ float hot[4][64 * MAXC];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float acc[MAXC];
+#pragma unroll
+  for (int j = 0; j < MAXC; ++j) acc[j] = 0.f;
+  bool any_hot = false;
+  for (long row = blockIdx.x * 4L + wv; row < n; row += gridDim.x * 4L) {
     const int dst = idx[row];
     if (dst < 0) continue;
+    if (dst == 0 && dim <= 64 * MAXC) {
+      any_hot = true;
+#pragma unroll
+      for (int j = 0; j < MAXC; ++j) {
+        const int c = lane + 64 * j;
+        if (c < dim) {
+          float v = dout[row * dim + c];
+          if (thr) v = nnr_keep(seed, (uint64_t)row * dim + c, thr) ? v * scale : 0.f;
+          acc[j] += v;
+        }
+      }
+      continue;
+    }
     for (int c = lane; c < dim; c += 64) {
       float v = dout[row * dim + c];
       if (thr) v = nnr_keep(seed, (uint64_t)row * dim + c, thr) ? v * scale : 0.f;
       atomicAdd(&dtable[(long)dst * dim + c], v);
     }
   }
+#pragma unroll
+  for (int j = 0; j < MAXC; ++j) hot[wv][lane + 64 * j] = acc[j];
+  const int hot_waves = __syncthreads_count(any_hot ? 1 : 0);
+  if (hot_waves == 0) return;
+  for (int c = threadIdx.x; c < dim; c += 256) atomicAdd(&dtable[c], hot[0][c] + hot[1][c] + hot[2][c] + hot[3][c]);
 }
 // ---- out[c, r] = in[r, c]  (weight re-layouts, e.g. Conv1d [C_out*C_in, k] -> [k, C_out*C_in])
 __global__ void transpose2d_kernel(const float* __restrict__ in, float* __restrict__ out, long rows, int cols, int accumulate) {

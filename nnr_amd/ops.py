@@ -52,8 +52,8 @@ def gemm(A, B, C_=None, *, M, N, K, lda, ldb, ldc=0, trans_a=False, trans_b=Fals
     if not _prof.active():
         L.check(L.lib().nnr_gemm_f32(C.byref(g), _s()), 'nnr_gemm_f32')
         return
-    t = tile if tile else (3 if rowdot_w is not None else (2 if M <= 512 else 4))
-    fam = 'gemm_%s_%s' % ('tn' if trans_a else ('nn' if trans_b else 'nt'), {1: '256x80', 2: '64x80', 3: '128x208', 4: '128x80'}[t])
+    t = tile if tile else (3 if rowdot_w is not None else (2 if M <= 512 else (5 if not (trans_a or trans_b) else 4)))
+    fam = 'gemm_%s_%s' % ('tn' if trans_a else ('nn' if trans_b else 'nt'), {1: '256x80', 2: '64x80', 3: '128x208', 4: '128x80', 5: '128x80k32'}[t])
 
     def flops(M=M, N=N, K=K, dyn=dyn, dyn_dim=dyn_dim, batch=batch):
         m, k = M, K

@@ -9,11 +9,11 @@ _on = False
 _records = []          # (family, start, end, flops_fn)
 
 KERNEL_OF = {
-    'gemm_nt_256x80': 'gemm_kernel<4, 5, false, false>', 'gemm_nn_256x80': 'gemm_kernel<4, 5, false, true>',
-    'gemm_tn_256x80': 'gemm_kernel<4, 5, true, true>', 'gemm_nt_64x80': 'gemm_kernel<1, 5, false, false>',
-    'gemm_nn_64x80': 'gemm_kernel<1, 5, false, true>', 'gemm_tn_64x80': 'gemm_kernel<1, 5, true, true>',
-    'gemm_nt_128x208': 'gemm_kernel<2, 13, false, false>', 'gemm_nt_128x80': 'gemm_kernel<2, 5, false, false>',
-    'gemm_nn_128x80': 'gemm_kernel<2, 5, false, true>', 'gemm_tn_128x80': 'gemm_kernel<2, 5, true, true>', 'lstm_fwd': 'lstm_fwd_kernel<13>', 'lstm_bwd': 'lstm_bwd_kernel<13>',
+    'gemm_nt_256x80': 'gemm_kernel<4, 5, false, false, 16>', 'gemm_nn_256x80': 'gemm_kernel<4, 5, false, true, 16>',
+    'gemm_tn_256x80': 'gemm_kernel<4, 5, true, true, 16>', 'gemm_nt_64x80': 'gemm_kernel<1, 5, false, false, 16>',
+    'gemm_nn_64x80': 'gemm_kernel<1, 5, false, true, 16>', 'gemm_tn_64x80': 'gemm_kernel<1, 5, true, true, 16>',
+    'gemm_nt_128x208': 'gemm_kernel<2, 13, false, false, 16>', 'gemm_nt_128x80': 'gemm_kernel<2, 5, false, false, 16>', 'gemm_nt_128x80k32': 'gemm_kernel<2, 5, false, false, 32>',
+    'gemm_nn_128x80': 'gemm_kernel<2, 5, false, true, 16>', 'gemm_tn_128x80': 'gemm_kernel<2, 5, true, true, 16>', 'lstm_fwd': 'lstm_fwd_kernel<13>', 'lstm_bwd': 'lstm_bwd_kernel<13>',
 }
 
 

@@ -34,6 +34,24 @@ def test_gemm_nt_bias_relu_and_unaligned():
         close(out, torch.relu(x.double() @ w.double().t() + b.double()), what='NT %s' % ((M, N, K),))
 
 
+@pytest.mark.parametrize('tile', [1, 2, 4, 5])
+def test_gemm_all_tiles_all_modes(tile):
+    from nnr_amd import ops
+    d = dev()
+    M, N, K = 700, 300, 404
+    a, b = rnd(M, K, seed=1), rnd(N, K, seed=2)
+    out = torch.empty(M, N, device=d)
+    ops.gemm(a.to(d), b.to(d), out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, tile=tile)
+    close(out, a.double() @ b.double().t(), what='NT tile %d' % tile)
+    bt = rnd(K, N, seed=3)
+    ops.gemm(a.to(d), bt.to(d), out, M=M, N=N, K=K, lda=K, ldb=N, ldc=N, trans_b=True, tile=tile)
+    close(out, a.double() @ bt.double(), what='NN tile %d' % tile)
+    at = rnd(K, M, seed=4)
+    o2 = torch.zeros(M, N, device=d)
+    ops.gemm(at.to(d), bt.to(d), o2, M=M, N=N, K=K, lda=M, ldb=N, ldc=N, trans_a=True, trans_b=True, split_k=3, atomic=True, tile=tile)
+    close(o2, at.double().t() @ bt.double(), tol=5e-5, what='TN tile %d' % tile)
+
+
 def test_gemm_nn_accumulate_and_tn_splitk_dyn():
     from nnr_amd import ops
     dy, w = rnd(300, 225, seed=1), rnd(225, 900, seed=2)
