@@ -14,7 +14,7 @@
 namespace {
 
 constexpr int MAXT = 2;   // positions per lane: supports L <= 128 (the selects below assume exactly 2)
-constexpr int MAXV = 4;   // float4 per lane:   supports D <= 1024
+constexpr int MAXV_ALL = 4;   // float4 per lane:   supports D <= 1024
 
 struct PoolArgs {
   const float* x; int ldx; int D; int n; int L;
@@ -36,8 +36,9 @@ __device__ __forceinline__ long item_row(const PoolArgs& a, int s, int t) {
   return a.packed ? (long)a.off[t] + s : (long)s * a.L + t;
 }
 
-template <bool BWD>
+template <bool BWD, int NV, int UR>
 __global__ __launch_bounds__(256) void pool_kernel(PoolArgs a) {
+  constexpr int MAXV = NV;     // float4 per lane actually needed for this D (shadows the file-level bound)
   const int lane = threadIdx.x & 63;
   const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (s >= a.n) return;
@@ -61,19 +62,28 @@ __global__ __launch_bounds__(256) void pool_kernel(PoolArgs a) {
 #pragma unroll
     for (int k = 0; k < MAXT; ++k) sc[k] = -INFINITY;
     if (dot) {
-      for (int t = 0; t < len; ++t) {
-        const float* xr = a.x + item_row(a, s, t) * a.ldx;
-        float p = 0.f;
+      // UR rows in flight per iteration: the row loads are independent, only the shuffle reductions are serial
+      for (int t0 = 0; t0 < len; t0 += UR) {
+        f32x4 xv[UR][MAXV];
 #pragma unroll
-        for (int j = 0; j < MAXV; ++j) {
-          const int c = lane + 64 * j;
-          if (c < nv) {
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + 4 * c);
-            p += xv[0] * q[j][0] + xv[1] * q[j][1] + xv[2] * q[j][2] + xv[3] * q[j][3];
+        for (int u = 0; u < UR; ++u) {
+          const int t = min(t0 + u, len - 1);
+          const float* xr = a.x + item_row(a, s, t) * a.ldx;
+#pragma unroll
+          for (int j = 0; j < MAXV; ++j) {
+            const int c = lane + 64 * j;
+            xv[u][j] = (c < nv) ? *reinterpret_cast<const f32x4*>(xr + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
           }
         }
-        p = wave_sum(p) * a.scale;
-        if ((t & 63) == lane) { if (t < 64) sc[0] = p; else sc[1] = p; }
+#pragma unroll
+        for (int u = 0; u < UR; ++u) {
+          const int t = t0 + u;
+          float p = 0.f;
+#pragma unroll
+          for (int j = 0; j < MAXV; ++j) p += xv[u][j][0] * q[j][0] + xv[u][j][1] * q[j][1] + xv[u][j][2] * q[j][2] + xv[u][j][3] * q[j][3];
+          p = wave_sum(p) * a.scale;
+          if (t < len && (t & 63) == lane) { if (t < 64) sc[0] = p; else sc[1] = p; }
+        }
       }
     } else {
 #pragma unroll
@@ -113,16 +123,24 @@ __global__ __launch_bounds__(256) void pool_kernel(PoolArgs a) {
     f32x4 acc[MAXV];
 #pragma unroll
     for (int j = 0; j < MAXV; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int t = 0; t < len; ++t) {
-      const float al = __shfl(t < 64 ? e[0] : e[1], t & 63, 64);
-      const float* xr = a.x + item_row(a, s, t) * a.ldx;
+    for (int t0 = 0; t0 < len; t0 += UR) {
+      f32x4 xv[UR][MAXV];
 #pragma unroll
-      for (int j = 0; j < MAXV; ++j) {
-        const int c = lane + 64 * j;
-        if (c < nv) {
-          const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + 4 * c);
-          acc[j] += al * xv;
+      for (int u = 0; u < UR; ++u) {
+        const int t = min(t0 + u, len - 1);
+        const float* xr = a.x + item_row(a, s, t) * a.ldx;
+#pragma unroll
+        for (int j = 0; j < MAXV; ++j) {
+          const int c = lane + 64 * j;
+          xv[u][j] = (c < nv) ? *reinterpret_cast<const f32x4*>(xr + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
+      }
+#pragma unroll
+      for (int u = 0; u < UR; ++u) {
+        const int t = t0 + u;
+        const float al = (t < len) ? __shfl(t < 64 ? e[0] : e[1], t & 63, 64) : 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXV; ++j) acc[j] += al * xv[u][j];
       }
     }
 #pragma unroll
@@ -153,20 +171,28 @@ __global__ __launch_bounds__(256) void pool_kernel(PoolArgs a) {
       al[k] = (t < len) ? a.alpha[item_row(a, s, t)] : 0.f;
       da[k] = 0.f;
     }
-    // dalpha_t = <dout, x_t>
-    for (int t = 0; t < len; ++t) {
-      const float* xr = a.x + item_row(a, s, t) * a.ldx;
-      float p = 0.f;
+    // dalpha_t = <dout, x_t>   (UR rows in flight)
+    for (int t0 = 0; t0 < len; t0 += UR) {
+      f32x4 xv[UR][MAXV];
 #pragma unroll
-      for (int j = 0; j < MAXV; ++j) {
-        const int c = lane + 64 * j;
-        if (c < nv) {
-          const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + 4 * c);
-          p += xv[0] * go[j][0] + xv[1] * go[j][1] + xv[2] * go[j][2] + xv[3] * go[j][3];
+      for (int u = 0; u < UR; ++u) {
+        const int t = min(t0 + u, len - 1);
+        const float* xr = a.x + item_row(a, s, t) * a.ldx;
+#pragma unroll
+        for (int j = 0; j < MAXV; ++j) {
+          const int c = lane + 64 * j;
+          xv[u][j] = (c < nv) ? *reinterpret_cast<const f32x4*>(xr + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
       }
-      p = wave_sum(p);
-      if ((t & 63) == lane) { if (t < 64) da[0] = p; else da[1] = p; }
+#pragma unroll
+      for (int u = 0; u < UR; ++u) {
+        const int t = t0 + u;
+        float p = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXV; ++j) p += xv[u][j][0] * go[j][0] + xv[u][j][1] * go[j][1] + xv[u][j][2] * go[j][2] + xv[u][j][3] * go[j][3];
+        p = wave_sum(p);
+        if (t < len && (t & 63) == lane) { if (t < 64) da[0] = p; else da[1] = p; }
+      }
     }
     float dsum = 0.f;
 #pragma unroll
@@ -182,25 +208,37 @@ __global__ __launch_bounds__(256) void pool_kernel(PoolArgs a) {
     f32x4 dvacc[MAXV];
 #pragma unroll
     for (int j = 0; j < MAXV; ++j) dvacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int t = 0; t < len; ++t) {
-      const float alt = __shfl(t < 64 ? al[0] : al[1], t & 63, 64);
-      const float dst = __shfl(t < 64 ? ds[0] : ds[1], t & 63, 64) * a.scale;
-      const long row = item_row(a, s, t);
-      const float* xr = a.x + row * a.ldx;
+    for (int t0 = 0; t0 < len; t0 += UR) {
+      f32x4 xv[UR][MAXV], old[UR][MAXV];
+      long rows[UR];
 #pragma unroll
-      for (int j = 0; j < MAXV; ++j) {
-        const int c = lane + 64 * j;
-        if (c < nv) {
-          f32x4 g = alt * go[j];
-          if (dot) {
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + 4 * c);
-            g += dst * q[j];
-            dvacc[j] += dst * xv;
-          }
-          if (a.dx) {
-            f32x4* dp = reinterpret_cast<f32x4*>(a.dx + row * a.lddx + 4 * c);
-            if (a.dx_accumulate) g += *dp;
-            *dp = g;
+      for (int u = 0; u < UR; ++u) {
+        const int t = min(t0 + u, len - 1);
+        rows[u] = item_row(a, s, t);
+#pragma unroll
+        for (int j = 0; j < MAXV; ++j) {
+          const int c = lane + 64 * j;
+          xv[u][j] = (dot && c < nv) ? *reinterpret_cast<const f32x4*>(a.x + rows[u] * a.ldx + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+          old[u][j] = (a.dx && a.dx_accumulate && c < nv) ? *reinterpret_cast<const f32x4*>(a.dx + rows[u] * a.lddx + 4 * c)
+                                                          : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UR; ++u) {
+        const int t = t0 + u;
+        if (t >= len) continue;
+        const float alt = __shfl(t < 64 ? al[0] : al[1], t & 63, 64);
+        const float dst = __shfl(t < 64 ? ds[0] : ds[1], t & 63, 64) * a.scale;
+#pragma unroll
+        for (int j = 0; j < MAXV; ++j) {
+          const int c = lane + 64 * j;
+          if (c < nv) {
+            f32x4 g = alt * go[j] + old[u][j];
+            if (dot) {
+              g += dst * q[j];
+              dvacc[j] += dst * xv[u][j];
+            }
+            if (a.dx) *reinterpret_cast<f32x4*>(a.dx + rows[u] * a.lddx + 4 * c) = g;
           }
         }
       }
@@ -219,7 +257,7 @@ __global__ __launch_bounds__(256) void pool_kernel(PoolArgs a) {
 
 static int pool_check(const nnr_pool_args* p) {
   if (!p || !p->x || p->n <= 0) return NNR_ERR_ARG;
-  if ((p->D & 3) || p->D > 4 * 64 * MAXV || (p->ldx & 3)) return NNR_ERR_UNSUPPORTED;
+  if ((p->D & 3) || p->D > 4 * 64 * MAXV_ALL || (p->ldx & 3)) return NNR_ERR_UNSUPPORTED;
   if (p->L > 64 * MAXT) return NNR_ERR_UNSUPPORTED;
   if (p->packed && (!p->off || !p->slen || !p->order)) return NNR_ERR_ARG;
   if (!p->v && !p->score && !p->alpha) return NNR_ERR_ARG;
@@ -237,20 +275,28 @@ static PoolArgs to_args(const nnr_pool_args* p) {
   return a;
 }
 
+template <bool BWD>
+static int pool_launch(const nnr_pool_args* p, hipStream_t stream) {
+  const PoolArgs a = to_args(p);
+  const dim3 grid((p->n + 3) / 4), block(256);
+  const int nv = (p->D + 3) / 4;
+  if (nv <= 64) hipLaunchKernelGGL((pool_kernel<BWD, 1, 4>), grid, block, 0, stream, a);
+  else if (nv <= 128) hipLaunchKernelGGL((pool_kernel<BWD, 2, 4>), grid, block, 0, stream, a);
+  else hipLaunchKernelGGL((pool_kernel<BWD, 4, 2>), grid, block, 0, stream, a);
+  NNR_CHECK_LAUNCH();
+  return NNR_OK;
+}
+
 extern "C" int nnr_attn_pool_fwd(const nnr_pool_args* p, hipStream_t stream) {
   int rc = pool_check(p);
   if (rc != NNR_OK) return rc;
   if (!p->out || (!p->v && !p->score)) return NNR_ERR_ARG;
-  hipLaunchKernelGGL((pool_kernel<false>), dim3((p->n + 3) / 4), dim3(256), 0, stream, to_args(p));
-  NNR_CHECK_LAUNCH();
-  return NNR_OK;
+  return pool_launch<false>(p, stream);
 }
 
 extern "C" int nnr_attn_pool_bwd(const nnr_pool_args* p, hipStream_t stream) {
   int rc = pool_check(p);
   if (rc != NNR_OK) return rc;
   if (!p->dout || !p->alpha) return NNR_ERR_ARG;
-  hipLaunchKernelGGL((pool_kernel<true>), dim3((p->n + 3) / 4), dim3(256), 0, stream, to_args(p));
-  NNR_CHECK_LAUNCH();
-  return NNR_OK;
+  return pool_launch<true>(p, stream);
 }
