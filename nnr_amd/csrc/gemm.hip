@@ -98,6 +98,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(nnr_gemm_args g) {
 
   f32x4 ra[NAL];
   f32x4 rb[NBL];
+  // optional fused bias gradient (trans_a only): colsum_out[m] += sum_k A[k][m], taken from the A^T tile registers of
+  // the column-block-0 workgroups -- the weight-gradient GEMM streams exactly the tensor whose column sums are db
+  const bool do_colsum = TA && g.colsum_out != nullptr && bn == 0;
+  f32x4 csum[NAL];
+#pragma unroll
+  for (int j = 0; j < NAL; ++j) csum[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   auto load_tiles = [&](int k0) {
     // ---------------- A
@@ -226,13 +232,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(nnr_gemm_args g) {
     for (int n = 0; n < TN; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   load_tiles(kbeg);
+  if (do_colsum) {
+#pragma unroll
+    for (int j = 0; j < NAL; ++j) csum[j] += ra[j];
+  }
   store_tiles(0);
   __syncthreads();
 
   int buf = 0;
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
     const bool more = (k0 + BK) < kend;
-    if (more) load_tiles(k0 + BK);
+    if (more) {
+      load_tiles(k0 + BK);
+      if (do_colsum) {
+#pragma unroll
+        for (int j = 0; j < NAL; ++j) csum[j] += ra[j];
+      }
+    }
 
     const float* As = lds + buf * (A_SZ + B_SZ);
     const float* Bs = As + A_SZ;
@@ -269,6 +285,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(nnr_gemm_args g) {
     if (more) store_tiles(buf ^ 1);
     __syncthreads();
     buf ^= 1;
+  }
+
+  if (do_colsum) {
+    // thread (kr, mq) holds partial sums for columns 4*mq..4*mq+3; threads with equal mq differ in kr: reduce through LDS
+    float* red = lds;                                   // [BM] floats, the tile buffers are free now
+    for (int i = tid; i < BM; i += 256) red[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NAL; ++j) {
+      const int f = tid + 256 * j, kr = f / (BM / 4), mq = f - kr * (BM / 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) atomicAdd(&red[4 * mq + e], csum[j][e]);
+    }
+    __syncthreads();
+    for (int i = tid; i < BM; i += 256)
+      if (m0 + i < M) atomicAdd(&g.colsum_out[m0 + i], red[i]);
+    __syncthreads();
   }
 
   // ---------------------------------------------------------------- epilogue
@@ -416,6 +449,7 @@ extern "C" int nnr_gemm_f32(const nnr_gemm_args* a, hipStream_t stream) {
   if (g.split_k > 1 && (g.bias || g.rowvec || g.act || g.aux_out || g.mul || g.resid || g.batch > 1 || g.rowdot_w))
     return NNR_ERR_ARG;
   if ((g.a_idx && g.trans_a) || (g.b_idx && !g.trans_b)) return NNR_ERR_ARG;
+  if (g.colsum_out && !g.trans_a) return NNR_ERR_ARG;
   if ((g.dyn_dim != 0) != (g.dyn_dev != nullptr)) return NNR_ERR_ARG;
   {
     auto ok = [](const void* p, int ld) { return p == nullptr || ((((uintptr_t)p) & 15) == 0 && (ld & 3) == 0); };

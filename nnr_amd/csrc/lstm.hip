@@ -593,7 +593,6 @@ static int lstm_run(const nnr_lstm_problem* probs, int nprob, int H, bool backwa
     p.dh = q.dh; p.dcn = q.dcn;
     if (!p.bs || !p.off || !p.slen || !p.gates || !p.cell || !p.wfrag || p.n <= 0) return NNR_ERR_ARG;
     if (backward ? (!p.dh || !p.prev_f || !p.prev_r) : (!p.hout || !p.cn)) return NNR_ERR_ARG;
-    if ((long)p.n * p.L * (2L * UB * 64) >= (1L << 31)) return NNR_ERR_UNSUPPORTED;   // 32-bit element offsets in the kernels
     max_tiles = max(max_tiles, (p.n + 15) / 16);
   }
   for (int i = nprob; i < 4; ++i) a.p[i] = a.p[0];

@@ -258,8 +258,7 @@ def _cne_bwd_pre(mod, sv, drep):
         ops.tanh_score_bwd(th, ds, sa.affine2.weight, grad_of(sa.affine2.weight), plan, A)    # th := dpre
         ops.gemm(th, sa.affine1.weight, st['dHt'], M=cap, N=H2, K=A, lda=A, ldb=H2, ldc=H2, trans_b=True, accumulate=True,
                  dyn=plan.total, dyn_dim=1)
-        ops.linear_bwd_weight(th, st['Ht'], grad_of(sa.affine1.weight), dyn=plan.total)
-        ops.bias_grad(th, grad_of(sa.affine1.bias), dyn=plan.total)
+        ops.linear_bwd_weight(th, st['Ht'], grad_of(sa.affine1.weight), dyn=plan.total, db=grad_of(sa.affine1.bias))
         # gate: Ht = hout * G
         st['dH'] = torch.empty((cap, H2), **f32)
         dpre = st['Ht']                                   # reuse: Ht is dead after the GEMM above
@@ -293,8 +292,8 @@ def _cne_bwd_post(mod, sv):
         db_p = torch.zeros(2 * NP, **f32)
         dw_hhp = torch.zeros((2, NP, H), **f32)
         ops.gemm(dg, emb, dw_ihp, M=2 * NP, N=E, K=cap, lda=2 * NP, ldb=E, ldc=E, trans_a=True, trans_b=True, b_idx=plan.tok,
-                 drop=(2, p, st['seed'], E), split_k=ops.split_for(2 * NP, E, cap), atomic=True, dyn=plan.total, dyn_dim=2)
-        ops.bias_grad(dg, db_p, dyn=plan.total, rows=cap)
+                 drop=(2, p, st['seed'], E), split_k=ops.split_for(2 * NP, E, cap), atomic=True, dyn=plan.total, dyn_dim=2,
+                 colsum_out=db_p)
         for d, prev in ((0, plan.prev_f), (1, plan.prev_r)):
             ops.gemm(dg[:, d * NP:], st['hout'][:, d * H:], dw_hhp[d], M=NP, N=H, K=cap, lda=2 * NP, ldb=H2, ldc=H, trans_a=True,
                      trans_b=True, b_idx=prev, split_k=ops.split_for(NP, H, cap), atomic=True, dyn=plan.total, dyn_dim=2)

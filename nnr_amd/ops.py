@@ -32,7 +32,7 @@ def split_for(m, n, k, tile_m=128, tile_n=80, target_blocks=2048, kmin=256):
 def gemm(A, B, C_=None, *, M, N, K, lda, ldb, ldc=0, trans_a=False, trans_b=False, dyn=None, dyn_dim=0, a_idx=None, b_idx=None,
          drop=None, alpha=1.0, bias=None, rowvec=None, ldrv=0, rowvec_map=None, act=0, aux_out=None, ldaux=0, mul=None, ldmul=0,
          resid=None, ldres=0, accumulate=False, atomic=False, c_idx=None, split_k=1, rowdot_w=None, rowdot_out=None, batch=1,
-         strideA=0, strideB=0, strideC=0, stride_aux=0, stride_res=0, tile=0):
+         strideA=0, strideB=0, strideC=0, stride_aux=0, stride_res=0, tile=0, colsum_out=None):
     g = L.GemmArgs()
     g.A, g.B, g.C = _p(A), _p(B), _p(C_)
     g.M, g.N, g.K, g.lda, g.ldb, g.ldc = M, N, K, lda, ldb, ldc
@@ -49,6 +49,7 @@ def gemm(A, B, C_=None, *, M, N, K, lda, ldb, ldc=0, trans_a=False, trans_b=Fals
     g.rowdot_w, g.rowdot_out = _p(rowdot_w), _p(rowdot_out)
     g.batch, g.strideA, g.strideB, g.strideC, g.stride_aux, g.stride_res = batch, strideA, strideB, strideC, stride_aux, stride_res
     g.tile = tile
+    g.colsum_out = _p(colsum_out)
     if not _prof.active():
         L.check(L.lib().nnr_gemm_f32(C.byref(g), _s()), 'nnr_gemm_f32')
         return
@@ -86,12 +87,13 @@ def linear_bwd_data(dy, w, out=None, accumulate=False, **kw):
     return out
 
 
-def linear_bwd_weight(dy, x, dw, dyn=None, rows=None, **kw):
-    """dw[N,K] += dy[rows,N]^T . x[rows,K]   (split-K atomics; dw must already hold the running gradient)"""
+def linear_bwd_weight(dy, x, dw, dyn=None, rows=None, db=None, **kw):
+    """dw[N,K] += dy[rows,N]^T . x[rows,K]   (split-K atomics; dw must already hold the running gradient);
+    db[N] += column sums of dy, fused into the same launch."""
     R = dy.shape[0] if rows is None else rows
     N, K = dw.shape
     gemm(dy, x, dw, M=N, N=K, K=R, lda=dy.stride(0), ldb=x.stride(0), ldc=dw.stride(0), trans_a=True, trans_b=True,
-         split_k=split_for(N, K, R), atomic=True, dyn=dyn, dyn_dim=2, **kw)
+         split_k=split_for(N, K, R), atomic=True, dyn=dyn, dyn_dim=2, colsum_out=db, **kw)
 
 
 def bias_grad(dy, db, dyn=None, rows=None):

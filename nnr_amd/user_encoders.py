@@ -133,8 +133,7 @@ def sue_backward(mod, sv, dout):
     dfeat = torch.empty((B * N * Cn, D), **f32)
     ops.relu_drop_bwd(df2, sv['rc'], dS, dfeat, p, seed + 2)
     ops.linear_bwd_data(dS, mod.clusterFeatureAffine.weight, out=dfeat, accumulate=True)
-    ops.linear_bwd_weight(dS, sv['feat'], grad_of(mod.clusterFeatureAffine.weight))
-    ops.bias_grad(dS, grad_of(mod.clusterFeatureAffine.bias))
+    ops.linear_bwd_weight(dS, sv['feat'], grad_of(mod.clusterFeatureAffine.weight), db=grad_of(mod.clusterFeatureAffine.bias))
     # ---- intra-cluster attention
     dg = torch.empty((B, Hn, D), **f32)
     dkf = torch.empty((B * Hn, A), **f32)

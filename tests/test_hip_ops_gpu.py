@@ -489,3 +489,17 @@ def test_embed_gather_scatter_and_transpose():
     o = torch.empty(5, 37, device=d)
     ops.transpose2d(a.to(d), o, 37, 5)
     close(o, a.t(), tol=0, what='transpose')
+
+
+def test_gemm_fused_bias_gradient():
+    """colsum_out of the weight-gradient GEMM == column sums of dy over the live rows (split-K, dynamic K)."""
+    from nnr_amd import ops
+    d = dev()
+    R, used, N, K = 6000, 4711, 200, 400
+    dy, x = rnd(R, N, seed=1), rnd(R, K, seed=2)
+    dw = torch.zeros(N, K, device=d)
+    db = torch.full((N,), 0.25, device=d)
+    dyn = torch.tensor([used], dtype=torch.int32, device=d)
+    ops.linear_bwd_weight(dy.to(d), x.to(d), dw, dyn=dyn, db=db)
+    close(dw, dy[:used].double().t() @ x[:used].double(), tol=5e-5, what='dw')
+    close(db, 0.25 + dy[:used].double().sum(0), tol=5e-5, what='fused db')
