@@ -1,0 +1,152 @@
+"""Edge cases and bench-shaped batches at FULL model dimensions, HIP path vs the CPU oracle (the reference has no tests of
+its own; these are the ragged / empty / maximum-size inputs its data pipeline can produce)."""
+import numpy as np
+import pytest
+import torch
+
+from nnr_amd.config import make_config
+from nnr_amd.synth import SynthSpec, SynthCorpus, BATCH_FIELDS, to_torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _models(cfg, seed=0):
+    from nnr_amd.model import Model
+    from oracle import nnr_oracle as O
+    torch.manual_seed(seed)
+    ref = O.Model(cfg)
+    ref.initialize()
+    with torch.no_grad():
+        for p in ref.parameters():                 # zero-initialised tensors (proxy nodes, biases) get signal too
+            if float(p.abs().max()) == 0.0:
+                p.normal_(0, 0.05)
+    ref.train()
+    model = Model(cfg)
+    model.load_state_dict(ref.state_dict())
+    return model.cuda().train(), ref
+
+
+def _cfg(**kw):
+    return make_config(['--news_encoder=CNE', '--user_encoder=SUE'], corpus_sizes=dict(vocabulary_size=800), dropout_rate=0.0,
+                       tie_order='stable', **kw)
+
+
+def _edge_batch(cfg):
+    """sample 0: empty history; sample 1: 50 history news, every title / abstract at maximum length; sample 2: every sequence of
+    length 1 and all candidates identical; sample 3: ordinary."""
+    spec = SynthSpec(vocabulary_size=cfg.vocabulary_size, news_pool=300, seed=5)
+    normal = SynthCorpus(spec)
+    dense = SynthCorpus(SynthSpec(vocabulary_size=cfg.vocabulary_size, news_pool=120, seed=6, dense=True))
+    rng = np.random.default_rng(3)
+    b = normal.batch(4, rng)
+    bd = dense.batch(1, rng)
+    H = spec.max_history_num
+    # sample 1 <- dense corpus, full history
+    hist = rng.integers(1, dense.spec.news_pool, size=H)
+    g, cm, ci = dense.history_graph(dense.category[hist], H)
+    for k in BATCH_FIELDS:
+        if k.startswith('news_'):
+            b[k][1] = bd[k][0]
+    b['user_title_text'][1], b['user_title_mask'][1] = dense.title_text[hist], dense.title_mask[hist]
+    b['user_content_text'][1], b['user_content_mask'][1] = dense.content_text[hist], dense.content_mask[hist]
+    b['user_category'][1], b['user_subCategory'][1] = dense.category[hist], dense.subCategory[hist]
+    b['user_history_mask'][1] = True
+    b['user_history_graph'][1], b['user_history_category_mask'][1], b['user_history_category_indices'][1] = g, cm, ci
+    # sample 0 <- empty history (all <PAD> news, identity graph)
+    g, cm, ci = normal.history_graph(np.zeros(H, np.int32), 0)
+    for k in ('user_title_text', 'user_content_text', 'user_category', 'user_subCategory'):
+        b[k][0] = 0
+    b['user_title_mask'][0] = False
+    b['user_content_mask'][0] = False
+    b['user_title_mask'][0][:, 0] = True
+    b['user_content_mask'][0][:, 0] = True
+    b['user_history_mask'][0] = False
+    b['user_history_graph'][0], b['user_history_category_mask'][0], b['user_history_category_indices'][0] = g, cm, ci
+    # sample 2 <- length-1 sequences everywhere, identical candidates
+    for k in ('user_title_mask', 'user_content_mask', 'news_title_mask', 'news_content_mask'):
+        b[k][2][:, 1:] = False
+    for k in ('user_title_text', 'user_content_text', 'news_title_text', 'news_content_text'):
+        b[k][2][:, 1:] = 0
+    for k in BATCH_FIELDS:
+        if k.startswith('news_'):
+            b[k][2][:] = b[k][2][0]
+    return {k: np.ascontiguousarray(v) for k, v in b.items()}
+
+
+def _compare(model, ref, batch, tol=1e-4):
+    from nnr_amd.model import negative_log_softmax
+    from oracle import nnr_oracle as O
+    for p in model.parameters():
+        p.grad = None
+    logits = model(*to_torch(batch, 'cuda'))
+    loss = negative_log_softmax(logits)
+    loss.backward()
+    rl = ref(*to_torch(batch))
+    rloss = O.negative_log_softmax(rl)
+    ref.zero_grad()
+    rloss.backward()
+    err = float((logits.detach().cpu() - rl.detach()).abs().max())
+    assert err <= tol, 'logits differ by %.3e' % err
+    assert abs(float(loss) - float(rloss)) <= tol
+    total = float(torch.sqrt(sum((q.grad.double() ** 2).sum() for q in ref.parameters())))
+    rp = dict(ref.named_parameters())
+    for k, p in model.named_parameters():
+        g, rg = p.grad.detach().cpu().double(), rp[k].grad.double()
+        assert float((g - rg).abs().max()) <= 1e-4 * max(1e-3, 0.05 * total, float(rg.norm())), 'grad ' + k
+    return logits.detach()
+
+
+def test_edge_cases_empty_max_and_unit_lengths():
+    cfg = _cfg(batch_size=4)
+    model, ref = _models(cfg)
+    _compare(model, ref, _edge_batch(cfg))
+
+
+def test_bench_shaped_batch_matches_oracle():
+    cfg = _cfg(batch_size=8)
+    model, ref = _models(cfg, seed=1)
+    corpus = SynthCorpus(SynthSpec(vocabulary_size=cfg.vocabulary_size, news_pool=2000, seed=9))
+    _compare(model, ref, corpus.batch(8, np.random.default_rng(4)))
+
+
+def test_forward_bitwise_deterministic_and_backward_accumulates():
+    from nnr_amd.model import negative_log_softmax
+    cfg = _cfg(batch_size=4)
+    model, _ = _models(cfg, seed=2)
+    batch = _edge_batch(cfg)
+    a = model(*to_torch(batch, 'cuda')).detach()
+    b = model(*to_torch(batch, 'cuda')).detach()
+    assert torch.equal(a, b), 'forward must be bitwise reproducible (no atomics on the forward path)'
+    for p in model.parameters():
+        p.grad = None
+    negative_log_softmax(model(*to_torch(batch, 'cuda'))).backward()
+    g1 = {k: p.grad.clone() for k, p in model.named_parameters()}
+    negative_log_softmax(model(*to_torch(batch, 'cuda'))).backward()          # second backward ACCUMULATES like autograd
+    for k, p in model.named_parameters():
+        scale = max(1e-6, float(g1[k].abs().max()))
+        assert float((p.grad - 2 * g1[k]).abs().max()) <= 1e-5 * scale, k
+
+
+def test_mhsa_and_cnn_pairs_on_ragged_batch():
+    """MHSA+MHSA and CNN+ATT at full dims on a MIND-shaped batch incl. an empty history (fully masked attention rows)."""
+    from nnr_amd.model import Model, negative_log_softmax
+    from oracle import nnr_oracle as O
+    for ne, ue in (('MHSA', 'MHSA'), ('CNN', 'ATT')):
+        cfg = make_config(['--news_encoder=' + ne, '--user_encoder=' + ue], corpus_sizes=dict(vocabulary_size=800), dropout_rate=0.0)
+        torch.manual_seed(3)
+        ref = O.Model(cfg)
+        ref.initialize()
+        ref.eval()                                  # MHSA-user has a hard-wired F.dropout(p=0.5) in train mode
+        model = Model(cfg)
+        model.load_state_dict(ref.state_dict())
+        model = model.cuda().eval()
+        batch = _edge_batch(cfg)
+        logits = model(*to_torch(batch, 'cuda'))
+        rl = ref(*to_torch(batch))
+        assert float((logits.detach().cpu() - rl.detach()).abs().max()) <= 1e-4, (ne, ue)
+        negative_log_softmax(logits).backward()
+        O.negative_log_softmax(rl).backward()
+        rp = dict(ref.named_parameters())
+        total = float(torch.sqrt(sum((q.grad.double() ** 2).sum() for q in ref.parameters())))
+        for k, p in model.named_parameters():
+            assert float((p.grad.cpu().double() - rp[k].grad.double()).abs().max()) <= 1e-4 * max(1e-3, 0.05 * total), (ne, ue, k)
