@@ -65,7 +65,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(nnr_gemm_args g) {
   float* __restrict__ C = g.C;
   int kbeg = 0, kend = K;
   const int z = blockIdx.z;
-  if (g.split_k > 1) {
+  if (g.k_chunk > 0) {
+    // fixed-size reduction slices: the slice count follows the LIVE token count (device side), the grid covers capacity
+    kbeg = z * g.k_chunk;
+    kend = min(K, kbeg + g.k_chunk);
+    if (kbeg >= kend) return;
+  } else if (g.split_k > 1) {
     const int ktiles = (K + BK - 1) / BK;
     const int per = (ktiles + g.split_k - 1) / g.split_k;
     kbeg = z * per * BK;
@@ -308,11 +313,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(nnr_gemm_args g) {
   // Accumulators go through LDS in TM passes of 64 rows (tiny fully-unrolled store loop: the MFMA registers are only
   // ever indexed statically), then a rolled, runtime-flagged loop applies the epilogue with consecutive lanes on
   // consecutive columns: every global access (C, aux, mul, resid, atomics) is a contiguous 256-B wave access.
-  const bool use_atomic = g.atomic || g.split_k > 1;
+  const bool use_atomic = g.atomic || g.split_k > 1 || g.k_chunk > 0;
   float* aux = g.aux_out;
   const float* res = g.resid;
   const float* mulp = g.mul;
-  if (g.batch > 1 && g.split_k <= 1) {
+  if (g.batch > 1 && g.split_k <= 1 && g.k_chunk <= 0) {
     if (aux) aux += (long)z * g.stride_aux;
     if (res) res += (long)z * g.stride_res;
   }
@@ -426,7 +431,7 @@ int launch_cfg(const nnr_gemm_args& g, hipStream_t s) {
   constexpr int BM = 64 * TM, BN = 16 * TN;
   const int nbm = (g.M + BM - 1) / BM, nbn = (g.N + BN - 1) / BN;
   if (g.rowdot_w && nbn != 1) return NNR_ERR_ARG;
-  dim3 grid(nbm * nbn, 1, g.split_k > 1 ? g.split_k : (g.batch > 1 ? g.batch : 1));
+  dim3 grid(nbm * nbn, 1, g.k_chunk > 0 ? (g.K + g.k_chunk - 1) / g.k_chunk : (g.split_k > 1 ? g.split_k : (g.batch > 1 ? g.batch : 1)));
   dim3 block(256);
   if (!g.trans_a && !g.trans_b) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, false, BK>), grid, block, 0, s, g);
   else if (!g.trans_a && g.trans_b) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, true, BK>), grid, block, 0, s, g);
@@ -446,6 +451,7 @@ extern "C" int nnr_gemm_f32(const nnr_gemm_args* a, hipStream_t stream) {
   g.drop_thresh = nnr_drop_thresh(g.drop_target ? g.drop_p : 0.f);
   g.drop_scale = (g.drop_target && g.drop_p > 0.f) ? 1.f / (1.f - g.drop_p) : 1.f;
   if (g.drop_thresh == 0u) g.drop_target = 0;
+  if (g.k_chunk > 0) { if ((g.k_chunk & 31) || g.batch > 1) return NNR_ERR_ARG; g.split_k = 2; }   // shares split-K's restrictions below
   if (g.split_k > 1 && (g.bias || g.rowvec || g.act || g.aux_out || g.mul || g.resid || g.batch > 1 || g.rowdot_w))
     return NNR_ERR_ARG;
   if ((g.a_idx && g.trans_a) || (g.b_idx && !g.trans_b)) return NNR_ERR_ARG;
@@ -460,8 +466,9 @@ extern "C" int nnr_gemm_f32(const nnr_gemm_args* a, hipStream_t stream) {
   }
   int tile = g.tile;
   if (tile == 0) {
+    const long wg128 = (long)((g.M + 127) / 128) * ((g.N + 79) / 80) * (g.k_chunk > 0 ? (g.K + g.k_chunk - 1) / g.k_chunk : (g.split_k > 1 ? g.split_k : (g.batch > 1 ? g.batch : 1)));
     if (g.rowdot_w) tile = 3;
-    else if (g.M <= 512) tile = 2;
+    else if (g.M <= 512 || (wg128 < 640 && !g.dyn_dev)) tile = 2;   // too few 128-row tiles to fill 256 CUs x 4: use 64-row tiles
     else if (!g.trans_a && !g.trans_b) tile = 5;   // NT: BK = 32 measured +7 % (97.7 vs 90.9 TF); the K-major operands of NN / TN lose with it
     else tile = 4;           // 128 x 80: 117 VGPRs -> 4 waves/SIMD, 4 workgroups per CU hide barriers, prologue and epilogue
                              // (measured 84-96 TF vs 63-79 TF for the 256 x 80 tile on the CNE shapes)

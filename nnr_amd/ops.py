@@ -9,6 +9,7 @@ from . import _lib as L
 from . import profile as _prof
 
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
+K_CHUNK = 1024      # reduction rows per slice of the token-reduction (weight-gradient) GEMMs, see nnr_gemm_args.k_chunk
 
 
 def _p(t):
@@ -32,7 +33,7 @@ def split_for(m, n, k, tile_m=128, tile_n=80, target_blocks=2048, kmin=256):
 def gemm(A, B, C_=None, *, M, N, K, lda, ldb, ldc=0, trans_a=False, trans_b=False, dyn=None, dyn_dim=0, a_idx=None, b_idx=None,
          drop=None, alpha=1.0, bias=None, rowvec=None, ldrv=0, rowvec_map=None, act=0, aux_out=None, ldaux=0, mul=None, ldmul=0,
          resid=None, ldres=0, accumulate=False, atomic=False, c_idx=None, split_k=1, rowdot_w=None, rowdot_out=None, batch=1,
-         strideA=0, strideB=0, strideC=0, stride_aux=0, stride_res=0, tile=0, colsum_out=None):
+         strideA=0, strideB=0, strideC=0, stride_aux=0, stride_res=0, tile=0, colsum_out=None, k_chunk=0):
     g = L.GemmArgs()
     g.A, g.B, g.C = _p(A), _p(B), _p(C_)
     g.M, g.N, g.K, g.lda, g.ldb, g.ldc = M, N, K, lda, ldb, ldc
@@ -50,10 +51,12 @@ def gemm(A, B, C_=None, *, M, N, K, lda, ldb, ldc=0, trans_a=False, trans_b=Fals
     g.batch, g.strideA, g.strideB, g.strideC, g.stride_aux, g.stride_res = batch, strideA, strideB, strideC, stride_aux, stride_res
     g.tile = tile
     g.colsum_out = _p(colsum_out)
+    g.k_chunk = int(k_chunk)
     if not _prof.active():
         L.check(L.lib().nnr_gemm_f32(C.byref(g), _s()), 'nnr_gemm_f32')
         return
-    t = tile if tile else (3 if rowdot_w is not None else (2 if M <= 512 else (5 if not (trans_a or trans_b) else 4)))
+    wg128 = ((M + 127) // 128) * ((N + 79) // 80) * (split_k if split_k > 1 else max(1, batch)) * (1 if k_chunk <= 0 else max(1, K // k_chunk))
+    t = tile if tile else (3 if rowdot_w is not None else (2 if (M <= 512 or (wg128 < 640 and dyn is None)) else (5 if not (trans_a or trans_b) else 4)))
     fam = 'gemm_%s_%s' % ('tn' if trans_a else ('nn' if trans_b else 'nt'), {1: '256x80', 2: '64x80', 3: '128x208', 4: '128x80', 5: '128x80k32'}[t])
 
     def flops(M=M, N=N, K=K, dyn=dyn, dyn_dim=dyn_dim, batch=batch):
@@ -62,7 +65,7 @@ def gemm(A, B, C_=None, *, M, N, K, lda, ldb, ldc=0, trans_a=False, trans_b=Fals
             d = int(dyn.item())
             m, k = (min(M, d), K) if dyn_dim == 1 else (M, min(K, d))
         return 2.0 * m * N * k * max(1, batch)
-    flops.tag = 'M%d N%d K%d%s%s%s' % (M, N, K, ' b%d' % batch if batch > 1 else '', ' sk%d' % split_k if split_k > 1 else '', ' dyn' if dyn is not None else '')
+    flops.tag = 'M%d N%d K%d%s%s%s' % (M, N, K, ' b%d' % batch if batch > 1 else '', (' sk%d' % split_k if split_k > 1 else '') + (' kc%d' % k_chunk if k_chunk > 0 else ''), ' dyn' if dyn is not None else '')
     with _prof.span(fam, flops):
         L.check(L.lib().nnr_gemm_f32(C.byref(g), _s()), 'nnr_gemm_f32')
 
@@ -92,8 +95,9 @@ def linear_bwd_weight(dy, x, dw, dyn=None, rows=None, db=None, **kw):
     db[N] += column sums of dy, fused into the same launch."""
     R = dy.shape[0] if rows is None else rows
     N, K = dw.shape
+    sk = dict(split_k=split_for(N, K, R))      # (k_chunk slices measured no better than a static split at these sizes)
     gemm(dy, x, dw, M=N, N=K, K=R, lda=dy.stride(0), ldb=x.stride(0), ldc=dw.stride(0), trans_a=True, trans_b=True,
-         split_k=split_for(N, K, R), atomic=True, dyn=dyn, dyn_dim=2, colsum_out=db, **kw)
+         atomic=True, dyn=dyn, dyn_dim=2, colsum_out=db, **sk, **kw)
 
 
 def bias_grad(dy, db, dyn=None, rows=None):
