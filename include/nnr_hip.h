@@ -161,6 +161,7 @@ int nnr_embed_scatter(const float* dout, const int* idx, long n, int dim, float*
                       hipStream_t stream);
 int nnr_transpose2d(const float* in, float* out, long rows, int cols, int accumulate, hipStream_t stream);
 int nnr_add(float* y, const float* x, long n, float alpha, hipStream_t stream);
+int nnr_add_atomic(float* y, const float* x, long n, float alpha, hipStream_t stream);   /* y += alpha*x with f32 atomics */
 int nnr_add2d(float* y, int ldy, const float* x, int ldx, int rows, int cols, float alpha, int accumulate, hipStream_t stream);
 int nnr_dropout(const float* x, float* y, long n, float p, uint32_t seed, hipStream_t stream);
 int nnr_relu_bwd(const float* dy, const float* y, float* dx, long n, hipStream_t stream);

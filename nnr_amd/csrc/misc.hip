@@ -164,6 +164,10 @@ __global__ void transpose2d_kernel(const float* __restrict__ in, float* __restri
 __global__ void add_kernel(float* __restrict__ y, const float* __restrict__ x, long n, float alpha) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] += alpha * x[i];
 }
+// same with f32 atomics: for accumulators that two HIP streams add into concurrently (parameter gradients)
+__global__ void add_atomic_kernel(float* __restrict__ y, const float* __restrict__ x, long n, float alpha) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) atomicAdd(&y[i], alpha * x[i]);
+}
 __global__ void add2d_kernel(float* __restrict__ y, int ldy, const float* __restrict__ x, int ldx, int rows, int cols,
                              float alpha, int accumulate) {
   const long total = (long)rows * cols;
@@ -492,6 +496,9 @@ extern "C" int nnr_transpose2d(const float* in, float* out, long rows, int cols,
 }
 
 extern "C" int nnr_add(float* y, const float* x, long n, float alpha, hipStream_t stream) { EW_LAUNCH(add_kernel, n, y, x, n, alpha); }
+extern "C" int nnr_add_atomic(float* y, const float* x, long n, float alpha, hipStream_t stream) {
+  EW_LAUNCH(add_atomic_kernel, n, y, x, n, alpha);
+}
 extern "C" int nnr_add2d(float* y, int ldy, const float* x, int ldx, int rows, int cols, float alpha, int accumulate,
                          hipStream_t stream) {
   EW_LAUNCH(add2d_kernel, (long)rows * cols, y, ldy, x, ldx, rows, cols, alpha, accumulate);

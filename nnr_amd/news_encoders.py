@@ -107,15 +107,61 @@ def cne_forward(mod, title_text, title_mask, content_text, content_mask, categor
     return rep, saved
 
 
+_SIDE = {}
+
+
+def _side_stream(dev):
+    """One extra HIP stream per device for the small (candidate) encoder call."""
+    key = (dev.type, dev.index)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=dev)
+    return _SIDE[key]
+
+
+class _on:
+    """Run a phase of call #0 on the side stream when there are several calls; main-stream phases pass through."""
+
+    def __init__(self, side):
+        self.side = side
+
+    def __enter__(self):
+        if self.side is not None:
+            self.ctx = torch.cuda.stream(self.side)
+            self.ctx.__enter__()
+
+    def __exit__(self, *a):
+        if self.side is not None:
+            self.ctx.__exit__(*a)
+
+
+def _fork_join(n_calls, dev, phase):
+    """phase(i) for every call: call 0 (the candidates: ~10 % of the rows, launch-latency-bound kernels) on the side stream,
+    concurrently with the other calls on the current stream; returns after both streams are joined."""
+    if n_calls == 1:
+        return [phase(0)]
+    main = torch.cuda.current_stream(dev)
+    side = _side_stream(dev)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        first = phase(0)
+    rest = [phase(i) for i in range(1, n_calls)]
+    main.wait_stream(side)
+    return [first] + rest
+
+
 def cne_forward_many(mod, calls):
     """Run several independent CNE calls in lock-step: everything is per call except the Bi-LSTM recurrence, which is ONE
-    launch over all streams of all calls (it is latency-bound by its longest sequence, not throughput-bound)."""
+    launch over all streams of all calls (it is latency-bound by its longest sequence, not throughput-bound).  The per-call
+    phases of the first (small) call run on a second HIP stream, filling the gaps of the big call's kernels."""
     H = mod.hidden_dim
-    pre = [_cne_fwd_pre(mod, *c) for c in calls]
+    dev = calls[0][0].device
+    mod._packed_weights('title', mod.title_lstm)        # (re)pack on the main stream BEFORE forking: both calls read them
+    mod._packed_weights('content', mod.content_lstm)
+    pre = _fork_join(len(calls), dev, lambda i: _cne_fwd_pre(mod, *calls[i]))
     items = [st for sv in pre for st in (sv['streams'][1],)] + [st for sv in pre for st in (sv['streams'][0],)]   # content streams first
     for i in range(0, len(items), 4):
         ops.lstm_fwd(items[i:i + 4], H)
-    return [_cne_fwd_post(mod, sv) for sv in pre]
+    return _fork_join(len(calls), dev, lambda i: _cne_fwd_post(mod, pre[i]))
 
 
 def _cne_fwd_pre(mod, title_text, title_mask, content_text, content_mask, category, subCategory):
@@ -209,15 +255,16 @@ def cne_backward(mod, sv, drep):
 
 
 def cne_backward_many(mod, pairs):
-    """Backward of cne_forward_many: per-call stages around ONE shared recurrence-backward launch."""
+    """Backward of cne_forward_many: per-call stages (call 0 on the side stream) around ONE shared recurrence-backward launch."""
     H = mod.hidden_dim
-    for sv, drep in pairs:
-        _cne_bwd_pre(mod, sv, drep)
+    dev = pairs[0][1].device
+    for q in mod.parameters():          # materialise (zero-fill) missing .grad buffers on the main stream BEFORE forking
+        grad_of(q)
+    _fork_join(len(pairs), dev, lambda i: _cne_bwd_pre(mod, pairs[i][0], pairs[i][1]))
     items = [sv['streams'][1] for sv, _ in pairs] + [sv['streams'][0] for sv, _ in pairs]
     for i in range(0, len(items), 4):
         ops.lstm_bwd(items[i:i + 4], H)
-    for sv, _ in pairs:
-        _cne_bwd_post(mod, sv)
+    _fork_join(len(pairs), dev, lambda i: _cne_bwd_post(mod, pairs[i][0]))
 
 
 def _cne_bwd_pre(mod, sv, drep):

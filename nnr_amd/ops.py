@@ -162,7 +162,7 @@ def lstm_unpack_grads(dw_ihp, db_p, dw_hhp, H, E, grads):
     L.check(L.lib().nnr_lstm_unpack_grads(_p(dw_ihp), _p(db_p), _p(dw_hhp), H, E, *[_p(t) for t in order], _s()),
             'nnr_lstm_unpack_grads')
     for g, t in zip(grads, tmp):
-        add_(g, t)
+        add_atomic_(g, t)       # parameter gradients may be accumulated from two HIP streams at once
 
 
 def _lstm_probs(items):
@@ -225,6 +225,12 @@ def pool_bwd(**kw):
 def add_(y, x, alpha=1.0):
     assert y.is_contiguous() and x.is_contiguous() and y.numel() == x.numel()
     L.check(L.lib().nnr_add(_p(y), _p(x), C.c_long(y.numel()), C.c_float(alpha), _s()), 'nnr_add')
+    return y
+
+
+def add_atomic_(y, x, alpha=1.0):
+    assert y.is_contiguous() and x.is_contiguous() and y.numel() == x.numel()
+    L.check(L.lib().nnr_add_atomic(_p(y), _p(x), C.c_long(y.numel()), C.c_float(alpha), _s()), 'nnr_add_atomic')
     return y
 
 
