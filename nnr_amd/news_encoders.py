@@ -261,10 +261,22 @@ def cne_backward_many(mod, pairs):
     for q in mod.parameters():          # materialise (zero-fill) missing .grad buffers on the main stream BEFORE forking
         grad_of(q)
     _fork_join(len(pairs), dev, lambda i: _cne_bwd_pre(mod, pairs[i][0], pairs[i][1]))
-    items = [sv['streams'][1] for sv, _ in pairs] + [sv['streams'][0] for sv, _ in pairs]
-    for i in range(0, len(items), 4):
-        ops.lstm_bwd(items[i:i + 4], H)
-    _fork_join(len(pairs), dev, lambda i: _cne_bwd_post(mod, pairs[i][0]))
+
+    # recurrence backward + token-reduction GEMMs, per token stream kind: the content recurrence is one long dependent chain
+    # (128 steps) that leaves most CUs idle in its tail; the title recurrence (32 steps) and the title GEMMs run on the side
+    # stream and fill them.  All parameter-gradient accumulation below is atomic.
+    def run_kind(kind):
+        ops.lstm_bwd([sv['streams'][kind] for sv, _ in pairs], H)
+        for sv, _ in pairs:
+            _cne_bwd_post(mod, sv, sv['streams'][kind])
+
+    main = torch.cuda.current_stream(dev)
+    side = _side_stream(dev)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        run_kind(0)
+    run_kind(1)
+    main.wait_stream(side)
 
 
 def _cne_bwd_pre(mod, sv, drep):
@@ -324,14 +336,14 @@ def _cne_bwd_pre(mod, sv, drep):
         st['dh'] = st['dH']
 
 
-def _cne_bwd_post(mod, sv):
-    t_, c_ = sv['streams']
+def _cne_bwd_post(mod, sv, st):
+    """After the recurrence backward of token stream `st`: weight / bias gradients of the LSTM and the embedding-row scatter."""
     p = sv['p']
     H, E = mod.hidden_dim, mod.word_embedding_dim
     H2 = 2 * H
-    f32 = dict(device=t_['gates'].device, dtype=torch.float32)
+    f32 = dict(device=st['gates'].device, dtype=torch.float32)
     emb = mod.word_embedding.weight
-    for st in (t_, c_):
+    if True:
         plan, w, cap = st['plan'], st['w'], st['plan'].cap
         dg = st['gates']                                  # now d(pre-activation gates), p-order
         NP = w.NP
