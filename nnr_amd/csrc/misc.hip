@@ -110,45 +110,36 @@ __global__ __launch_bounds__(256) void embed_gather_kernel(const float* __restri
   }
 }
 // backward: dtable[idx[row], :] += mask * dout[row, :]  -- f32 atomics, each wave-instruction = 256 contiguous bytes of one row.
-// Dense id tensors are mostly <PAD> (id 0) past each title's length, and atomics into ONE row run ~14x slower than spread
-// ones (MI355X_MICROARCH.md, global float atomics): rows with the block's hot id (0) are pre-reduced in registers / LDS and
-// leave the block as a single atomic row.
+// Global float atomics into ONE row run ~14x slower than spread ones (MI355X_MICROARCH.md), and word ids are far from uniform:
+// dense id tensors are mostly <PAD> (id 0) past each title's length, and the vocabulary is frequency-ordered (MIND_corpus.py:
+// rows >= 2 by descending frequency), so the hot destinations are the SMALL ids.  Rows whose id is < HOT are accumulated in an
+// LDS table per workgroup (ds_add_f32) and leave the block as one atomic row per hot id; the workgroups are persistent
+// (grid-stride) so there are few such flushes.
+constexpr int SC_HOT = 32, SC_MAXD = 320;
 __global__ __launch_bounds__(256) void embed_scatter_kernel(const float* __restrict__ dout, const int* __restrict__ idx, long n, int dim,
                                                             float* __restrict__ dtable, uint32_t seed, uint32_t thr, float scale) {
-  constexpr int MAXC = 8;                      // columns per lane: dim <= 512
-  __shared__ float hot[4][64 * MAXC];
+  __shared__ float hot[SC_HOT * SC_MAXD];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  float acc[MAXC];
-#pragma unroll
-  for (int j = 0; j < MAXC; ++j) acc[j] = 0.f;
-  bool any_hot = false;
+  const bool use_hot = dim <= SC_MAXD;
+  if (use_hot) for (int i = threadIdx.x; i < SC_HOT * dim; i += 256) hot[i] = 0.f;
+  __syncthreads();
   for (long row = blockIdx.x * 4L + wv; row < n; row += gridDim.x * 4L) {
     const int dst = idx[row];
     if (dst < 0) continue;
-    if (dst == 0 && dim <= 64 * MAXC) {
-      any_hot = true;
-#pragma unroll
-      for (int j = 0; j < MAXC; ++j) {
-        const int c = lane + 64 * j;
-        if (c < dim) {
-          float v = dout[row * dim + c];
-          if (thr) v = nnr_keep(seed, (uint64_t)row * dim + c, thr) ? v * scale : 0.f;
-          acc[j] += v;
-        }
-      }
-      continue;
-    }
+    const bool h = use_hot && dst < SC_HOT;
     for (int c = lane; c < dim; c += 64) {
       float v = dout[row * dim + c];
       if (thr) v = nnr_keep(seed, (uint64_t)row * dim + c, thr) ? v * scale : 0.f;
-      atomicAdd(&dtable[(long)dst * dim + c], v);
+      if (h) atomicAdd(&hot[dst * dim + c], v);
+      else atomicAdd(&dtable[(long)dst * dim + c], v);
     }
   }
-#pragma unroll
-  for (int j = 0; j < MAXC; ++j) hot[wv][lane + 64 * j] = acc[j];
-  const int hot_waves = __syncthreads_count(any_hot ? 1 : 0);
-  if (hot_waves == 0) return;
-  for (int c = threadIdx.x; c < dim; c += 256) atomicAdd(&dtable[c], hot[0][c] + hot[1][c] + hot[2][c] + hot[3][c]);
+  __syncthreads();
+  if (use_hot)
+    for (int i = threadIdx.x; i < SC_HOT * dim; i += 256) {
+      const float v = hot[i];
+      if (v != 0.f) atomicAdd(&dtable[i], v);      // hot rows are rows 0..HOT-1 of the table: same flat offset
+    }
 }
 // ---- out[c, r] = in[r, c]  (weight re-layouts, e.g. Conv1d [C_out*C_in, k] -> [k, C_out*C_in])
 __global__ void transpose2d_kernel(const float* __restrict__ in, float* __restrict__ out, long rows, int cols, int accumulate) {
@@ -487,7 +478,9 @@ extern "C" int nnr_embed_gather(const float* table, const int* idx, long n, int 
 }
 extern "C" int nnr_embed_scatter(const float* dout, const int* idx, long n, int dim, float* dtable, float p, uint32_t seed, hipStream_t stream) {
   const float sc = p > 0.f ? 1.f / (1.f - p) : 1.f;
-  hipLaunchKernelGGL(embed_scatter_kernel, dim3(ew_grid(n, 4)), dim3(256), 0, stream, dout, idx, n, dim, dtable, seed, nnr_drop_thresh(p), sc);
+  const long want = (n + 3) / 4;
+  hipLaunchKernelGGL(embed_scatter_kernel, dim3((int)(want < 1 ? 1 : (want > 1024 ? 1024 : want))), dim3(256), 0, stream, dout, idx, n, dim, dtable, seed,
+                     nnr_drop_thresh(p), sc);
   NNR_CHECK_LAUNCH();
   return NNR_OK;
 }
