@@ -117,7 +117,12 @@ typedef struct nnr_lstm_problem {
   const float* wb;    /* backward fragment-layout W_hh */
   const float* dh;    /* bwd: dL/dH [rows, 2*H] */
   const float* dcn;   /* bwd: dL/dc_n [n, 2*H] or NULL */
+  unsigned* sync;     /* optional workspace of nnr_lstm_sync_bytes(n) bytes (zeroed by the library): when every problem of a
+                       * launch has one and H = 200, each 16-sequence tile runs on a PAIR of CUs with W_hh resident in
+                       * registers/LDS, exchanging half of h_t per step; after the launch its last 64 bytes hold diagnostics
+                       * (word 0 = spin-wait timeouts, must be 0) */
 } nnr_lstm_problem;
+size_t nnr_lstm_sync_bytes(int n);
 /* up to 4 problems (title + content streams of the candidate call and of the history call) run in ONE launch: the
  * recurrence is bound by its longest dependent chain, so independent streams are free to share it */
 int nnr_lstm_fwd(const nnr_lstm_problem* probs, int nprob, int H, hipStream_t stream);

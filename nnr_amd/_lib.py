@@ -25,7 +25,7 @@ class GemmArgs(C.Structure):
 
 class LstmProblem(C.Structure):
     _fields_ = [('bs', vp), ('off', vp), ('slen', vp), ('prev_f', vp), ('prev_r', vp), ('n', ci), ('L', ci), ('gates', vp),
-                ('cell', vp), ('hout', vp), ('cn', vp), ('wf', vp), ('wb', vp), ('dh', vp), ('dcn', vp)]
+                ('cell', vp), ('hout', vp), ('cn', vp), ('wf', vp), ('wb', vp), ('dh', vp), ('dcn', vp), ('sync', vp)]
 
 
 class PoolArgs(C.Structure):
@@ -39,7 +39,7 @@ class PoolArgs(C.Structure):
 # every symbol include/nnr_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
     'nnr_version', 'nnr_gemm_f32', 'nnr_seq_plan', 'nnr_lstm_dims', 'nnr_lstm_pack_weights', 'nnr_lstm_unpack_grads',
-    'nnr_lstm_fwd', 'nnr_lstm_bwd', 'nnr_attn_pool_fwd', 'nnr_attn_pool_bwd', 'nnr_gate_bwd', 'nnr_packed_seq_sum',
+    'nnr_lstm_fwd', 'nnr_lstm_bwd', 'nnr_lstm_sync_bytes', 'nnr_attn_pool_fwd', 'nnr_attn_pool_bwd', 'nnr_gate_bwd', 'nnr_packed_seq_sum',
     'nnr_tanh_score_bwd', 'nnr_colsum', 'nnr_small_embed_fwd', 'nnr_small_embed_bwd', 'nnr_add', 'nnr_add_atomic', 'nnr_add2d', 'nnr_dropout',
     'nnr_relu_bwd', 'nnr_relu_drop_bwd', 'nnr_sue_x0_fwd', 'nnr_sue_x0_bwd', 'nnr_sue_slice_fwd', 'nnr_sue_slice_bwd',
     'nnr_sue_intra_fwd', 'nnr_sue_intra_bwd', 'nnr_logits_loss_fwd', 'nnr_logits_fwd', 'nnr_nls_loss', 'nnr_logits_bwd', 'nnr_sumsq', 'nnr_clip_adam',
@@ -71,6 +71,7 @@ def lib():
         _lib = C.CDLL(LIB_PATH)
         for s in SYMBOLS:
             getattr(_lib, s).restype = ci
+        _lib.nnr_lstm_sync_bytes.restype = C.c_size_t
     return _lib
 
 

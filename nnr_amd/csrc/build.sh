@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")"
 OUT=../libnnr_hip.so
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-pass-failed"
+FLAGS="${NNR_EXTRA_FLAGS} --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-pass-failed"
 mkdir -p build
 pids=()
 for f in gemm seq_plan lstm pool misc mhsa; do

@@ -49,7 +49,58 @@ struct LstmProblem {
   const float* wfrag;  // fwd: Wf [2][UB][4][KG][64][4] ; bwd: Wb [2][UB][NP/16][64][4]
   const float* dh;     // bwd: upstream dL/dH [rows, 2*H]
   const float* dcn;    // bwd: upstream dL/dc_n [n, 2*H] (sorted order) or null
+  unsigned* sync;      // pair kernels: [2][ntiles][2][SYNC_PAD] step counters + [SYNC_PAD] diagnostics
 };
+constexpr int SYNC_PAD = 16;                 // diagnostics block (64 bytes) at the end of the workspace
+constexpr int SPIN_LIMIT = 1 << 20;          // ~seconds: a partner workgroup may still be waiting for a free CU
+
+// Exchange between two RUNNING workgroups.  Every value travels as one 8-byte (value, step tag) word, so the payload
+// carries its own readiness: no flag, no fence, no store-acknowledge wait -- the reader polls the words it needs.
+// Two flavours, chosen per pair at kernel start from the XCC_ID hardware register of both workgroups:
+//  * same XCD (the normal case: workgroups i and i + 8 of a dispatch land on the same XCD, 128/128 pairs in
+//    tools/micro/xcdpp.hip): plain stores (the per-CU cache is write-through) + NON-TEMPORAL loads, which never retain a
+//    line in the per-CU cache and therefore always read the XCD's L2 -- 1.2 us per full exchange round, 256 workgroups
+//    at once, 0 stale words in 300 x 128 x 1792 checked;
+//  * different XCDs (their L2s are not coherent with each other): relaxed agent-scope atomics = write-through stores /
+//    cache-bypassing loads (sc1) through the fabric -- 2.1-3.3 us per round.  (Agent-scope release/acquire FENCES cost
+//    14-19 us per round at that occupancy, tools/micro/pingpong.hip; group-scope sc0 loads hit stale per-CU lines.)
+__device__ __forceinline__ unsigned xcc_id() {
+  unsigned v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+  return v & 0xf;
+}
+__device__ __forceinline__ void st_tag(unsigned long long* p, float v, unsigned tag, bool same_xcd) {
+  const unsigned long long word = ((unsigned long long)tag << 32) | __float_as_uint(v);
+  if (same_xcd) __hip_atomic_store(p, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // a plain store: no wait, no cache-policy bits
+  else __hip_atomic_store(p, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long ld_tag(const unsigned long long* p, bool same_xcd) {
+  if (same_xcd) {
+    unsigned long long v;      // asm: a polling loop must re-issue the load every time
+    asm volatile("global_load_dwordx2 %0, %1, off nt\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+  }
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// first (batched) read of a step: compiler-tracked, so several can be in flight
+__device__ __forceinline__ unsigned long long ld_tag_first(const unsigned long long* p, bool same_xcd) {
+  if (same_xcd) return __builtin_nontemporal_load(p);
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// re-poll one word until its tag matches (bounded: never hang the GPU -- count the timeout and go on)
+__device__ __forceinline__ float wait_tag(const unsigned long long* p, unsigned long long v, unsigned tag, bool same_xcd, unsigned* diag) {
+  int spins = 0;
+  while ((unsigned)(v >> 32) != tag) {
+    __builtin_amdgcn_s_sleep(1);
+    v = ld_tag(p, same_xcd);
+    if (++spins > SPIN_LIMIT) { atomicAdd(diag, 1u); break; }
+  }
+#ifdef NNR_LSTM_COUNT_REPOLLS
+  if (spins) { atomicAdd(diag + 1, 1u); atomicAdd(diag + 2, (unsigned)spins); }
+#endif
+  return __uint_as_float((unsigned)v);
+}
+
 struct LstmArgs { LstmProblem p[4]; int nprob; int H; int dbg; };   // dbg: timing-attribution mask (NNR_LSTM_DBG), 0 in production
 
 // ------------------------------------------------------------------------------------------------ forward
@@ -305,6 +356,221 @@ __global__ __launch_bounds__((UB > 4 ? 16 : 4) * 64) void lstm_fwd_kernel(LstmAr
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------ forward, 2 CUs per tile
+// Weights-stationary variant: a tile's gate columns are split over a PAIR of workgroups (pair_tile / pair_half) on two CUs
+// of one XCD.  Half 0 owns unit blocks [0, UB0), half 1 owns [UB0, UB).  Each of a workgroup's compute waves keeps the W_hh
+// fragments of its unit block RESIDENT for the whole sequence -- 3 gates in registers (3*KG f32x4 = 156 VGPRs at H = 200),
+// the 4th in LDS -- so nothing is streamed from L2 inside the time loop (the one-CU kernel re-reads 640 KB per step), and
+// the per-step MFMA chain per SIMD is halved.  The price is one exchange per step: each half needs the other half's units
+// of h_{t-1}.  h_t is written to `hout` anyway; it is written with write-through stores, a per-workgroup step counter is
+// published, and a helper wave of the partner copies the rows into its LDS tile with cache-bypassing loads while the
+// compute waves are busy with the K range they own (phase A); the partner's K range follows after a barrier (phase B).
+// Dispatch is in blockIdx order, so a waiting workgroup's partner is always the next one to get a CU: no deadlock; the
+// spin loops are bounded anyway.
+// Pairing: workgroups x and x + 8 of a dispatch share an XCD (round-robin placement), so within every group of 16
+// consecutive workgroups the first 8 are halves 0 and the next 8 the matching halves 1 of 8 tiles.
+__device__ __forceinline__ int pair_tile(int bx) { return (bx >> 4) * 8 + (bx & 7); }
+__device__ __forceinline__ int pair_half(int bx) { return (bx >> 3) & 1; }
+
+template <int UB, int hv>
+__device__ __forceinline__ void lstm_fwd_pair_body(const LstmArgs& a, float (*hbuf)[16 * UB * 16], f32x4 (*wl)[UB][64]) {
+  constexpr int HP = UB * 16, NP = UB * 64, KG = UB, UB0 = (UB + 1) / 2, NW = 8, NT = NW * 64;
+  const LstmProblem& P = a.p[blockIdx.z];
+  const int H = a.H;
+  const int tile = pair_tile(blockIdx.x);
+  const int s0 = tile * 16;
+  if (s0 >= P.n) return;
+  const int d = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, kk = lane >> 4;
+  constexpr int ub_lo = hv ? UB0 : 0, nb = hv ? UB - UB0 : UB0;
+  const int tmax = P.slen[s0];
+  const int ntiles = (P.n + 15) >> 4;
+  // exchange slots: [d][tile][half][step parity][16 rows][XW] tagged words, written by `half`, read by its partner
+  constexpr int XW = UB0 * 16, XT = 16 * XW, XS = 2 * XT + 8;        // + one line for the placement handshake
+  unsigned long long* xmine = reinterpret_cast<unsigned long long*>(P.sync) + ((long)(d * ntiles + tile) * 2 + hv) * XS;
+  const unsigned long long* xtheirs = reinterpret_cast<const unsigned long long*>(P.sync) + ((long)(d * ntiles + tile) * 2 + (hv ^ 1)) * XS;
+  unsigned* diag = P.sync + (long)2 * ntiles * 2 * XS * 2;
+  // placement handshake through the fabric path (valid wherever the partner runs): do both halves sit on one XCD?
+  if (tid == 0) {
+    const unsigned mine = xcc_id();
+    st_tag(xmine + 2 * XT, __uint_as_float(mine), 0x7fffffffu, false);
+    const float theirs = wait_tag(xtheirs + 2 * XT, ld_tag(xtheirs + 2 * XT, false), 0x7fffffffu, false, diag);
+    hbuf[0][0] = (__float_as_uint(theirs) == mine && !(a.dbg & 64)) ? 1.f : 0.f;
+  }
+  __syncthreads();
+  const bool same_xcd = __builtin_amdgcn_readfirstlane(hbuf[0][0] != 0.f);
+  __syncthreads();
+  for (int i = tid; i < 2 * 16 * HP; i += NT) (&hbuf[0][0])[i] = 0.f;
+  unsigned long long* tbuf = reinterpret_cast<unsigned long long*>(diag + SYNC_PAD);
+  const bool stamp = (a.dbg & 32) && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0;
+#define STAMP(slot) do { if (stamp && step < 128) tbuf[step * 16 + (slot)] = wall_clock64(); } while (0)
+
+  // the partner's REAL units (its padded ones stay 0 in LDS)
+  const int pu0 = hv ? 0 : UB0 * 16, pw = (hv ? UB0 * 16 : H) - pu0;
+  const bool compute = w < nb;
+  const int ub = ub_lo + (compute ? w : 0);
+  const int ldg = 2 * NP, ldc = 2 * HP, ldh = 2 * H;
+  // resident weights: gates i, f, g in registers, gate o in LDS
+  f32x4 wr[3][KG];
+  {
+    const f32x4* wf = reinterpret_cast<const f32x4*>(P.wfrag) + ((long)(d * UB + ub) * 4 * KG) * 64 + lane;
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int kg = 0; kg < KG; ++kg) wr[g][kg] = wf[(g * KG + kg) * 64];
+    if (compute) {
+#pragma unroll
+      for (int kg = 0; kg < KG; ++kg) wl[w][kg][lane] = wf[(3 * KG + kg) * 64];
+    }
+  }
+  float c[4] = {0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+
+  for (int step = 0; step < tmax; ++step) {
+    const int t = d ? (tmax - 1 - step) : step;
+    const int nact = min(16, P.bs[t] - s0);
+    const long row0 = (long)P.off[t] + s0;
+    float* hc = hbuf[step & 1];
+    float* hn = hbuf[(step & 1) ^ 1];
+    f32x4 acc[4];
+    STAMP(4);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // every wave fetches its share of the partner's half of h_{t-1}: on either path a wave sustains only a few of these
+    // requests (one wave fetching the whole tile takes 5.5 us through L2 and ~10 us through the fabric, eight waves sharing
+    // it ~1 us; tools/micro/pingpong.hip).  The loads are
+    // issued part-way through phase A -- late enough that the partner's stores (sent ~1 us before this step began, visible
+    // ~2 us after being sent) have landed, early enough that the round trip hides under the remaining MFMAs.
+    constexpr int MAXW = (XT + NT - 1) / NT;
+    constexpr int KSPLIT = 3;                               // own k-groups done before the fetch is issued
+    unsigned long long v[MAXW];
+    const int tp = d ? t + 1 : t - 1;
+    const int nprev = step > 0 ? min(16, P.bs[tp] - s0) : 0;
+    const unsigned long long* src = xtheirs + ((step + 1) & 1) * XT;
+    auto phase_a = [&](int k_from, int k_to) __attribute__((always_inline)) {
+#pragma unroll
+      for (int kg = 0; kg < KG; ++kg) {
+        const int own = kg - (hv ? UB0 : 0);                // index inside the own K range
+        if ((kg < UB0) == (hv == 0) && own >= k_from && own < k_to) {
+          const f32x4 af = *reinterpret_cast<const f32x4*>(&hc[r * HP + kg * 16 + 4 * (kk ^ swz16(r))]);
+          const f32x4 b3 = wl[w][kg][lane];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], wr[g][kg][i], acc[g], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], b3[i], acc[3], 0, 0, 0);
+          }
+        }
+      }
+    };
+    if (compute && !(a.dbg & 16)) phase_a(0, KSPLIT);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(a.dbg & 1)) {
+#pragma unroll
+      for (int j = 0; j < MAXW; ++j) {
+        const int i = tid + NT * j, row = i / XW, cc = i - row * XW;
+        v[j] = 0;
+        if (row < nprev && cc < pw) v[j] = ld_tag_first(src + i, same_xcd);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (compute && !(a.dbg & 16)) phase_a(KSPLIT, KG);
+    STAMP(5);
+    if (!(a.dbg & 1)) {
+      const unsigned tag = (unsigned)step;
+#pragma unroll
+      for (int j = 0; j < MAXW; ++j) {
+        const int i = tid + NT * j, row = i / XW, cc = i - row * XW;
+        if (row < nprev && cc < pw) hc[lds_off(row, pu0 + cc, HP)] = wait_tag(src + i, v[j], tag, same_xcd, diag);
+      }
+    }
+    STAMP(2);
+    __syncthreads();                                     // the partner's half of h_{t-1} is in LDS
+    STAMP(6);
+    if (compute) {
+      f32x4 x[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = kk * 4 + e;
+        x[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (row < nact) x[e] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(P.gates + (row0 + row) * ldg + d * NP + ub * 64 + r * 4));
+      }
+      if (!(a.dbg & 8)) {
+#pragma unroll
+      for (int kg = 0; kg < KG; ++kg) {
+        if ((kg < UB0) != (hv == 0)) {
+          const f32x4 af = *reinterpret_cast<const f32x4*>(&hc[r * HP + kg * 16 + 4 * (kk ^ swz16(r))]);
+          const f32x4 b3 = wl[w][kg][lane];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], wr[g][kg][i], acc[g], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], b3[i], acc[3], 0, 0, 0);
+          }
+        }
+      }
+      }
+      if (stamp && step < 128) tbuf[step * 16 + 7] = wall_clock64() + (unsigned long long)(acc[0][0] == 123.456f);
+      const int unit = ub * 16 + r;
+      float hv_[4], cn_[4];
+      f32x4 gt[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float gi = fast_sigmoid(acc[0][e] + x[e][0]);
+        const float gf = fast_sigmoid(acc[1][e] + x[e][1]);
+        const float gg = fast_tanh(acc[2][e] + x[e][2]);
+        const float go = fast_sigmoid(acc[3][e] + x[e][3]);
+        cn_[e] = gf * c[e] + gi * gg;
+        hv_[e] = go * fast_tanh(cn_[e]);
+        gt[e] = f32x4{gi, gf, gg, go};
+      }
+      if (stamp && step < 128) tbuf[step * 16 + 9] = wall_clock64() + (unsigned long long)(hv_[0] == 123.456f);
+      // the partner waits for these: send them first
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = kk * 4 + e;
+        if (row < nact && unit < H && !(a.dbg & 2)) st_tag(xmine + (step & 1) * XT + row * XW + (unit - ub_lo * 16), hv_[e], (unsigned)(step + 1), same_xcd);
+      }
+      STAMP(10);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = kk * 4 + e;
+        if (row < nact) {
+          c[e] = cn_[e];
+          hn[lds_off(row, unit, HP)] = hv_[e];
+          if (a.dbg & 4) continue;
+          if (unit < H) P.hout[(row0 + row) * ldh + d * H + unit] = hv_[e];
+          *reinterpret_cast<f32x4*>(P.gates + (row0 + row) * ldg + d * NP + ub * 64 + r * 4) = gt[e];
+          P.cell[(row0 + row) * ldc + d * HP + unit] = cn_[e];
+        }
+      }
+    }
+    STAMP(8);
+    __syncthreads();
+  }
+#undef STAMP
+  if (compute) {
+    const int unit = ub * 16 + r;
+    if (unit < H) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int s = s0 + kk * 4 + e;
+        if (s < P.n) P.cn[(long)s * ldh + d * H + unit] = c[e];
+      }
+    }
+  }
+}
+
+template <int UB>
+__global__ __launch_bounds__(512) void lstm_fwd_pair_kernel(LstmArgs a) {
+  // the two halves are separate instantiations: every K-range loop is static, so the LDS operand reads software-pipeline
+  __shared__ __attribute__((aligned(16))) float hbuf[2][16 * UB * 16];
+  __shared__ f32x4 wl[(UB + 1) / 2][UB][64];             // gate 3 ("o") fragments of every compute wave
+  if (pair_half(blockIdx.x)) lstm_fwd_pair_body<UB, 1>(a, hbuf, wl);
+  else lstm_fwd_pair_body<UB, 0>(a, hbuf, wl);
+}
+
 // ------------------------------------------------------------------------------------------------ backward
 // Per step: (1) lane-local gate gradients from the saved activations -> dgates tile in LDS (+ global, in place over
 // the saved gates);  (2) dh_{prev} = dgates[16, 4H] . W_hh on the matrix cores, W_hh streamed from L2 in fragment
@@ -450,6 +716,182 @@ __global__ __launch_bounds__((UB > 4 ? 16 : 4) * 64) void lstm_bwd_kernel(LstmAr
   }
 }
 
+// ------------------------------------------------------------------------------------------------ backward, 2 CUs per tile
+// Same pairing and exchange as the forward pair kernel.  dh_{prev}[16, HP] = dgates[16, NP] . W_hh is split over K: each
+// half multiplies ITS OWN gate-gradient columns (the unit blocks it owns, so the dgates tile in LDS never leaves the CU)
+// with W_hh for ALL units -- one 16-unit output tile of its own per wave, plus one of the partner's.  The partner's tile
+// is computed first and sent as tagged words straight from the accumulator registers; the receiving wave has the SAME
+// lane layout (row = 4*(lane>>4)+e, unit = lane&15), so it adds the four words to its own partial sums in registers at
+// the start of the next step: no LDS staging, no extra barrier, and the round trip hides under the own-tile MFMAs.
+// W_hh fragments are resident: the own tile's K range in registers, the partner tile's half in registers, half in LDS.
+template <int UB, int hv>
+__device__ __forceinline__ void lstm_bwd_pair_body(const LstmArgs& a, float* dg, f32x4 (*wl)[64]) {
+  constexpr int HP = UB * 16, NP = UB * 64, KGB = NP / 16, UB0 = (UB + 1) / 2, NW = 8;
+  constexpr int ub_lo = hv ? UB0 : 0, nb = hv ? UB - UB0 : UB0;          // own unit blocks
+  constexpr int npb = UB - nb, pb_lo = hv ? 0 : UB0;                     // the partner's unit blocks
+  constexpr int KO = nb * 4, k_lo = ub_lo * 4;                           // own K range (16-column groups of p-ordered gate columns)
+  constexpr int KR = KO / 2, KL = KO - KR;                               // partner-tile fragments in registers / in LDS
+  constexpr int DLD = nb * 64 + 16;                                      // row stride = 4 (mod 16) 16-byte chunks (swizzle)
+  static_assert((DLD / 4) % 16 == 4, "dgates tile stride must keep the ds_read_b128 swizzle conflict-free");
+  const LstmProblem& P = a.p[blockIdx.z];
+  const int H = a.H;
+  const int tile = pair_tile(blockIdx.x);
+  const int s0 = tile * 16;
+  if (s0 >= P.n) return;
+  const int d = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, kk = lane >> 4;
+  const int tmax = P.slen[s0];
+  const int ntiles = (P.n + 15) >> 4;
+  constexpr int XT = UB0 * 4 * 64, XS = 2 * XT + 8;                      // [step parity][tile][e][lane] tagged words (+ handshake line)
+  unsigned long long* xmine = reinterpret_cast<unsigned long long*>(P.sync) + ((long)(d * ntiles + tile) * 2 + hv) * XS;
+  const unsigned long long* xtheirs = reinterpret_cast<const unsigned long long*>(P.sync) + ((long)(d * ntiles + tile) * 2 + (hv ^ 1)) * XS;
+  unsigned* diag = P.sync + (long)2 * ntiles * 2 * XS * 2;
+  if (tid == 0) {
+    const unsigned mine = xcc_id();
+    st_tag(xmine + 2 * XT, __uint_as_float(mine), 0x7fffffffu, false);
+    const float theirs = wait_tag(xtheirs + 2 * XT, ld_tag(xtheirs + 2 * XT, false), 0x7fffffffu, false, diag);
+    dg[0] = (__float_as_uint(theirs) == mine && !(a.dbg & 64)) ? 1.f : 0.f;
+  }
+  __syncthreads();
+  const bool same_xcd = __builtin_amdgcn_readfirstlane(dg[0] != 0.f);
+  __syncthreads();
+
+  const bool own = w < nb;                               // this wave owns unit block ub_lo + w (gate gradients + own output tile)
+  const bool par = w < npb;                              // ... and computes the partner's output tile pb_lo + w
+  if (!own && !par) {                                    // nothing to do: keep the barrier count
+    for (int step = 0; step < tmax; ++step) { __syncthreads(); __syncthreads(); }
+    return;
+  }
+  const int ub = ub_lo + (own ? w : 0);
+  const int unit = ub * 16 + r;
+  const int ldg = 2 * NP, ldc = 2 * HP, ldh = 2 * H;
+  int mylen[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int s = s0 + kk * 4 + e;
+    mylen[e] = (s < P.n) ? P.slen[s] : 0;
+  }
+  // resident weights: wb[d][n-tile][kg][lane] (lstm_pack_kernel)
+  f32x4 wo[KO], wp[KR];
+  {
+    const f32x4* wb = reinterpret_cast<const f32x4*>(P.wfrag) + (long)d * UB * KGB * 64 + lane;
+#pragma unroll
+    for (int k = 0; k < KO; ++k) wo[k] = own ? wb[((long)ub * KGB + k_lo + k) * 64] : f32x4{0.f, 0.f, 0.f, 0.f};
+    const int pb = pb_lo + (par ? w : 0);
+#pragma unroll
+    for (int k = 0; k < KR; ++k) wp[k] = par ? wb[((long)pb * KGB + k_lo + k) * 64] : f32x4{0.f, 0.f, 0.f, 0.f};
+    if (par) {
+#pragma unroll
+      for (int k = 0; k < KL; ++k) wl[w * KL + k][lane] = wb[((long)pb * KGB + k_lo + KR + k) * 64];
+    }
+  }
+  float dhr[4] = {0.f, 0.f, 0.f, 0.f}, dcr[4] = {0.f, 0.f, 0.f, 0.f};
+  // software-pipelined inputs of the gate-gradient phase (loaded under the MFMA phase of the previous step)
+  f32x4 in_g[4];
+  float in_ct[4], in_cp[4], in_dh[4];
+  auto load_inputs = [&](int step) __attribute__((always_inline)) {
+    const int t = d ? step : (tmax - 1 - step);
+    const int nact = min(16, P.bs[t] - s0);
+    const long row0 = (long)P.off[t] + s0;
+    const int tp = d ? t + 1 : t - 1;
+    const long prow0 = (tp >= 0 && tp < P.L) ? (long)P.off[tp] + s0 : 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = kk * 4 + e;
+      in_g[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+      in_ct[e] = 0.f; in_cp[e] = 0.f; in_dh[e] = 0.f;
+      if (own && row < nact) {
+        const long grow = row0 + row;
+        in_g[e] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(P.gates + grow * ldg + d * NP + ub * 64 + r * 4));
+        in_ct[e] = __builtin_nontemporal_load(P.cell + grow * ldc + d * HP + unit);
+        const bool has_prev = d ? (t + 1 < mylen[e]) : (t > 0);
+        if (has_prev) in_cp[e] = __builtin_nontemporal_load(P.cell + (prow0 + row) * ldc + d * HP + unit);
+        if (unit < H) in_dh[e] = __builtin_nontemporal_load(P.dh + grow * ldh + d * H + unit);
+      }
+    }
+  };
+  load_inputs(0);
+
+  for (int step = 0; step < tmax; ++step) {
+    const int t = d ? step : (tmax - 1 - step);
+    const int nact = min(16, P.bs[t] - s0);
+    const long row0 = (long)P.off[t] + s0;
+    // ---- (1) gate gradients of the own unit block
+    if (own) {
+      // the partner's contribution to dh of these units (its own-K partial sums of the previous step)
+      if (step > 0) {
+        const unsigned long long* src = xtheirs + ((step + 1) & 1) * XT + (w * 4) * 64 + lane;
+        unsigned long long v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = ld_tag_first(src + e * 64, same_xcd);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dhr[e] += wait_tag(src + e * 64, v[e], (unsigned)step, same_xcd, diag);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = kk * 4 + e;
+        f32x4 dgv = {0.f, 0.f, 0.f, 0.f};
+        if (row < nact) {
+          const long grow = row0 + row;
+          const float gi = in_g[e][0], gf = in_g[e][1], gg = in_g[e][2], go = in_g[e][3];
+          const float ct = in_ct[e], cp = in_cp[e];
+          const float dh = dhr[e] + in_dh[e];
+          float dc = dcr[e];
+          const bool last_fwd_step = d ? (t == 0) : (t == mylen[e] - 1);
+          if (last_fwd_step && P.dcn && unit < H) dc += P.dcn[(long)(s0 + row) * ldh + d * H + unit];
+          const float tc = fast_tanh(ct);
+          dgv[3] = dh * tc * go * (1.f - go);
+          dc += dh * go * (1.f - tc * tc);
+          dgv[0] = dc * gg * gi * (1.f - gi);
+          dgv[1] = dc * cp * gf * (1.f - gf);
+          dgv[2] = dc * gi * (1.f - gg * gg);
+          dcr[e] = dc * gf;
+          *reinterpret_cast<f32x4*>(P.gates + grow * ldg + d * NP + ub * 64 + r * 4) = dgv;
+        }
+        *reinterpret_cast<f32x4*>(&dg[lds_off(row, w * 64 + r * 4, DLD)]) = dgv;
+      }
+    }
+    __syncthreads();
+    if (step + 1 < tmax) load_inputs(step + 1);
+    // ---- (2) the partner's output tile over the own K range: compute, send
+    if (par) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < KO; ++k) {
+        const f32x4 af = *reinterpret_cast<const f32x4*>(&dg[r * DLD + k * 16 + 4 * (kk ^ swz16(r))]);
+        const f32x4 b = k < KR ? wp[k < KR ? k : 0] : wl[w * KL + (k >= KR ? k - KR : 0)][lane];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], b[i], acc, 0, 0, 0);
+      }
+      unsigned long long* dst = xmine + (step & 1) * XT + (w * 4) * 64 + lane;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) st_tag(dst + e * 64, acc[e], (unsigned)(step + 1), same_xcd);
+    }
+    // ---- (3) the own output tile over the own K range (stays in registers: same lane needs it next step)
+    if (own) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < KO; ++k) {
+        const f32x4 af = *reinterpret_cast<const f32x4*>(&dg[r * DLD + k * 16 + 4 * (kk ^ swz16(r))]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], wo[k][i], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dhr[e] = acc[e];
+    }
+    __syncthreads();
+  }
+}
+
+template <int UB>
+__global__ __launch_bounds__(512) void lstm_bwd_pair_kernel(LstmArgs a) {
+  constexpr int UB0 = (UB + 1) / 2;
+  __shared__ __attribute__((aligned(16))) float dg[16 * (UB0 * 64 + 16)];
+  __shared__ f32x4 wl[UB0 * (UB0 * 4 - UB0 * 2)][64];    // partner-tile fragments kept in LDS: [wave][KL]
+  if (pair_half(blockIdx.x)) lstm_bwd_pair_body<UB, 1>(a, dg, wl);
+  else lstm_bwd_pair_body<UB, 0>(a, dg, wl);
+}
+
 // ------------------------------------------------------------------------------------------------ weight (un)packing
 __global__ void lstm_pack_kernel(const float* __restrict__ w_ih_f, const float* __restrict__ w_hh_f,
                                  const float* __restrict__ b_ih_f, const float* __restrict__ b_hh_f,
@@ -534,6 +976,15 @@ __global__ void lstm_unpack_kernel(const float* __restrict__ dw_ihp, const float
 }
 
 template <int UB>
+int launch_pair(const LstmArgs& a, bool backward, int max_tiles, hipStream_t s) {
+  dim3 grid(((max_tiles + 7) / 8) * 16, 2, a.nprob), block(512);       // groups of 8 tiles x 2 halves (pair_tile / pair_half)
+  if (backward) hipLaunchKernelGGL((lstm_bwd_pair_kernel<UB>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((lstm_fwd_pair_kernel<UB>), grid, block, 0, s, a);
+  NNR_CHECK_LAUNCH();
+  return NNR_OK;
+}
+
+template <int UB>
 int launch_rec(const LstmArgs& a, bool backward, int max_tiles, hipStream_t s) {
   dim3 grid(max_tiles, 2, a.nprob), block((UB > 4 ? 16 : 4) * 64);
   if (backward) hipLaunchKernelGGL((lstm_bwd_kernel<UB>), grid, block, 0, s, a);
@@ -550,6 +1001,12 @@ extern "C" int nnr_lstm_dims(int H, int* UB, int* HP, int* NP) {
   if (HP) *HP = ub * 16;
   if (NP) *NP = ub * 64;
   return (ub == 1 || ub == 2 || ub == 13) ? NNR_OK : NNR_ERR_UNSUPPORTED;
+}
+
+extern "C" size_t nnr_lstm_sync_bytes(int n) {
+  const size_t ntiles = (size_t)(n + 15) / 16;
+  // [2 directions][ntiles][2 halves][2 step parities][16 rows][7 * 16 units] tagged 8-byte words + 64 bytes of diagnostics
+  return 2 * ntiles * 2 * (2 * 16 * 112 + 8) * 8 + SYNC_PAD * sizeof(unsigned) + 128 * 16 * 8;
 }
 
 extern "C" int nnr_lstm_pack_weights(const float* w_ih_f, const float* w_hh_f, const float* b_ih_f, const float* b_hh_f,
@@ -590,12 +1047,21 @@ static int lstm_run(const nnr_lstm_problem* probs, int nprob, int H, bool backwa
     p.n = q.n; p.L = q.L;
     p.gates = q.gates; p.cell = q.cell; p.hout = q.hout; p.cn = q.cn;
     p.wfrag = backward ? q.wb : q.wf;
-    p.dh = q.dh; p.dcn = q.dcn;
+    p.dh = q.dh; p.dcn = q.dcn; p.sync = q.sync;
     if (!p.bs || !p.off || !p.slen || !p.gates || !p.cell || !p.wfrag || p.n <= 0) return NNR_ERR_ARG;
     if (backward ? (!p.dh || !p.prev_f || !p.prev_r) : (!p.hout || !p.cn)) return NNR_ERR_ARG;
     max_tiles = max(max_tiles, (p.n + 15) / 16);
   }
   for (int i = nprob; i < 4; ++i) a.p[i] = a.p[0];
+  // 2-CU weights-stationary recurrence when the caller provides the exchange workspace
+  bool pair = UB == 13 && (H % 2 == 0);
+  for (int i = 0; i < nprob; ++i) pair = pair && a.p[i].sync != nullptr;
+  { const char* e = getenv("NNR_LSTM_PAIR"); if (e && atoi(e) == 0) pair = false; }
+  if (pair) {
+    for (int i = 0; i < nprob; ++i)
+      if (hipMemsetAsync(a.p[i].sync, 0, nnr_lstm_sync_bytes(a.p[i].n), stream) != hipSuccess) return NNR_ERR_LAUNCH;
+    return launch_pair<13>(a, backward, max_tiles, stream);
+  }
   switch (UB) {
     case 1: return launch_rec<1>(a, backward, max_tiles, stream);
     case 2: return launch_rec<2>(a, backward, max_tiles, stream);

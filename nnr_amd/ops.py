@@ -2,6 +2,7 @@
 Tensors are only used as (device pointer, size) carriers; views are fine as long as the leading dimension is passed."""
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -165,10 +166,24 @@ def lstm_unpack_grads(dw_ihp, db_p, dw_hhp, H, E, grads):
         add_atomic_(g, t)       # parameter gradients may be accumulated from two HIP streams at once
 
 
-def _lstm_probs(items):
+LSTM_PAIR = os.environ.get('NNR_LSTM_PAIR', '1') != '0'      # 2-CU weights-stationary recurrence (lstm.hip) when H = 200
+LAST_LSTM_SYNC = []                                           # step-counter workspaces of the last launch (diagnostics)
+
+
+def lstm_sync_timeouts():
+    """Spin-wait timeouts recorded by the last pair-kernel launch (must be 0; synchronises)."""
+    return sum(int(t[-16].item()) for t in LAST_LSTM_SYNC)
+
+
+def _lstm_probs(items, H=0):
     arr = (L.LstmProblem * len(items))()
+    del LAST_LSTM_SYNC[:]
     for a, it in zip(arr, items):
         pl = it['plan']
+        if LSTM_PAIR and H == 200:
+            it['sync'] = torch.empty(L.lib().nnr_lstm_sync_bytes(pl.n) // 4, dtype=torch.int32, device=it['gates'].device)
+            LAST_LSTM_SYNC.append(it['sync'])
+        a.sync = _p(it.get('sync'))
         a.bs, a.off, a.slen, a.prev_f, a.prev_r = _p(pl.bs), _p(pl.off), _p(pl.slen), _p(pl.prev_f), _p(pl.prev_r)
         a.n, a.L = pl.n, pl.L
         a.gates, a.cell, a.hout, a.cn = _p(it['gates']), _p(it['cell']), _p(it.get('hout')), _p(it.get('cn'))
@@ -183,13 +198,13 @@ def _lstm_flops(items, H):
 
 
 def lstm_fwd(items, H):
-    arr = _lstm_probs(items)
+    arr = _lstm_probs(items, H)
     with _prof.span('lstm_fwd', _lstm_flops(items, H)):
         L.check(L.lib().nnr_lstm_fwd(arr, len(items), H, _s()), 'nnr_lstm_fwd')
 
 
 def lstm_bwd(items, H):
-    arr = _lstm_probs(items)
+    arr = _lstm_probs(items, H)
     with _prof.span('lstm_bwd', _lstm_flops(items, H)):
         L.check(L.lib().nnr_lstm_bwd(arr, len(items), H, _s()), 'nnr_lstm_bwd')
 

@@ -13,7 +13,7 @@ HEADER = os.path.join(ROOT, 'include', 'nnr_hip.h')
 
 def _declared():
     src = open(HEADER).read()
-    return sorted(set(re.findall(r'^\s*int\s+(nnr_\w+)\s*\(', src, flags=re.M)))
+    return sorted(set(re.findall(r'^\s*(?:int|size_t)\s+(nnr_\w+)\s*\(', src, flags=re.M)))
 
 
 def test_library_exports_every_declared_symbol():

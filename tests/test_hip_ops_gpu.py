@@ -193,11 +193,19 @@ def test_seq_plan_matches_stable_sort():
     assert torch.equal(plan2.order.cpu(), perm)
 
 
-@pytest.mark.parametrize('n,Lx,E,H', [(37, 12, 16, 8), (100, 32, 300, 200), (45, 128, 300, 200)])
-def test_bilstm_forward_backward_matches_oracle(n, Lx, E, H):
+@pytest.mark.parametrize('n,Lx,E,H,variant', [(37, 12, 16, 8, 'one'), (100, 32, 300, 200, 'one'), (45, 128, 300, 200, 'one'),
+                                              (100, 32, 300, 200, 'pair'), (45, 128, 300, 200, 'pair'), (200, 128, 300, 200, 'pair'),
+                                              (45, 128, 300, 200, 'pair_fabric')])
+def test_bilstm_forward_backward_matches_oracle(n, Lx, E, H, variant, monkeypatch):
+    """'one': one workgroup per 16-sequence tile (W_hh streamed from L2);  'pair': two workgroups on two CUs of one XCD with
+    W_hh resident, exchanging through that XCD's L2;  'pair_fabric': the same with the cross-XCD (write-through) exchange
+    flavour forced -- the fallback the kernel takes when the placement handshake finds the halves on different XCDs."""
     from nnr_amd import ops
     from nnr_amd.layers import LSTMParams
     from oracle.nnr_oracle import BiLSTM
+    monkeypatch.setattr(ops, 'LSTM_PAIR', variant != 'one')
+    if variant == 'pair_fabric':
+        monkeypatch.setenv('NNR_LSTM_DBG', '64')
     d = dev()
     torch.manual_seed(n)
     lens = _lengths(n, Lx, n)
@@ -228,6 +236,7 @@ def test_bilstm_forward_backward_matches_oracle(n, Lx, E, H):
     ops.gemm(table, w.w_ihp, st['gates'], M=cap, N=2 * w.NP, K=E, lda=E, ldb=E, ldc=2 * w.NP, a_idx=plan.tok, dyn=plan.total, dyn_dim=1,
              bias=w.b_p)
     ops.lstm_fwd([st], H)
+    assert ('sync' in st) == (variant != 'one') and ops.lstm_sync_timeouts() == 0
     off, rank, order = plan.off.cpu().long(), plan.rank.cpu().long(), plan.order.cpu().long()
     rows = (off[:Lx][None, :] + rank[:, None])                      # packed row of (i, t)
     hout = st['hout'].cpu()
@@ -240,6 +249,7 @@ def test_bilstm_forward_backward_matches_oracle(n, Lx, E, H):
     st['dh'] = dh_packed.to(d)
     st['dcn'] = dc[order].contiguous().to(d)
     ops.lstm_bwd([st], H)
+    assert ops.lstm_sync_timeouts() == 0
     dg = st['gates']
     NP = w.NP
     dw_ihp = torch.zeros((2 * NP, E), **f32)
