@@ -6,7 +6,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libnnr_hip.so')
+LIB_PATH = os.environ.get('NNR_HIP_LIB') or os.path.join(_HERE, 'libnnr_hip.so')      # NNR_HIP_LIB: A/B a differently built library
 _lib = None
 
 vp, ci, cf, cu32, cl = C.c_void_p, C.c_int, C.c_float, C.c_uint32, C.c_long
