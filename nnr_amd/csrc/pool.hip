@@ -1,4 +1,4 @@
-// Masked-softmax attention pooling, one wave (64 lanes) per sequence / group; wave-shuffle softmax.
+// Masked-softmax attention pooling, one workgroup (4 waves) per sequence / group; wave-shuffle softmax.
 // Replaces the softmax + bmm(alpha, feature) tails of `Attention` (layers.py:169-175) and
 // `ScaledDotProduct_CandidateAttention` (layers.py:197-203) and their backward.
 //
@@ -36,18 +36,25 @@ __device__ __forceinline__ long item_row(const PoolArgs& a, int s, int t) {
   return a.packed ? (long)a.off[t] + s : (long)s * a.L + t;
 }
 
+// One WORKGROUP (4 waves) per sequence: wave w owns the token chunks c = w, w+4, ... (UR tokens each), so a 128-token abstract
+// is 8 dependent iterations per pass instead of 32 (one wave per sequence measured 70 / 187 us fwd / bwd on the history call,
+// a quarter of the HBM rate, bound by that serial walk).  Per-token scalars (scores, d alpha) meet in LDS and the softmax is
+// recomputed by every wave (L <= 128 values); partial D-vectors (weighted sum, d v) are reduced across the waves through LDS.
 template <bool BWD, int NV, int UR>
 __global__ __launch_bounds__(256) void pool_kernel(PoolArgs a) {
   constexpr int MAXV = NV;     // float4 per lane actually needed for this D (shadows the file-level bound)
-  const int lane = threadIdx.x & 63;
-  const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+  constexpr int NWV = 4;
+  __shared__ float tok[64 * MAXT];                       // per-token scalars of the sequence (scores / d alpha)
+  __shared__ f32x4 part[NWV][64 * NV];                   // per-wave partial vectors
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int s = blockIdx.x;
   if (s >= a.n) return;
   const int len = a.packed ? a.slen[s] : a.L;
   const int oidx = a.packed ? a.order[s] : s;
   const int nv = (a.D + 3) >> 2;           // float4 per row (D % 4 == 0 required)
   const bool dot = a.v != nullptr;
 
-  f32x4 q[MAXV];                           // DOT: query vector v ; BWD: dout
+  f32x4 q[MAXV];                           // DOT: query vector v
   if (dot) {
 #pragma unroll
     for (int j = 0; j < MAXV; ++j) {
@@ -55,26 +62,35 @@ __global__ __launch_bounds__(256) void pool_kernel(PoolArgs a) {
       q[j] = (c < nv) ? *reinterpret_cast<const f32x4*>(a.v + (long)oidx * a.ldv + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   }
+  // UR rows in flight per iteration: the row loads are independent, only the shuffle reductions are serial
+  auto load_rows = [&](int t0, f32x4 (&xv)[UR][MAXV]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      const int t = min(t0 + u, len - 1);
+      const float* xr = a.x + item_row(a, s, t) * a.ldx;
+#pragma unroll
+      for (int j = 0; j < MAXV; ++j) {
+        const int c = lane + 64 * j;
+        xv[u][j] = (c < nv) ? *reinterpret_cast<const f32x4*>(xr + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  };
+  // sum of the 4 waves' partial vectors -> every wave gets the total
+  auto reduce_vec = [&](f32x4 (&v)[MAXV]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) part[w][lane + 64 * j] = v[j];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) v[j] = part[0][lane + 64 * j] + part[1][lane + 64 * j] + part[2][lane + 64 * j] + part[3][lane + 64 * j];
+  };
 
   if (!BWD) {
     // ---- scores
     float sc[MAXT];
-#pragma unroll
-    for (int k = 0; k < MAXT; ++k) sc[k] = -INFINITY;
     if (dot) {
-      // UR rows in flight per iteration: the row loads are independent, only the shuffle reductions are serial
-      for (int t0 = 0; t0 < len; t0 += UR) {
+      for (int t0 = w * UR; t0 < len; t0 += NWV * UR) {
         f32x4 xv[UR][MAXV];
-#pragma unroll
-        for (int u = 0; u < UR; ++u) {
-          const int t = min(t0 + u, len - 1);
-          const float* xr = a.x + item_row(a, s, t) * a.ldx;
-#pragma unroll
-          for (int j = 0; j < MAXV; ++j) {
-            const int c = lane + 64 * j;
-            xv[u][j] = (c < nv) ? *reinterpret_cast<const f32x4*>(xr + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
-          }
-        }
+        load_rows(t0, xv);
 #pragma unroll
         for (int u = 0; u < UR; ++u) {
           const int t = t0 + u;
@@ -82,14 +98,20 @@ __global__ __launch_bounds__(256) void pool_kernel(PoolArgs a) {
 #pragma unroll
           for (int j = 0; j < MAXV; ++j) p += xv[u][j][0] * q[j][0] + xv[u][j][1] * q[j][1] + xv[u][j][2] * q[j][2] + xv[u][j][3] * q[j][3];
           p = wave_sum(p) * a.scale;
-          if (t < len && (t & 63) == lane) { if (t < 64) sc[0] = p; else sc[1] = p; }
+          if (t < len && lane == 0) tok[t] = p;
         }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < MAXT; ++k) {
+        const int t = lane + 64 * k;
+        sc[k] = (t < len) ? tok[t] : -INFINITY;
       }
     } else {
 #pragma unroll
       for (int k = 0; k < MAXT; ++k) {
         const int t = lane + 64 * k;
-        if (t < len) sc[k] = a.score[item_row(a, s, t)];
+        sc[k] = (t < len) ? a.score[item_row(a, s, t)] : -INFINITY;
       }
     }
     if (a.mask) {
@@ -99,7 +121,7 @@ __global__ __launch_bounds__(256) void pool_kernel(PoolArgs a) {
         if (t < len && !a.mask[(long)(s / a.mask_div) * a.L + t]) sc[k] = -1e9f;
       }
     }
-    // ---- softmax over t < len
+    // ---- softmax over t < len (every wave computes the same values)
     float m = -INFINITY;
 #pragma unroll
     for (int k = 0; k < MAXT; ++k) m = fmaxf(m, sc[k]);
@@ -117,24 +139,15 @@ __global__ __launch_bounds__(256) void pool_kernel(PoolArgs a) {
     for (int k = 0; k < MAXT; ++k) {
       const int t = lane + 64 * k;
       e[k] *= inv;
-      if (t < len && a.alpha) a.alpha[item_row(a, s, t)] = e[k];
+      if (w == 0 && t < len && a.alpha) a.alpha[item_row(a, s, t)] = e[k];
     }
     // ---- weighted sum
     f32x4 acc[MAXV];
 #pragma unroll
     for (int j = 0; j < MAXV; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int t0 = 0; t0 < len; t0 += UR) {
+    for (int t0 = w * UR; t0 < len; t0 += NWV * UR) {
       f32x4 xv[UR][MAXV];
-#pragma unroll
-      for (int u = 0; u < UR; ++u) {
-        const int t = min(t0 + u, len - 1);
-        const float* xr = a.x + item_row(a, s, t) * a.ldx;
-#pragma unroll
-        for (int j = 0; j < MAXV; ++j) {
-          const int c = lane + 64 * j;
-          xv[u][j] = (c < nv) ? *reinterpret_cast<const f32x4*>(xr + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-      }
+      load_rows(t0, xv);
 #pragma unroll
       for (int u = 0; u < UR; ++u) {
         const int t = t0 + u;
@@ -143,13 +156,16 @@ __global__ __launch_bounds__(256) void pool_kernel(PoolArgs a) {
         for (int j = 0; j < MAXV; ++j) acc[j] += al * xv[u][j];
       }
     }
+    reduce_vec(acc);
+    if (w == 0) {
 #pragma unroll
-    for (int j = 0; j < MAXV; ++j) {
-      const int c = lane + 64 * j;
-      if (c < nv) {
-        f32x4 o = acc[j];
-        if (a.add_in) o += *reinterpret_cast<const f32x4*>(a.add_in + (long)oidx * a.ldadd + 4 * c);
-        *reinterpret_cast<f32x4*>(a.out + (long)oidx * a.ldo + 4 * c) = o;
+      for (int j = 0; j < MAXV; ++j) {
+        const int c = lane + 64 * j;
+        if (c < nv) {
+          f32x4 o = acc[j];
+          if (a.add_in) o += *reinterpret_cast<const f32x4*>(a.add_in + (long)oidx * a.ldadd + 4 * c);
+          *reinterpret_cast<f32x4*>(a.out + (long)oidx * a.ldo + 4 * c) = o;
+        }
       }
     }
   } else {
@@ -169,21 +185,11 @@ __global__ __launch_bounds__(256) void pool_kernel(PoolArgs a) {
     for (int k = 0; k < MAXT; ++k) {
       const int t = lane + 64 * k;
       al[k] = (t < len) ? a.alpha[item_row(a, s, t)] : 0.f;
-      da[k] = 0.f;
     }
-    // dalpha_t = <dout, x_t>   (UR rows in flight)
-    for (int t0 = 0; t0 < len; t0 += UR) {
+    // dalpha_t = <dout, x_t>
+    for (int t0 = w * UR; t0 < len; t0 += NWV * UR) {
       f32x4 xv[UR][MAXV];
-#pragma unroll
-      for (int u = 0; u < UR; ++u) {
-        const int t = min(t0 + u, len - 1);
-        const float* xr = a.x + item_row(a, s, t) * a.ldx;
-#pragma unroll
-        for (int j = 0; j < MAXV; ++j) {
-          const int c = lane + 64 * j;
-          xv[u][j] = (c < nv) ? *reinterpret_cast<const f32x4*>(xr + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-      }
+      load_rows(t0, xv);
 #pragma unroll
       for (int u = 0; u < UR; ++u) {
         const int t = t0 + u;
@@ -191,8 +197,14 @@ __global__ __launch_bounds__(256) void pool_kernel(PoolArgs a) {
 #pragma unroll
         for (int j = 0; j < MAXV; ++j) p += xv[u][j][0] * go[j][0] + xv[u][j][1] * go[j][1] + xv[u][j][2] * go[j][2] + xv[u][j][3] * go[j][3];
         p = wave_sum(p);
-        if (t < len && (t & 63) == lane) { if (t < 64) da[0] = p; else da[1] = p; }
+        if (t < len && lane == 0) tok[t] = p;
       }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < MAXT; ++k) {
+      const int t = lane + 64 * k;
+      da[k] = (t < len) ? tok[t] : 0.f;
     }
     float dsum = 0.f;
 #pragma unroll
@@ -203,12 +215,12 @@ __global__ __launch_bounds__(256) void pool_kernel(PoolArgs a) {
     for (int k = 0; k < MAXT; ++k) {
       const int t = lane + 64 * k;
       ds[k] = al[k] * (da[k] - dsum);          // d loss / d score_t (masked items have alpha = 0 -> 0)
-      if (t < len && a.dscore) a.dscore[item_row(a, s, t)] = ds[k];
+      if (w == 0 && t < len && a.dscore) a.dscore[item_row(a, s, t)] = ds[k];
     }
     f32x4 dvacc[MAXV];
 #pragma unroll
     for (int j = 0; j < MAXV; ++j) dvacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int t0 = 0; t0 < len; t0 += UR) {
+    for (int t0 = w * UR; t0 < len; t0 += NWV * UR) {
       f32x4 xv[UR][MAXV], old[UR][MAXV];
       long rows[UR];
 #pragma unroll
@@ -244,10 +256,13 @@ __global__ __launch_bounds__(256) void pool_kernel(PoolArgs a) {
       }
     }
     if (dot && a.dv) {
+      reduce_vec(dvacc);
+      if (w == 0) {
 #pragma unroll
-      for (int j = 0; j < MAXV; ++j) {
-        const int c = lane + 64 * j;
-        if (c < nv) *reinterpret_cast<f32x4*>(a.dv + (long)oidx * a.lddv + 4 * c) = dvacc[j];
+        for (int j = 0; j < MAXV; ++j) {
+          const int c = lane + 64 * j;
+          if (c < nv) *reinterpret_cast<f32x4*>(a.dv + (long)oidx * a.lddv + 4 * c) = dvacc[j];
+        }
       }
     }
   }
@@ -278,7 +293,7 @@ static PoolArgs to_args(const nnr_pool_args* p) {
 template <bool BWD>
 static int pool_launch(const nnr_pool_args* p, hipStream_t stream) {
   const PoolArgs a = to_args(p);
-  const dim3 grid((p->n + 3) / 4), block(256);
+  const dim3 grid(p->n), block(256);
   const int nv = (p->D + 3) / 4;
   if (nv <= 64) hipLaunchKernelGGL((pool_kernel<BWD, 1, 4>), grid, block, 0, stream, a);
   else if (nv <= 128) hipLaunchKernelGGL((pool_kernel<BWD, 2, 4>), grid, block, 0, stream, a);
