@@ -193,7 +193,8 @@ int nnr_sue_slice_bwd(const float* dgfeat, float* dpad, int B, int Hn, int G, in
 int nnr_sue_intra_fwd(const float* kf, const float* qc, const float* g, const long* cidx, int B, int N, int Hn, int C, int A, int D,
                       float* alpha, float* feat, hipStream_t stream);
 int nnr_sue_intra_bwd(const float* kf, const float* qc, const float* g, const long* cidx, const float* alpha, const float* dfeat, int B,
-                      int N, int Hn, int C, int A, int D, float* dg, float* dkf, float* dqc, hipStream_t stream);
+                      int N, int Hn, int C, int A, int D, float* dg, float* dkf, float* dqc, float* ds_ws /* [B*N*Hn] scratch */,
+                      hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------ click predictor, loss, optimiser */
 int nnr_logits_loss_fwd(const float* user, const float* cand, int B, int N, int D, float* logits, float* loss, float* dlogits,

@@ -231,12 +231,35 @@ __global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __res
 // One workgroup per (sample b, candidate n).  scores over the Hn history items, softmax WITHIN each cluster id
 // (segments held in LDS), cluster-wise weighted sum of the [Hn, D] features -> [C, D]; empty clusters give 0.
 constexpr int SUE_MAXH = 64, SUE_MAXC = 32;
+// cluster member lists of one sample in LDS: order[cstart[c] .. cstart[c] + ccnt[c]) = the items of cluster c, ascending
+__device__ __forceinline__ void sue_members(const int* cid, int Hn, int C, int* ccnt, int* cstart, int* order) {
+  const int tid = threadIdx.x;
+  if (tid < C) {
+    int n = 0;
+    for (int j = 0; j < Hn; ++j) n += (cid[j] == tid);
+    ccnt[tid] = n;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int c = 0; c < C; ++c) { cstart[c] = acc; acc += ccnt[c]; }
+  }
+  __syncthreads();
+  if (tid < C) {
+    int k = cstart[tid];
+    for (int j = 0; j < Hn; ++j) if (cid[j] == tid) order[k++] = j;
+  }
+  __syncthreads();
+}
+
+// forward: grid (B*N, ceil(D/256)) -- every workgroup recomputes the (tiny) scores and segment softmax of its (b, n) and
+// produces one 256-column slice of the C cluster features, walking each cluster's member list once
 __global__ __launch_bounds__(256) void sue_intra_fwd_kernel(const float* __restrict__ kf, const float* __restrict__ qc,
                                                             const float* __restrict__ g, const long* __restrict__ cidx,
                                                             int N, int Hn, int C, int A, int D, float inv_scale,
                                                             float* __restrict__ alpha, float* __restrict__ feat) {
   __shared__ float sc[SUE_MAXH], al[SUE_MAXH], cmax[SUE_MAXC], csum[SUE_MAXC];
-  __shared__ int cid[SUE_MAXH];
+  __shared__ int cid[SUE_MAXH], order[SUE_MAXH], ccnt[SUE_MAXC], cstart[SUE_MAXC];
   const int bn = blockIdx.x, b = bn / N;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   for (int j = tid; j < Hn; j += 256) cid[j] = (int)cidx[(long)b * Hn + j];
@@ -249,85 +272,121 @@ __global__ __launch_bounds__(256) void sue_intra_fwd_kernel(const float* __restr
     if (lane == 0) sc[j] = p * inv_scale;
   }
   __syncthreads();
+  sue_members(cid, Hn, C, ccnt, cstart, order);
   if (tid < C) {
     float m = -INFINITY;
-    for (int j = 0; j < Hn; ++j) if (cid[j] == tid) m = fmaxf(m, sc[j]);
-    float s = 0.f;
-    for (int j = 0; j < Hn; ++j) if (cid[j] == tid) s += expf(sc[j] - m);
-    cmax[tid] = m; csum[tid] = s;
+    for (int k = 0; k < ccnt[tid]; ++k) m = fmaxf(m, sc[order[cstart[tid] + k]]);
+    float sm = 0.f;
+    for (int k = 0; k < ccnt[tid]; ++k) sm += expf(sc[order[cstart[tid] + k]] - m);
+    cmax[tid] = m; csum[tid] = sm;
   }
   __syncthreads();
   for (int j = tid; j < Hn; j += 256) {
     const float v = expf(sc[j] - cmax[cid[j]]) / csum[cid[j]];
     al[j] = v;
-    alpha[(long)bn * Hn + j] = v;
+    if (blockIdx.y == 0) alpha[(long)bn * Hn + j] = v;
   }
   __syncthreads();
-  const float* gb = g + (long)b * Hn * D;
-  float* fo = feat + (long)bn * C * D;
-  for (int col = tid; col < D; col += 256) {
-    for (int c = 0; c < C; ++c) {
-      float acc = 0.f;
-      for (int j = 0; j < Hn; ++j) if (cid[j] == c) acc += al[j] * gb[(long)j * D + col];
-      fo[(long)c * D + col] = acc;
+  const int col = blockIdx.y * 256 + tid;
+  if (col >= D) return;
+  const float* gb = g + (long)b * Hn * D + col;
+  float* fo = feat + (long)bn * C * D + col;
+  for (int c = 0; c < C; ++c) {
+    float acc = 0.f;
+    for (int k = 0; k < ccnt[c]; ++k) {
+      const int j = order[cstart[c] + k];
+      acc += al[j] * gb[(long)j * D];
     }
+    fo[(long)c * D] = acc;              // empty cluster -> 0, as scatter_sum
   }
 }
 
-// backward, one workgroup per sample b (loops the N candidates so dg needs no atomics)
-__global__ __launch_bounds__(256) void sue_intra_bwd_kernel(const float* __restrict__ kf, const float* __restrict__ qc,
-                                                            const float* __restrict__ g, const long* __restrict__ cidx,
-                                                            const float* __restrict__ alpha, const float* __restrict__ dfeat,
-                                                            int N, int Hn, int C, int A, int D, float inv_scale,
-                                                            float* __restrict__ dg, float* __restrict__ dkf,
-                                                            float* __restrict__ dqc) {
-  __shared__ float al[SUE_MAXH], da[SUE_MAXH], dsn[8][SUE_MAXH], csum[SUE_MAXC];
+// backward part 1, grid B*N: d alpha, segment-softmax backward -> ds[b, n, :] (workspace), dqc[b, n, :]
+__global__ __launch_bounds__(256) void sue_intra_bwd_ds_kernel(const float* __restrict__ kf, const float* __restrict__ g,
+                                                               const long* __restrict__ cidx, const float* __restrict__ alpha,
+                                                               const float* __restrict__ dfeat, int N, int Hn, int C, int A, int D,
+                                                               float inv_scale, float* __restrict__ ds_ws, float* __restrict__ dqc) {
+  __shared__ float al[SUE_MAXH], da[SUE_MAXH], ds[SUE_MAXH], csum[SUE_MAXC];
   __shared__ int cid[SUE_MAXH];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  for (int j = tid; j < Hn; j += 256) cid[j] = (int)cidx[(long)b * Hn + j];
-  const float* gb = g + (long)b * Hn * D;
+  const int bn = blockIdx.x, b = bn / N, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  for (int j = tid; j < Hn; j += 256) { cid[j] = (int)cidx[(long)b * Hn + j]; al[j] = alpha[(long)bn * Hn + j]; }
   __syncthreads();
-  for (int n = 0; n < N; ++n) {
-    const long bn = (long)b * N + n;
-    const float* df = dfeat + bn * C * D;
-    for (int j = tid; j < Hn; j += 256) al[j] = alpha[bn * Hn + j];
-    // dalpha_j = <dfeat[cid_j], g_j>
-    for (int j = w; j < Hn; j += 4) {
-      const float* dr = df + (long)cid[j] * D;
-      const float* gr = gb + (long)j * D;
-      float p = 0.f;
-      for (int x = lane; x < D; x += 64) p += dr[x] * gr[x];
-      p = wave_sum(p);
-      if (lane == 0) da[j] = p;
-    }
-    __syncthreads();
-    if (tid < C) {
-      float s = 0.f;
-      for (int j = 0; j < Hn; ++j) if (cid[j] == tid) s += al[j] * da[j];
-      csum[tid] = s;
-    }
-    __syncthreads();
-    for (int j = tid; j < Hn; j += 256) dsn[n][j] = al[j] * (da[j] - csum[cid[j]]) * inv_scale;
-    // dg[b, j, :] (+)= alpha_j * dfeat[cid_j, :]
-    for (int col = tid; col < D; col += 256)
-      for (int j = 0; j < Hn; ++j) {
-        const float v = al[j] * df[(long)cid[j] * D + col];
-        float* p = dg + ((long)b * Hn + j) * D + col;
-        *p = (n == 0) ? v : *p + v;
-      }
-    __syncthreads();
+  const float* gb = g + (long)b * Hn * D;
+  const float* df = dfeat + (long)bn * C * D;
+  // dalpha_j = <dfeat[cid_j], g_j>
+  for (int j = w; j < Hn; j += 4) {
+    const float* dr = df + (long)cid[j] * D;
+    const float* gr = gb + (long)j * D;
+    float p = 0.f;
+    for (int x = lane; x < D; x += 64) p += dr[x] * gr[x];
+    p = wave_sum(p);
+    if (lane == 0) da[j] = p;
   }
-  // dkf[b, j, :] = sum_n ds[n][j] * qc[b, n, :] ;  dqc[b, n, :] = sum_j ds[n][j] * kf[b, j, :]
+  __syncthreads();
+  if (tid < C) {
+    float sm = 0.f;
+    for (int j = 0; j < Hn; ++j) if (cid[j] == tid) sm += al[j] * da[j];
+    csum[tid] = sm;
+  }
+  __syncthreads();
+  for (int j = tid; j < Hn; j += 256) {
+    const float v = al[j] * (da[j] - csum[cid[j]]) * inv_scale;
+    ds[j] = v;
+    ds_ws[(long)bn * Hn + j] = v;
+  }
+  __syncthreads();
+  // dqc[b, n, :] = sum_j ds[j] * kf[b, j, :]
   for (int x = tid; x < A; x += 256) {
-    for (int j = 0; j < Hn; ++j) {
-      float acc = 0.f;
-      for (int n = 0; n < N; ++n) acc += dsn[n][j] * qc[((long)b * N + n) * A + x];
-      dkf[((long)b * Hn + j) * A + x] = acc;
+    float acc = 0.f;
+    for (int j = 0; j < Hn; ++j) acc += ds[j] * kf[((long)b * Hn + j) * A + x];
+    dqc[(long)bn * A + x] = acc;
+  }
+}
+
+// backward part 2, grid (B, ceil(D/256) + 1): slices y < last -> dg[b, j, cols] = sum_n alpha[b,n,j] * dfeat[b,n,cid_j,cols]
+// (each row written exactly once, no read-modify-write); the last slice -> dkf[b, j, :] = sum_n ds[b,n,j] * qc[b,n,:]
+__global__ __launch_bounds__(256) void sue_intra_bwd_dg_kernel(const float* __restrict__ qc, const long* __restrict__ cidx,
+                                                               const float* __restrict__ alpha, const float* __restrict__ dfeat,
+                                                               const float* __restrict__ ds_ws, int N, int Hn, int C, int A, int D,
+                                                               float* __restrict__ dg, float* __restrict__ dkf) {
+  __shared__ float al[8][SUE_MAXH];
+  __shared__ int cid[SUE_MAXH], order[SUE_MAXH], ccnt[SUE_MAXC], cstart[SUE_MAXC];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const bool last = blockIdx.y == gridDim.y - 1;
+  for (int i = tid; i < N * Hn; i += 256) {
+    const int n = i / Hn, j = i - n * Hn;
+    al[n][j] = last ? ds_ws[((long)b * N + n) * Hn + j] : alpha[((long)b * N + n) * Hn + j];
+  }
+  for (int j = tid; j < Hn; j += 256) cid[j] = (int)cidx[(long)b * Hn + j];
+  __syncthreads();
+  if (last) {
+    for (int x = tid; x < A; x += 256) {
+      float qv[8];
+#pragma unroll
+      for (int n = 0; n < 8; ++n) qv[n] = n < N ? qc[((long)b * N + n) * A + x] : 0.f;
+      for (int j = 0; j < Hn; ++j) {
+        float acc = 0.f;
+#pragma unroll
+        for (int n = 0; n < 8; ++n) acc += al[n][j] * qv[n];
+        dkf[((long)b * Hn + j) * A + x] = acc;
+      }
     }
-    for (int n = 0; n < N; ++n) {
+    return;
+  }
+  sue_members(cid, Hn, C, ccnt, cstart, order);
+  const int col = blockIdx.y * 256 + tid;
+  if (col >= D) return;
+  for (int c = 0; c < C; ++c) {
+    if (ccnt[c] == 0) continue;
+    float dv[8];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) dv[n] = n < N ? dfeat[(((long)b * N + n) * C + c) * D + col] : 0.f;
+    for (int k = 0; k < ccnt[c]; ++k) {
+      const int j = order[cstart[c] + k];
       float acc = 0.f;
-      for (int j = 0; j < Hn; ++j) acc += dsn[n][j] * kf[((long)b * Hn + j) * A + x];
-      dqc[((long)b * N + n) * A + x] = acc;
+#pragma unroll
+      for (int n = 0; n < 8; ++n) acc += al[n][j] * dv[n];
+      dg[((long)b * Hn + j) * D + col] = acc;
     }
   }
 }
@@ -532,17 +591,21 @@ extern "C" int nnr_relu_bwd(const float* dy, const float* y, float* dx, long n, 
 extern "C" int nnr_sue_intra_fwd(const float* kf, const float* qc, const float* g, const long* cidx, int B, int N, int Hn, int C, int A,
                                  int D, float* alpha, float* feat, hipStream_t stream) {
   if (Hn > SUE_MAXH || C > SUE_MAXC) return NNR_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(sue_intra_fwd_kernel, dim3(B * N), dim3(256), 0, stream, kf, qc, g, cidx, N, Hn, C, A, D, 1.f / sqrtf((float)A),
-                     alpha, feat);
+  hipLaunchKernelGGL(sue_intra_fwd_kernel, dim3(B * N, (D + 255) / 256), dim3(256), 0, stream, kf, qc, g, cidx, N, Hn, C, A, D,
+                     1.f / sqrtf((float)A), alpha, feat);
   NNR_CHECK_LAUNCH();
   return NNR_OK;
 }
 extern "C" int nnr_sue_intra_bwd(const float* kf, const float* qc, const float* g, const long* cidx, const float* alpha,
                                  const float* dfeat, int B, int N, int Hn, int C, int A, int D, float* dg, float* dkf, float* dqc,
-                                 hipStream_t stream) {
+                                 float* ds_ws, hipStream_t stream) {
   if (Hn > SUE_MAXH || C > SUE_MAXC || N > 8) return NNR_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(sue_intra_bwd_kernel, dim3(B), dim3(256), 0, stream, kf, qc, g, cidx, alpha, dfeat, N, Hn, C, A, D,
-                     1.f / sqrtf((float)A), dg, dkf, dqc);
+  if (!ds_ws) return NNR_ERR_ARG;
+  hipLaunchKernelGGL(sue_intra_bwd_ds_kernel, dim3(B * N), dim3(256), 0, stream, kf, g, cidx, alpha, dfeat, N, Hn, C, A, D,
+                     1.f / sqrtf((float)A), ds_ws, dqc);
+  NNR_CHECK_LAUNCH();
+  hipLaunchKernelGGL(sue_intra_bwd_dg_kernel, dim3(B, (D + 255) / 256 + 1), dim3(256), 0, stream, qc, cidx, alpha, dfeat, ds_ws, N, Hn, C,
+                     A, D, dg, dkf);
   NNR_CHECK_LAUNCH();
   return NNR_OK;
 }

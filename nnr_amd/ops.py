@@ -318,8 +318,9 @@ def sue_intra_fwd(kf, qc, g, cidx, B, N, Hn, Cn, A, D, alpha, feat):
 
 
 def sue_intra_bwd(kf, qc, g, cidx, alpha, dfeat, B, N, Hn, Cn, A, D, dg, dkf, dqc):
+    ws = torch.empty(B * N * Hn, device=kf.device, dtype=torch.float32)
     L.check(L.lib().nnr_sue_intra_bwd(_p(kf), _p(qc), _p(g), _p(cidx), _p(alpha), _p(dfeat), B, N, Hn, Cn, A, D, _p(dg), _p(dkf), _p(dqc),
-                                      _s()), 'nnr_sue_intra_bwd')
+                                      _p(ws), _s()), 'nnr_sue_intra_bwd')
 
 
 def logits_loss_fwd(user, cand, B, N, D, logits, loss, dlogits):
