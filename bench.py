@@ -44,6 +44,8 @@ def parse():
     ap.add_argument('--global_batch', type=int, default=0, help='>0: strong scaling, this GLOBAL batch split over the GPUs')
     ap.add_argument('--vocabulary_size', type=int, default=60000)
     ap.add_argument('--dense', action='store_true', help='all titles/abstracts at full length (worst-case roofline variant)')
+    ap.add_argument('--device_corpus', action='store_true', help='build every batch inside the timed step from the device-resident '
+                    'corpus (id-only batches: nnr_corpus_batch + nnr_history_graph) instead of re-using pre-built batches')
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--cpu_baseline_batch', type=int, default=8)
     ap.add_argument('--cpu_baseline_steps', type=int, default=2)
@@ -108,10 +110,18 @@ def main():
     corpus = SynthCorpus(spec)
     rng = np.random.default_rng(100 + rank)
     nb = min(8, a.steps + a.warmup)
-    batches = [to_torch(corpus.batch(per_gpu, rng), dev) for _ in range(nb)]
+    if a.device_corpus:
+        from nnr_amd.corpus import from_synth
+        dcorpus = from_synth(corpus, 4096, rng, dev, graph='build')
+        order = [torch.from_numpy(rng.permutation(4096)[:per_gpu].astype(np.int32)).to(dev) for _ in range(nb)]
 
-    def fresh(i):          # masks are mutated in place by the model; mutation is idempotent, so batches can be reused
-        return batches[i % nb]
+        def fresh(i):      # 256 bytes of behaviour ids per batch; the 21 tensors are gathered / built in HBM
+            return dcorpus.train_batch(order[i % nb])
+    else:
+        batches = [to_torch(corpus.batch(per_gpu, rng), dev) for _ in range(nb)]
+
+        def fresh(i):      # masks are mutated in place by the model; mutation is idempotent, so batches can be reused
+            return batches[i % nb]
 
     for i in range(a.warmup):
         trainer.train_step(fresh(i))
@@ -141,7 +151,8 @@ def main():
             'config': {'workload': '%s+%s train step, MIND-200k-shaped synthetic batches, dropout %.2f, gcn_layer_num %d%s' %
                                    (a.news_encoder, a.user_encoder, cfg.dropout_rate, cfg.gcn_layer_num, ', dense lengths' if a.dense else ''),
                        'global_batch': global_batch, 'per_gpu_batch': per_gpu, 'parallelism': 'dp%d' % world,
-                       'synth': {k: v for k, v in spec.describe().items() if k in ('vocabulary_size', 'title_len_mean', 'content_len_mean', 'news_pool', 'dense')}},
+                       'synth': {k: v for k, v in spec.describe().items() if k in ('vocabulary_size', 'title_len_mean', 'content_len_mean', 'news_pool', 'dense')},
+                       'batches': 'device-resident corpus, id-only' if a.device_corpus else 'pre-built, resident in HBM'},
             'roofline': roof,
         }
         if not a.no_cpu_baseline and world == 1:

@@ -196,6 +196,34 @@ int nnr_sue_intra_bwd(const float* kf, const float* qc, const float* g, const lo
                       int N, int Hn, int C, int A, int D, float* dg, float* dkf, float* dqc, float* ds_ws /* [B*N*Hn] scratch */,
                       hipStream_t stream);
 
+/* ------------------------------------------------------------------------------------------------ device-resident corpus
+ * (SURVEY.md section 8 f-1 / f-2).  The corpus tables MIND_Corpus builds (MIND_corpus.py:261-268, 336-353) live in HBM;
+ * a training batch is described by behaviour indices + the (1 + K) sampled news ids of each behaviour.
+ * nnr_corpus_batch   = MIND_Train_Dataset.__getitem__ + default collate (MIND_dataset.py:70-76): fills the 21 batch tensors
+ *                      (dtypes of the reference's DataLoader: int64 user ids / cluster indices, int32 ids, 1-byte bools, fp32 graph).
+ *                      With graph_table == NULL the graph / cluster mask / cluster indices are left to nnr_history_graph.
+ * nnr_history_graph  = MIND_Corpus.preprocess step 6 (MIND_corpus.py:162-221) for a batch, from the history's category ids:
+ *                      norm 0 = none, 1 = symmetric D^-1/2 A D^-1/2, 2 = asymmetric D^-1 A; self connections always on
+ *                      (the reference asserts normalisation needs them, config.py:111).  Bit-identical to the numpy result. */
+typedef struct nnr_corpus_tables {
+  const int* news_category; const int* news_subCategory;                       /* [news] */
+  const int* title_text; const uint8_t* title_mask; const int* title_entity;   /* [news, T] */
+  const int* abstract_text; const uint8_t* abstract_mask; const int* abstract_entity;   /* [news, C] */
+  const long* beh_user; const int* beh_history; const uint8_t* beh_history_mask; const int* beh_line;   /* [behaviours(, H)] */
+  const float* graph_table; const uint8_t* cmask_table; const long* cidx_table;   /* optional [lines, G, G] / [lines, K1] / [lines, H] */
+  int T, C, H, G, K1;                                                          /* G = H + category_num, K1 = category_num + 1 */
+} nnr_corpus_tables;
+typedef struct nnr_batch_out {                                                 /* the 21 tensors, argument order of trainer.py:105-106 */
+  long* user_id;
+  int* u_cat; int* u_sub; int* u_tt; uint8_t* u_tm; int* u_te; int* u_ct; uint8_t* u_cm; int* u_ce;
+  uint8_t* u_hmask; float* u_graph; uint8_t* u_cmask; long* u_cidx;
+  int* n_cat; int* n_sub; int* n_tt; uint8_t* n_tm; int* n_te; int* n_ct; uint8_t* n_cm; int* n_ce;
+} nnr_batch_out;
+int nnr_corpus_batch(const nnr_corpus_tables* t, const nnr_batch_out* o, const int* beh_idx, const int* samples, int ld_samples, int B,
+                     int S, hipStream_t stream);
+int nnr_history_graph(const int* cats, const uint8_t* hmask, int B, int H, int K, int norm, float* graph, uint8_t* cmask, long* cidx,
+                      hipStream_t stream);
+
 /* ------------------------------------------------------------------------------------------------ click predictor, loss, optimiser */
 int nnr_logits_loss_fwd(const float* user, const float* cand, int B, int N, int D, float* logits, float* loss, float* dlogits,
                         hipStream_t stream);                                     /* model.py:126-127, trainer.py:64-66 */

@@ -28,6 +28,17 @@ class LstmProblem(C.Structure):
                 ('cell', vp), ('hout', vp), ('cn', vp), ('wf', vp), ('wb', vp), ('dh', vp), ('dcn', vp), ('sync', vp)]
 
 
+class CorpusTables(C.Structure):
+    _fields_ = [(k, vp) for k in ('news_category', 'news_subCategory', 'title_text', 'title_mask', 'title_entity', 'abstract_text',
+                                  'abstract_mask', 'abstract_entity', 'beh_user', 'beh_history', 'beh_history_mask', 'beh_line',
+                                  'graph_table', 'cmask_table', 'cidx_table')] + [(k, ci) for k in ('T', 'C', 'H', 'G', 'K1')]
+
+
+class BatchOut(C.Structure):
+    _fields_ = [(k, vp) for k in ('user_id', 'u_cat', 'u_sub', 'u_tt', 'u_tm', 'u_te', 'u_ct', 'u_cm', 'u_ce', 'u_hmask', 'u_graph',
+                                  'u_cmask', 'u_cidx', 'n_cat', 'n_sub', 'n_tt', 'n_tm', 'n_te', 'n_ct', 'n_cm', 'n_ce')]
+
+
 class PoolArgs(C.Structure):
     _fields_ = [('x', vp), ('ldx', ci), ('D', ci), ('n', ci), ('L', ci), ('packed', ci), ('off', vp), ('slen', vp),
                 ('order', vp), ('mask', vp), ('mask_div', ci), ('score', vp), ('v', vp), ('ldv', ci), ('scale', cf),
@@ -43,7 +54,7 @@ SYMBOLS = [
     'nnr_tanh_score_bwd', 'nnr_colsum', 'nnr_small_embed_fwd', 'nnr_small_embed_bwd', 'nnr_add', 'nnr_add_atomic', 'nnr_add2d', 'nnr_dropout',
     'nnr_relu_bwd', 'nnr_relu_drop_bwd', 'nnr_sue_x0_fwd', 'nnr_sue_x0_bwd', 'nnr_sue_slice_fwd', 'nnr_sue_slice_bwd',
     'nnr_sue_intra_fwd', 'nnr_sue_intra_bwd', 'nnr_logits_loss_fwd', 'nnr_logits_fwd', 'nnr_nls_loss', 'nnr_logits_bwd', 'nnr_sumsq', 'nnr_clip_adam',
-    'nnr_mhsa_fwd', 'nnr_mhsa_bwd', 'nnr_embed_gather', 'nnr_embed_scatter', 'nnr_transpose2d',
+    'nnr_mhsa_fwd', 'nnr_mhsa_bwd', 'nnr_embed_gather', 'nnr_embed_scatter', 'nnr_transpose2d', 'nnr_corpus_batch', 'nnr_history_graph',
 ]
 
 

@@ -32,14 +32,16 @@ def test_library_exports_every_declared_symbol():
 def test_ctypes_structs_match_c_layout(tmp_path):
     from nnr_amd import _lib
     src = tmp_path / 'sz.cpp'
-    src.write_text('#include "%s"\n#include <stdio.h>\n#include <stddef.h>\nint main(){printf("%%zu %%zu %%zu %%zu %%zu\\n",'
+    src.write_text('#include "%s"\n#include <stdio.h>\n#include <stddef.h>\nint main(){printf("%%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu\\n",'
                    'sizeof(nnr_gemm_args),sizeof(nnr_lstm_problem),sizeof(nnr_pool_args),offsetof(nnr_gemm_args,tile),'
-                   'offsetof(nnr_pool_args,lddv));}\n' % HEADER)
+                   'offsetof(nnr_pool_args,lddv),sizeof(nnr_corpus_tables),sizeof(nnr_batch_out),offsetof(nnr_corpus_tables,K1),'
+                   'offsetof(nnr_lstm_problem,sync));}\n' % HEADER)
     exe = tmp_path / 'sz'
     subprocess.check_call(['hipcc', '-o', str(exe), str(src)], stderr=subprocess.DEVNULL)
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     want = [ctypes.sizeof(_lib.GemmArgs), ctypes.sizeof(_lib.LstmProblem), ctypes.sizeof(_lib.PoolArgs), _lib.GemmArgs.tile.offset,
-            _lib.PoolArgs.lddv.offset]
+            _lib.PoolArgs.lddv.offset, ctypes.sizeof(_lib.CorpusTables), ctypes.sizeof(_lib.BatchOut), _lib.CorpusTables.K1.offset,
+            _lib.LstmProblem.sync.offset]
     assert got == want
 
 
