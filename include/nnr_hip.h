@@ -223,6 +223,11 @@ int nnr_corpus_batch(const nnr_corpus_tables* t, const nnr_batch_out* o, const i
                      int S, hipStream_t stream);
 int nnr_history_graph(const int* cats, const uint8_t* hmask, int B, int H, int K, int norm, float* graph, uint8_t* cmask, long* cidx,
                       hipStream_t stream);
+/* Evaluation tail: util.py:50-59 (per-impression ranks by descending score, ties in file order) +
+ * evaluate.py:8-29,76-81 (AUC, MRR, nDCG@5, nDCG@10 per impression, float64).  offsets [n_impressions + 1] delimit the
+ * (contiguous) candidates of each impression; per_impression [n_impressions, 4]; NaN row for a single-class impression. */
+int nnr_rank_metrics(const float* scores, const uint8_t* labels, const long* offsets, int n_impressions, int* ranks,
+                     double* per_impression, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------ click predictor, loss, optimiser */
 int nnr_logits_loss_fwd(const float* user, const float* cand, int B, int N, int D, float* logits, float* loss, float* dlogits,

@@ -163,3 +163,80 @@ extern "C" int nnr_history_graph(const int* cats, const uint8_t* hmask, int B, i
   NNR_CHECK_LAUNCH();
   return NNR_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ ranking metrics (f-4)
+// The tail of util.compute_scores (util.py:50-59) and evaluate.scoring (evaluate.py:32-89) on the device: one workgroup per
+// impression ranks its candidates by descending score (equal scores keep file order, like Python's stable sort) and
+// evaluates AUC (roc_auc_score on 1/rank = correctly ordered (positive, negative) pairs / all pairs), MRR, nDCG@5, nDCG@10
+// in float64.  An impression with no click or only clicks has no AUC (sklearn raises): its four values are NaN.
+namespace {
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+  const int tid = threadIdx.x;
+  sh[tid] = v;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) sh[tid] += sh[tid + o];
+    __syncthreads();
+  }
+  const double r = sh[0];
+  __syncthreads();
+  return r;
+}
+
+__global__ __launch_bounds__(256) void rank_metrics_kernel(const float* __restrict__ scores, const uint8_t* __restrict__ labels,
+                                                          const long* __restrict__ offsets, int* __restrict__ ranks,
+                                                          double* __restrict__ per_imp) {
+  __shared__ double sh[256];
+  const int imp = blockIdx.x, tid = threadIdx.x;
+  const long o = offsets[imp];
+  const int n = (int)(offsets[imp + 1] - o);
+  const float* s = scores + o;
+  const uint8_t* y = labels + o;
+  double pos = 0, auc_num = 0, rr = 0, dcg5 = 0, dcg10 = 0;
+  for (int i = tid; i < n; i += 256) {
+    const float si = s[i];
+    int better = 0, neg_below = 0;
+    for (int j = 0; j < n; ++j) {
+      const float sj = s[j];
+      const bool before = (sj > si) || (sj == si && j < i);        // j is ranked ahead of i
+      better += before;
+      neg_below += (!before && j != i && !y[j]);                   // negatives ranked after i
+    }
+    const int rank = better + 1;
+    ranks[o + i] = rank;
+    if (y[i]) {
+      pos += 1;
+      auc_num += neg_below;
+      rr += 1.0 / rank;
+      const double g = 1.0 / log2((double)rank + 1.0);
+      if (rank <= 5) dcg5 += g;
+      if (rank <= 10) dcg10 += g;
+    }
+  }
+  const double P = block_sum(pos, sh);
+  const double A = block_sum(auc_num, sh), R = block_sum(rr, sh), D5 = block_sum(dcg5, sh), D10 = block_sum(dcg10, sh);
+  if (tid == 0) {
+    const double N = n - P;
+    double best5 = 0, best10 = 0;
+    for (int k = 0; k < 10 && k < (int)P; ++k) {
+      const double g = 1.0 / log2((double)k + 2.0);
+      if (k < 5) best5 += g;
+      best10 += g;
+    }
+    const bool ok = P > 0 && N > 0;
+    const double nan = __longlong_as_double(0x7ff8000000000000LL);
+    per_imp[4 * imp + 0] = ok ? A / (P * N) : nan;
+    per_imp[4 * imp + 1] = ok ? R / P : nan;
+    per_imp[4 * imp + 2] = ok ? D5 / best5 : nan;
+    per_imp[4 * imp + 3] = ok ? D10 / best10 : nan;
+  }
+}
+}  // namespace
+
+extern "C" int nnr_rank_metrics(const float* scores, const uint8_t* labels, const long* offsets, int n_impressions, int* ranks,
+                                double* per_impression, hipStream_t stream) {
+  if (!scores || !labels || !offsets || !ranks || !per_impression || n_impressions <= 0) return NNR_ERR_ARG;
+  hipLaunchKernelGGL(rank_metrics_kernel, dim3(n_impressions), dim3(256), 0, stream, scores, labels, offsets, ranks, per_impression);
+  NNR_CHECK_LAUNCH();
+  return NNR_OK;
+}
