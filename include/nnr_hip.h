@@ -161,7 +161,8 @@ int nnr_small_embed_bwd(const int* idx, int n, int dim, const float* dout, int l
                         hipStream_t stream);
 /* nn.Embedding forward / backward for a dense id tensor (newsEncoders.py:117-118, 163, 193) with the in-place dropout fused:
  * out[row,:] = dropout(table[idx[row],:]) (negative idx: zero row); dtable[idx[row],:] += mask * dout[row,:] (f32 atomics). */
-int nnr_embed_gather(const float* table, const int* idx, long n, int dim, float* out, float p, uint32_t seed, hipStream_t stream);
+int nnr_embed_gather(const float* table, const int* idx, long n, const int* n_dev /* optional live row count */, int dim, float* out,
+                     float p, uint32_t seed, hipStream_t stream);
 int nnr_embed_scatter(const float* dout, const int* idx, long n, int dim, float* dtable_accum, float p, uint32_t seed,
                       hipStream_t stream);
 int nnr_transpose2d(const float* in, float* out, long rows, int cols, int accumulate, hipStream_t stream);

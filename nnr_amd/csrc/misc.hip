@@ -90,9 +90,11 @@ __global__ void small_embed_kernel(const float* __restrict__ table, const int* _
 // One wave per row: the index is wave-uniform, the row is read as contiguous 16-byte lanes (a 300-float row = 75 float4 =
 // two fully coalesced 1 KiB / 176 B wave accesses).  Pure HBM/L2 streaming: out bytes written once, table rows read once.
 __global__ __launch_bounds__(256) void embed_gather_kernel(const float* __restrict__ table, const int* __restrict__ idx, long n,
-                                                           int dim, float* __restrict__ out, uint32_t seed, uint32_t thr, float scale) {
+                                                           const int* __restrict__ n_dev, int dim, float* __restrict__ out, uint32_t seed,
+                                                           uint32_t thr, float scale) {
   const int lane = threadIdx.x & 63;
   const int nv = dim >> 2;
+  if (n_dev) n = min(n, (long)*n_dev);                 // live row count kept on the device (packed token streams)
   for (long row = blockIdx.x * 4L + (threadIdx.x >> 6); row < n; row += gridDim.x * 4L) {
     const int src = idx[row];
     const f32x4* tp = reinterpret_cast<const f32x4*>(table + (long)src * dim);
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(256) void sue_intra_bwd_dg_kernel(const float* __re
       for (int j = 0; j < Hn; ++j) {
         float acc = 0.f;
 #pragma unroll
-        for (int n = 0; n < 8; ++n) acc += al[n][j] * qv[n];
+        for (int n = 0; n < 8; ++n) if (n < N) acc += al[n][j] * qv[n];      // rows n >= N of `al` are never written (stale LDS may hold NaN)
         dkf[((long)b * Hn + j) * A + x] = acc;
       }
     }
@@ -385,7 +387,7 @@ __global__ __launch_bounds__(256) void sue_intra_bwd_dg_kernel(const float* __re
       const int j = order[cstart[c] + k];
       float acc = 0.f;
 #pragma unroll
-      for (int n = 0; n < 8; ++n) acc += al[n][j] * dv[n];
+      for (int n = 0; n < 8; ++n) if (n < N) acc += al[n][j] * dv[n];
       dg[((long)b * Hn + j) * D + col] = acc;
     }
   }
@@ -528,10 +530,12 @@ extern "C" int nnr_small_embed_bwd(const int* idx, int n, int dim, const float* 
 }
 
 
-extern "C" int nnr_embed_gather(const float* table, const int* idx, long n, int dim, float* out, float p, uint32_t seed, hipStream_t stream) {
+extern "C" int nnr_embed_gather(const float* table, const int* idx, long n, const int* n_dev, int dim, float* out, float p, uint32_t seed,
+                                hipStream_t stream) {
   if (dim & 3) return NNR_ERR_UNSUPPORTED;
   const float sc = p > 0.f ? 1.f / (1.f - p) : 1.f;
-  hipLaunchKernelGGL(embed_gather_kernel, dim3(ew_grid(n, 4)), dim3(256), 0, stream, table, idx, n, dim, out, seed, nnr_drop_thresh(p), sc);
+  hipLaunchKernelGGL(embed_gather_kernel, dim3(ew_grid(n, 4)), dim3(256), 0, stream, table, idx, n, n_dev, dim, out, seed,
+                     nnr_drop_thresh(p), sc);
   NNR_CHECK_LAUNCH();
   return NNR_OK;
 }

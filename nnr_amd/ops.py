@@ -368,11 +368,12 @@ def mhsa_prob_size(n, Lq, heads):
     return n * heads * nb * nb * 1024
 
 
-def embed_gather(table, idx, p, seed, out=None):
+def embed_gather(table, idx, p, seed, out=None, dyn=None):
+    """out[row] = dropout(table[idx[row]]); `dyn`: device int32 holding the live row count (rows beyond it are left untouched)."""
     n, dim = idx.numel(), table.shape[1]
     if out is None:
         out = torch.empty((n, dim), device=table.device, dtype=torch.float32)
-    L.check(L.lib().nnr_embed_gather(_p(table), _p(idx), C.c_long(n), dim, _p(out), C.c_float(p), C.c_uint32(seed & 0xFFFFFFFF), _s()),
+    L.check(L.lib().nnr_embed_gather(_p(table), _p(idx), C.c_long(n), _p(dyn), dim, _p(out), C.c_float(p), C.c_uint32(seed & 0xFFFFFFFF), _s()),
             'nnr_embed_gather')
     return out
 
