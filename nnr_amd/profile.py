@@ -13,7 +13,7 @@ KERNEL_OF = {
     'gemm_tn_256x80': 'gemm_kernel<4, 5, true, true, 16>', 'gemm_nt_64x80': 'gemm_kernel<1, 5, false, false, 16>',
     'gemm_nn_64x80': 'gemm_kernel<1, 5, false, true, 16>', 'gemm_tn_64x80': 'gemm_kernel<1, 5, true, true, 16>',
     'gemm_nt_128x208': 'gemm_kernel<2, 13, false, false, 16>', 'gemm_nt_128x80': 'gemm_kernel<2, 5, false, false, 16>', 'gemm_nt_128x80k32': 'gemm_kernel<2, 5, false, false, 32>',
-    'gemm_nn_128x80': 'gemm_kernel<2, 5, false, true, 16>', 'gemm_tn_128x80': 'gemm_kernel<2, 5, true, true, 16>', 'lstm_fwd': 'lstm_fwd_kernel<13>', 'lstm_bwd': 'lstm_bwd_kernel<13>',
+    'gemm_nn_128x80': 'gemm_kernel<2, 5, false, true, 16>', 'gemm_tn_128x80': 'gemm_kernel<2, 5, true, true, 16>', 'lstm_fwd': 'lstm_fwd_pair_kernel<13>', 'lstm_bwd': 'lstm_bwd_pair_kernel<13>',
 }
 
 
@@ -76,6 +76,21 @@ def summary():
     return fam
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes of this same command (profiles/pmc_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, corrected for gfx950 by tools/pmc_traffic.py), or None."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'pmc_traffic.json')
+    try:
+        for k in json.load(open(path))['kernels']:
+            if k['kernel'] == kernel:
+                return k['hbm_bytes_per_launch']
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def roofline(peak_tflops):
     fam = summary()
     if not fam:
@@ -86,7 +101,7 @@ def roofline(peak_tflops):
     ach = d['flops'] / (d['ms'] * 1e-3) / 1e12 if d['ms'] > 0 else 0.0
     return {
         'bound': 'mfma', 'achieved': round(ach, 3), 'peak': peak_tflops, 'unit': 'TFLOP/s', 'frac': round(ach / peak_tflops, 4),
-        'traffic': None, 'kernel': KERNEL_OF.get(name, name), 'launches': d['launches'],
+        'traffic': pmc_traffic(KERNEL_OF.get(name, name)), 'kernel': KERNEL_OF.get(name, name), 'launches': d['launches'],
         'avg_launch_us': round(1000 * d['ms'] / max(1, d['launches']), 2),
         'share_of_instrumented_time': round(d['ms'] / total_ms, 3),
         'families': {k: {'ms': round(v['ms'], 3), 'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2) if v['ms'] > 0 else 0.0,

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Aggregate the two rocprofv3 PMC passes of the bench (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, each with --kernel-trace,
+--output-format csv) into per-kernel HBM traffic per launch, corrected as MI355X_MICROARCH.md (HBM / rocprofv3) prescribes:
+FETCH_SIZE (KB) under-reports wide coalesced reads on gfx950 by exactly 2x -> doubled; WRITE_SIZE (KB) is exact.
+Usage: python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json>"""
+import collections
+import csv
+import json
+import re
+import sys
+
+
+def short(n):
+    return re.sub(r'^void ', '', n).replace('(anonymous namespace)::', '').split('(')[0]
+
+
+def load(path, counter):
+    agg = collections.defaultdict(lambda: [0.0, 0])
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r['Counter_Name'] == counter:
+                a = agg[short(r['Kernel_Name'])]
+                a[0] += float(r['Counter_Value'])
+                a[1] += 1
+    return agg
+
+
+fetch, write = load(sys.argv[1], 'FETCH_SIZE'), load(sys.argv[2], 'WRITE_SIZE')
+out = []
+for k in sorted(fetch, key=lambda k: -(2 * fetch[k][0] + write.get(k, [0, 0])[0])):
+    fk, n = fetch[k]
+    wk = write.get(k, [0.0, 0])[0]
+    out.append(dict(kernel=k, launches=n, fetch_bytes_per_launch=round(2 * fk * 1024 / n), write_bytes_per_launch=round(wk * 1024 / max(1, write.get(k, [0, 1])[1])),
+                    hbm_bytes_per_launch=round((2 * fk + wk) * 1024 / n)))
+json.dump(dict(note='FETCH_SIZE x2 (gfx950 caveat) + WRITE_SIZE, bytes per launch averaged over the launches of one bench run', kernels=out),
+          open(sys.argv[3], 'w'), indent=1)
+for o in out[:12]:
+    print('%-44s %4d launches  fetch %8.1f MB  write %8.1f MB per launch' % (o['kernel'][:44], o['launches'], o['fetch_bytes_per_launch'] / 1e6, o['write_bytes_per_launch'] / 1e6))

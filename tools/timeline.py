@@ -64,3 +64,43 @@ for key in sorted(byq, key=lambda k: -byq[k][0]):
     print('stream %s:' % (key,))
     for k, v in sorted(nt.items(), key=lambda kv: -kv[1][0])[:14]:
         print('  %-62s %8.3f ms/step  %6.1f launches/step' % (k, v[0] / 1e6 / nstep, v[1] / nstep))
+
+# ---- when is only ONE of the streams busy?  (side-only time = the main stream waiting at a join, or idle)
+def union(iv):
+    iv = sorted(iv); out = []
+    for s_, e_ in iv:
+        if out and s_ <= out[-1][1]: out[-1][1] = max(out[-1][1], e_)
+        else: out.append([s_, e_])
+    return out
+def total(u): return sum(e_ - s_ for s_, e_ in u)
+def inter(a, b):
+    i = j = 0; t = 0
+    while i < len(a) and j < len(b):
+        lo, hi = max(a[i][0], b[j][0]), min(a[i][1], b[j][1])
+        if hi > lo: t += hi - lo
+        if a[i][1] < b[j][1]: i += 1
+        else: j += 1
+    return t
+keys = sorted(byq, key=lambda k: -byq[k][0])
+if len(keys) >= 2:
+    um = union([(s_, e_) for s_, e_, n_, q_, st_ in seg if (q_, st_) == keys[0]])
+    us = union([(s_, e_) for s_, e_, n_, q_, st_ in seg if (q_, st_) == keys[1]])
+    both = inter(um, us)
+    print('main busy %.3f, side busy %.3f, both %.3f, main-only %.3f, side-only %.3f ms/step' %
+          (total(um) / 1e6 / nstep, total(us) / 1e6 / nstep, both / 1e6 / nstep, (total(um) - both) / 1e6 / nstep, (total(us) - both) / 1e6 / nstep))
+    # side-only stretches longer than 50 us: which kernels run there
+    gaps_m = []
+    for i in range(len(um) - 1):
+        gaps_m.append((um[i][1], um[i + 1][0]))
+    big = [(a_, b_) for a_, b_ in gaps_m if b_ - a_ > 50000]
+    agg = collections.defaultdict(float)
+    for s_, e_, n_, q_, st_ in seg:
+        if (q_, st_) != keys[1]: continue
+        for a_, b_ in big:
+            lo, hi = max(s_, a_), min(e_, b_)
+            if hi > lo:
+                short = re.sub(r'^void ', '', n_).replace('(anonymous namespace)::', '').split('(')[0][:50]
+                agg[short] += hi - lo
+    print('main-stream gaps > 50 us: %.3f ms/step in %d gaps/step; side kernels running inside them:' % (sum(b_ - a_ for a_, b_ in big) / 1e6 / nstep, len(big) / nstep))
+    for k, v in sorted(agg.items(), key=lambda kv: -kv[1])[:8]:
+        print('   %-52s %.3f ms/step' % (k, v / 1e6 / nstep))
