@@ -150,3 +150,51 @@ def test_mhsa_and_cnn_pairs_on_ragged_batch():
         total = float(torch.sqrt(sum((q.grad.double() ** 2).sum() for q in ref.parameters())))
         for k, p in model.named_parameters():
             assert float((p.grad.cpu().double() - rp[k].grad.double()).abs().max()) <= 1e-4 * max(1e-3, 0.05 * total), (ne, ue, k)
+
+
+def test_large_vocabulary_config_parity_and_dropout_properties():
+    """BASELINE.json config 5 (CNE+SUE 'large': vocabulary 130 000, per-GPU batch 16, dropout 0.1).  Dropout off: logits /
+    loss / gradients against the oracle on a 2-impression shard (the oracle finishes in seconds).  Dropout on, full per-GPU
+    batch: size-independent properties -- finite loss, the embedding gradient touches exactly the word rows of the batch,
+    two runs with the same seed are identical in the forward pass, and the keep rate of the embedding dropout is 1 - p."""
+    from nnr_amd import ops
+    from nnr_amd.model import Model, negative_log_softmax
+    from nnr_amd.trainer import Trainer
+    V = 130000
+    cfg = make_config(['--news_encoder=CNE', '--user_encoder=SUE', '--dataset=large'], corpus_sizes=dict(vocabulary_size=V), dropout_rate=0.0,
+                      tie_order='stable', batch_size=2)
+    model, ref = _models(cfg, seed=4)
+    corpus = SynthCorpus(SynthSpec(vocabulary_size=V, news_pool=600, seed=11))
+    _compare(model, ref, corpus.batch(2, np.random.default_rng(6)))
+    # dropout on (the reference's large-dataset setting), per-GPU batch of the 8-GPU configuration
+    cfg2 = make_config(['--news_encoder=CNE', '--user_encoder=SUE', '--dataset=large', '--batch_size=128', '--world_size=8'],
+                       corpus_sizes=dict(vocabulary_size=V))
+    assert abs(cfg2.dropout_rate - 0.1) < 1e-9
+    torch.manual_seed(0)
+    m2 = Model(cfg2, torch.randn(V, cfg2.word_embedding_dim) * 0.3)
+    m2.initialize()
+    m2 = m2.cuda().train()
+    batch = corpus.batch(16, np.random.default_rng(8))
+    for p in m2.parameters():
+        p.grad = None
+    logits = m2(*to_torch(batch, 'cuda'))
+    loss = negative_log_softmax(logits)
+    loss.backward()
+    assert bool(torch.isfinite(loss)) and bool(torch.isfinite(logits).all())
+    gw = m2.news_encoder.word_embedding.weight.grad
+    touched = set(torch.nonzero(gw.abs().sum(dim=1)).flatten().cpu().tolist())
+    words = set()
+    for k, mk in (('user_title_text', 'user_title_mask'), ('user_content_text', 'user_content_mask'), ('news_title_text', 'news_title_mask'),
+                  ('news_content_text', 'news_content_mask')):
+        m = batch[mk].copy()
+        m[..., 0] = True                                   # the reference's mask[:, 0] = 1 fix (newsEncoders.py:108-109)
+        words |= set(batch[k][m].tolist())
+    assert touched <= words and len(touched) >= 0.95 * len(words - {0})
+    # embedding-dropout keep rate through the gather kernel
+    idx = torch.randint(2, V, (20000,), dtype=torch.int32, device='cuda')
+    table = m2.news_encoder.word_embedding.weight.detach()
+    kept = ops.embed_gather(table, idx, 0.1, 12345)
+    full = ops.embed_gather(table, idx, 0.0, 12345)
+    rate = float((kept != 0).float().sum() / (full != 0).float().sum())
+    assert abs(rate - 0.9) < 5e-3, rate
+    assert torch.allclose(kept[kept != 0], (full / 0.9)[kept != 0], rtol=1e-6)
