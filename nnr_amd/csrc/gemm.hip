@@ -469,6 +469,8 @@ extern "C" int nnr_gemm_f32(const nnr_gemm_args* a, hipStream_t stream) {
     const long wg128 = (long)((g.M + 127) / 128) * ((g.N + 79) / 80) * (g.k_chunk > 0 ? (g.K + g.k_chunk - 1) / g.k_chunk : (g.split_k > 1 ? g.split_k : (g.batch > 1 ? g.batch : 1)));
     if (g.rowdot_w) tile = 3;
     else if (g.M <= 512 || (wg128 < 640 && !g.dyn_dev)) tile = 2;   // too few 128-row tiles to fill 256 CUs x 4: use 64-row tiles
+    else if (g.trans_a) tile = 2;   // TN (token-reduction dW): 64 x 80 measured 5-10 % faster than 128 x 80 on every in-step shape
+                                    // (84.7 vs 81.0, 81.0 vs 75.1, 66.7 vs 60.2, 53.7 vs 48.7 TF; tools/gemm_tn_shapes.py)
     else if (!g.trans_a && !g.trans_b) tile = 5;   // NT: BK = 32 measured +7 % (97.7 vs 90.9 TF); the K-major operands of NN / TN lose with it
     else tile = 4;           // 128 x 80: 117 VGPRs -> 4 waves/SIMD, 4 workgroups per CU hide barriers, prologue and epilogue
                              // (measured 84-96 TF vs 63-79 TF for the 256 x 80 tile on the CNE shapes)
