@@ -118,6 +118,27 @@ def _side_stream(dev):
     return _SIDE[key]
 
 
+def _two_chains(dev, enable, title_fn, content_fn):
+    """The title and the content chain of ONE encoder call are independent between their exchange points (c_n before the
+    gate, the self-attention vectors before the cross attention and their gradients on the way back): on the big call the
+    title chain runs on a third HIP stream next to the content chain.  Half of the step at batch 64 (7 of 16 ms) is the
+    latency of dependent launches, not throughput; the title kernels are a quarter of the content kernels' size."""
+    if not enable:
+        title_fn()
+        content_fn()
+        return
+    main = torch.cuda.current_stream(dev)
+    key = (dev.type, dev.index, 2)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=dev)
+    s2 = _SIDE[key]
+    s2.wait_stream(main)
+    with torch.cuda.stream(s2):
+        title_fn()
+    content_fn()
+    main.wait_stream(s2)
+
+
 class _on:
     """Run a phase of call #0 on the side stream when there are several calls; main-stream phases pass through."""
 
@@ -138,13 +159,13 @@ def _fork_join(n_calls, dev, phase):
     """phase(i) for every call: call 0 (the candidates: ~10 % of the rows, launch-latency-bound kernels) on the side stream,
     concurrently with the other calls on the current stream; returns after both streams are joined."""
     if n_calls == 1:
-        return [phase(0)]
+        return [phase(0, True)]
     main = torch.cuda.current_stream(dev)
     side = _side_stream(dev)
     side.wait_stream(main)
     with torch.cuda.stream(side):
-        first = phase(0)
-    rest = [phase(i) for i in range(1, n_calls)]
+        first = phase(0, False)
+    rest = [phase(i, True) for i in range(1, n_calls)]
     main.wait_stream(side)
     return [first] + rest
 
@@ -157,11 +178,11 @@ def cne_forward_many(mod, calls):
     dev = calls[0][0].device
     mod._packed_weights('title', mod.title_lstm)        # (re)pack on the main stream BEFORE forking: both calls read them
     mod._packed_weights('content', mod.content_lstm)
-    pre = _fork_join(len(calls), dev, lambda i: _cne_fwd_pre(mod, *calls[i]))
+    pre = _fork_join(len(calls), dev, lambda i, on_main: _cne_fwd_pre(mod, *calls[i]))
     items = [st for sv in pre for st in (sv['streams'][1],)] + [st for sv in pre for st in (sv['streams'][0],)]   # content streams first
     for i in range(0, len(items), 4):
         ops.lstm_fwd(items[i:i + 4], H)
-    return _fork_join(len(calls), dev, lambda i: _cne_fwd_post(mod, pre[i]))
+    return _fork_join(len(calls), dev, lambda i, on_main: _cne_fwd_post(mod, pre[i], on_main))
 
 
 def _cne_fwd_pre(mod, title_text, title_mask, content_text, content_mask, category, subCategory):
@@ -203,7 +224,7 @@ def _cne_fwd_pre(mod, title_text, title_mask, content_text, content_mask, catego
     return dict(streams=streams, n=n, B=B, N=N, p=p, seed=seed, category=category, subCategory=subCategory)
 
 
-def _cne_fwd_post(mod, sv):
+def _cne_fwd_post(mod, sv, par=False):
     t_, c_ = sv['streams']
     n, B, N, p, seed = sv['n'], sv['B'], sv['N'], sv['p'], sv['seed']
     dev = t_['gates'].device
@@ -212,7 +233,7 @@ def _cne_fwd_post(mod, sv):
     D = mod.news_embedding_dim
     f32 = dict(device=dev, dtype=torch.float32)
 
-    for st, other in ((t_, c_), (c_, t_)):
+    def gate_and_self(st, other):
         plan, cap = st['plan'], st['plan'].cap
         # title_M(sorted_content_m): both indexed by sorted RANK (newsEncoders.py:128-129)
         st['mproj'] = ops.linear_fwd(other['cn'], st['Mlin'].weight, st['Mlin'].bias)
@@ -232,8 +253,11 @@ def _cne_fwd_post(mod, sv):
         ops.pool_fwd(x=st['Ht'], ldx=H2, D=H2, n=n, Lx=st['L'], plan=plan, score=st['score'], alpha=st['alpha_s'],
                      out=st['selfv'], ldo=H2)
 
+    _two_chains(dev, par, lambda: gate_and_self(t_, c_), lambda: gate_and_self(c_, t_))
+
     rep = torch.empty((n, D), **f32)
-    for st, other, col0 in ((t_, c_, 0), (c_, t_, H2)):
+
+    def cross(st, other, col0):
         plan, ca = st['plan'], st['catt']
         st['qv'] = ops.linear_fwd(other['selfv'], ca.Q.weight, ca.Q.bias)                    # [n, A]
         st['v'] = torch.empty((n, H2), **f32)
@@ -241,6 +265,8 @@ def _cne_fwd_post(mod, sv):
         st['alpha_c'] = torch.empty(plan.cap, **f32)
         ops.pool_fwd(x=st['Ht'], ldx=H2, D=H2, n=n, Lx=st['L'], plan=plan, v=st['v'], ldv=H2, scale=1.0 / math.sqrt(A),
                      alpha=st['alpha_c'], out=rep[:, col0:], ldo=D, add_in=st['selfv'], ldadd=H2)
+
+    _two_chains(dev, par, lambda: cross(t_, c_, 0), lambda: cross(c_, t_, H2))
     cat = _i32(sv.pop('category')).reshape(n).contiguous()
     sub = _i32(sv.pop('subCategory')).reshape(n).contiguous()
     cd, sd = mod.category_embedding.weight.shape[1], mod.subCategory_embedding.weight.shape[1]
@@ -262,7 +288,7 @@ def cne_backward_many(mod, pairs):
     dev = pairs[0][1].device
     for q in mod.parameters():          # materialise (zero-fill) missing .grad buffers on the main stream BEFORE forking
         grad_of(q)
-    _fork_join(len(pairs), dev, lambda i: _cne_bwd_pre(mod, pairs[i][0], pairs[i][1]))
+    _fork_join(len(pairs), dev, lambda i, on_main: _cne_bwd_pre(mod, pairs[i][0], pairs[i][1], on_main))
 
     # recurrence backward + token-reduction GEMMs, per token stream kind: the content recurrence is one long dependent chain
     # (128 steps) that leaves most CUs idle in its tail; the title recurrence (32 steps) and the title GEMMs run on the side
@@ -281,7 +307,7 @@ def cne_backward_many(mod, pairs):
     main.wait_stream(side)
 
 
-def _cne_bwd_pre(mod, sv, drep):
+def _cne_bwd_pre(mod, sv, drep, par=False):
     t_, c_ = sv['streams']
     n, p, seed = sv['n'], sv['p'], sv['seed']
     H, E, A = mod.hidden_dim, mod.word_embedding_dim, mod.attention_dim
@@ -296,7 +322,7 @@ def _cne_bwd_pre(mod, sv, drep):
     ops.small_embed_bwd(sv['sub'], sv['sd'], drep[:, 2 * H2 + sv['cd']:], D, grad_of(mod.subCategory_embedding.weight), p, seed + _SITE['sub'])
 
     # ---- cross attention pools: dHt (overwrite), dv -> K / Q params and the gradient of the OTHER stream's self vector
-    for st, other, col0 in ((t_, c_, 0), (c_, t_, H2)):
+    def cross_bwd(st, other, col0):
         plan, ca, cap = st['plan'], st['catt'], st['plan'].cap
         st['dHt'] = torch.empty((cap, H2), **f32)
         dv = torch.empty((n, H2), **f32)
@@ -309,8 +335,10 @@ def _cne_bwd_pre(mod, sv, drep):
         ops.bias_grad(dqv, grad_of(ca.Q.bias))
         other['dself_x'] = ops.linear_bwd_data(dqv, ca.Q.weight)                              # grad of other.selfv via the query
 
+    _two_chains(dev, par, lambda: cross_bwd(t_, c_, 0), lambda: cross_bwd(c_, t_, H2))
+
     # ---- self attention pools, additive score, gate
-    for st, other, col0 in ((t_, c_, 0), (c_, t_, H2)):
+    def self_gate_bwd(st, other, col0):
         plan, sa, cap = st['plan'], st['satt'], st['plan'].cap
         ds = torch.empty(cap, **f32)
         ops.pool_bwd(x=st['Ht'], ldx=H2, D=H2, n=n, Lx=st['L'], plan=plan, score=None, alpha=st['alpha_s'],
@@ -333,6 +361,8 @@ def _cne_bwd_pre(mod, sv, drep):
         ops.bias_grad(dP, grad_of(st['Mlin'].bias))
         other['dcn'] = ops.linear_bwd_data(dP, st['Mlin'].weight)                             # [n, H2], rank-indexed
         st['dHt'] = None
+
+    _two_chains(dev, par, lambda: self_gate_bwd(t_, c_, 0), lambda: self_gate_bwd(c_, t_, H2))
 
     for st in (t_, c_):
         st['dh'] = st['dH']
