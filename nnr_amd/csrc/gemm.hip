@@ -19,9 +19,9 @@ namespace {
 
 template <int BK>
 __device__ __forceinline__ int swz(int r16) {  // chunk XOR for row r (0..15) of a 16-row block
-  // BK=16 (4 chunks / row): f(r>>2) = {0,3,2,1};  BK=32 (8 chunks / row): (r>>1)&7.
-  // Either makes the four ds_read_b128 lane groups hit 16 distinct 16-B slots (brute-force checked).
-  return BK == 16 ? ((4 - (r16 >> 2)) & 3) : ((r16 >> 1) & 7);
+  // BK=16 (4 chunks / row): f(r>>2) = {0,3,2,1};  BK=32 (8 chunks / row): (r>>1)&7;  BK=64 (16 chunks = one 256-B bank row
+  // per row): r itself.  Each makes the four ds_read_b128 lane groups hit 16 distinct 16-B slots (brute-force checked).
+  return BK == 16 ? ((4 - (r16 >> 2)) & 3) : BK == 32 ? ((r16 >> 1) & 7) : (r16 & 15);
 }
 
 template <int TM, int TN, bool TA, bool TB, int BK>
@@ -467,7 +467,10 @@ extern "C" int nnr_gemm_f32(const nnr_gemm_args* a, hipStream_t stream) {
   int tile = g.tile;
   if (tile == 0) {
     const long wg128 = (long)((g.M + 127) / 128) * ((g.N + 79) / 80) * (g.k_chunk > 0 ? (g.K + g.k_chunk - 1) / g.k_chunk : (g.split_k > 1 ? g.split_k : (g.batch > 1 ? g.batch : 1)));
+    const long wg64 = (long)((g.M + 63) / 64) * ((g.N + 79) / 80) * (g.split_k > 1 ? g.split_k : (g.batch > 1 ? g.batch : 1));
     if (g.rowdot_w) tile = 3;
+    else if (wg64 <= 512 && !g.dyn_dev && g.k_chunk <= 0 && g.K >= 128) tile = 6;   // at most 2 workgroups per CU: nothing hides the
+                             // memory round trip each k-stage pays with a one-stage prefetch -> BK = 64, 4x fewer stages
     else if (g.M <= 512 || (wg128 < 640 && !g.dyn_dev)) tile = 2;   // too few 128-row tiles to fill 256 CUs x 4: use 64-row tiles
     else if (g.trans_a) tile = 2;   // TN (token-reduction dW): 64 x 80 measured 5-10 % faster than 128 x 80 on every in-step shape
                                     // (84.7 vs 81.0, 81.0 vs 75.1, 66.7 vs 60.2, 53.7 vs 48.7 TF; tools/gemm_tn_shapes.py)
@@ -481,6 +484,7 @@ extern "C" int nnr_gemm_f32(const nnr_gemm_args* a, hipStream_t stream) {
     case 3: return launch_cfg<2, 13, 16>(g, stream);   // 128 x 208 (whole rows in one wave: fused row-dot)
     case 4: return launch_cfg<2, 5, 16>(g, stream);    // 128 x 80 (4 waves/SIMD: more workgroups in flight per CU)
     case 5: return launch_cfg<2, 5, 32>(g, stream);   // 128 x 80, BK = 32: half the barriers per FLOP, 3 workgroups per CU
+    case 6: return launch_cfg<1, 5, 64>(g, stream);   //  64 x 80, BK = 64: latency-bound small launches (few stages, 74 KB LDS)
     default: return NNR_ERR_ARG;
   }
 }
