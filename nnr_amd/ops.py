@@ -57,8 +57,20 @@ def gemm(A, B, C_=None, *, M, N, K, lda, ldb, ldc=0, trans_a=False, trans_b=Fals
         L.check(L.lib().nnr_gemm_f32(C.byref(g), _s()), 'nnr_gemm_f32')
         return
     wg128 = ((M + 127) // 128) * ((N + 79) // 80) * (split_k if split_k > 1 else max(1, batch)) * (1 if k_chunk <= 0 else max(1, K // k_chunk))
-    t = tile if tile else (3 if rowdot_w is not None else (2 if (M <= 512 or (wg128 < 640 and dyn is None)) else (5 if not (trans_a or trans_b) else 4)))
-    fam = 'gemm_%s_%s' % ('tn' if trans_a else ('nn' if trans_b else 'nt'), {1: '256x80', 2: '64x80', 3: '128x208', 4: '128x80', 5: '128x80k32'}[t])
+    # mirror of the library's tile choice (csrc/gemm.hip:nnr_gemm_f32), only to NAME the kernel family in the live profile
+    wg64 = ((M + 63) // 64) * ((N + 79) // 80) * (split_k if split_k > 1 else max(1, batch))
+    if tile:
+        t = tile
+    elif rowdot_w is not None:
+        t = 3
+    elif wg64 <= 512 and dyn is None and k_chunk <= 0 and K >= 128:
+        t = 6
+    elif M <= 512 or (wg128 < 640 and dyn is None) or trans_a:
+        t = 2
+    else:
+        t = 5 if not trans_b else 4
+    fam = 'gemm_%s_%s' % ('tn' if trans_a else ('nn' if trans_b else 'nt'),
+                          {1: '256x80', 2: '64x80', 3: '128x208', 4: '128x80', 5: '128x80k32', 6: '64x80k64'}[t])
 
     def flops(M=M, N=N, K=K, dyn=dyn, dyn_dim=dyn_dim, batch=batch):
         m, k = M, K
