@@ -945,7 +945,9 @@ __global__ void lstm_unpack_kernel(const float* __restrict__ dw_ihp, const float
                                    const float* __restrict__ dw_hhp, int H, int E, int UB, float* __restrict__ dw_ih_f,
                                    float* __restrict__ dw_hh_f, float* __restrict__ db_ih_f, float* __restrict__ db_hh_f,
                                    float* __restrict__ dw_ih_r, float* __restrict__ dw_hh_r, float* __restrict__ db_ih_r,
-                                   float* __restrict__ db_hh_r) {
+                                   float* __restrict__ db_hh_r, int accumulate) {
+  // accumulate: atomic += into the running parameter gradients (several token streams / HIP streams add concurrently)
+  auto put = [&](float* p, float v) __attribute__((always_inline)) { if (accumulate) atomicAdd(p, v); else *p = v; };
   const int NP = UB * 64;
   const long n_ih = (long)2 * 4 * H * E, n_hh = (long)2 * 4 * H * H, n_b = 2 * 4 * H;
   const long total = n_ih + n_hh + n_b;
@@ -954,14 +956,14 @@ __global__ void lstm_unpack_kernel(const float* __restrict__ dw_ihp, const float
     if (i < n_ih) {
       const int e = i % E; long q = i / E; const int row = q % (4 * H); const int d = q / (4 * H);
       const int g = row / H, unit = row % H, p = (unit / 16) * 64 + (unit % 16) * 4 + g;
-      (d ? dw_ih_r : dw_ih_f)[(long)row * E + e] = dw_ihp[(long)(d * NP + p) * E + e];
+      put(&(d ? dw_ih_r : dw_ih_f)[(long)row * E + e], dw_ihp[(long)(d * NP + p) * E + e]);
       continue;
     }
     i -= n_ih;
     if (i < n_hh) {
       const int k = i % H; long q = i / H; const int row = q % (4 * H); const int d = q / (4 * H);
       const int g = row / H, unit = row % H, p = (unit / 16) * 64 + (unit % 16) * 4 + g;
-      (d ? dw_hh_r : dw_hh_f)[(long)row * H + k] = dw_hhp[((long)d * NP + p) * H + k];
+      put(&(d ? dw_hh_r : dw_hh_f)[(long)row * H + k], dw_hhp[((long)d * NP + p) * H + k]);
       continue;
     }
     i -= n_hh;
@@ -969,8 +971,8 @@ __global__ void lstm_unpack_kernel(const float* __restrict__ dw_ihp, const float
       const int row = i % (4 * H), d = i / (4 * H);
       const int g = row / H, unit = row % H, p = (unit / 16) * 64 + (unit % 16) * 4 + g;
       const float v = db_p[d * NP + p];
-      (d ? db_ih_r : db_ih_f)[row] = v;
-      (d ? db_hh_r : db_hh_f)[row] = v;
+      put(&(d ? db_ih_r : db_ih_f)[row], v);
+      put(&(d ? db_hh_r : db_hh_f)[row], v);
     }
   }
 }
@@ -1022,11 +1024,11 @@ extern "C" int nnr_lstm_pack_weights(const float* w_ih_f, const float* w_hh_f, c
 
 extern "C" int nnr_lstm_unpack_grads(const float* dw_ihp, const float* db_p, const float* dw_hhp, int H, int E,
                                      float* dw_ih_f, float* dw_hh_f, float* db_ih_f, float* db_hh_f, float* dw_ih_r,
-                                     float* dw_hh_r, float* db_ih_r, float* db_hh_r, hipStream_t stream) {
+                                     float* dw_hh_r, float* db_ih_r, float* db_hh_r, int accumulate, hipStream_t stream) {
   int UB;
   if (nnr_lstm_dims(H, &UB, nullptr, nullptr) != NNR_OK) return NNR_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(lstm_unpack_kernel, dim3(1024), dim3(256), 0, stream, dw_ihp, db_p, dw_hhp, H, E, UB, dw_ih_f,
-                     dw_hh_f, db_ih_f, db_hh_f, dw_ih_r, dw_hh_r, db_ih_r, db_hh_r);
+                     dw_hh_f, db_ih_f, db_hh_f, dw_ih_r, dw_hh_r, db_ih_r, db_hh_r, accumulate);
   NNR_CHECK_LAUNCH();
   return NNR_OK;
 }

@@ -510,7 +510,10 @@ extern "C" int nnr_tanh_score_bwd(float* th, const float* ds, const float* w2, f
 
 extern "C" int nnr_colsum(const float* x, int ld, const int* rows_dev, int rows, int N, float* out, hipStream_t stream) {
   if (rows <= 0 || N <= 0) return NNR_OK;
-  const int rpb = 128;
+  // rows per workgroup: few enough that mid-size inputs (3 200 .. 6 080 rows here) still spread over the chip -- with 128 rows
+  // per block a [3200, 200] bias gradient was 25 workgroups walking 128 rows each (43 us); many enough to bound the atomics
+  int rpb = rows / 512;
+  rpb = rpb < 8 ? 8 : (rpb > 128 ? 128 : rpb);
   hipLaunchKernelGGL(colsum_kernel, dim3((rows + rpb - 1) / rpb, (N + 255) / 256), dim3(256), 0, stream, x, ld, rows_dev, rows, N, out, rpb);
   NNR_CHECK_LAUNCH();
   return NNR_OK;

@@ -169,13 +169,10 @@ class LstmPacked:
 
 
 def lstm_unpack_grads(dw_ihp, db_p, dw_hhp, H, E, grads):
-    """grads: 8 tensors in nn.LSTM order (w_ih, w_hh, b_ih, b_hh, then *_reverse); accumulated into."""
-    tmp = [torch.empty_like(g) for g in grads]
-    order = [tmp[0], tmp[1], tmp[2], tmp[3], tmp[4], tmp[5], tmp[6], tmp[7]]
-    L.check(L.lib().nnr_lstm_unpack_grads(_p(dw_ihp), _p(db_p), _p(dw_hhp), H, E, *[_p(t) for t in order], _s()),
+    """grads: 8 tensors in nn.LSTM order (w_ih, w_hh, b_ih, b_hh, then *_reverse); accumulated into with f32 atomics
+    (parameter gradients may be accumulated from several HIP streams at once)."""
+    L.check(L.lib().nnr_lstm_unpack_grads(_p(dw_ihp), _p(db_p), _p(dw_hhp), H, E, *[_p(t) for t in grads], 1, _s()),
             'nnr_lstm_unpack_grads')
-    for g, t in zip(grads, tmp):
-        add_atomic_(g, t)       # parameter gradients may be accumulated from two HIP streams at once
 
 
 LSTM_PAIR = os.environ.get('NNR_LSTM_PAIR', '1') != '0'      # 2-CU weights-stationary recurrence (lstm.hip) when H = 200
