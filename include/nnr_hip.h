@@ -76,7 +76,8 @@ typedef struct nnr_gemm_args {
   int k_chunk;              /* > 0: like split_k but with fixed-size slices of k_chunk reduction rows (multiple of 32): the number of
                                live slices follows the device-side K; atomicAdd into a pre-zeroed / running C */
   float* colsum_out;        /* trans_a only: colsum_out[m] += sum_k A[k][m]  (fused bias gradient, f32 atomics) */
-  int tile;                 /* 0 auto, 1: 256x80, 2: 64x80, 3: 128x208, 4: 128x80, 5: 128x80 with BK=32, 6: 64x80 with BK=64 (small launches) */
+  int tile;                 /* 0 auto, 1: 256x80, 2: 64x80, 3: 128x208, 4: 128x80, 5: 128x80 with BK=32, 6: 64x80 with BK=64,
+                             * 7: 16x80 skinny (K split over the waves; plain NT / NN launches only) */
   /* filled by the library */
   uint32_t drop_thresh;
   float drop_scale;

@@ -441,6 +441,124 @@ int launch_cfg(const nnr_gemm_args& g, hipStream_t s) {
   return NNR_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------ skinny GEMM (small launches)
+// For launches that cannot fill the chip (M of a few hundred to a few thousand rows: per-news vectors, SUE heads) the tiled
+// kernel is bound by its own dependent chain -- one workgroup walks K / 16 stages of (global load -> LDS -> barrier -> MFMA),
+// ~0.8 us each with nothing else on the CU to hide them: 20-50 us for a few MFLOP.  Here a workgroup owns a 16 x 80 output
+// tile and its four waves split the K range (wave w takes the 16-wide k-groups w, w+4, ...): 4x shorter chains, 4x more
+// workgroups, MFMA fragments loaded straight from global memory (no LDS staging, no barrier inside the loop), one LDS
+// reduction of the four partial tiles, then the same element-wise epilogue as the tiled kernel.
+template <bool TB>
+__global__ __launch_bounds__(256) void skinny_gemm_kernel(nnr_gemm_args g) {
+  constexpr int TN = 5, BN = 16 * TN, E_LD = BN + 4;
+  __shared__ float red[4][16 * E_LD];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, kk = lane >> 4;
+  const int nbn = (g.N + BN - 1) / BN;
+  const int bm = blockIdx.x / nbn, bn = blockIdx.x - bm * nbn;
+  const int m0 = bm * 16, n0 = bn * BN;
+  const int M = g.M, N = g.N, K = g.K;
+  const float* __restrict__ A = g.A;
+  const float* __restrict__ B = g.B;
+  float* __restrict__ C = g.C;
+  float* aux = g.aux_out;
+  const float* res = g.resid;
+  const int z = blockIdx.z;
+  if (g.batch > 1) {
+    A += (long)z * g.strideA; B += (long)z * g.strideB; C += (long)z * g.strideC;
+    if (aux) aux += (long)z * g.stride_aux;
+    if (res) res += (long)z * g.stride_res;
+  }
+  const bool vecA = ((g.lda & 3) == 0) && ((((uintptr_t)A) & 15) == 0);
+  const bool vecB = ((g.ldb & 3) == 0) && ((((uintptr_t)B) & 15) == 0);
+  const int arow = m0 + r;
+  auto load_frags = [&](int k0, f32x4& af, f32x4 (&bf)[TN]) __attribute__((always_inline)) {
+    const int k = k0 + 4 * kk;
+    af = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (arow < M && k < K) {
+      const float* p = A + (long)arow * g.lda + k;
+      if (vecA && k + 3 < K) af = *reinterpret_cast<const f32x4*>(p);
+      else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (k + e < K) af[e] = p[e];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      bf[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int col = n0 + 16 * j + r;
+      if (col < N && k < K) {
+        if (!TB) {
+          const float* p = B + (long)col * g.ldb + k;
+          if (vecB && k + 3 < K) bf[j] = *reinterpret_cast<const f32x4*>(p);
+          else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (k + e < K) bf[j][e] = p[e];
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (k + e < K) bf[j][e] = B[(long)(k + e) * g.ldb + col];
+        }
+      }
+    }
+  };
+  f32x4 acc[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 af, bf[TN];
+  int k0 = w * 16;
+  if (k0 < K) load_frags(k0, af, bf);
+  for (; k0 < K; k0 += 64) {
+    f32x4 an = {0.f, 0.f, 0.f, 0.f}, bn_[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bn_[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (k0 + 64 < K) load_frags(k0 + 64, an, bn_);          // next group in flight under this group's MFMAs
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j][i], acc[j], 0, 0, 0);
+    af = an;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bf[j] = bn_[j];
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) red[w][(kk * 4 + reg) * E_LD + 16 * j + r] = acc[j][reg];
+  __syncthreads();
+  const float* mulp = g.mul;
+  for (int idx = tid; idx < 16 * BN; idx += 256) {
+    const int lr = idx / BN, c = idx - lr * BN;
+    const int row = m0 + lr, col = n0 + c;
+    if (row >= M || col >= N) continue;
+    float x = (red[0][lr * E_LD + c] + red[1][lr * E_LD + c] + red[2][lr * E_LD + c] + red[3][lr * E_LD + c]) * g.alpha;
+    if (g.accumulate == 2) x += C[(long)row * g.ldc + col];      // running sum BEFORE bias / activation
+    if (g.bias) x += g.bias[col];
+    if (g.rowvec) x += g.rowvec[(long)(g.rowvec_map ? g.rowvec_map[row] : row) * g.ldrv + col];
+    if (g.act == 1) x = fmaxf(x, 0.f);
+    else if (g.act == 2) x = tanhf(x);
+    else if (g.act == 3) x = sigmoidf_(x);
+    if (aux) aux[(long)row * g.ldaux + col] = x;
+    if (mulp) x *= mulp[(long)row * g.ldmul + col];
+    if (res) x += res[(long)row * g.ldres + col];
+    if (g.drop_target == 3)
+      x = nnr_keep(g.drop_seed, (uint64_t)(row + (long)z * g.M) * g.drop_cols + col, g.drop_thresh) ? x * g.drop_scale : 0.f;
+    if (C) {
+      float* cp = C + (long)row * g.ldc + col;
+      if (g.accumulate == 1) x += *cp;
+      *cp = x;
+    }
+  }
+}
+
+int launch_skinny(const nnr_gemm_args& g, hipStream_t s) {
+  dim3 grid(((g.M + 15) / 16) * ((g.N + 79) / 80), 1, g.batch > 1 ? g.batch : 1), block(256);
+  if (g.trans_b) hipLaunchKernelGGL((skinny_gemm_kernel<true>), grid, block, 0, s, g);
+  else hipLaunchKernelGGL((skinny_gemm_kernel<false>), grid, block, 0, s, g);
+  NNR_CHECK_LAUNCH();
+  return NNR_OK;
+}
+
 }  // namespace
 
 extern "C" int nnr_gemm_f32(const nnr_gemm_args* a, hipStream_t stream) {
@@ -468,7 +586,10 @@ extern "C" int nnr_gemm_f32(const nnr_gemm_args* a, hipStream_t stream) {
   if (tile == 0) {
     const long wg128 = (long)((g.M + 127) / 128) * ((g.N + 79) / 80) * (g.k_chunk > 0 ? (g.K + g.k_chunk - 1) / g.k_chunk : (g.split_k > 1 ? g.split_k : (g.batch > 1 ? g.batch : 1)));
     const long wg64 = (long)((g.M + 63) / 64) * ((g.N + 79) / 80) * (g.split_k > 1 ? g.split_k : (g.batch > 1 ? g.batch : 1));
+    const bool plain = !g.trans_a && !g.a_idx && !g.b_idx && !g.c_idx && !g.dyn_dev && g.split_k <= 1 && g.k_chunk <= 0 && !g.rowdot_w &&
+                       !g.colsum_out && !g.atomic && (g.drop_target == 0 || g.drop_target == 3);
     if (g.rowdot_w) tile = 3;
+    else if (plain && wg64 <= 512 && g.K >= 64) tile = 7;   // small row-parallel launch: 16 x 80 tiles, K split over the 4 waves
     else if (wg64 <= 512 && !g.dyn_dev && g.k_chunk <= 0 && g.K >= 128) tile = 6;   // at most 2 workgroups per CU: nothing hides the
                              // memory round trip each k-stage pays with a one-stage prefetch -> BK = 64, 4x fewer stages
     else if (g.M <= 512 || (wg128 < 640 && !g.dyn_dev)) tile = 2;   // too few 128-row tiles to fill 256 CUs x 4: use 64-row tiles
@@ -485,6 +606,10 @@ extern "C" int nnr_gemm_f32(const nnr_gemm_args* a, hipStream_t stream) {
     case 4: return launch_cfg<2, 5, 16>(g, stream);    // 128 x 80 (4 waves/SIMD: more workgroups in flight per CU)
     case 5: return launch_cfg<2, 5, 32>(g, stream);   // 128 x 80, BK = 32: half the barriers per FLOP, 3 workgroups per CU
     case 6: return launch_cfg<1, 5, 64>(g, stream);   //  64 x 80, BK = 64: latency-bound small launches (few stages, 74 KB LDS)
+    case 7:
+      if (g.trans_a || g.a_idx || g.b_idx || g.c_idx || g.dyn_dev || g.split_k > 1 || g.k_chunk > 0 || g.rowdot_w || g.colsum_out || g.atomic ||
+          (g.drop_target != 0 && g.drop_target != 3)) return NNR_ERR_ARG;
+      return launch_skinny(g, stream);
     default: return NNR_ERR_ARG;
   }
 }

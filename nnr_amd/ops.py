@@ -63,6 +63,9 @@ def gemm(A, B, C_=None, *, M, N, K, lda, ldb, ldc=0, trans_a=False, trans_b=Fals
         t = tile
     elif rowdot_w is not None:
         t = 3
+    elif (not trans_a and a_idx is None and b_idx is None and c_idx is None and dyn is None and split_k <= 1 and k_chunk <= 0
+          and colsum_out is None and not atomic and wg64 <= 512 and K >= 64 and drop is None):
+        t = 7
     elif wg64 <= 512 and dyn is None and k_chunk <= 0 and K >= 128:
         t = 6
     elif M <= 512 or (wg128 < 640 and dyn is None) or trans_a:
@@ -70,7 +73,7 @@ def gemm(A, B, C_=None, *, M, N, K, lda, ldb, ldc=0, trans_a=False, trans_b=Fals
     else:
         t = 5 if not trans_b else 4
     fam = 'gemm_%s_%s' % ('tn' if trans_a else ('nn' if trans_b else 'nt'),
-                          {1: '256x80', 2: '64x80', 3: '128x208', 4: '128x80', 5: '128x80k32', 6: '64x80k64'}[t])
+                          {1: '256x80', 2: '64x80', 3: '128x208', 4: '128x80', 5: '128x80k32', 6: '64x80k64', 7: '16x80skinny'}[t])
 
     def flops(M=M, N=N, K=K, dyn=dyn, dyn_dim=dyn_dim, batch=batch):
         m, k = M, K

@@ -52,6 +52,37 @@ def test_gemm_all_tiles_all_modes(tile):
     close(o2, at.double().t() @ bt.double(), tol=5e-5, what='TN tile %d' % tile)
 
 
+@pytest.mark.parametrize('M,N,K', [(37, 83, 70), (320, 400, 400), (3200, 200, 400), (1, 80, 64), (500, 225, 901)])
+def test_gemm_skinny_tile_all_epilogues(M, N, K):
+    """tile 7 (16 x 80 tiles, K split over the four waves): NT and NN, ragged sizes, unaligned leading dimensions, every
+    element-wise epilogue option, batched; and the automatic choice for small launches gives the same numbers."""
+    from nnr_amd import ops
+    d = dev()
+    a, b, bt = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(K, N, seed=3)
+    bias, resid, mul, base = rnd(N, seed=4), rnd(M, N, seed=5), rnd(M, N, seed=6), rnd(M, N, seed=7)
+    rv, rmap = rnd(5, N, seed=8), torch.randint(0, 5, (M,), generator=torch.Generator().manual_seed(9)).int()
+    for tile in (7, 0):
+        out = torch.empty(M, N, device=d)
+        ops.gemm(a.to(d), b.to(d), out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, tile=tile)
+        close(out, a.double() @ b.double().t(), what='skinny NT')
+        ops.gemm(a.to(d), bt.to(d), out, M=M, N=N, K=K, lda=K, ldb=N, ldc=N, trans_b=True, tile=tile)
+        close(out, a.double() @ bt.double(), what='skinny NN')
+        aux = torch.empty(M, N, device=d)
+        out = base.to(d).clone()
+        ops.gemm(a.to(d), b.to(d), out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, alpha=0.5, bias=bias.to(d), rowvec=rv.to(d), ldrv=N, rowvec_map=rmap.to(d),
+                 act=ops.ACT_TANH, aux_out=aux, ldaux=N, mul=mul.to(d), ldmul=N, resid=resid.to(d), ldres=N, accumulate=True, tile=tile)
+        pre = torch.tanh(0.5 * (a.double() @ b.double().t()) + bias.double() + rv.double()[rmap.long()])
+        close(aux, pre, what='skinny aux')
+        close(out, base.double() + pre * mul.double() + resid.double(), what='skinny full epilogue')
+        out = base.to(d).clone()
+        ops.gemm(a.to(d), b.to(d), out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias.to(d), act=ops.ACT_RELU, accumulate=2, tile=tile)
+        close(out, torch.relu(base.double() + a.double() @ b.double().t() + bias.double()), what='skinny accumulate-before-activation')
+    ab, bb = rnd(6, M, K, seed=10), rnd(6, K, N, seed=11)
+    ob = torch.empty(6, M, N, device=d)
+    ops.gemm(ab.to(d), bb.to(d), ob, M=M, N=N, K=K, lda=K, ldb=N, ldc=N, trans_b=True, batch=6, strideA=M * K, strideB=K * N, strideC=M * N, tile=7)
+    close(ob, ab.double() @ bb.double(), what='skinny batched NN')
+
+
 def test_gemm_nn_accumulate_and_tn_splitk_dyn():
     from nnr_amd import ops
     dy, w = rnd(300, 225, seed=1), rnd(225, 900, seed=2)
