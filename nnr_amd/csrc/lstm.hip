@@ -87,13 +87,17 @@ __device__ __forceinline__ unsigned long long ld_tag_first(const unsigned long l
   if (same_xcd) return __builtin_nontemporal_load(p);
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// re-poll one word until its tag matches (bounded: never hang the GPU -- count the timeout and go on)
+// re-poll one word until its tag matches (bounded: never hang the GPU -- on timeout count it and return NaN)
 __device__ __forceinline__ float wait_tag(const unsigned long long* p, unsigned long long v, unsigned tag, bool same_xcd, unsigned* diag) {
   int spins = 0;
   while ((unsigned)(v >> 32) != tag) {
     __builtin_amdgcn_s_sleep(1);
     v = ld_tag(p, same_xcd);
-    if (++spins > SPIN_LIMIT) { atomicAdd(diag, 1u); break; }
+    if (++spins > SPIN_LIMIT) {                      // the partner never delivered: fail LOUDLY -- count it, and poison the value so
+      atomicAdd(diag, 1u);                           // the step's loss becomes NaN instead of silently training on stale data
+      v = 0x7fc00000ull;
+      break;
+    }
   }
 #ifdef NNR_LSTM_COUNT_REPOLLS
   if (spins) { atomicAdd(diag + 1, 1u); atomicAdd(diag + 2, (unsigned)spins); }

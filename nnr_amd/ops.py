@@ -26,7 +26,8 @@ def _s():
 
 
 def split_for(m, n, k, tile_m=128, tile_n=80, target_blocks=2048, kmin=256):
-    """split-K factor for the token-reduction (weight-gradient) GEMMs: enough blocks to fill 256 CUs x ~3."""
+    """split-K factor for the token-reduction (weight-gradient) GEMMs: enough blocks to fill 256 CUs x ~3.  (Cutting short
+    reductions finer, kmin 64, measured no better.)"""
     tiles = max(1, ((m + tile_m - 1) // tile_m) * ((n + tile_n - 1) // tile_n))
     return int(max(1, min((k + kmin - 1) // kmin, (target_blocks + tiles - 1) // tiles)))
 
