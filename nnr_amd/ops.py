@@ -25,7 +25,7 @@ def _s():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def split_for(m, n, k, tile_m=128, tile_n=80, target_blocks=2048, kmin=256):
+def split_for(m, n, k, tile_m=64, tile_n=80, target_blocks=2048, kmin=256):
     """split-K factor for the token-reduction (weight-gradient) GEMMs: enough blocks to fill 256 CUs x ~3.  (Cutting short
     reductions finer, kmin 64, measured no better.)"""
     tiles = max(1, ((m + tile_m - 1) // tile_m) * ((n + tile_n - 1) // tile_n))
