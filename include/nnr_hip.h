@@ -156,6 +156,8 @@ int nnr_packed_seq_sum(const float* x, int D, const int* off, const int* slen, i
 int nnr_tanh_score_bwd(float* th, const float* ds, const float* w2, float* dw2, const int* rows_dev, int rows, int A,
                        hipStream_t stream);                                      /* layers.py:168-169 backward */
 int nnr_colsum(const float* x, int ld, const int* rows_dev, int rows, int N, float* out_accum, hipStream_t stream);
+int nnr_rowdot(const float* x, int ld, const float* w, const int* rows_dev, int rows, int N, float* out,
+               hipStream_t stream);                                              /* out[row] = <x[row, :N], w>  (layers.py:168) */
 int nnr_small_embed_fwd(const float* table, const int* idx, int n, int dim, float* out, int ldo, float p, uint32_t seed,
                         hipStream_t stream);                                     /* newsEncoders.py:51-53 */
 int nnr_small_embed_bwd(const int* idx, int n, int dim, const float* dout, int lddo, float* dtable_accum, float p, uint32_t seed,

@@ -59,6 +59,26 @@ __global__ __launch_bounds__(256) void tanh_score_bwd_kernel(float* __restrict__
   }
 }
 
+// ---- out[row] = <x[row, :N], w>   (the w2 . tanh(.) score of the additive attention, layers.py:168; one wave per row, float4 lanes)
+// The GEMM can fuse this into its epilogue only with a 208-wide tile (whole rows in one workgroup), which costs more than
+// it saves: 486 us fused vs 300 us (64 x 80 tile) + 25 us for this HBM-bound pass on the history abstracts.
+__global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ x, int ld, const float* __restrict__ w, const int* rows_dev,
+                                                     int rows, int N, float* __restrict__ out) {
+  const int R = dyn_rows(rows_dev, rows);
+  const int lane = threadIdx.x & 63;
+  const int nv = N >> 2;
+  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < R; row += gridDim.x * 4) {
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x + (long)row * ld);
+    float p = 0.f;
+    for (int c = lane; c < nv; c += 64) {
+      const f32x4 a = xr[c], b = reinterpret_cast<const f32x4*>(w)[c];
+      p += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+    }
+    p = wave_sum(p);
+    if (lane == 0) out[row] = p;
+  }
+}
+
 // ---- out[c] += sum_rows x[row, c]   (bias gradients)
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int ld, const int* rows_dev, int rows, int N,
                                                      float* __restrict__ out, int rows_per_block) {
@@ -504,6 +524,15 @@ extern "C" int nnr_tanh_score_bwd(float* th, const float* ds, const float* w2, f
                                   hipStream_t stream) {
   const int rpb = 64;
   hipLaunchKernelGGL(tanh_score_bwd_kernel, dim3((rows + rpb - 1) / rpb), dim3(256), 0, stream, th, ds, w2, dw2, rows_dev, rows, A, rpb);
+  NNR_CHECK_LAUNCH();
+  return NNR_OK;
+}
+
+extern "C" int nnr_rowdot(const float* x, int ld, const float* w, const int* rows_dev, int rows, int N, float* out, hipStream_t stream) {
+  if (!x || !w || !out || rows <= 0) return rows <= 0 ? NNR_OK : NNR_ERR_ARG;
+  if ((N & 3) || (ld & 3) || ((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return NNR_ERR_UNSUPPORTED;
+  const int blocks = (rows + 3) / 4;
+  hipLaunchKernelGGL(rowdot_kernel, dim3(blocks > 8192 ? 8192 : blocks), dim3(256), 0, stream, x, ld, w, rows_dev, rows, N, out);
   NNR_CHECK_LAUNCH();
   return NNR_OK;
 }

@@ -42,7 +42,7 @@ class LSTMParams(nn.Module):
 
 # ------------------------------------------------------------------------------------------------ additive attention
 class _AttentionFn(torch.autograd.Function):
-    """layers.py:167-175 on a dense [n, L, F] feature: GEMM with fused tanh.w2 row-dot, then the wave-softmax pool."""
+    """layers.py:167-175 on a dense [n, L, F] feature: tanh GEMM, w2 row-dot, then the softmax pool."""
 
     @staticmethod
     def forward(ctx, feature, mod, mask):
@@ -52,8 +52,8 @@ class _AttentionFn(torch.autograd.Function):
         f32 = dict(device=x.device, dtype=torch.float32)
         th = torch.empty((n * Lx, A), **f32)
         score = torch.empty(n * Lx, **f32)
-        ops.gemm(x, mod.affine1.weight, None, M=n * Lx, N=A, K=F, lda=F, ldb=F, bias=mod.affine1.bias, act=ops.ACT_TANH, aux_out=th,
-                 ldaux=A, rowdot_w=mod.affine2.weight, rowdot_out=score, tile=3)
+        ops.gemm(x, mod.affine1.weight, th, M=n * Lx, N=A, K=F, lda=F, ldb=F, ldc=A, bias=mod.affine1.bias, act=ops.ACT_TANH)
+        ops.rowdot(th, mod.affine2.weight, score)
         alpha = torch.empty(n * Lx, **f32)
         out = torch.empty((n, F), **f32)
         ops.pool_fwd(x=x, ldx=F, D=F, n=n, Lx=Lx, mask=mask, score=score, alpha=alpha, out=out, ldo=F)

@@ -245,9 +245,9 @@ def _cne_fwd_post(mod, sv, par=False):
         st['th'] = torch.empty((cap, A), **f32)
         st['score'] = torch.empty(cap, **f32)
         sa = st['satt']
-        ops.gemm(st['Ht'], sa.affine1.weight, None, M=cap, N=A, K=H2, lda=H2, ldb=H2, dyn=plan.total, dyn_dim=1,
-                 bias=sa.affine1.bias, act=ops.ACT_TANH, aux_out=st['th'], ldaux=A, rowdot_w=sa.affine2.weight,
-                 rowdot_out=st['score'], tile=3)
+        ops.gemm(st['Ht'], sa.affine1.weight, st['th'], M=cap, N=A, K=H2, lda=H2, ldb=H2, ldc=A, dyn=plan.total, dyn_dim=1,
+                 bias=sa.affine1.bias, act=ops.ACT_TANH)
+        ops.rowdot(st['th'], sa.affine2.weight, st['score'], dyn=plan.total)
         st['alpha_s'] = torch.empty(cap, **f32)
         st['selfv'] = torch.empty((n, H2), **f32)
         ops.pool_fwd(x=st['Ht'], ldx=H2, D=H2, n=n, Lx=st['L'], plan=plan, score=st['score'], alpha=st['alpha_s'],

@@ -117,6 +117,12 @@ def linear_bwd_weight(dy, x, dw, dyn=None, rows=None, db=None, **kw):
          atomic=True, dyn=dyn, dyn_dim=2, colsum_out=db, **sk, **kw)
 
 
+def rowdot(x, w, out, dyn=None, rows=None):
+    """out[row] = <x[row], w> for the live rows of a 2-D x (the w2 . tanh(.) attention score)."""
+    R = x.shape[0] if rows is None else rows
+    L.check(L.lib().nnr_rowdot(_p(x), x.stride(0), _p(w), _p(dyn), R, x.shape[1], _p(out), _s()), 'nnr_rowdot')
+
+
 def bias_grad(dy, db, dyn=None, rows=None):
     R = dy.shape[0] if rows is None else rows
     L.check(L.lib().nnr_colsum(_p(dy), dy.stride(0), _p(dyn), R, db.numel(), _p(db), _s()), 'nnr_colsum')
