@@ -7,6 +7,8 @@
 //   on the 16-byte chunk so a fragment is ONE conflict-free ds_read_b128 feeding 4 MFMAs;
 //   K-major operands ([K,M] / [K,N], used by the backward GEMMs) live as [16][R+4] and are read with
 //   conflict-free ds_read_b32.
+// * Epilogue activations use the hardware transcendentals (v_exp_f32 / v_rcp_f32, common.h: abs error ~2e-7) -- the
+//   tanh / sigmoid GEMMs of the attention and gate layers apply them to 30-60 M elements per launch.
 // * blockIdx -> tile mapping is XCD-aware: the 8 XCDs each walk a contiguous range of tiles, column blocks
 //   fastest, so the A row-panel of a tile row stays in ONE XCD's L2 while its column blocks run.
 // * Row gather on A (embedding rows feeding the LSTM input projection) / on B's k-rows (backward weight
@@ -342,8 +344,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(nnr_gemm_args g) {
               float x = stage[lr * E_LD + c] * g.alpha;
               if (g.bias) x += g.bias[col];
               if (g.act == 1) x = fmaxf(x, 0.f);
-              else if (g.act == 2) x = tanhf(x);
-              else if (g.act == 3) x = sigmoidf_(x);
+              else if (g.act == 2) x = fast_tanh(x);
+              else if (g.act == 3) x = fast_sigmoid(x);
               if (aux) aux[(long)row * g.ldaux + col] = x;
               dot += g.rowdot_w[col] * x;
               if (C) C[(long)row * g.ldc + col] = x;
@@ -370,10 +372,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(nnr_gemm_args g) {
           for (int e = 0; e < 4; ++e) x[e] = fmaxf(x[e], 0.f);
         } else if (g.act == 2) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) x[e] = tanhf(x[e]);
+          for (int e = 0; e < 4; ++e) x[e] = fast_tanh(x[e]);
         } else if (g.act == 3) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) x[e] = sigmoidf_(x[e]);
+          for (int e = 0; e < 4; ++e) x[e] = fast_sigmoid(x[e]);
         }
         if (aux) *reinterpret_cast<f32x4*>(aux + (long)row * g.ldaux + col) = x;
         if (mulp) x *= *reinterpret_cast<const f32x4*>(mulp + (long)row * g.ldmul + col);
@@ -403,8 +405,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(nnr_gemm_args g) {
         if (g.bias) x += g.bias[col];
         if (g.rowvec) x += g.rowvec[(long)(g.rowvec_map ? g.rowvec_map[row] : row) * g.ldrv + col];
         if (g.act == 1) x = fmaxf(x, 0.f);
-        else if (g.act == 2) x = tanhf(x);
-        else if (g.act == 3) x = sigmoidf_(x);
+        else if (g.act == 2) x = fast_tanh(x);
+        else if (g.act == 3) x = fast_sigmoid(x);
         if (aux) aux[(long)row * g.ldaux + col] = x;
         if (mulp) x *= mulp[(long)row * g.ldmul + col];
         if (res) x += res[(long)row * g.ldres + col];
@@ -536,8 +538,8 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(nnr_gemm_args g) {
     if (g.bias) x += g.bias[col];
     if (g.rowvec) x += g.rowvec[(long)(g.rowvec_map ? g.rowvec_map[row] : row) * g.ldrv + col];
     if (g.act == 1) x = fmaxf(x, 0.f);
-    else if (g.act == 2) x = tanhf(x);
-    else if (g.act == 3) x = sigmoidf_(x);
+    else if (g.act == 2) x = fast_tanh(x);
+    else if (g.act == 3) x = fast_sigmoid(x);
     if (aux) aux[(long)row * g.ldaux + col] = x;
     if (mulp) x *= mulp[(long)row * g.ldmul + col];
     if (res) x += res[(long)row * g.ldres + col];
