@@ -178,14 +178,14 @@ def cne_forward_many(mod, calls):
     dev = calls[0][0].device
     mod._packed_weights('title', mod.title_lstm)        # (re)pack on the main stream BEFORE forking: both calls read them
     mod._packed_weights('content', mod.content_lstm)
-    pre = _fork_join(len(calls), dev, lambda i, on_main: _cne_fwd_pre(mod, *calls[i]))
+    pre = _fork_join(len(calls), dev, lambda i, on_main: _cne_fwd_pre(mod, *calls[i], par=on_main))
     items = [st for sv in pre for st in (sv['streams'][1],)] + [st for sv in pre for st in (sv['streams'][0],)]   # content streams first
     for i in range(0, len(items), 4):
         ops.lstm_fwd(items[i:i + 4], H)
     return _fork_join(len(calls), dev, lambda i, on_main: _cne_fwd_post(mod, pre[i], on_main))
 
 
-def _cne_fwd_pre(mod, title_text, title_mask, content_text, content_mask, category, subCategory):
+def _cne_fwd_pre(mod, title_text, title_mask, content_text, content_mask, category, subCategory, par=False):
     B, N = title_text.shape[:2]
     n = B * N
     dev = title_text.device
@@ -196,12 +196,9 @@ def _cne_fwd_pre(mod, title_text, title_mask, content_text, content_mask, catego
     seed = mod._next_seed()
     emb = mod.word_embedding.weight
 
-    streams = []
-    for name, ids, mask, Lx, lstm, Hlin, Mlin, satt, catt in (
-            ('title', title_text, title_mask, mod.max_title_length, mod.title_lstm, mod.title_H, mod.title_M,
-             mod.title_self_attention, mod.title_cross_attention),
-            ('content', content_text, content_mask, mod.max_content_length, mod.content_lstm, mod.content_H, mod.content_M,
-             mod.content_self_attention, mod.content_cross_attention)):
+    streams = [None, None]
+
+    def prepare(slot, name, ids, mask, Lx, lstm, Hlin, Mlin, satt, catt):
         ids2 = _i32(ids).reshape(n, Lx).contiguous()
         mask2 = mask.view(n, Lx)                        # a view: the in-place mask[:,0]=1 must reach the caller's tensor
         perm = None
@@ -220,7 +217,15 @@ def _cne_fwd_pre(mod, title_text, title_mask, content_text, content_mask, catego
         st['cell'] = torch.empty((cap, 2 * w.HP), **f32)
         st['hout'] = torch.empty((cap, H2), **f32)
         st['cn'] = torch.empty((n, H2), **f32)
-        streams.append(st)
+        streams[slot] = st
+
+    # the title and the content stream are independent up to the recurrence: plan + gather + input projection of the
+    # (small) title stream run next to the content stream's on the big call
+    _two_chains(dev, par,
+                lambda: prepare(0, 'title', title_text, title_mask, mod.max_title_length, mod.title_lstm, mod.title_H, mod.title_M,
+                                mod.title_self_attention, mod.title_cross_attention),
+                lambda: prepare(1, 'content', content_text, content_mask, mod.max_content_length, mod.content_lstm, mod.content_H,
+                                mod.content_M, mod.content_self_attention, mod.content_cross_attention))
     return dict(streams=streams, n=n, B=B, N=N, p=p, seed=seed, category=category, subCategory=subCategory)
 
 
