@@ -59,3 +59,17 @@ def test_graph_rule():
     A0, cm0, ci0 = corp.history_graph(cats, 0)                       # empty history: identity, un-normalised
     np.testing.assert_array_equal(A0, np.identity(G, dtype=np.float32))
     assert not cm0.any() and (ci0 == 4).all()
+
+
+def test_device_corpus_refuses_cpu_and_negative_sampling_rules():
+    """The data side has no CPU path either; the host-side sampler follows MIND_dataset.py:27-47."""
+    import numpy as np
+    import pytest
+    from nnr_amd import _lib
+    from nnr_amd.corpus import DeviceCorpus, negative_sampling
+    with pytest.raises(_lib.NnrHipError):
+        DeviceCorpus({}, 'cpu', 18)
+    rs = np.random.RandomState(0)
+    s = negative_sampling([(9, [4]), (8, [1, 2, 3, 5, 6, 7])], 4, rs.randint)
+    assert s.dtype == np.int32 and s[0].tolist() == [9, 4, 4, 4, 4]
+    assert s[1, 0] == 8 and len(set(s[1, 1:].tolist())) == 4 and set(s[1, 1:].tolist()) <= {1, 2, 3, 5, 6, 7}
