@@ -246,6 +246,18 @@ int nnr_sumsq(const float* g, long n, float* out_zeroed, hipStream_t stream);
 int nnr_clip_adam(float* p, const float* g, float* m, float* v, long n, const float* sumsq, float grad_scale, float clip, float lr,
                   float beta1, float beta2, float eps, float weight_decay, int step, hipStream_t stream);
 
+/* ------------------------------------------------------------------------------------------------ data parallelism (RCCL over xGMI)
+ * Replaces DistributedDataParallel's gradient all-reduce / parameter broadcast (trainer.py:212-219,297): one communicator per
+ * process = per GPU, ONE in-place fp32 sum all-reduce of the flat gradient buffer per step; the 1/world average is folded into
+ * nnr_clip_adam.  RCCL is resolved at run time from the copy already loaded in the process (PyTorch-ROCm's).  Rank 0 creates
+ * the 128-byte id and the launcher distributes it (any side channel: the torchrun store, a file, MPI). */
+typedef struct nnr_dp_ctx nnr_dp_ctx;
+int nnr_dp_unique_id(void* out128);
+int nnr_dp_init(const void* uid128, int rank, int world, nnr_dp_ctx** ctx);          /* binds to the current HIP device */
+int nnr_dp_allreduce(nnr_dp_ctx* ctx, float* flat, size_t n, hipStream_t stream);
+int nnr_dp_broadcast(nnr_dp_ctx* ctx, float* flat, size_t n, int root, hipStream_t stream);
+int nnr_dp_destroy(nnr_dp_ctx* ctx);
+
 #ifdef __cplusplus
 }
 #endif

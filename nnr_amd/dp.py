@@ -4,6 +4,7 @@ One process per GPU, `torch.distributed` with backend "nccl" (= RCCL over xGMI o
 Impressions are independent, so the only exchange is ONE all-reduce(sum) of the flat fp32 gradient buffer per step
 (4*P bytes); the 1/world_size average is folded into the fused clip+Adam kernel.  Parameters are broadcast from
 rank 0 once (DDP's constructor does the same).  Every rank keeps a full optimizer replica, as the reference does."""
+import ctypes as C
 import os
 
 import torch
@@ -30,16 +31,68 @@ def world_size():
     return dist.get_world_size() if dist.is_initialized() else 1
 
 
+class NativeExchange:
+    """The same exchange through the C-ABI (`nnr_dp_*`, csrc/dp.hip: RCCL called directly on the launch stream, no
+    ProcessGroup in between).  The 128-byte communicator id travels over the already-initialised torch.distributed group
+    (any backend) when world > 1.  Opt-in: NNR_DP_NATIVE=1; `torch.distributed` ("nccl" = the same RCCL) is the default."""
+
+    def __init__(self, rank, world):
+        from . import _lib as L
+        self.L, self.rank, self.world = L, rank, world
+        uid = (C.c_ubyte * 128)()
+        if rank == 0:
+            L.check(L.lib().nnr_dp_unique_id(uid), 'nnr_dp_unique_id')
+        if world > 1:
+            box = [bytes(uid)]
+            dist.broadcast_object_list(box, src=0)
+            uid = (C.c_ubyte * 128).from_buffer_copy(box[0])
+        self.ctx = C.c_void_p()
+        L.check(L.lib().nnr_dp_init(uid, rank, world, C.byref(self.ctx)), 'nnr_dp_init')
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def allreduce(self, flat):
+        self.L.check(self.L.lib().nnr_dp_allreduce(self.ctx, C.c_void_p(flat.data_ptr()), C.c_size_t(flat.numel()), self._stream()), 'nnr_dp_allreduce')
+
+    def broadcast(self, flat, root=0):
+        self.L.check(self.L.lib().nnr_dp_broadcast(self.ctx, C.c_void_p(flat.data_ptr()), C.c_size_t(flat.numel()), root, self._stream()), 'nnr_dp_broadcast')
+
+    def close(self):
+        if self.ctx:
+            self.L.check(self.L.lib().nnr_dp_destroy(self.ctx), 'nnr_dp_destroy')
+            self.ctx = C.c_void_p()
+
+
+_native = None
+
+
+def _native_exchange():
+    global _native
+    if _native is None and os.environ.get('NNR_DP_NATIVE') == '1' and torch.cuda.is_available():
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        _native = NativeExchange(rank, world_size())
+    return _native
+
+
 def broadcast_parameters(flat_params):
     if world_size() > 1:
-        dist.broadcast(flat_params, src=0)
+        nx = _native_exchange() if flat_params.is_cuda else None
+        if nx is not None:
+            nx.broadcast(flat_params, 0)
+        else:
+            dist.broadcast(flat_params, src=0)
 
 
 def allreduce_gradients(flat_grads):
     """Sum the flat gradient over ranks; returns the scale (1/world) the optimizer must apply."""
     w = world_size()
     if w > 1:
-        dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM)
+        nx = _native_exchange() if flat_grads.is_cuda else None
+        if nx is not None:
+            nx.allreduce(flat_grads)
+        else:
+            dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM)
     return 1.0 / w
 
 

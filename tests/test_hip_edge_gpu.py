@@ -198,3 +198,17 @@ def test_large_vocabulary_config_parity_and_dropout_properties():
     rate = float((kept != 0).float().sum() / (full != 0).float().sum())
     assert abs(rate - 0.9) < 5e-3, rate
     assert torch.allclose(kept[kept != 0], (full / 0.9)[kept != 0], rtol=1e-6)
+
+
+def test_native_rccl_exchange_single_rank():
+    """nnr_dp_* (RCCL called through the C-ABI): a one-rank communicator on this GPU -- all-reduce and broadcast are the
+    identity, on the launch stream, and the communicator is created / destroyed cleanly.  (Multi-rank: driver's scaling run.)"""
+    from nnr_amd.dp import NativeExchange
+    nx = NativeExchange(0, 1)
+    x = torch.randn(1 << 20, device='cuda')
+    y = x.clone()
+    nx.allreduce(y)
+    nx.broadcast(y, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(x, y)
+    nx.close()
