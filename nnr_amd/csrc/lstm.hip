@@ -111,9 +111,6 @@ struct LstmArgs { LstmProblem p[4]; int nprob; int H; int dbg; };   // dbg: timi
 template <int UB>
 __global__ __launch_bounds__((UB > 4 ? 16 : 4) * 64) void lstm_fwd_kernel(LstmArgs a) {
   constexpr int NW = UB > 4 ? 16 : 4, NT = NW * 64;      // one 16-unit block per wave when the hidden size is large
-  // balanced variant kept for reference: under hipcc's scheduling (no room for the fragment double buffer in 128 VGPRs) it
-  // measured 2.21 ms vs 2.08 ms for the one-block-per-wave schedule on the 128-step critical path, so it stays off
-  constexpr bool SPLIT = false && (UB > 4) && (UB % 4 == 1) && (UB + 2 < NW);
   constexpr int HP = UB * 16, NP = UB * 64, KG = UB, OWN = (UB + NW - 1) / NW;
   const LstmProblem& P = a.p[blockIdx.z];
   const int H = a.H;
@@ -126,128 +123,6 @@ __global__ __launch_bounds__((UB > 4 ? 16 : 4) * 64) void lstm_fwd_kernel(LstmAr
   const int tmax = P.slen[s0];
   set_prio_by_length(tmax);
   const int ldg = 2 * NP, ldc = 2 * HP, ldh = 2 * H;
-  if constexpr (SPLIT) {
-    // ---- balanced schedule (UB = 4q + 1, e.g. H = 200 -> 13 blocks on 16 waves): waves 0..UB-2 own one unit block each
-    // (4 gate chains = 4 * KG * 4 MFMAs); the LAST block's four gate chains go to waves UB-1..UB+2 (one chain each), so every
-    // SIMD issues exactly (UB-1)/4 * 4 + 1 = UB chains per step instead of 16 vs 12.  The four chains meet through a 4 KB LDS
-    // exchange; the split waves then update 4 rows each (one (row, unit) item per lane).
-    __shared__ float zx[4 * 16 * 16];
-    const bool full = w < UB - 1;
-    const int ub = full ? w : UB - 1;
-    const int pg = w - (UB - 1);
-    const f32x4* wf = reinterpret_cast<const f32x4*>(P.wfrag) + ((long)(d * UB + ub) * 4 * KG) * 64 + lane;
-    f32x4 bcur[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) bcur[g] = wf[((full ? g : pg) * KG + 0) * 64];
-    f32x4 x[4];
-    float c[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) c[e] = 0.f;
-    // 32-bit element offsets off the scalar base pointers (the launcher checks rows * ld < 2^31): 64-bit per-lane
-    // addresses would not fit the 128-VGPR budget of a 16-wave workgroup next to the MFMA operands
-    auto load_x = [&](int step) __attribute__((always_inline)) {
-      const int t = d ? (tmax - 1 - step) : step;
-      const int nact = min(16, P.bs[t] - s0);
-      const unsigned row0 = (unsigned)(P.off[t] + s0);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int row = full ? kk * 4 + e : pg * 4 + kk;
-        x[e] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if ((full || e == 0) && row < nact)
-          x[e] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(P.gates + ((row0 + row) * (unsigned)ldg + d * NP + ub * 64 + r * 4)));
-      }
-    };
-    auto cell_update = [&](int row, int unit, unsigned row0, float zi, float zf, float zg, float zo, f32x4 xv, float cst, float* hn)
-        __attribute__((always_inline)) -> float {
-      const float gi = fast_sigmoid(zi + xv[0]);
-      const float gf = fast_sigmoid(zf + xv[1]);
-      const float gg = fast_tanh(zg + xv[2]);
-      const float go = fast_sigmoid(zo + xv[3]);
-      const float cn = gf * cst + gi * gg;
-      const float hv = go * fast_tanh(cn);
-      const unsigned rr = row0 + row;
-      *reinterpret_cast<f32x4*>(P.gates + (rr * (unsigned)ldg + d * NP + (unit >> 4) * 64 + (unit & 15) * 4)) = f32x4{gi, gf, gg, go};
-      P.cell[rr * (unsigned)ldc + d * HP + unit] = cn;
-      if (unit < H) P.hout[rr * (unsigned)ldh + d * H + unit] = hv;
-      hn[lds_off(row, unit, HP)] = hv;
-      return cn;
-    };
-    __syncthreads();
-    load_x(0);
-    int cur = 0;
-    for (int step = 0; step < tmax; ++step) {
-      const int t = d ? (tmax - 1 - step) : step;
-      const int nact = min(16, P.bs[t] - s0);
-      const unsigned row0 = (unsigned)(P.off[t] + s0);
-      const float* hc = hbuf[cur];
-      float* hn = hbuf[cur ^ 1];
-      if (full) {
-        f32x4 acc[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // no explicit double buffer here: with 4 waves per SIMD a wave's fragment loads (L2 hits) hide under the other three
-        // waves' 3 x 16 MFMAs, and the 16 VGPRs a second fragment set would cost push this path over the 128-register budget
-        // (rolled loop on purpose: fully unrolled, hipcc hoists many fragment loads ahead and spills)
-#pragma unroll 1
-        for (int kg = 0; kg < KG; ++kg) {
-          f32x4 b[4];
-#pragma unroll
-          for (int g = 0; g < 4; ++g) b[g] = (kg == 0) ? bcur[g] : wf[(g * KG + kg) * 64];
-          const f32x4 af = *reinterpret_cast<const f32x4*>(&hc[r * HP + kg * 16 + 4 * (kk ^ swz16(r))]);
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], b[g][i], acc[g], 0, 0, 0);
-        }
-        // the first fragments of the NEXT step load under this step's cell update and barriers
-#pragma unroll
-        for (int g = 0; g < 4; ++g) bcur[g] = wf[(g * KG + 0) * 64];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int row = kk * 4 + e;
-          if (row < nact) c[e] = cell_update(row, ub * 16 + r, row0, acc[0][e], acc[1][e], acc[2][e], acc[3][e], x[e], c[e], hn);
-        }
-      } else {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kg = 0; kg < KG; ++kg) {
-          const int kn = (kg + 1 < KG) ? kg + 1 : 0;
-          const f32x4 bn = wf[(pg * KG + kn) * 64];
-          __builtin_amdgcn_sched_barrier(0);
-          const f32x4 af = *reinterpret_cast<const f32x4*>(&hc[r * HP + kg * 16 + 4 * (kk ^ swz16(r))]);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bcur[0][i], acc, 0, 0, 0);
-          bcur[0] = bn;
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) zx[(pg * 16 + kk * 4 + e) * 16 + r] = acc[e];
-      }
-      __syncthreads();
-      if (!full) {
-        const int row = pg * 4 + kk;
-        if (row < nact)
-          c[0] = cell_update(row, ub * 16 + r, row0, zx[(0 * 16 + row) * 16 + r], zx[(1 * 16 + row) * 16 + r], zx[(2 * 16 + row) * 16 + r],
-                             zx[(3 * 16 + row) * 16 + r], x[0], c[0], hn);
-      }
-      if (step + 1 < tmax) load_x(step + 1);
-      __syncthreads();
-      cur ^= 1;
-    }
-    const int unit = ub * 16 + r;
-    if (unit < H) {
-      if (full) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int sq = s0 + kk * 4 + e;
-          if (sq < P.n) P.cn[(long)sq * ldh + d * H + unit] = c[e];
-        }
-      } else {
-        const int sq = s0 + pg * 4 + kk;
-        if (sq < P.n) P.cn[(long)sq * ldh + d * H + unit] = c[0];
-      }
-    }
-    return;
-  }
   float c[OWN][4];
 #pragma unroll
   for (int o = 0; o < OWN; ++o)
