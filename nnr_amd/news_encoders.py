@@ -178,7 +178,7 @@ def cne_forward_many(mod, calls):
     dev = calls[0][0].device
     mod._packed_weights('title', mod.title_lstm)        # (re)pack on the main stream BEFORE forking: both calls read them
     mod._packed_weights('content', mod.content_lstm)
-    pre = _fork_join(len(calls), dev, lambda i, on_main: _cne_fwd_pre(mod, *calls[i], par=on_main))
+    pre = _fork_join(len(calls), dev, lambda i, on_main: _cne_fwd_pre(mod, *calls[i], par=False))   # two GPU-filling input projections side by side gain nothing
     items = [st for sv in pre for st in (sv['streams'][1],)] + [st for sv in pre for st in (sv['streams'][0],)]   # content streams first
     for i in range(0, len(items), 4):
         ops.lstm_fwd(items[i:i + 4], H)
