@@ -11,7 +11,8 @@ from nnr_amd.model import Model
 from nnr_amd.synth import SynthSpec, SynthCorpus
 from nnr_amd.trainer import Trainer
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-cfg = make_config(['--news_encoder=CNE', '--user_encoder=SUE', '--dataset=200k', '--batch_size=64'], corpus_sizes=dict(vocabulary_size=60000))
+BS = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+cfg = make_config(['--news_encoder=CNE', '--user_encoder=SUE', '--dataset=200k', '--batch_size=%d' % BS], corpus_sizes=dict(vocabulary_size=60000))
 torch.manual_seed(0)
 model = Model(cfg, torch.randn(cfg.vocabulary_size, cfg.word_embedding_dim) * 0.3)
 model.initialize()
@@ -22,13 +23,13 @@ rng = np.random.default_rng(0)
 dc = from_synth(synth, 8192, rng, 'cuda')
 losses, timeouts = [], 0
 for i in range(steps):
-    idx = torch.from_numpy(rng.permutation(8192)[:64].astype(np.int32)).cuda()
+    idx = torch.from_numpy(rng.permutation(8192)[:BS].astype(np.int32)).cuda()
     _, loss = tr.train_step(dc.train_batch(idx))
     losses.append(loss)
     if i % 25 == 0:
         timeouts += ops.lstm_sync_timeouts()
 l = torch.stack(losses).cpu().numpy()
 flat = tr.flat.flat
-print('steps %d: loss first %.4f last-50 mean %.4f min %.4f max %.4f; finite loss %s; finite params %s; exchange timeouts %d' %
-      (steps, l[0], l[-50:].mean(), l.min(), l.max(), bool(np.isfinite(l).all()), bool(torch.isfinite(flat).all()), timeouts))
+print('batch %d steps %d: loss first %.4f last-50 mean %.4f min %.4f max %.4f; finite loss %s; finite params %s; exchange timeouts %d' %
+      (BS, steps, l[0], l[-50:].mean(), l.min(), l.max(), bool(np.isfinite(l).all()), bool(torch.isfinite(flat).all()), timeouts))
 assert np.isfinite(l).all() and bool(torch.isfinite(flat).all()) and timeouts == 0
