@@ -25,6 +25,46 @@ def _s():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# ---------------------------------------------------------------------------------------------- leaf work on its own stream
+# Weight-gradient GEMMs are LEAVES of the backward pass: nothing downstream reads them before the optimizer.  Issued inline
+# they sit on the critical chain of the (latency-bound) data-gradient kernels; here they go to a separate HIP stream that
+# waits for the producer of their inputs, and the caller joins it before its backward returns (every accumulation into a
+# parameter gradient is atomic, so concurrent leaves are safe).  `record_stream` tells the caching allocator that the
+# inputs are in use on the leaf stream, so a buffer freed on the main stream is not handed out again under a pending read.
+_LEAF = {}
+
+
+class leaf_scope:
+    """with leaf_scope(device) as leaf:  leaf(fn, *input_tensors)  ...   -- joined on exit."""
+
+    def __init__(self, dev, enable=True):
+        self.dev, self.enable = dev, enable
+
+    def __enter__(self):
+        if self.enable:
+            key = (self.dev.type, self.dev.index)
+            if key not in _LEAF:
+                _LEAF[key] = torch.cuda.Stream(device=self.dev)
+            self.leaf = _LEAF[key]
+            self.main = torch.cuda.current_stream(self.dev)
+        return self
+
+    def __call__(self, fn, *tensors):
+        if not self.enable:
+            fn()
+            return
+        self.leaf.wait_stream(self.main)
+        for t in tensors:
+            if t is not None:
+                t.record_stream(self.leaf)
+        with torch.cuda.stream(self.leaf):
+            fn()
+
+    def __exit__(self, *a):
+        if self.enable:
+            self.main.wait_stream(self.leaf)
+
+
 def split_for(m, n, k, tile_m=64, tile_n=80, target_blocks=2048, kmin=256):
     """split-K factor for the token-reduction (weight-gradient) GEMMs: enough blocks to fill 256 CUs x ~3.  (Cutting short
     reductions finer, kmin 64, measured no better.)"""

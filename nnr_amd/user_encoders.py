@@ -117,6 +117,11 @@ def sue_backward(mod, sv, dout):
     cand2 = sv['cand'].view(B * N, D)
     dout = dout.view(B * N, D)
     ia = mod.interClusterAttention
+    with ops.leaf_scope(dev) as leaf:
+        return _sue_backward_body(mod, sv, dout, leaf, B, Hn, D, N, Kc, G, Cn, A, p, seed, dev, f32, cand2, ia)
+
+
+def _sue_backward_body(mod, sv, dout, leaf, B, Hn, D, N, Kc, G, Cn, A, p, seed, dev, f32, cand2, ia):
     # ---- inter-cluster pool
     df2 = torch.empty((B * N * Cn, D), **f32)
     dv = torch.empty((B * N, D), **f32)
@@ -124,26 +129,25 @@ def sue_backward(mod, sv, dout):
                  alpha=sv['alpha_o'], dout=dout, lddo=D, dx=df2, lddx=D, dv=dv, lddv=D)
     dqv = torch.empty((B * N, A), **f32)
     ops.gemm(dv, ia.K.weight, dqv, M=B * N, N=A, K=D, lda=D, ldb=D, ldc=A)
-    ops.linear_bwd_weight(sv['qv'], dv, grad_of(ia.K.weight))
-    ops.linear_bwd_weight(dqv, cand2, grad_of(ia.Q.weight))
-    ops.bias_grad(dqv, grad_of(ia.Q.bias))
+    leaf(lambda: (ops.linear_bwd_weight(sv['qv'], dv, grad_of(ia.K.weight)), ops.linear_bwd_weight(dqv, cand2, grad_of(ia.Q.weight)),
+                  ops.bias_grad(dqv, grad_of(ia.Q.bias))), dv, dqv)
     dcand = ops.linear_bwd_data(dqv, ia.Q.weight)                                                        # [B*N, D]
     # ---- cluster affine
     dS = torch.empty((B * N * Cn, D), **f32)
     dfeat = torch.empty((B * N * Cn, D), **f32)
     ops.relu_drop_bwd(df2, sv['rc'], dS, dfeat, p, seed + 2)
     ops.linear_bwd_data(dS, mod.clusterFeatureAffine.weight, out=dfeat, accumulate=True)
-    ops.linear_bwd_weight(dS, sv['feat'], grad_of(mod.clusterFeatureAffine.weight), db=grad_of(mod.clusterFeatureAffine.bias))
+    dS_aff = dS
+    leaf(lambda: ops.linear_bwd_weight(dS_aff, sv['feat'], grad_of(mod.clusterFeatureAffine.weight), db=grad_of(mod.clusterFeatureAffine.bias)), dS_aff)
     # ---- intra-cluster attention
     dg = torch.empty((B, Hn, D), **f32)
     dkf = torch.empty((B * Hn, A), **f32)
     dqc = torch.empty((B * N, A), **f32)
     ops.sue_intra_bwd(sv['kf'], sv['qc'], sv['gfeat'], sv['cidx'], sv['alpha_i'], dfeat, B, N, Hn, Cn, A, D, dg, dkf, dqc)
     ops.linear_bwd_data(dkf, mod.intraCluster_K.weight, out=dg.view(B * Hn, D), accumulate=True)
-    ops.linear_bwd_weight(dkf, sv['gfeat'].view(B * Hn, D), grad_of(mod.intraCluster_K.weight))
     ops.linear_bwd_data(dqc, mod.intraCluster_Q.weight, out=dcand, accumulate=True)
-    ops.linear_bwd_weight(dqc, cand2, grad_of(mod.intraCluster_Q.weight))
-    ops.bias_grad(dqc, grad_of(mod.intraCluster_Q.bias))
+    leaf(lambda: (ops.linear_bwd_weight(dkf, sv['gfeat'].view(B * Hn, D), grad_of(mod.intraCluster_K.weight)),
+                  ops.linear_bwd_weight(dqc, cand2, grad_of(mod.intraCluster_Q.weight)), ops.bias_grad(dqc, grad_of(mod.intraCluster_Q.bias))), dkf, dqc)
     # ---- GCN (+ outer residual)
     dpad = torch.empty((B, G, D), **f32)
     ops.sue_slice_bwd(dg, dpad, B, Hn, G, D)
@@ -158,12 +162,12 @@ def sue_backward(mod, sv, dout):
         ops.relu_drop_bwd(dy, sv['rs'][l], dS, dx, pl, seed + 10 + l)        # dx = masked dy (residual branch)
         if not mod.gcn.residual:
             dx.zero_()
-        ops.bias_grad(dS.view(B * G, D), grad_of(layer.W.bias))
         dz = torch.empty((B, G, D), **f32)                                   # dZ_b = A_b^T dS_b
         ops.gemm(graph, dS, dz, M=G, N=D, K=G, lda=G, ldb=D, ldc=D, trans_a=True, trans_b=True, batch=B, strideA=G * G, strideB=G * D,
                  strideC=G * D, tile=2)
         ops.linear_bwd_data(dz.view(B * G, D), layer.W.weight, out=dx.view(B * G, D), accumulate=True)
-        ops.linear_bwd_weight(dz.view(B * G, D), sv['xs'][l].view(B * G, D), grad_of(layer.W.weight))
+        leaf(lambda dS=dS, dz=dz, l=l, layer=layer: (ops.bias_grad(dS.view(B * G, D), grad_of(layer.W.bias)),
+                                                     ops.linear_bwd_weight(dz.view(B * G, D), sv['xs'][l].view(B * G, D), grad_of(layer.W.weight))), dS, dz)
         dy = dx
     ops.add_(dy, dpad)                                                       # gcn(X0) + X0
     dhist = torch.empty((B, Hn, D), **f32)
