@@ -293,7 +293,12 @@ def cne_backward_many(mod, pairs):
     dev = pairs[0][1].device
     for q in mod.parameters():          # materialise (zero-fill) missing .grad buffers on the main stream BEFORE forking
         grad_of(q)
-    _fork_join(len(pairs), dev, lambda i, on_main: _cne_bwd_pre(mod, pairs[i][0], pairs[i][1], on_main))
+    with ops.leaf_scope(dev) as leaf:        # weight-gradient GEMMs of the pre phase: leaves, joined after the recurrence + post phase
+        _cne_bwd_rest(mod, pairs, H, dev, leaf)
+
+
+def _cne_bwd_rest(mod, pairs, H, dev, leaf):
+    _fork_join(len(pairs), dev, lambda i, on_main: _cne_bwd_pre(mod, pairs[i][0], pairs[i][1], on_main, leaf))
 
     # recurrence backward + token-reduction GEMMs, per token stream kind: the content recurrence is one long dependent chain
     # (128 steps) that leaves most CUs idle in its tail; the title recurrence (32 steps) and the title GEMMs run on the side
@@ -312,7 +317,9 @@ def cne_backward_many(mod, pairs):
     main.wait_stream(side)
 
 
-def _cne_bwd_pre(mod, sv, drep, par=False):
+def _cne_bwd_pre(mod, sv, drep, par=False, leaf=None):
+    if leaf is None:
+        leaf = lambda fn, *tensors: fn()
     t_, c_ = sv['streams']
     n, p, seed = sv['n'], sv['p'], sv['seed']
     H, E, A = mod.hidden_dim, mod.word_embedding_dim, mod.attention_dim
@@ -335,9 +342,8 @@ def _cne_bwd_pre(mod, sv, drep, par=False):
                      alpha=st['alpha_c'], dout=drep[:, col0:], lddo=D, dx=st['dHt'], lddx=H2, dv=dv, lddv=H2)
         dqv = torch.empty((n, A), **f32)
         ops.gemm(dv, ca.K.weight, dqv, M=n, N=A, K=H2, lda=H2, ldb=H2, ldc=A)                 # dqv = dv . K^T
-        ops.linear_bwd_weight(st['qv'], dv, grad_of(ca.K.weight))                             # dK[A,H2] += qv^T dv
-        ops.linear_bwd_weight(dqv, other['selfv'], grad_of(ca.Q.weight))
-        ops.bias_grad(dqv, grad_of(ca.Q.bias))
+        leaf(lambda: (ops.linear_bwd_weight(st['qv'], dv, grad_of(ca.K.weight)),             # dK[A,H2] += qv^T dv
+                      ops.linear_bwd_weight(dqv, other['selfv'], grad_of(ca.Q.weight)), ops.bias_grad(dqv, grad_of(ca.Q.bias))), dv, dqv)
         other['dself_x'] = ops.linear_bwd_data(dqv, ca.Q.weight)                              # grad of other.selfv via the query
 
     _two_chains(dev, par, lambda: cross_bwd(t_, c_, 0), lambda: cross_bwd(c_, t_, H2))
@@ -352,18 +358,17 @@ def _cne_bwd_pre(mod, sv, drep, par=False):
         ops.tanh_score_bwd(th, ds, sa.affine2.weight, grad_of(sa.affine2.weight), plan, A)    # th := dpre
         ops.gemm(th, sa.affine1.weight, st['dHt'], M=cap, N=H2, K=A, lda=A, ldb=H2, ldc=H2, trans_b=True, accumulate=True,
                  dyn=plan.total, dyn_dim=1)
-        ops.linear_bwd_weight(th, st['Ht'], grad_of(sa.affine1.weight), dyn=plan.total, db=grad_of(sa.affine1.bias))
+        leaf(lambda: ops.linear_bwd_weight(th, st['Ht'], grad_of(sa.affine1.weight), dyn=plan.total, db=grad_of(sa.affine1.bias)), th, st['Ht'])
         # gate: Ht = hout * G
         st['dH'] = torch.empty((cap, H2), **f32)
-        dpre = st['Ht']                                   # reuse: Ht is dead after the GEMM above
+        dpre = torch.empty((cap, H2), **f32)             # (not Ht's buffer: the deferred weight-gradient GEMM above still reads it)
         ops.gate_bwd(st['dHt'], st['hout'], st['G'], st['dH'], dpre, plan, H2)
         ops.gemm(dpre, st['Hlin'].weight, st['dH'], M=cap, N=H2, K=H2, lda=H2, ldb=H2, ldc=H2, trans_b=True, accumulate=True,
                  dyn=plan.total, dyn_dim=1)
-        ops.linear_bwd_weight(dpre, st['hout'], grad_of(st['Hlin'].weight), dyn=plan.total)
+        leaf(lambda: ops.linear_bwd_weight(dpre, st['hout'], grad_of(st['Hlin'].weight), dyn=plan.total), dpre, st['hout'])
         dP = torch.empty((n, H2), **f32)                  # d mproj[rank]
         ops.packed_seq_sum(dpre, H2, plan, dP)
-        ops.linear_bwd_weight(dP, other['cn'], grad_of(st['Mlin'].weight))
-        ops.bias_grad(dP, grad_of(st['Mlin'].bias))
+        leaf(lambda: (ops.linear_bwd_weight(dP, other['cn'], grad_of(st['Mlin'].weight)), ops.bias_grad(dP, grad_of(st['Mlin'].bias))), dP)
         other['dcn'] = ops.linear_bwd_data(dP, st['Mlin'].weight)                             # [n, H2], rank-indexed
         st['dHt'] = None
 

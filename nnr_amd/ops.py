@@ -53,7 +53,7 @@ class leaf_scope:
         if not self.enable:
             fn()
             return
-        self.leaf.wait_stream(self.main)
+        self.leaf.wait_stream(torch.cuda.current_stream(self.dev))     # the producer of the inputs (may be a side stream)
         for t in tensors:
             if t is not None:
                 t.record_stream(self.leaf)
