@@ -37,7 +37,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=6)
     ap.add_argument('--news_encoder', default='CNE')
     ap.add_argument('--user_encoder', default='SUE')
     ap.add_argument('--batch_size', type=int, default=64, help='impressions per GPU per step (weak scaling, the default)')
