@@ -46,6 +46,8 @@ def parse():
     ap.add_argument('--dense', action='store_true', help='all titles/abstracts at full length (worst-case roofline variant)')
     ap.add_argument('--device_corpus', action='store_true', help='build every batch inside the timed step from the device-resident '
                     'corpus (id-only batches: nnr_corpus_batch + nnr_history_graph) instead of re-using pre-built batches')
+    ap.add_argument('--roofline_every', type=int, default=4, help='instrument every n-th timed step with HIP events (the two events per '
+                    'launch cost ~5 %% of a step when all steps carry them)')
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--cpu_baseline_batch', type=int, default=8)
     ap.add_argument('--cpu_baseline_steps', type=int, default=2)
@@ -127,9 +129,10 @@ def main():
         trainer.train_step(fresh(i))
     dp.barrier()
     torch.cuda.synchronize()
-    prof.enable()
+    prof.enable(every=a.roofline_every)     # live HIP-event spans on every `roofline_every`-th step of the timed region
     t0 = time.perf_counter()
     for i in range(a.steps):
+        prof.begin_step(i)
         trainer.train_step(fresh(a.warmup + i))
     dp.barrier()
     torch.cuda.synchronize()

@@ -19,15 +19,26 @@ KERNEL_OF = {
 }
 
 
-def enable():
-    global _on
+_enabled, _every = False, 1
+
+
+def enable(every=1):
+    """Start recording spans; with every > 1 only the steps announced by begin_step(i) with i % every == 0 are instrumented
+    (two HIP events per launch cost ~5 % of a step when every launch of every step carries them)."""
+    global _on, _enabled, _every
+    _enabled, _every = True, max(1, int(every))
     _on = True
     _records.clear()
 
 
-def disable():
+def begin_step(i):
     global _on
-    _on = False
+    _on = _enabled and (i % _every == 0)
+
+
+def disable():
+    global _on, _enabled
+    _on = _enabled = False
 
 
 def active():
