@@ -36,8 +36,11 @@ def _s():
 # Weight-gradient GEMMs are LEAVES of the backward pass: nothing downstream reads them before the optimizer.  Issued inline
 # they sit on the critical chain of the (latency-bound) data-gradient kernels; here they go to a separate HIP stream that
 # waits for the producer of their inputs, and the caller joins it before its backward returns (every accumulation into a
-# parameter gradient is atomic, so concurrent leaves are safe).  `record_stream` tells the caching allocator that the
-# inputs are in use on the leaf stream, so a buffer freed on the main stream is not handed out again under a pending read.
+# parameter gradient is atomic, so concurrent leaves are safe).  The scope holds a reference to every input until the join,
+# so a buffer the caller drops early cannot be handed out again under a pending read.  (`Tensor.record_stream` would do the
+# same through the caching allocator, but a recorded multi-GB buffer that is freed while the leaf stream is still busy is
+# not reusable until its event completes: the allocator then grows with hipMalloc and the step time turned bimodal,
+# 14 ms or 50-67 ms per step -- measured when the 2.7 GB gate buffer was recorded.)
 _LEAF = {}
 
 
@@ -48,6 +51,7 @@ class leaf_scope:
         self.dev, self.enable = dev, enable
 
     def __enter__(self):
+        self.keep = []
         if self.enable:
             key = (self.dev.type, self.dev.index)
             if key not in _LEAF:
@@ -61,15 +65,14 @@ class leaf_scope:
             fn()
             return
         self.leaf.wait_stream(torch.cuda.current_stream(self.dev))     # the producer of the inputs (may be a side stream)
-        for t in tensors:
-            if t is not None:
-                t.record_stream(self.leaf)
+        self.keep.extend(tensors)
         with torch.cuda.stream(self.leaf):
             fn()
 
     def __exit__(self, *a):
         if self.enable:
             self.main.wait_stream(self.leaf)
+        self.keep = []                   # (dropped on the host after the join was ENQUEUED: later main-stream work is ordered behind it)
 
 
 def split_for(m, n, k, tile_m=64, tile_n=80, target_blocks=2048, kmin=256):

@@ -21,15 +21,19 @@ tr = Trainer(model, cfg)
 synth = SynthCorpus(SynthSpec(vocabulary_size=60000))
 rng = np.random.default_rng(0)
 dc = from_synth(synth, 8192, rng, 'cuda')
-losses, timeouts = [], 0
+import time
+losses, timeouts, times = [], 0, []
 for i in range(steps):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
     idx = torch.from_numpy(rng.permutation(8192)[:BS].astype(np.int32)).cuda()
     _, loss = tr.train_step(dc.train_batch(idx))
     losses.append(loss)
-    if i % 25 == 0:
-        timeouts += ops.lstm_sync_timeouts()
+    torch.cuda.synchronize(); times.append(time.perf_counter() - t0)
+    timeouts += ops.lstm_sync_timeouts()
 l = torch.stack(losses).cpu().numpy()
 flat = tr.flat.flat
 print('batch %d steps %d: loss first %.4f last-50 mean %.4f min %.4f max %.4f; finite loss %s; finite params %s; exchange timeouts %d' %
       (BS, steps, l[0], l[-50:].mean(), l.min(), l.max(), bool(np.isfinite(l).all()), bool(torch.isfinite(flat).all()), timeouts))
+ts = np.array(times[5:]) * 1e3
+print('step time (sync each step): median %.2f ms, p99 %.2f ms, max %.2f ms' % (np.median(ts), np.percentile(ts, 99), ts.max()))
 assert np.isfinite(l).all() and bool(torch.isfinite(flat).all()) and timeouts == 0
