@@ -155,7 +155,8 @@ def main():
                                    (a.news_encoder, a.user_encoder, cfg.dropout_rate, cfg.gcn_layer_num, ', dense lengths' if a.dense else ''),
                        'global_batch': global_batch, 'per_gpu_batch': per_gpu, 'parallelism': 'dp%d' % world,
                        'synth': {k: v for k, v in spec.describe().items() if k in ('vocabulary_size', 'title_len_mean', 'content_len_mean', 'news_pool', 'dense')},
-                       'batches': 'device-resident corpus, id-only' if a.device_corpus else 'pre-built, resident in HBM'},
+                       'batches': 'device-resident corpus, id-only' if a.device_corpus else 'pre-built, resident in HBM',
+                       'peak_hbm_reserved_gb': round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 2)},
             'roofline': roof,
         }
         if not a.no_cpu_baseline and world == 1:
