@@ -635,6 +635,9 @@ __device__ __forceinline__ void lstm_bwd_pair_body(const LstmArgs& a, float* dg,
   const bool same_xcd = __builtin_amdgcn_readfirstlane(dg[0] != 0.f);
   __syncthreads();
 
+  unsigned long long* tbuf = reinterpret_cast<unsigned long long*>(diag + SYNC_PAD);
+  const bool stamp = (a.dbg & 32) && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0;
+#define STAMP(slot) do { if (stamp && step < 128) tbuf[step * 16 + (slot)] = wall_clock64(); } while (0)
   const bool own = w < nb;                               // this wave owns unit block ub_lo + w (gate gradients + own output tile)
   const bool par = w < npb;                              // ... and computes the partner's output tile pb_lo + w
   if (!own && !par) {                                    // nothing to do: keep the barrier count
@@ -696,6 +699,7 @@ __device__ __forceinline__ void lstm_bwd_pair_body(const LstmArgs& a, float* dg,
     const int nact = min(16, P.bs[t] - s0);
     const long row0 = (long)P.off[t] + s0;
     // ---- (1) gate gradients of the own unit block
+    STAMP(4);
     if (own) {
       // the partner's contribution to dh of these units (its own-K partial sums of the previous step)
       if (step > 0) {
@@ -706,6 +710,7 @@ __device__ __forceinline__ void lstm_bwd_pair_body(const LstmArgs& a, float* dg,
 #pragma unroll
         for (int e = 0; e < 4; ++e) dhr[e] += wait_tag(src + e * 64, v[e], (unsigned)step, same_xcd, diag);
       }
+      if (stamp && step < 128) tbuf[step * 16 + 5] = wall_clock64() + (unsigned long long)(dhr[0] == 123.456f);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int row = kk * 4 + e;
@@ -730,7 +735,9 @@ __device__ __forceinline__ void lstm_bwd_pair_body(const LstmArgs& a, float* dg,
         *reinterpret_cast<f32x4*>(&dg[lds_off(row, w * 64 + r * 4, DLD)]) = dgv;
       }
     }
+    STAMP(6);
     __syncthreads();
+    STAMP(7);
     if (step + 1 < tmax) load_inputs(step + 1);
     // ---- (2) the partner's output tile over the own K range: compute, send
     if (par) {
@@ -745,6 +752,7 @@ __device__ __forceinline__ void lstm_bwd_pair_body(const LstmArgs& a, float* dg,
       unsigned long long* dst = xmine + (step & 1) * XT + (w * 4) * 64 + lane;
 #pragma unroll
       for (int e = 0; e < 4; ++e) st_tag(dst + e * 64, acc[e], (unsigned)(step + 1), same_xcd);
+      STAMP(8);
     }
     // ---- (3) the own output tile over the own K range (stays in registers: same lane needs it next step)
     if (own) {
@@ -757,9 +765,11 @@ __device__ __forceinline__ void lstm_bwd_pair_body(const LstmArgs& a, float* dg,
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) dhr[e] = acc[e];
+      if (stamp && step < 128) tbuf[step * 16 + 9] = wall_clock64() + (unsigned long long)(dhr[0] == 123.456f);
     }
     __syncthreads();
   }
+#undef STAMP
 }
 
 template <int UB>

@@ -13,7 +13,7 @@ sync = ops.LAST_LSTM_SYNC[0]
 tb = sync[-(128 * 16 * 2):].view(torch.int64).view(128, 16).cpu().numpy().astype(np.float64)
 tb = tb[8:120]
 base = tb[:, 4:5]                      # compute wave: step start
-names = {2: 'partner tile in LDS', 4: 'compute: step start', 5: 'compute: phase A done',
+names = {4: 'step start', 5: 'partner partials added', 6: 'gate gradients written', 7: 'after barrier', 8: 'partner tile sent', 9: 'own tile done'} if '--bwd' in sys.argv else {2: 'partner tile in LDS', 4: 'compute: step start', 5: 'compute: phase A done',
          6: 'compute: after B2', 7: 'compute: phase B done', 8: 'compute: stores issued', 9: 'compute: activations done', 10: 'compute: tagged stores issued', 11: 'first fetched word returned'}
 print('ticks are 10 ns (100 MHz wall clock); mean offset from the compute wave\'s step start, steps 8..119')
 for k in sorted(names):
