@@ -143,6 +143,8 @@ def main():
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = float(tmax)
     roof = prof.roofline(PEAK_F32_TFLOPS)
+    exchange_timeouts = ops.lstm_sync_timeouts()      # the CU-pair recurrence's exchange must never time out (last launch's counter)
+    assert exchange_timeouts == 0, 'pair-recurrence exchange timed out %d times: results are poisoned with NaN' % exchange_timeouts
 
     if rank == 0:
         out = {

@@ -52,7 +52,8 @@ struct LstmProblem {
   unsigned* sync;      // pair kernels: [2][ntiles][2][SYNC_PAD] step counters + [SYNC_PAD] diagnostics
 };
 constexpr int SYNC_PAD = 16;                 // diagnostics block (64 bytes) at the end of the workspace
-constexpr int SPIN_LIMIT = 1 << 20;          // ~seconds: a partner workgroup may still be waiting for a free CU
+constexpr int SPIN_LIMIT = 1 << 17;          // ~0.2 s: a partner workgroup may still be waiting for a free CU (that wait is bounded by
+                                             // the kernels running next to this one: milliseconds)
 
 // Exchange between two RUNNING workgroups.  Every value travels as one 8-byte (value, step tag) word, so the payload
 // carries its own readiness: no flag, no fence, no store-acknowledge wait -- the reader polls the words it needs.
@@ -93,8 +94,10 @@ __device__ __forceinline__ float wait_tag(const unsigned long long* p, unsigned 
   while ((unsigned)(v >> 32) != tag) {
     __builtin_amdgcn_s_sleep(1);
     v = ld_tag(p, same_xcd);
-    if (++spins > SPIN_LIMIT) {                      // the partner never delivered: fail LOUDLY -- count it, and poison the value so
-      atomicAdd(diag, 1u);                           // the step's loss becomes NaN instead of silently training on stale data
+    // the partner never delivered (or another wait of this launch already gave up: do not stack timeouts): fail LOUDLY --
+    // count it, and poison the value so the step's loss becomes NaN instead of silently training on stale data
+    if (++spins > SPIN_LIMIT || ((spins & 1023) == 0 && __hip_atomic_load(diag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+      atomicAdd(diag, 1u);
       v = 0x7fc00000ull;
       break;
     }
