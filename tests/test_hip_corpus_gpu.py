@@ -129,3 +129,53 @@ def test_negative_sampling_restatement():
     assert s[0].tolist() == [5, 7, 7, 7, 7] and s[1].tolist() == [6, 8, 9, 8, 9] and s[2].tolist() == [1, 2, 3, 4, 10]
     assert s[3, 0] == 11 and len(set(s[3, 1:].tolist())) == 4 and all(20 <= v < 40 for v in s[3, 1:])
     assert c['train_samples'].shape[1] == 5
+
+
+def test_training_epoch_over_device_corpus_matches_oracle_loop():
+    """End to end over the reference-built corpus (tiny MIND tree): DistributedSampler-order batches produced by DeviceCorpus
+    (graphs built on the device) -> Trainer.train_step, against the oracle's train_step on numpy-gathered batches of the same
+    behaviours -- the loop of trainer.py:78-120 with both of its ends replaced.  Dropout off; loss per step within 5e-5."""
+    from nnr_amd import dp
+    from nnr_amd.corpus import DeviceCorpus
+    from nnr_amd.model import Model
+    from nnr_amd.trainer import Trainer
+    from oracle import corpus_oracle as CO, nnr_oracle as O
+    c = load('tiny_h50_sym')
+    V = int(max(c['news_title_text'].max(), c['news_abstract_text'].max())) + 1
+    cfg = O.default_config(news_encoder='CNE', user_encoder='SUE', dataset='small', vocabulary_size=V, word_embedding_dim=16, hidden_dim=8,
+                           attention_dim=8, max_history_num=int(c['max_history_num']), max_title_length=8, max_abstract_length=16,
+                           category_num=int(c['category_num']), subCategory_num=int(c['news_subCategory'].max()) + 1, category_embedding_dim=4,
+                           subCategory_embedding_dim=4, negative_sample_num=4, head_num=2, head_dim=4, cnn_kernel_num=12, gcn_layer_num=2,
+                           dropout_rate=0.0, lr=1e-2, user_num=int(c['beh_user'].max()) + 1, tie_order='stable', batch_size=4)
+    torch.manual_seed(3)
+    ref = O.Model(cfg)
+    ref.initialize()
+    with torch.no_grad():
+        for p in ref.parameters():
+            if float(p.abs().max()) == 0.0:
+                p.normal_(0, 0.05)
+            p.mul_(1.5)
+    ref.train()
+    model = Model(cfg, torch.zeros(V, 16))
+    model.load_state_dict(ref.state_dict())
+    model = model.cuda().train()
+    trainer = Trainer(model, cfg)
+    opt = O.make_optimizer(ref, cfg)
+    dc = DeviceCorpus(c, 'cuda', int(c['category_num']), graph='build', norm='symmetric')
+    dc.set_samples(c['train_samples'])
+    n = int(c['beh_user'].shape[0])
+    order = torch.randperm(n, generator=torch.Generator().manual_seed(0)).numpy()          # DistributedSampler(seed 0, epoch 0), world 1
+    worst = 0.0
+    for start in range(0, n - 3, 4):
+        idx = order[start:start + 4].astype(np.int32)
+        _, loss = trainer.train_step(dc.train_batch(idx))
+        ref_batch = [torch.from_numpy(np.ascontiguousarray(a)) for a in CO.train_batch(c, idx)]
+        _, ref_loss = O.train_step(ref, opt, ref_batch, cfg.gradient_clip_norm)
+        worst = max(worst, abs(float(loss) - float(ref_loss)))
+    print('epoch of %d steps: worst |loss - oracle loss| = %.2e' % (n // 4, worst))
+    assert worst <= 5e-5
+    rp = dict(ref.named_parameters())
+    for k, p in model.named_parameters():
+        if k.startswith('user_encoder.news_encoder.'):
+            continue
+        assert float((p.detach().cpu() - rp[k].detach()).abs().max()) <= 4 * float(cfg.lr) + 1e-4, k     # Adam: <= lr per step per element
