@@ -96,6 +96,21 @@ def allreduce_gradients(flat_grads):
     return 1.0 / w
 
 
+def sampler_indices(n, rank, world, epoch, seed=0):
+    """The behaviour indices rank `rank` visits in epoch `epoch`, exactly as torch's DistributedSampler(shuffle=True, seed)
+    after set_epoch(epoch) -- the sampler of trainer.py:256-257,264: randperm(n) from Generator(seed + epoch), padded by
+    wrapping around to a multiple of `world`, then every world-th index from `rank`.  Feed slices of it to
+    DeviceCorpus.train_batch."""
+    g = torch.Generator()
+    g.manual_seed(seed + epoch)
+    idx = torch.randperm(n, generator=g).tolist()
+    total = -(-n // world) * world
+    pad = total - len(idx)
+    if pad > 0:
+        idx += (idx * (-(-pad // len(idx))))[:pad]
+    return torch.tensor(idx[rank:total:world], dtype=torch.int32)
+
+
 def shard_batch(batch, rank, world):
     """Per-rank slice of a global batch: rank r takes samples r::world (DistributedSampler order, trainer.py:256-258)."""
     if world == 1:

@@ -80,3 +80,16 @@ def test_shard_batch_follows_distributed_sampler_order():
     s = dp.shard_batch(b, 1, 4)
     assert s[0].tolist() == [1, 5] and s[1].tolist() == [[2, 3], [10, 11]]
     assert dp.shard_batch(b, 0, 1) is b
+
+
+def test_sampler_indices_equal_torch_distributed_sampler():
+    """nnr_amd.dp.sampler_indices == torch.utils.data.DistributedSampler (the reference's sampler, trainer.py:256-257,264)."""
+    import torch
+    from torch.utils.data import DistributedSampler
+    from nnr_amd import dp
+    for n, world in ((18, 1), (18, 4), (37, 8), (5, 8), (1000, 3)):
+        for epoch in (0, 1, 7):
+            for rank in range(world):
+                s = DistributedSampler(list(range(n)), num_replicas=world, rank=rank, shuffle=True, seed=0)
+                s.set_epoch(epoch)
+                assert dp.sampler_indices(n, rank, world, epoch).tolist() == list(iter(s)), (n, world, epoch, rank)

@@ -164,7 +164,7 @@ def test_training_epoch_over_device_corpus_matches_oracle_loop():
     dc = DeviceCorpus(c, 'cuda', int(c['category_num']), graph='build', norm='symmetric')
     dc.set_samples(c['train_samples'])
     n = int(c['beh_user'].shape[0])
-    order = torch.randperm(n, generator=torch.Generator().manual_seed(0)).numpy()          # DistributedSampler(seed 0, epoch 0), world 1
+    order = dp.sampler_indices(n, 0, 1, epoch=0).numpy()                                   # DistributedSampler(seed 0), epoch 0, world 1
     worst = 0.0
     for start in range(0, n - 3, 4):
         idx = order[start:start + 4].astype(np.int32)
