@@ -114,7 +114,7 @@ def _side_stream(dev):
     """One extra HIP stream per device for the small (candidate) encoder call."""
     key = (dev.type, dev.index)
     if key not in _SIDE:
-        _SIDE[key] = torch.cuda.Stream(device=dev)
+        _SIDE[key] = ops.new_stream(dev)
     return _SIDE[key]
 
 
@@ -130,7 +130,7 @@ def _two_chains(dev, enable, title_fn, content_fn):
     main = torch.cuda.current_stream(dev)
     key = (dev.type, dev.index, 2)
     if key not in _SIDE:
-        _SIDE[key] = torch.cuda.Stream(device=dev)
+        _SIDE[key] = ops.new_stream(dev)
     s2 = _SIDE[key]
     s2.wait_stream(main)
     with torch.cuda.stream(s2):

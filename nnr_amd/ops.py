@@ -42,6 +42,22 @@ def _s():
 # not reusable until its event completes: the allocator then grows with hipMalloc and the step time turned bimodal,
 # 14 ms or 50-67 ms per step -- measured when the 2.7 GB gate buffer was recorded.)
 _LEAF = {}
+EXTRA_STREAMS = []          # every HIP stream this package created (side, title, leaf): see join_extra_streams()
+
+
+def new_stream(dev):
+    st = torch.cuda.Stream(device=dev)
+    EXTRA_STREAMS.append(st)
+    return st
+
+
+def join_extra_streams(dev=None):
+    """Make the current stream wait for everything enqueued on the package's own streams.  Every backward function joins
+    the streams it used before it returns; the trainer calls this once more before the gradient exchange / optimizer
+    (parameter gradients are written out of autograd's sight, so autograd's own stream bookkeeping does not cover them)."""
+    cur = torch.cuda.current_stream(dev)
+    for st in EXTRA_STREAMS:
+        cur.wait_stream(st)
 
 
 class leaf_scope:
@@ -55,7 +71,7 @@ class leaf_scope:
         if self.enable:
             key = (self.dev.type, self.dev.index)
             if key not in _LEAF:
-                _LEAF[key] = torch.cuda.Stream(device=self.dev)
+                _LEAF[key] = new_stream(self.dev)
             self.leaf = _LEAF[key]
             self.main = torch.cuda.current_stream(self.dev)
         return self

@@ -56,6 +56,7 @@ class Trainer:
         logits = model(*batch)
         loss = negative_log_softmax(logits)
         loss.backward()
+        ops.join_extra_streams()
         scale = dp.allreduce_gradients(self.flat.grad)
         self.optimizer_step(scale)
         return logits.detach(), loss.detach()
