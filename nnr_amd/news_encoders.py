@@ -306,7 +306,7 @@ def _cne_bwd_rest(mod, pairs, H, dev, leaf):
     def run_kind(kind):
         ops.lstm_bwd([sv['streams'][kind] for sv, _ in pairs], H)
         for sv, _ in pairs:
-            _cne_bwd_post(mod, sv, sv['streams'][kind])
+            _cne_bwd_post(mod, sv, sv['streams'][kind], leaf if kind == 1 else None)
 
     main = torch.cuda.current_stream(dev)
     side = _side_stream(dev)
@@ -378,17 +378,20 @@ def _cne_bwd_pre(mod, sv, drep, par=False, leaf=None):
         st['dh'] = st['dH']
 
 
-def _cne_bwd_post(mod, sv, st):
-    """After the recurrence backward of token stream `st`: weight / bias gradients of the LSTM and the embedding-row scatter."""
+def _cne_bwd_post(mod, sv, st, leaf=None):
+    """After the recurrence backward of token stream `st`: weight / bias gradients of the LSTM and the embedding-row scatter.
+    All of it is leaf work; with `leaf` given the three weight-gradient GEMMs go to the leaf stream and run next to the scatter
+    GEMM (each has a partially filled last wave of workgroups that the other fills)."""
     p = sv['p']
     H, E = mod.hidden_dim, mod.word_embedding_dim
     H2 = 2 * H
     f32 = dict(device=st['gates'].device, dtype=torch.float32)
     emb = mod.word_embedding.weight
-    if True:
-        plan, w, cap = st['plan'], st['w'], st['plan'].cap
-        dg = st['gates']                                  # now d(pre-activation gates), p-order
-        NP = w.NP
+    plan, w, cap = st['plan'], st['w'], st['plan'].cap
+    dg = st['gates']                                  # now d(pre-activation gates), p-order
+    NP = w.NP
+
+    def weights():
         dw_ihp = torch.zeros((2 * NP, E), **f32)
         db_p = torch.zeros(2 * NP, **f32)
         dw_hhp = torch.zeros((2, NP, H), **f32)
@@ -398,9 +401,15 @@ def _cne_bwd_post(mod, sv, st):
             ops.gemm(dg[:, d * NP:], st['hout'][:, d * H:], dw_hhp[d], M=NP, N=H, K=cap, lda=2 * NP, ldb=H2, ldc=H, trans_a=True,
                      trans_b=True, b_idx=prev, split_k=ops.split_for(NP, H, cap), atomic=True, dyn=plan.total, dyn_dim=2)
         ops.lstm_unpack_grads(dw_ihp, db_p, dw_hhp, H, E, [grad_of(q) for q in st['lstm'].param_list()])
-        # d(embedding rows): dX = dgates . W_ihp, scattered (atomic) into the table gradient through the dropout mask
-        ops.gemm(dg, w.w_ihp, grad_of(emb), M=cap, N=E, K=2 * NP, lda=2 * NP, ldb=E, ldc=E, trans_b=True, c_idx=plan.tok, atomic=True,
-                 drop=(4, p, st['seed'], E), dyn=plan.total, dyn_dim=1)
+        return dw_ihp, db_p, dw_hhp
+
+    if leaf is not None:
+        leaf(lambda: leaf.keep.extend(weights()))     # (the temporaries are allocated on the leaf stream and held until the join)
+    else:
+        weights()
+    # d(embedding rows): dX = dgates . W_ihp, scattered (atomic) into the table gradient through the dropout mask
+    ops.gemm(dg, w.w_ihp, grad_of(emb), M=cap, N=E, K=2 * NP, lda=2 * NP, ldb=E, ldc=E, trans_b=True, c_idx=plan.tok, atomic=True,
+             drop=(4, p, st['seed'], E), dyn=plan.total, dyn_dim=1)
 
 
 class CNE(NewsEncoder):
