@@ -178,7 +178,7 @@ def cne_forward_many(mod, calls):
     dev = calls[0][0].device
     mod._packed_weights('title', mod.title_lstm)        # (re)pack on the main stream BEFORE forking: both calls read them
     mod._packed_weights('content', mod.content_lstm)
-    pre = _fork_join(len(calls), dev, lambda i, on_main: _cne_fwd_pre(mod, *calls[i], par=False))   # two GPU-filling input projections side by side gain nothing
+    pre = _fork_join(len(calls), dev, lambda i, on_main: _cne_fwd_pre(mod, *calls[i], par=on_main))
     items = [st for sv in pre for st in (sv['streams'][1],)] + [st for sv in pre for st in (sv['streams'][0],)]   # content streams first
     for i in range(0, len(items), 4):
         ops.lstm_fwd(items[i:i + 4], H)
@@ -391,25 +391,34 @@ def _cne_bwd_post(mod, sv, st, leaf=None):
     dg = st['gates']                                  # now d(pre-activation gates), p-order
     NP = w.NP
 
-    def weights():
-        dw_ihp = torch.zeros((2 * NP, E), **f32)
-        db_p = torch.zeros(2 * NP, **f32)
-        dw_hhp = torch.zeros((2, NP, H), **f32)
+    dw_ihp = torch.zeros((2 * NP, E), **f32)
+    db_p = torch.zeros(2 * NP, **f32)
+    dw_hhp = torch.zeros((2, NP, H), **f32)
+
+    def dw_ih():
         ops.gemm(dg, st['xd'], dw_ihp, M=2 * NP, N=E, K=cap, lda=2 * NP, ldb=E, ldc=E, trans_a=True, trans_b=True,
                  split_k=ops.split_for(2 * NP, E, cap), atomic=True, dyn=plan.total, dyn_dim=2, colsum_out=db_p)
-        for d, prev in ((0, plan.prev_f), (1, plan.prev_r)):
-            ops.gemm(dg[:, d * NP:], st['hout'][:, d * H:], dw_hhp[d], M=NP, N=H, K=cap, lda=2 * NP, ldb=H2, ldc=H, trans_a=True,
-                     trans_b=True, b_idx=prev, split_k=ops.split_for(NP, H, cap), atomic=True, dyn=plan.total, dyn_dim=2)
-        ops.lstm_unpack_grads(dw_ihp, db_p, dw_hhp, H, E, [grad_of(q) for q in st['lstm'].param_list()])
-        return dw_ihp, db_p, dw_hhp
 
-    if leaf is not None:
-        leaf(lambda: leaf.keep.extend(weights()))     # (the temporaries are allocated on the leaf stream and held until the join)
+    def dw_hh(d):
+        ops.gemm(dg[:, d * NP:], st['hout'][:, d * H:], dw_hhp[d], M=NP, N=H, K=cap, lda=2 * NP, ldb=H2, ldc=H, trans_a=True,
+                 trans_b=True, b_idx=(plan.prev_f, plan.prev_r)[d], split_k=ops.split_for(NP, H, cap), atomic=True, dyn=plan.total, dyn_dim=2)
+
+    def dx_scatter():
+        # d(embedding rows): dX = dgates . W_ihp, scattered (atomic) into the table gradient through the dropout mask
+        ops.gemm(dg, w.w_ihp, grad_of(emb), M=cap, N=E, K=2 * NP, lda=2 * NP, ldb=E, ldc=E, trans_b=True, c_idx=plan.tok, atomic=True,
+                 drop=(4, p, st['seed'], E), dyn=plan.total, dyn_dim=1)
+
+    if leaf is None:
+        dw_ih(); dw_hh(0); dw_hh(1)
     else:
-        weights()
-    # d(embedding rows): dX = dgates . W_ihp, scattered (atomic) into the table gradient through the dropout mask
-    ops.gemm(dg, w.w_ihp, grad_of(emb), M=cap, N=E, K=2 * NP, lda=2 * NP, ldb=E, ldc=E, trans_b=True, c_idx=plan.tok, atomic=True,
-             drop=(4, p, st['seed'], E), dyn=plan.total, dyn_dim=1)
+        # two balanced halves: leaf stream dW_ih + dW_hh(reverse), this stream the scatter GEMM + dW_hh(forward)
+        leaf(lambda: (dw_ih(), dw_hh(1)), dw_ihp, db_p, dw_hhp)
+        dx_scatter()
+        dw_hh(0)
+        leaf.sync()
+    ops.lstm_unpack_grads(dw_ihp, db_p, dw_hhp, H, E, [grad_of(q) for q in st['lstm'].param_list()])
+    if leaf is None:
+        dx_scatter()
 
 
 class CNE(NewsEncoder):

@@ -85,6 +85,11 @@ class leaf_scope:
         with torch.cuda.stream(self.leaf):
             fn()
 
+    def sync(self):
+        """Make the CURRENT stream wait for the leaf work issued so far (for a consumer in the middle of the scope)."""
+        if self.enable:
+            torch.cuda.current_stream(self.dev).wait_stream(self.leaf)
+
     def __exit__(self, *a):
         if self.enable:
             self.main.wait_stream(self.leaf)
