@@ -142,7 +142,8 @@ def main():
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = float(tmax)
-    roof = prof.roofline(PEAK_F32_TFLOPS)
+    sampled = len(range(0, a.steps, max(1, a.roofline_every)))
+    roof = prof.roofline(PEAK_F32_TFLOPS, sampled_steps=sampled, ms_per_step=1000 * dt / a.steps)
     exchange_timeouts = ops.lstm_sync_timeouts()      # the CU-pair recurrence's exchange must never time out (last launch's counter)
     if exchange_timeouts:
         print('WARNING: pair-recurrence exchange timed out %d times (values poisoned with NaN)' % exchange_timeouts, file=sys.stderr)

@@ -104,7 +104,7 @@ def pmc_traffic(kernel):
     return None
 
 
-def roofline(peak_tflops):
+def roofline(peak_tflops, sampled_steps=None, ms_per_step=None):
     fam = summary()
     if not fam:
         return None
@@ -119,4 +119,8 @@ def roofline(peak_tflops):
         'share_of_instrumented_time': round(d['ms'] / total_ms, 3),
         'families': {k: {'ms': round(v['ms'], 3), 'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2) if v['ms'] > 0 else 0.0,
                          'launches': v['launches']} for k, v in sorted(fam.items(), key=lambda kv: -kv[1]['ms'])},
+        # whole-step view: the launches of several HIP streams overlap, so per-kernel wall durations double-count the chip;
+        # algorithmic FLOPs of all instrumented GEMM / recurrence launches of one step over the step time do not
+        'step': (None if not (sampled_steps and ms_per_step) else (lambda tf: {'gflop': round(sum(v['flops'] for v in fam.values()) / sampled_steps / 1e9, 1),
+                 'tflops': round(tf, 2), 'frac': round(tf / peak_tflops, 4)})(sum(v['flops'] for v in fam.values()) / sampled_steps / (ms_per_step * 1e-3) / 1e12)),
     }
