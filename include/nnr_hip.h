@@ -179,7 +179,8 @@ int nnr_relu_drop_bwd(const float* dy, const float* r, float* ds, float* dx, lon
 /* ------------------------------------------------------------------------------------------------ multi-head self-attention core
  * MultiHeadAttention.forward after the W_Q/W_K/W_V projections (layers.py:137-147) on v_mfma_f32_32x32x2_f32:
  * qkv [n*Lq, 3*heads*dh] = [Q | K | V] (head h at columns h*dh), key mask [n, Lq] (0 -> -1e9) or NULL, scale = 1/sqrt(dh);
- * out [n*Lq, heads*dh]; prob [n*heads, NB*NB*1024] (NB = 1 for Lq <= 32, 2 for Lq <= 64) saved for backward. */
+ * out [n*Lq, heads*dh]; prob [n*heads, NB*NB*1024] (NB = 1 for Lq <= 32, 2 for Lq <= 64) saved for backward, or NULL in
+ * both calls: backward then recomputes the probabilities from Q, K (the product path does this). */
 int nnr_mhsa_fwd(const float* qkv, const uint8_t* mask, int n, int Lq, int heads, int dh, float scale, float* out, float* prob,
                  hipStream_t stream);
 int nnr_mhsa_bwd(const float* qkv, const uint8_t* mask, const float* prob, const float* dout, int n, int Lq, int heads, int dh,

@@ -33,6 +33,107 @@ __device__ __forceinline__ void stage(float* dst, const float* src, int ld, int 
   }
 }
 
+// Cooperative path (heads % 4 == 0, dh % 4 == 0): the 4 waves of a workgroup own 4 CONSECUTIVE heads of one sample, whose
+// slices are adjacent in memory, so the workgroup moves [Lq] row segments of 4*dh contiguous floats (320 B at dh = 20) as
+// float4 -- ALL loads of all NMAT matrices are issued before the first LDS write, so a wave pays the HBM latency once
+// instead of once per loop trip -- and scatters them into the per-wave tiles (tile m of wave w at w*wstride + m*LP*SD).
+template <int NMAT, int LP>
+__device__ __forceinline__ void stage4v(float* smem, int wstride, const float* const (&src)[NMAT], const int (&ld)[NMAT],
+                                        int Lq, int dh, int SD, int tid) {
+  const int n4 = LP * dh;                  // float4 per matrix: LP rows x (4 heads * dh / 4)
+  constexpr int U = 3;
+  for (int b0 = 0; b0 < n4; b0 += 256 * U) {
+    float4 r[NMAT][U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int idx = b0 + u * 256 + tid, q = idx / dh, c4 = idx - q * dh;
+      const bool live = idx < n4 && q < Lq;
+#pragma unroll
+      for (int m = 0; m < NMAT; ++m)
+        r[m][u] = live ? *(const float4*)(src[m] + (long)q * ld[m] + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int idx = b0 + u * 256 + tid, q = idx / dh, c = 4 * (idx - q * dh), w = c / dh, d = c - w * dh;
+      if (idx < n4) {
+#pragma unroll
+        for (int m = 0; m < NMAT; ++m) {
+          float* t = smem + w * wstride + m * LP * SD + q * SD + d;
+          t[0] = r[m][u].x; t[1] = r[m][u].y; t[2] = r[m][u].z; t[3] = r[m][u].w;
+        }
+      }
+    }
+  }
+}
+
+// the reverse: per-wave result tiles [LP][SD] (rows = sequence position) -> [Lq] row segments of 4*dh floats, float4 stores
+template <int LP>
+__device__ __forceinline__ void unstage4v(const float* tile0, int wstride, float* dst, int ld, int Lq, int dh, int SD, int tid) {
+  const int n4 = Lq * dh;
+  for (int idx = tid; idx < n4; idx += 256) {
+    const int q = idx / dh, c = 4 * (idx - q * dh), w = c / dh, d = c - w * dh;
+    const float* t = tile0 + w * wstride + q * SD + d;
+    *(float4*)(dst + (long)q * ld + c) = make_float4(t[0], t[1], t[2], t[3]);
+  }
+}
+
+// R^T accumulators (rows = feature d, cols = sequence position i) -> LDS tile[i][d]
+template <int NB>
+__device__ __forceinline__ void tile_T(float* tile, int SD, const f32x16 (&o)[NB], int dh, int lane) {
+  const int l31 = lane & 31, half = lane >> 5;
+#pragma unroll
+  for (int ib = 0; ib < NB; ++ib)
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int d = acc_row(reg, half);
+      if (d < dh) tile[(ib * 32 + l31) * SD + d] = o[ib][reg];
+    }
+}
+
+// the sample's key mask as one wave-uniform 64-bit word (bit j = key j is live): one byte load per lane + a ballot, instead
+// of 16 byte loads per lane in every consumer
+__device__ __forceinline__ unsigned long long key_bits(const MhsaArgs& a, int smp, int lane) {
+  if (!a.mask) return ~0ull;
+  const bool live = lane < a.Lq && a.mask[(long)smp * a.Lq + lane] != 0;
+  return __ballot(live);
+}
+
+// key mask + softmax over keys (rows) of S^T for this lane's query column(s); p: raw scores in, probabilities out
+template <int NB>
+__device__ __forceinline__ void softmax_T(f32x16 (&p)[NB][NB], const MhsaArgs& a, unsigned long long live, int half) {
+#pragma unroll
+  for (int ib = 0; ib < NB; ++ib) {
+    float m = -INFINITY;
+#pragma unroll
+    for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int j = jb * 32 + acc_row(reg, half);
+        float sc = p[jb][ib][reg] * a.scale;
+        if (j >= a.Lq) sc = -INFINITY;
+        else if (!((live >> j) & 1)) sc = -1e9f;
+        p[jb][ib][reg] = sc;
+        m = fmaxf(m, sc);
+      }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const float e = expf(p[jb][ib][reg] - m);
+        p[jb][ib][reg] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) p[jb][ib][reg] *= inv;
+  }
+}
+
 // C^T[x][y] (NB x NB blocks of 32x32) = sum_k X[x][k] Y[y][k], X and Y staged [LP][SD], k < dh (dh even)
 template <int NB>
 __device__ __forceinline__ void rows_dot(const float* X, const float* Y, int dh, int SD, int lane, f32x16 (&c)[NB][NB]) {
@@ -87,56 +188,37 @@ __device__ __forceinline__ void store_T(float* dst, int ld, const f32x16 (&o)[NB
 }
 
 template <int NB>
-__global__ __launch_bounds__(256) void mhsa_fwd_kernel(MhsaArgs a) {
+__global__ __launch_bounds__(256) void mhsa_fwd_kernel(MhsaArgs a, int coop) {
   constexpr int LP = 32 * NB;
   extern __shared__ float smem[];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l31 = lane & 31, half = lane >> 5;
-  const int pair = blockIdx.x * (blockDim.x >> 6) + wv;
-  if (pair >= a.n * a.heads) return;
-  const int smp = pair / a.heads, head = pair - smp * a.heads;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, half = lane >> 5;
+  const int nw = blockDim.x >> 6;
+  const int pair = blockIdx.x * nw + wv;
   const int dh = a.dh, SD = dh | 1, HD = a.heads * dh, ld = 3 * HD;
-  float* Qs = smem + wv * (3 * LP * SD);
+  const int wstride = 3 * LP * SD;
+  float* Qs = smem + wv * wstride;
   float* Ks = Qs + LP * SD;
   float* Vs = Ks + LP * SD;
-  const float* base = a.qkv + (long)smp * a.Lq * ld + head * dh;
-  stage(Qs, base, ld, a.Lq, dh, LP, SD, lane);
-  stage(Ks, base + HD, ld, a.Lq, dh, LP, SD, lane);
-  stage(Vs, base + 2 * HD, ld, a.Lq, dh, LP, SD, lane);
-  __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): this wave's own LDS writes (no cross-wave sharing)
+  const int pair0 = blockIdx.x * 4, smp0 = pair0 / a.heads, head0 = pair0 - smp0 * a.heads;    // coop: the workgroup's 4 heads
+  if (coop) {
+    const float* base0 = a.qkv + (long)smp0 * a.Lq * ld + head0 * dh;
+    const float* const src[3] = {base0, base0 + HD, base0 + 2 * HD};
+    const int lds[3] = {ld, ld, ld};
+    stage4v<3, LP>(smem, wstride, src, lds, a.Lq, dh, SD, threadIdx.x);
+    __syncthreads();
+  }
+  if (pair >= a.n * a.heads) return;       // never taken on the coop path (n * heads is a multiple of 4 there)
+  const int smp = pair / a.heads, head = pair - smp * a.heads;
+  if (!coop) {
+    const float* base = a.qkv + (long)smp * a.Lq * ld + head * dh;
+    stage(Qs, base, ld, a.Lq, dh, LP, SD, lane);
+    stage(Ks, base + HD, ld, a.Lq, dh, LP, SD, lane);
+    stage(Vs, base + 2 * HD, ld, a.Lq, dh, LP, SD, lane);
+    __builtin_amdgcn_s_waitcnt(0xc07f);    // lgkmcnt(0): this wave's own LDS writes (no cross-wave sharing)
+  }
   f32x16 p[NB][NB];                        // p[jb][ib] = S^T block: rows keys, cols queries
   rows_dot<NB>(Ks, Qs, dh, SD, lane, p);
-  // ---- key mask + softmax over keys (rows) for this lane's query column(s)
-#pragma unroll
-  for (int ib = 0; ib < NB; ++ib) {
-    float m = -INFINITY;
-#pragma unroll
-    for (int jb = 0; jb < NB; ++jb)
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int j = jb * 32 + acc_row(reg, half);
-        float s = p[jb][ib][reg] * a.scale;
-        if (j >= a.Lq) s = -INFINITY;
-        else if (a.mask && !a.mask[(long)smp * a.Lq + j]) s = -1e9f;
-        p[jb][ib][reg] = s;
-        m = fmaxf(m, s);
-      }
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
-    float sum = 0.f;
-#pragma unroll
-    for (int jb = 0; jb < NB; ++jb)
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const float e = expf(p[jb][ib][reg] - m);
-        p[jb][ib][reg] = e;
-        sum += e;
-      }
-    sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.f / sum;
-#pragma unroll
-    for (int jb = 0; jb < NB; ++jb)
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) p[jb][ib][reg] *= inv;
-  }
+  softmax_T<NB>(p, a, key_bits(a, smp, lane), half);
   if (a.prob) {
     float* pp = a.prob + (long)pair * (NB * NB * 1024);
 #pragma unroll
@@ -148,30 +230,48 @@ __global__ __launch_bounds__(256) void mhsa_fwd_kernel(MhsaArgs a) {
   }
   f32x16 o[NB];
   acc_as_b<NB>(Vs, p, dh, SD, lane, o);
-  store_T<NB>(a.out + (long)smp * a.Lq * HD + head * dh, HD, o, a.Lq, dh, lane);
+  if (coop) {                              // O -> this wave's Q tile (free since the score product) -> 320-B row segments
+    tile_T<NB>(Qs, SD, o, dh, lane);
+    __syncthreads();
+    unstage4v<LP>(smem, wstride, a.out + (long)smp0 * a.Lq * HD + head0 * dh, HD, a.Lq, dh, SD, threadIdx.x);
+  } else {
+    store_T<NB>(a.out + (long)smp * a.Lq * HD + head * dh, HD, o, a.Lq, dh, lane);
+  }
 }
 
 template <int NB>
-__global__ __launch_bounds__(256) void mhsa_bwd_kernel(MhsaArgs a) {
+__global__ __launch_bounds__(256) void mhsa_bwd_kernel(MhsaArgs a, int coop) {
   constexpr int LP = 32 * NB, ST = LP + 1;
   extern __shared__ float smem[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l31 = lane & 31, half = lane >> 5;
   const int pair = blockIdx.x * (blockDim.x >> 6) + wv;
-  if (pair >= a.n * a.heads) return;
-  const int smp = pair / a.heads, head = pair - smp * a.heads;
   const int dh = a.dh, SD = dh | 1, HD = a.heads * dh, ld = 3 * HD;
-  float* Qs = smem + wv * (4 * LP * SD + LP * ST);
+  const int wstride = 4 * LP * SD + LP * ST;
+  float* Qs = smem + wv * wstride;
   float* Ks = Qs + LP * SD;
   float* Vs = Ks + LP * SD;
   float* Gs = Vs + LP * SD;                // dO
   float* T = Gs + LP * SD;                 // [LP][ST] transpose tile
-  const float* base = a.qkv + (long)smp * a.Lq * ld + head * dh;
-  stage(Qs, base, ld, a.Lq, dh, LP, SD, lane);
-  stage(Ks, base + HD, ld, a.Lq, dh, LP, SD, lane);
-  stage(Vs, base + 2 * HD, ld, a.Lq, dh, LP, SD, lane);
-  stage(Gs, a.dout + (long)smp * a.Lq * HD + head * dh, HD, a.Lq, dh, LP, SD, lane);
+  const int pair0 = blockIdx.x * 4, smp0 = pair0 / a.heads, head0 = pair0 - smp0 * a.heads;
+  if (coop) {
+    const float* base0 = a.qkv + (long)smp0 * a.Lq * ld + head0 * dh;
+    const float* const src[4] = {base0, base0 + HD, base0 + 2 * HD, a.dout + (long)smp0 * a.Lq * HD + head0 * dh};
+    const int lds[4] = {ld, ld, ld, HD};
+    stage4v<4, LP>(smem, wstride, src, lds, a.Lq, dh, SD, threadIdx.x);
+    __syncthreads();
+  }
+  if (pair >= a.n * a.heads) return;
+  const int smp = pair / a.heads, head = pair - smp * a.heads;
+  if (!coop) {
+    const float* base = a.qkv + (long)smp * a.Lq * ld + head * dh;
+    stage(Qs, base, ld, a.Lq, dh, LP, SD, lane);
+    stage(Ks, base + HD, ld, a.Lq, dh, LP, SD, lane);
+    stage(Vs, base + 2 * HD, ld, a.Lq, dh, LP, SD, lane);
+    stage(Gs, a.dout + (long)smp * a.Lq * HD + head * dh, HD, a.Lq, dh, LP, SD, lane);
+  }
   f32x16 p[NB][NB], dp[NB][NB];
-  {
+  const unsigned long long live = key_bits(a, smp, lane);
+  if (a.prob) {
     const float* pp = a.prob + (long)pair * (NB * NB * 1024);
 #pragma unroll
     for (int jb = 0; jb < NB; ++jb)
@@ -179,8 +279,13 @@ __global__ __launch_bounds__(256) void mhsa_bwd_kernel(MhsaArgs a) {
       for (int ib = 0; ib < NB; ++ib)
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) p[jb][ib][reg] = pp[((jb * NB + ib) * 16 + reg) * 64 + lane];
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+  } else {
+    // recompute P^T from Q, K: one more 32 x 32 x dh product + softmax instead of 4 KB of HBM traffic each way per head
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    rows_dot<NB>(Ks, Qs, dh, SD, lane, p);
+    softmax_T<NB>(p, a, live, half);
   }
-  __builtin_amdgcn_s_waitcnt(0xc07f);
   // P^T -> LDS tile (rows keys j, cols queries i) for dV = P^T dO
 #pragma unroll
   for (int jb = 0; jb < NB; ++jb)
@@ -190,8 +295,8 @@ __global__ __launch_bounds__(256) void mhsa_bwd_kernel(MhsaArgs a) {
       for (int reg = 0; reg < 16; ++reg) T[(jb * 32 + acc_row(reg, half)) * ST + ib * 32 + l31] = p[jb][ib][reg];
   __builtin_amdgcn_s_waitcnt(0xc07f);
   float* dbase = a.dqkv + (long)smp * a.Lq * ld + head * dh;
-  // generic: R[x][d] = sum_i T[x][i] * Y[i][d]   (rows x = keys, reduce over queries i)
-  auto t_times = [&](const float* Y, float* dst) {
+  // generic: R[x][d] = sum_i T[x][i] * Y[i][d]   (rows x = keys, reduce over queries i); rows go to dst[x*dld + d]
+  auto t_times = [&](const float* Y, float* dst, int dld) {
 #pragma unroll
     for (int xb = 0; xb < NB; ++xb) {
       f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -205,14 +310,16 @@ __global__ __launch_bounds__(256) void mhsa_bwd_kernel(MhsaArgs a) {
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
           const int j = xb * 32 + acc_row(reg, half);
-          if (j < a.Lq) dst[(long)j * ld + l31] = acc[reg];
+          if (j < a.Lq) dst[(long)j * dld + l31] = acc[reg];
         }
       }
     }
   };
-  t_times(Gs, dbase + 2 * HD);             // dV
-  // dP^T = V dO^T ;  dS^T = P^T * (dP^T - delta_i) * scale
+  // dP^T = V dO^T first: afterwards the V tile is free and takes dV (coop path: results leave through LDS as row segments)
   rows_dot<NB>(Vs, Gs, dh, SD, lane, dp);
+  if (coop) t_times(Gs, Vs, SD);           // dV (LDS ops of one wave execute in order: the reads of V above are done)
+  else t_times(Gs, dbase + 2 * HD, ld);
+  // dS^T = P^T * (dP^T - delta_i) * scale
 #pragma unroll
   for (int ib = 0; ib < NB; ++ib) {
     float delta = 0.f;
@@ -228,14 +335,15 @@ __global__ __launch_bounds__(256) void mhsa_bwd_kernel(MhsaArgs a) {
         // masked_fill(mask == 0, -1e9) makes the score a constant: no gradient reaches Q/K through a masked key.  P is
         // exactly 0 there except when EVERY key of the sample is masked (uniform softmax) -- that case needs the explicit zero.
         const int j = jb * 32 + acc_row(reg, half);
-        const bool dead = a.mask && j < a.Lq && !a.mask[(long)smp * a.Lq + j];
+        const bool dead = j < a.Lq && !((live >> j) & 1);
         dp[jb][ib][reg] = dead ? 0.f : p[jb][ib][reg] * (dp[jb][ib][reg] - delta) * a.scale;
       }
   }
   // dQ^T[k][i] = sum_j K[j][k] dS^T[j][i]  (register operand)
   f32x16 dq[NB];
   acc_as_b<NB>(Ks, dp, dh, SD, lane, dq);
-  store_T<NB>(dbase, ld, dq, a.Lq, dh, lane);
+  if (coop) tile_T<NB>(Gs, SD, dq, dh, lane);            // the dO tile is free now
+  else store_T<NB>(dbase, ld, dq, a.Lq, dh, lane);
   // dK = dS^T Q through the LDS tile
   __builtin_amdgcn_s_waitcnt(0xc07f);
 #pragma unroll
@@ -245,7 +353,16 @@ __global__ __launch_bounds__(256) void mhsa_bwd_kernel(MhsaArgs a) {
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) T[(jb * 32 + acc_row(reg, half)) * ST + ib * 32 + l31] = dp[jb][ib][reg];
   __builtin_amdgcn_s_waitcnt(0xc07f);
-  t_times(Qs, dbase + HD);
+  if (coop) {
+    t_times(Qs, Ks, SD);                   // dK into the K tile (its last reader was the dQ product)
+    __syncthreads();
+    float* d0 = a.dqkv + (long)smp0 * a.Lq * ld + head0 * dh;
+    unstage4v<LP>(smem + 3 * LP * SD, wstride, d0, ld, a.Lq, dh, SD, threadIdx.x);            // dQ
+    unstage4v<LP>(smem + 1 * LP * SD, wstride, d0 + HD, ld, a.Lq, dh, SD, threadIdx.x);       // dK
+    unstage4v<LP>(smem + 2 * LP * SD, wstride, d0 + 2 * HD, ld, a.Lq, dh, SD, threadIdx.x);   // dV
+  } else {
+    t_times(Qs, dbase + HD, ld);
+  }
 }
 
 }  // namespace
@@ -257,25 +374,27 @@ extern "C" int nnr_mhsa_fwd(const float* qkv, const uint8_t* mask, int n, int Lq
   MhsaArgs a{qkv, mask, n, Lq, heads, dh, scale, out, prob, nullptr, nullptr};
   const int NB = Lq > 32 ? 2 : 1, LP = 32 * NB, SD = dh | 1;
   const int waves = 4;
+  const int coop = (heads % 4 == 0 && dh % 4 == 0) ? 1 : 0;        // a workgroup's 4 waves then are 4 adjacent heads of one sample
   const size_t shm = (size_t)waves * 3 * LP * SD * sizeof(float);
   const int blocks = (n * heads + waves - 1) / waves;
-  if (NB == 1) hipLaunchKernelGGL((mhsa_fwd_kernel<1>), dim3(blocks), dim3(64 * waves), shm, stream, a);
-  else hipLaunchKernelGGL((mhsa_fwd_kernel<2>), dim3(blocks), dim3(64 * waves), shm, stream, a);
+  if (NB == 1) hipLaunchKernelGGL((mhsa_fwd_kernel<1>), dim3(blocks), dim3(64 * waves), shm, stream, a, coop);
+  else hipLaunchKernelGGL((mhsa_fwd_kernel<2>), dim3(blocks), dim3(64 * waves), shm, stream, a, coop);
   NNR_CHECK_LAUNCH();
   return NNR_OK;
 }
 
 extern "C" int nnr_mhsa_bwd(const float* qkv, const uint8_t* mask, const float* prob, const float* dout, int n, int Lq, int heads, int dh,
                             float scale, float* dqkv, hipStream_t stream) {
-  if (!qkv || !prob || !dout || !dqkv || n <= 0) return NNR_ERR_ARG;
+  if (!qkv || !dout || !dqkv || n <= 0) return NNR_ERR_ARG;         // prob == NULL: P is recomputed from Q, K
   if (Lq > 64 || dh > 32 || (dh & 1)) return NNR_ERR_UNSUPPORTED;
   MhsaArgs a{qkv, mask, n, Lq, heads, dh, scale, nullptr, const_cast<float*>(prob), dout, dqkv};
   const int NB = Lq > 32 ? 2 : 1, LP = 32 * NB, SD = dh | 1;
   const int waves = NB == 1 ? 4 : 1;
+  const int coop = (waves == 4 && heads % 4 == 0 && dh % 4 == 0) ? 1 : 0;
   const size_t shm = (size_t)waves * (4 * LP * SD + LP * (LP + 1)) * sizeof(float);
   const int blocks = (n * heads + waves - 1) / waves;
-  if (NB == 1) hipLaunchKernelGGL((mhsa_bwd_kernel<1>), dim3(blocks), dim3(64 * waves), shm, stream, a);
-  else hipLaunchKernelGGL((mhsa_bwd_kernel<2>), dim3(blocks), dim3(64 * waves), shm, stream, a);
+  if (NB == 1) hipLaunchKernelGGL((mhsa_bwd_kernel<1>), dim3(blocks), dim3(64 * waves), shm, stream, a, coop);
+  else hipLaunchKernelGGL((mhsa_bwd_kernel<2>), dim3(blocks), dim3(64 * waves), shm, stream, a, coop);
   NNR_CHECK_LAUNCH();
   return NNR_OK;
 }

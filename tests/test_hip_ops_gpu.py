@@ -484,8 +484,9 @@ def test_elementwise_and_optimizer():
 
 
 # ------------------------------------------------------------------------------------------------ MFMA attention core
-@pytest.mark.parametrize('n,Lq,heads,dh', [(7, 32, 20, 20), (5, 50, 20, 20), (3, 5, 2, 4)])
-def test_mhsa_core_forward_backward(n, Lq, heads, dh):
+@pytest.mark.parametrize('saved_prob', [True, False])
+@pytest.mark.parametrize('n,Lq,heads,dh', [(7, 32, 20, 20), (5, 50, 20, 20), (3, 5, 2, 4), (2, 20, 4, 8), (3, 17, 6, 10)])
+def test_mhsa_core_forward_backward(n, Lq, heads, dh, saved_prob):
     from nnr_amd import ops
     d = dev()
     HD = heads * dh
@@ -501,7 +502,7 @@ def test_mhsa_core_forward_backward(n, Lq, heads, dh):
     dout = rnd(n * Lq, HD, seed=3)
     (ref * dout.double()).sum().backward()
     out = torch.empty(n * Lq, HD, device=d)
-    prob = torch.empty(ops.mhsa_prob_size(n, Lq, heads), device=d)
+    prob = torch.empty(ops.mhsa_prob_size(n, Lq, heads), device=d) if saved_prob else None     # None: backward recomputes P
     qd = qkv.to(d)
     ops.mhsa_fwd(qd, mask.to(d), n, Lq, heads, dh, out, prob)
     close(out, ref, what='mhsa out')
