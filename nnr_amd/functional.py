@@ -57,7 +57,19 @@ class LinearFn(torch.autograd.Function):
 
 
 class QKVFn(torch.autograd.Function):
-    """[Q | K | V] = x W_{Q,K,V}^T + b  into one [M, 3*h*d] buffer (layers.py:134-136)."""
+    """[Q | K | V] = x W_{Q,K,V}^T + b  into one [M, 3*h*d] buffer (layers.py:134-136).  When the three weights sit back to
+    back in the flat parameter buffer (trainer.FlatParams honours MultiHeadAttention.adjacent_parameter_groups) they ARE one
+    [3*h*d, d_model] matrix: one GEMM forward, one K = 3*h*d GEMM for dX (no read-modify-write of dX), one for dW, one bias
+    reduction.  Otherwise (module used on its own) the same three-GEMM sequence per projection."""
+
+    @staticmethod
+    def _stacked(mha, grads=False):
+        from .layers import stacked_view
+        ws, bs = (mha.W_Q.weight, mha.W_K.weight, mha.W_V.weight), (mha.W_Q.bias, mha.W_K.bias, mha.W_V.bias)
+        if grads:
+            ws, bs = [grad_of(w) for w in ws], [grad_of(b) for b in bs]
+        w, b = stacked_view(ws), stacked_view(bs)
+        return (w, b) if w is not None and b is not None else (None, None)
 
     @staticmethod
     def forward(ctx, x, mha):
@@ -65,8 +77,12 @@ class QKVFn(torch.autograd.Function):
         M, K = x.shape
         HD = mha.W_Q.weight.shape[0]
         qkv = torch.empty((M, 3 * HD), device=x.device, dtype=torch.float32)
-        for s, lin in enumerate((mha.W_Q, mha.W_K, mha.W_V)):
-            ops.gemm(x, lin.weight, qkv[:, s * HD:], M=M, N=HD, K=K, lda=K, ldb=K, ldc=3 * HD, bias=lin.bias)
+        w, b = QKVFn._stacked(mha)
+        if w is not None:
+            ops.gemm(x, w, qkv, M=M, N=3 * HD, K=K, lda=K, ldb=K, ldc=3 * HD, bias=b)
+        else:
+            for s, lin in enumerate((mha.W_Q, mha.W_K, mha.W_V)):
+                ops.gemm(x, lin.weight, qkv[:, s * HD:], M=M, N=HD, K=K, lda=K, ldb=K, ldc=3 * HD, bias=lin.bias)
         ctx.x, ctx.mha, ctx.HD = x, mha, HD
         return qkv
 
@@ -76,6 +92,14 @@ class QKVFn(torch.autograd.Function):
         x, mha, HD = ctx.x, ctx.mha, ctx.HD
         M, K = x.shape
         dx = torch.empty_like(x)
+        w, _ = QKVFn._stacked(mha)
+        gw, gb = QKVFn._stacked(mha, grads=True) if w is not None else (None, None)
+        if gw is not None:
+            ops.gemm(dqkv, w, dx, M=M, N=K, K=3 * HD, lda=3 * HD, ldb=K, ldc=K, trans_b=True)
+            ops.gemm(dqkv, x, gw, M=3 * HD, N=K, K=M, lda=3 * HD, ldb=K, ldc=K, trans_a=True, trans_b=True,
+                     split_k=ops.split_for(3 * HD, K, M), atomic=True)
+            ops.bias_grad(dqkv, gb, rows=M)
+            return dx, None
         for s, lin in enumerate((mha.W_Q, mha.W_K, mha.W_V)):
             d = dqkv[:, s * HD:]
             ops.gemm(d, lin.weight, dx, M=M, N=K, K=HD, lda=3 * HD, ldb=K, ldc=K, trans_b=True, accumulate=(s > 0))

@@ -23,6 +23,22 @@ def grad_of(p):
     return p.grad
 
 
+def stacked_view(ts):
+    """One [len(ts)*rows, ...] view over tensors that sit back to back in the same storage (see adjacent_parameter_groups),
+    or None when they do not (a model that was not re-homed by the trainer: the callers then take the per-tensor path)."""
+    t0 = ts[0]
+    if not t0.is_contiguous():
+        return None
+    step = t0.numel()
+    for i, t in enumerate(ts):
+        if t.shape != t0.shape or not t.is_contiguous() or t.untyped_storage().data_ptr() != t0.untyped_storage().data_ptr() \
+                or t.storage_offset() != t0.storage_offset() + i * step:
+            return None
+    shape = (len(ts) * t0.shape[0],) + tuple(t0.shape[1:])
+    stride = t0.stride()
+    return t0.as_strided(shape, stride)
+
+
 class LSTMParams(nn.Module):
     """Parameter holder with nn.LSTM(bidirectional=True, num_layers=1) names/shapes/default init (newsEncoders.py:66-67)."""
 
@@ -125,6 +141,14 @@ class MultiHeadAttention(nn.Module):
         nn.init.zeros_(self.W_K.bias)
         nn.init.xavier_uniform_(self.W_V.weight)
         nn.init.zeros_(self.W_V.bias)
+
+    def adjacent_parameter_groups(self):
+        """Parameters the flat buffer (trainer.FlatParams) should lay out back to back, in this order: the three projection
+        weights then form ONE [3*h*d, d_model] matrix (and the biases one vector) without any copy, and functional.QKVFn runs
+        one GEMM per direction instead of three.  Names, shapes and the state_dict stay the reference's."""
+        if self.W_Q.weight.shape != self.W_K.weight.shape or self.W_Q.weight.shape != self.W_V.weight.shape:
+            return []
+        return [[self.W_Q.weight, self.W_K.weight, self.W_V.weight], [self.W_Q.bias, self.W_K.bias, self.W_V.bias]]
 
 
 class Conv1D(nn.Module):

@@ -16,6 +16,16 @@ class FlatParams:
 
     def __init__(self, model: nn.Module):
         params = [p for p in model.parameters() if p.requires_grad]          # nn.Module dedups the shared news encoder
+        # groups a module wants back to back (MultiHeadAttention: W_Q | W_K | W_V as one matrix) go first, in group order;
+        # group members are multiples of 4 floats or the padding below would separate them (then the fused view is simply
+        # not formed and the per-tensor path runs)
+        grouped, seen = [], set()
+        for m in model.modules():
+            for g in getattr(m, 'adjacent_parameter_groups', lambda: [])():
+                if all(q.requires_grad and id(q) not in seen for q in g):
+                    grouped += g
+                    seen.update(id(q) for q in g)
+        params = grouped + [p for p in params if id(p) not in seen]
         self.params = params
         offs, total = [], 0
         for p in params:
