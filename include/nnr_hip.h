@@ -180,11 +180,13 @@ int nnr_relu_drop_bwd(const float* dy, const float* r, float* ds, float* dx, lon
  * MultiHeadAttention.forward after the W_Q/W_K/W_V projections (layers.py:137-147) on v_mfma_f32_32x32x2_f32:
  * qkv [n*Lq, 3*heads*dh] = [Q | K | V] (head h at columns h*dh), key mask [n, Lq] (0 -> -1e9) or NULL, scale = 1/sqrt(dh);
  * out [n*Lq, heads*dh]; prob [n*heads, NB*NB*1024] (NB = 1 for Lq <= 32, 2 for Lq <= 64) saved for backward, or NULL in
- * both calls: backward then recomputes the probabilities from Q, K (the product path does this). */
+ * both calls: backward then recomputes the probabilities from Q, K (the product path does this).
+ * drop_p > 0 fuses the dropout that follows the attention (newsEncoders.py:196): out = nnr_dropout(O, drop_p, seed) bit for bit
+ * (mask = f(seed, flat index in out)), and backward applies the same mask to dout while staging it. */
 int nnr_mhsa_fwd(const float* qkv, const uint8_t* mask, int n, int Lq, int heads, int dh, float scale, float* out, float* prob,
-                 hipStream_t stream);
+                 float drop_p, uint32_t seed, hipStream_t stream);
 int nnr_mhsa_bwd(const float* qkv, const uint8_t* mask, const float* prob, const float* dout, int n, int Lq, int heads, int dh,
-                 float scale, float* dqkv, hipStream_t stream);
+                 float scale, float* dqkv, float drop_p, uint32_t seed, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------ SUE (userEncoders.py:68-98) */
 int nnr_sue_x0_fwd(const float* hist, const float* proxy, float* x0, int B, int Hn, int Kc, int D, float p, uint32_t seed,

@@ -23,7 +23,8 @@ __device__ __forceinline__ int acc_row(int reg, int half) { return (reg & 3) + 8
 struct MhsaArgs {
   const float* qkv; const uint8_t* mask; int n, Lq, heads, dh; float scale;
   float* out; float* prob; const float* dout; float* dqkv;
-};
+  uint32_t seed, thr; float dscale;        // dropout on the attention output (thr == 0: off): out = keep(idx) ? O * dscale : 0
+};                                         // with idx = the flat element index in out / dout [n*Lq, heads*dh]
 
 // stage the [Lq, dh] slice (row stride ld) of one head into LDS as [LP][SD], zero rows >= Lq
 __device__ __forceinline__ void stage(float* dst, const float* src, int ld, int Lq, int dh, int LP, int SD, int lane) {
@@ -33,13 +34,28 @@ __device__ __forceinline__ void stage(float* dst, const float* src, int ld, int 
   }
 }
 
+// the same for the upstream gradient: dO = keep(idx) ? dout * dscale : 0   (e0 = flat index of src[0] in dout)
+__device__ __forceinline__ void stage_drop(float* dst, const float* src, long e0, int ld, int Lq, int dh, int LP, int SD, int lane,
+                                           const MhsaArgs& a) {
+  for (int idx = lane; idx < LP * dh; idx += 64) {
+    const int q = idx / dh, d = idx - q * dh;
+    float v = 0.f;
+    if (q < Lq) {
+      v = src[(long)q * ld + d];
+      if (a.thr) v = nnr_keep(a.seed, (uint64_t)(e0 + (long)q * ld + d), a.thr) ? v * a.dscale : 0.f;
+    }
+    dst[q * SD + d] = v;
+  }
+}
+
 // Cooperative path (heads % 4 == 0, dh % 4 == 0): the 4 waves of a workgroup own 4 CONSECUTIVE heads of one sample, whose
 // slices are adjacent in memory, so the workgroup moves [Lq] row segments of 4*dh contiguous floats (320 B at dh = 20) as
 // float4 -- ALL loads of all NMAT matrices are issued before the first LDS write, so a wave pays the HBM latency once
 // instead of once per loop trip -- and scatters them into the per-wave tiles (tile m of wave w at w*wstride + m*LP*SD).
-template <int NMAT, int LP>
+// DM >= 0: matrix DM is the upstream gradient and gets the dropout mask (e0 = flat index of src[DM][0] in dout).
+template <int NMAT, int LP, int DM = -1>
 __device__ __forceinline__ void stage4v(float* smem, int wstride, const float* const (&src)[NMAT], const int (&ld)[NMAT],
-                                        int Lq, int dh, int SD, int tid) {
+                                        int Lq, int dh, int SD, int tid, const MhsaArgs* a = nullptr, long e0 = 0) {
   const int n4 = LP * dh;                  // float4 per matrix: LP rows x (4 heads * dh / 4)
   constexpr int U = 3;
   for (int b0 = 0; b0 < n4; b0 += 256 * U) {
@@ -51,6 +67,13 @@ __device__ __forceinline__ void stage4v(float* smem, int wstride, const float* c
 #pragma unroll
       for (int m = 0; m < NMAT; ++m)
         r[m][u] = live ? *(const float4*)(src[m] + (long)q * ld[m] + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (DM >= 0 && a->thr && live) {
+        bool k[4];
+        nnr_keep4(a->seed, (uint64_t)(e0 + (long)q * ld[DM >= 0 ? DM : 0] + 4 * c4), a->thr, k);
+        float4& v = r[DM >= 0 ? DM : 0][u];
+        v.x = k[0] ? v.x * a->dscale : 0.f; v.y = k[1] ? v.y * a->dscale : 0.f;
+        v.z = k[2] ? v.z * a->dscale : 0.f; v.w = k[3] ? v.w * a->dscale : 0.f;
+      }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -67,13 +90,21 @@ __device__ __forceinline__ void stage4v(float* smem, int wstride, const float* c
 }
 
 // the reverse: per-wave result tiles [LP][SD] (rows = sequence position) -> [Lq] row segments of 4*dh floats, float4 stores
-template <int LP>
-__device__ __forceinline__ void unstage4v(const float* tile0, int wstride, float* dst, int ld, int Lq, int dh, int SD, int tid) {
+template <int LP, bool DROP = false>
+__device__ __forceinline__ void unstage4v(const float* tile0, int wstride, float* dst, int ld, int Lq, int dh, int SD, int tid,
+                                          const MhsaArgs* a = nullptr, long e0 = 0) {
   const int n4 = Lq * dh;
   for (int idx = tid; idx < n4; idx += 256) {
     const int q = idx / dh, c = 4 * (idx - q * dh), w = c / dh, d = c - w * dh;
     const float* t = tile0 + w * wstride + q * SD + d;
-    *(float4*)(dst + (long)q * ld + c) = make_float4(t[0], t[1], t[2], t[3]);
+    float4 v = make_float4(t[0], t[1], t[2], t[3]);
+    if (DROP && a->thr) {
+      bool k[4];
+      nnr_keep4(a->seed, (uint64_t)(e0 + (long)q * ld + c), a->thr, k);
+      v.x = k[0] ? v.x * a->dscale : 0.f; v.y = k[1] ? v.y * a->dscale : 0.f;
+      v.z = k[2] ? v.z * a->dscale : 0.f; v.w = k[3] ? v.w * a->dscale : 0.f;
+    }
+    *(float4*)(dst + (long)q * ld + c) = v;
   }
 }
 
@@ -233,9 +264,20 @@ __global__ __launch_bounds__(256) void mhsa_fwd_kernel(MhsaArgs a, int coop) {
   if (coop) {                              // O -> this wave's Q tile (free since the score product) -> 320-B row segments
     tile_T<NB>(Qs, SD, o, dh, lane);
     __syncthreads();
-    unstage4v<LP>(smem, wstride, a.out + (long)smp0 * a.Lq * HD + head0 * dh, HD, a.Lq, dh, SD, threadIdx.x);
+    const long e0 = (long)smp0 * a.Lq * HD + head0 * dh;
+    unstage4v<LP, true>(smem, wstride, a.out + e0, HD, a.Lq, dh, SD, threadIdx.x, &a, e0);
   } else {
-    store_T<NB>(a.out + (long)smp * a.Lq * HD + head * dh, HD, o, a.Lq, dh, lane);
+    const long e0 = (long)smp * a.Lq * HD + head * dh;
+    if (a.thr) {
+#pragma unroll
+      for (int ib = 0; ib < NB; ++ib)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const long e = e0 + (long)(ib * 32 + (lane & 31)) * HD + acc_row(reg, half);
+          o[ib][reg] = nnr_keep(a.seed, (uint64_t)e, a.thr) ? o[ib][reg] * a.dscale : 0.f;
+        }
+    }
+    store_T<NB>(a.out + e0, HD, o, a.Lq, dh, lane);
   }
 }
 
@@ -257,7 +299,7 @@ __global__ __launch_bounds__(256) void mhsa_bwd_kernel(MhsaArgs a, int coop) {
     const float* base0 = a.qkv + (long)smp0 * a.Lq * ld + head0 * dh;
     const float* const src[4] = {base0, base0 + HD, base0 + 2 * HD, a.dout + (long)smp0 * a.Lq * HD + head0 * dh};
     const int lds[4] = {ld, ld, ld, HD};
-    stage4v<4, LP>(smem, wstride, src, lds, a.Lq, dh, SD, threadIdx.x);
+    stage4v<4, LP, 3>(smem, wstride, src, lds, a.Lq, dh, SD, threadIdx.x, &a, (long)smp0 * a.Lq * HD + head0 * dh);
     __syncthreads();
   }
   if (pair >= a.n * a.heads) return;
@@ -267,7 +309,7 @@ __global__ __launch_bounds__(256) void mhsa_bwd_kernel(MhsaArgs a, int coop) {
     stage(Qs, base, ld, a.Lq, dh, LP, SD, lane);
     stage(Ks, base + HD, ld, a.Lq, dh, LP, SD, lane);
     stage(Vs, base + 2 * HD, ld, a.Lq, dh, LP, SD, lane);
-    stage(Gs, a.dout + (long)smp * a.Lq * HD + head * dh, HD, a.Lq, dh, LP, SD, lane);
+    stage_drop(Gs, a.dout + (long)smp * a.Lq * HD + head * dh, (long)smp * a.Lq * HD + head * dh, HD, a.Lq, dh, LP, SD, lane, a);
   }
   f32x16 p[NB][NB], dp[NB][NB];
   const unsigned long long live = key_bits(a, smp, lane);
@@ -368,10 +410,11 @@ __global__ __launch_bounds__(256) void mhsa_bwd_kernel(MhsaArgs a, int coop) {
 }  // namespace
 
 extern "C" int nnr_mhsa_fwd(const float* qkv, const uint8_t* mask, int n, int Lq, int heads, int dh, float scale, float* out,
-                            float* prob, hipStream_t stream) {
+                            float* prob, float drop_p, uint32_t seed, hipStream_t stream) {
   if (!qkv || !out || n <= 0) return NNR_ERR_ARG;
   if (Lq > 64 || dh > 32 || (dh & 1)) return NNR_ERR_UNSUPPORTED;
-  MhsaArgs a{qkv, mask, n, Lq, heads, dh, scale, out, prob, nullptr, nullptr};
+  MhsaArgs a{qkv, mask, n, Lq, heads, dh, scale, out, prob, nullptr, nullptr, seed, nnr_drop_thresh(drop_p),
+             drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f};
   const int NB = Lq > 32 ? 2 : 1, LP = 32 * NB, SD = dh | 1;
   const int waves = 4;
   const int coop = (heads % 4 == 0 && dh % 4 == 0) ? 1 : 0;        // a workgroup's 4 waves then are 4 adjacent heads of one sample
@@ -384,10 +427,11 @@ extern "C" int nnr_mhsa_fwd(const float* qkv, const uint8_t* mask, int n, int Lq
 }
 
 extern "C" int nnr_mhsa_bwd(const float* qkv, const uint8_t* mask, const float* prob, const float* dout, int n, int Lq, int heads, int dh,
-                            float scale, float* dqkv, hipStream_t stream) {
+                            float scale, float* dqkv, float drop_p, uint32_t seed, hipStream_t stream) {
   if (!qkv || !dout || !dqkv || n <= 0) return NNR_ERR_ARG;         // prob == NULL: P is recomputed from Q, K
   if (Lq > 64 || dh > 32 || (dh & 1)) return NNR_ERR_UNSUPPORTED;
-  MhsaArgs a{qkv, mask, n, Lq, heads, dh, scale, nullptr, const_cast<float*>(prob), dout, dqkv};
+  MhsaArgs a{qkv, mask, n, Lq, heads, dh, scale, nullptr, const_cast<float*>(prob), dout, dqkv, seed, nnr_drop_thresh(drop_p),
+             drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f};
   const int NB = Lq > 32 ? 2 : 1, LP = 32 * NB, SD = dh | 1;
   const int waves = NB == 1 ? 4 : 1;
   const int coop = (waves == 4 && heads % 4 == 0 && dh % 4 == 0) ? 1 : 0;

@@ -110,23 +110,24 @@ class QKVFn(torch.autograd.Function):
 
 
 class MhsaCoreFn(torch.autograd.Function):
-    """softmax(mask(Q K^T / sqrt(d_k))) V per head on the MFMA kernel (layers.py:137-147)."""
+    """softmax(mask(Q K^T / sqrt(d_k))) V per head on the MFMA kernel (layers.py:137-147); p > 0 also applies the dropout
+    that follows it (newsEncoders.py:196) in the kernel's output stage, same mask as DropoutFn(p, seed)."""
 
     @staticmethod
-    def forward(ctx, qkv, mask, n, Lq, heads, dh):
+    def forward(ctx, qkv, mask, n, Lq, heads, dh, p=0.0, seed=0):
         qkv = qkv.contiguous()
         out = torch.empty((n * Lq, heads * dh), device=qkv.device, dtype=torch.float32)
         # the probabilities are not saved: backward recomputes them from Q, K (4 KB per head less HBM traffic each way)
-        ops.mhsa_fwd(qkv, mask, n, Lq, heads, dh, out, None)
-        ctx.qkv, ctx.prob, ctx.mask, ctx.dims = qkv, None, mask, (n, Lq, heads, dh)
+        ops.mhsa_fwd(qkv, mask, n, Lq, heads, dh, out, None, p, seed)
+        ctx.qkv, ctx.prob, ctx.mask, ctx.dims, ctx.drop = qkv, None, mask, (n, Lq, heads, dh), (p, seed)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         n, Lq, heads, dh = ctx.dims
         dqkv = torch.empty_like(ctx.qkv)
-        ops.mhsa_bwd(ctx.qkv, ctx.mask, ctx.prob, dout.contiguous(), n, Lq, heads, dh, dqkv)
-        return dqkv, None, None, None, None, None
+        ops.mhsa_bwd(ctx.qkv, ctx.mask, ctx.prob, dout.contiguous(), n, Lq, heads, dh, dqkv, *ctx.drop)
+        return dqkv, None, None, None, None, None, None, None
 
 
 class DropoutFn(torch.autograd.Function):

@@ -513,8 +513,7 @@ class MHSA(NewsEncoder):
         mask = title_mask.view(n, Lx)
         w = Fn.EmbedDropFn.apply(self.word_embedding.weight, title_text, p, seed + 1)                       # [n*L, E]
         qkv = Fn.QKVFn.apply(w, self.multiheadAttention)
-        c = Fn.MhsaCoreFn.apply(qkv, mask, n, Lx, self.head_num, self.head_dim)                             # [n*L, h*d]
-        c = Fn.DropoutFn.apply(c, p, seed + 2)
+        c = Fn.MhsaCoreFn.apply(qkv, mask, n, Lx, self.head_num, self.head_dim, p, seed + 2)                # [n*L, h*d], dropout fused
         rep = self.attention(c.view(n, Lx, self.feature_dim), mask)                                         # [n, h*d]
         return Fn.FuseFn.apply(rep, self, category, subCategory, p, seed).view(B, N, self.news_embedding_dim)
 

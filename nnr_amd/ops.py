@@ -471,18 +471,19 @@ def clip_adam(p, g, m, v, sumsq_buf, grad_scale, clip, lr, beta1, beta2, eps, wd
             'nnr_clip_adam')
 
 
-def mhsa_fwd(qkv, mask, n, Lq, heads, dh, out, prob):
+def mhsa_fwd(qkv, mask, n, Lq, heads, dh, out, prob, p=0.0, seed=0):
+    """p > 0: the dropout that follows the attention is applied in the output stage (== ops.dropout(out, p, seed))."""
     if mask is not None and mask.dtype == torch.bool:
         mask = mask.view(torch.uint8)
-    L.check(L.lib().nnr_mhsa_fwd(_p(qkv), _p(mask), n, Lq,
-                                 heads, dh, C.c_float(1.0 / math.sqrt(dh)), _p(out), _p(prob), _s()), 'nnr_mhsa_fwd')
+    L.check(L.lib().nnr_mhsa_fwd(_p(qkv), _p(mask), n, Lq, heads, dh, C.c_float(1.0 / math.sqrt(dh)), _p(out), _p(prob),
+                                 C.c_float(p), C.c_uint32(seed & 0xFFFFFFFF), _s()), 'nnr_mhsa_fwd')
 
 
-def mhsa_bwd(qkv, mask, prob, dout, n, Lq, heads, dh, dqkv):
+def mhsa_bwd(qkv, mask, prob, dout, n, Lq, heads, dh, dqkv, p=0.0, seed=0):
     if mask is not None and mask.dtype == torch.bool:
         mask = mask.view(torch.uint8)
-    L.check(L.lib().nnr_mhsa_bwd(_p(qkv), _p(mask), _p(prob), _p(dout), n, Lq, heads, dh, C.c_float(1.0 / math.sqrt(dh)), _p(dqkv), _s()),
-            'nnr_mhsa_bwd')
+    L.check(L.lib().nnr_mhsa_bwd(_p(qkv), _p(mask), _p(prob), _p(dout), n, Lq, heads, dh, C.c_float(1.0 / math.sqrt(dh)), _p(dqkv),
+                                 C.c_float(p), C.c_uint32(seed & 0xFFFFFFFF), _s()), 'nnr_mhsa_bwd')
 
 
 def mhsa_prob_size(n, Lq, heads):

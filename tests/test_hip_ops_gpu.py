@@ -509,6 +509,15 @@ def test_mhsa_core_forward_backward(n, Lq, heads, dh, saved_prob):
     dqkv = torch.full_like(qd, 3.0)
     ops.mhsa_bwd(qd, mask.to(d), prob, dout.to(d), n, Lq, heads, dh, dqkv)
     close(dqkv, x.grad, what='mhsa dqkv')
+    # fused dropout == the standalone dropout kernel on the output / on the upstream gradient, bit for bit
+    p_, seed = 0.2, 1234
+    out_d = torch.empty_like(out)
+    ops.mhsa_fwd(qd, mask.to(d), n, Lq, heads, dh, out_d, prob, p_, seed)
+    assert torch.equal(out_d, ops.dropout(out, p_, seed)), 'fused dropout (forward)'
+    dq1, dq2 = torch.empty_like(qd), torch.empty_like(qd)
+    ops.mhsa_bwd(qd, mask.to(d), prob, dout.to(d), n, Lq, heads, dh, dq1, p_, seed)
+    ops.mhsa_bwd(qd, mask.to(d), prob, ops.dropout(dout.to(d), p_, seed), n, Lq, heads, dh, dq2)
+    assert torch.equal(dq1, dq2), 'fused dropout (backward)'
 
 
 def test_embed_gather_scatter_and_transpose():
