@@ -169,7 +169,8 @@ __global__ void transpose2d_kernel(const float* __restrict__ in, float* __restri
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long c = i / rows, r = i - c * rows;             // consecutive threads -> consecutive r : coalesced writes
     const float v = in[r * cols + c];
-    out[i] = accumulate ? out[i] + v : v;
+    if (accumulate) atomicAdd(&out[i], v);                 // parameter gradients: two HIP streams may add concurrently
+    else out[i] = v;
   }
 }
 

@@ -49,10 +49,9 @@ class LinearFn(torch.autograd.Function):
             ops.relu_drop_bwd(dy, r, dz, None, ctx.p, ctx.seed)
         else:
             dz = dy
+        gw, gb, x = grad_of(ctx.weight), (grad_of(ctx.bias) if ctx.bias is not None else None), ctx.x
+        ops.leaf_deferred(dz.device, dz.shape[0], lambda: ops.linear_bwd_weight(dz, x, gw, db=gb), dz, x)
         dx = ops.linear_bwd_data(dz, ctx.weight)
-        ops.linear_bwd_weight(dz, ctx.x, grad_of(ctx.weight))
-        if ctx.bias is not None:
-            ops.bias_grad(dz, grad_of(ctx.bias))
         return dx, None, None, None, None, None
 
 
@@ -95,10 +94,11 @@ class QKVFn(torch.autograd.Function):
         w, _ = QKVFn._stacked(mha)
         gw, gb = QKVFn._stacked(mha, grads=True) if w is not None else (None, None)
         if gw is not None:
+            # dW (+ the bias gradient, fused into the same launch) is a leaf: own stream, joined at the end of the pass
+            ops.leaf_deferred(x.device, M, lambda: ops.gemm(dqkv, x, gw, M=3 * HD, N=K, K=M, lda=3 * HD, ldb=K, ldc=K, trans_a=True,
+                                                         trans_b=True, split_k=ops.split_for(3 * HD, K, M), atomic=True,
+                                                         colsum_out=gb), dqkv, x)
             ops.gemm(dqkv, w, dx, M=M, N=K, K=3 * HD, lda=3 * HD, ldb=K, ldc=K, trans_b=True)
-            ops.gemm(dqkv, x, gw, M=3 * HD, N=K, K=M, lda=3 * HD, ldb=K, ldc=K, trans_a=True, trans_b=True,
-                     split_k=ops.split_for(3 * HD, K, M), atomic=True)
-            ops.bias_grad(dqkv, gb, rows=M)
             return dx, None
         for s, lin in enumerate((mha.W_Q, mha.W_K, mha.W_V)):
             d = dqkv[:, s * HD:]
@@ -175,14 +175,18 @@ class Conv1dReluFn(torch.autograd.Function):
         M = n * Lx
         dz = ops.relu_bwd(dy.contiguous(), ctx.y)
         dx = torch.zeros_like(ctx.x)
-        dwt = torch.zeros_like(ctx.wt)
+        x, idxs, gw, gb = ctx.x, ctx.idxs, grad_of(ctx.conv.weight), grad_of(ctx.conv.bias)
+
+        def weight_grads():              # leaves (ops.leaf_deferred); the bias gradient rides on the first launch's A tiles
+            dwt = torch.zeros_like(ctx.wt)
+            for j in range(k):
+                ops.gemm(dz, x, dwt[j], M=Cn, N=E, K=M, lda=Cn, ldb=E, ldc=E, trans_a=True, trans_b=True, b_idx=idxs[j],
+                         split_k=ops.split_for(Cn, E, M), atomic=True, colsum_out=gb if j == 0 else None)
+            ops.transpose2d(dwt, gw, k, Cn * E, accumulate=True)
+        ops.leaf_deferred(dz.device, M, weight_grads, dz, x)
         for j in range(k):
             # dx[(i, t+dt)] += dz[(i,t)] . W_dt : scattered to the shifted row (a bijection on valid rows -> plain accumulate)
             ops.gemm(dz, ctx.wt[j], dx, M=M, N=E, K=Cn, lda=Cn, ldb=E, ldc=E, trans_b=True, c_idx=ctx.idxs[j], accumulate=True)
-            ops.gemm(dz, ctx.x, dwt[j], M=Cn, N=E, K=M, lda=Cn, ldb=E, ldc=E, trans_a=True, trans_b=True, b_idx=ctx.idxs[j],
-                     split_k=ops.split_for(Cn, E, M), atomic=True)
-        ops.transpose2d(dwt, grad_of(ctx.conv.weight), k, Cn * E, accumulate=True)
-        ops.bias_grad(dz, grad_of(ctx.conv.bias))
         return dx, None, None, None
 
 

@@ -85,8 +85,9 @@ class _AttentionFn(torch.autograd.Function):
         ds = torch.empty(n * Lx, **f32)
         ops.pool_bwd(x=x, ldx=F, D=F, n=n, Lx=Lx, mask=ctx.mask, alpha=alpha, dout=dout.contiguous(), lddo=F, dx=dx, lddx=F, dscore=ds)
         ops.tanh_score_bwd(th, ds, mod.affine2.weight, grad_of(mod.affine2.weight), None, A)
+        gw, gb = grad_of(mod.affine1.weight), grad_of(mod.affine1.bias)
+        ops.leaf_deferred(x.device, n * Lx, lambda: ops.linear_bwd_weight(th, x, gw, db=gb), th, x)      # leaf: own stream (ops.leaf_deferred)
         ops.gemm(th, mod.affine1.weight, dx, M=n * Lx, N=F, K=A, lda=A, ldb=F, ldc=F, trans_b=True, accumulate=True)
-        ops.linear_bwd_weight(th, x, grad_of(mod.affine1.weight), db=grad_of(mod.affine1.bias))
         return dx.view(n, Lx, F), None, None
 
 

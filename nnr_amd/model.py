@@ -98,6 +98,8 @@ class Model(nn.Module):
                                                                 user_history_category_mask, user_history_category_indices,
                                                                 news_representation)
         else:
+            # size class of this step for ops.leaf_deferred: the token rows of the history call
+            ops.STEP_ROWS[0] = user_title_text.shape[0] * user_title_text.shape[1] * user_title_text.shape[2]
             news_representation = self.news_encoder(news_title_text, news_title_mask, news_title_entity, news_content_text, news_content_mask,
                                                     news_content_entity, news_category, news_subCategory, user_embedding)
             user_representation = self.user_encoder(user_title_text, user_title_mask, user_title_entity, user_content_text, user_content_mask,

@@ -42,6 +42,7 @@ def _s():
 # not reusable until its event completes: the allocator then grows with hipMalloc and the step time turned bimodal,
 # 14 ms or 50-67 ms per step -- measured when the 2.7 GB gate buffer was recorded.)
 _LEAF = {}
+_NO_DEFER = os.environ.get('NNR_LEAF_DEFER', '1') == '0'
 EXTRA_STREAMS = []          # every HIP stream this package created (side, title, leaf): see join_extra_streams()
 
 
@@ -94,6 +95,44 @@ class leaf_scope:
         if self.enable:
             self.main.wait_stream(self.leaf)
         self.keep = []                   # (dropped on the host after the join was ENQUEUED: later main-stream work is ordered behind it)
+
+
+_DEFER = {'keep': [], 'queued': False}
+
+
+LEAF_MIN_ROWS = 49152       # defer only when the step is big enough to be GPU-bound (Model.forward posts the history call's token
+STEP_ROWS = [0]             # rows here) or the reduction itself is this long: on small, launch-latency-bound steps the cross-stream
+                            # dependencies cost more than the overlap gains (CNN+ATT at batch 16: 6 607 impressions/s inline vs
+                            # 5 156 deferred; MHSA+MHSA at batch 64: 10 596 inline vs 11 120 with every weight gradient deferred)
+
+
+def leaf_deferred(dev, rows, fn, *tensors):
+    """Inside an autograd backward function: run `fn` (a weight-gradient launch, atomic accumulation) on the leaf stream
+    behind the current stream's work, and join it when THIS backward pass ends (autograd's end-of-pass callback), so the data
+    gradient chain on the main stream does not wait for it.  `tensors` (the inputs fn reads) are held until that join.
+    NNR_LEAF_DEFER=0 runs fn inline."""
+    if _NO_DEFER or max(rows, STEP_ROWS[0]) < LEAF_MIN_ROWS:
+        fn()
+        return
+    key = (dev.type, dev.index)
+    if key not in _LEAF:
+        _LEAF[key] = new_stream(dev)
+    leaf, main = _LEAF[key], torch.cuda.current_stream(dev)
+    leaf.wait_stream(main)
+    _DEFER['keep'].extend(tensors)
+    with torch.cuda.stream(leaf):
+        fn()
+    if not _DEFER['queued']:
+        _DEFER['queued'] = True
+
+        def done():
+            main.wait_stream(leaf)
+            _DEFER['keep'].clear()
+            _DEFER['queued'] = False
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(done)
+        except RuntimeError:             # not inside a backward pass (a backward function called by hand): join right away
+            done()
 
 
 def split_for(m, n, k, tile_m=64, tile_n=80, target_blocks=2048, kmin=256):
