@@ -48,6 +48,44 @@ __device__ __forceinline__ void stage_drop(float* dst, const float* src, long e0
   }
 }
 
+// Per-wave variant of the batched float4 staging below (one head per wave, dh % 4 == 0): NMAT tiles of [LP][SD] from row
+// slices of dh floats; all loads of a batch are in flight before the first LDS write.  DM as in stage4v.
+template <int NMAT, int LP, int DM = -1>
+__device__ __forceinline__ void stage1v(float* tiles, const float* const (&src)[NMAT], const int (&ld)[NMAT], int Lq, int dh, int SD,
+                                        int lane, const MhsaArgs* a = nullptr, long e0 = 0) {
+  const int dh4 = dh >> 2, n4 = LP * dh4;
+  constexpr int U = 5;
+  for (int b0 = 0; b0 < n4; b0 += 64 * U) {
+    float4 r[NMAT][U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int idx = b0 + u * 64 + lane, q = idx / dh4, c4 = idx - q * dh4;
+      const bool live = idx < n4 && q < Lq;
+#pragma unroll
+      for (int m = 0; m < NMAT; ++m)
+        r[m][u] = live ? *(const float4*)(src[m] + (long)q * ld[m] + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (DM >= 0 && a->thr && live) {
+        bool k[4];
+        nnr_keep4(a->seed, (uint64_t)(e0 + (long)q * ld[DM >= 0 ? DM : 0] + 4 * c4), a->thr, k);
+        float4& v = r[DM >= 0 ? DM : 0][u];
+        v.x = k[0] ? v.x * a->dscale : 0.f; v.y = k[1] ? v.y * a->dscale : 0.f;
+        v.z = k[2] ? v.z * a->dscale : 0.f; v.w = k[3] ? v.w * a->dscale : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int idx = b0 + u * 64 + lane, q = idx / dh4, d = 4 * (idx - q * dh4);
+      if (idx < n4) {
+#pragma unroll
+        for (int m = 0; m < NMAT; ++m) {
+          float* t = tiles + m * LP * SD + q * SD + d;
+          t[0] = r[m][u].x; t[1] = r[m][u].y; t[2] = r[m][u].z; t[3] = r[m][u].w;
+        }
+      }
+    }
+  }
+}
+
 // Cooperative path (heads % 4 == 0, dh % 4 == 0): the 4 waves of a workgroup own 4 CONSECUTIVE heads of one sample, whose
 // slices are adjacent in memory, so the workgroup moves [Lq] row segments of 4*dh contiguous floats (320 B at dh = 20) as
 // float4 -- ALL loads of all NMAT matrices are issued before the first LDS write, so a wave pays the HBM latency once
@@ -242,9 +280,15 @@ __global__ __launch_bounds__(256) void mhsa_fwd_kernel(MhsaArgs a, int coop) {
   const int smp = pair / a.heads, head = pair - smp * a.heads;
   if (!coop) {
     const float* base = a.qkv + (long)smp * a.Lq * ld + head * dh;
-    stage(Qs, base, ld, a.Lq, dh, LP, SD, lane);
-    stage(Ks, base + HD, ld, a.Lq, dh, LP, SD, lane);
-    stage(Vs, base + 2 * HD, ld, a.Lq, dh, LP, SD, lane);
+    if (!(dh & 3) && !(HD & 3)) {
+      const float* const src[3] = {base, base + HD, base + 2 * HD};
+      const int lds[3] = {ld, ld, ld};
+      stage1v<3, LP>(Qs, src, lds, a.Lq, dh, SD, lane);
+    } else {
+      stage(Qs, base, ld, a.Lq, dh, LP, SD, lane);
+      stage(Ks, base + HD, ld, a.Lq, dh, LP, SD, lane);
+      stage(Vs, base + 2 * HD, ld, a.Lq, dh, LP, SD, lane);
+    }
     __builtin_amdgcn_s_waitcnt(0xc07f);    // lgkmcnt(0): this wave's own LDS writes (no cross-wave sharing)
   }
   f32x16 p[NB][NB];                        // p[jb][ib] = S^T block: rows keys, cols queries
@@ -306,10 +350,17 @@ __global__ __launch_bounds__(256) void mhsa_bwd_kernel(MhsaArgs a, int coop) {
   const int smp = pair / a.heads, head = pair - smp * a.heads;
   if (!coop) {
     const float* base = a.qkv + (long)smp * a.Lq * ld + head * dh;
-    stage(Qs, base, ld, a.Lq, dh, LP, SD, lane);
-    stage(Ks, base + HD, ld, a.Lq, dh, LP, SD, lane);
-    stage(Vs, base + 2 * HD, ld, a.Lq, dh, LP, SD, lane);
-    stage_drop(Gs, a.dout + (long)smp * a.Lq * HD + head * dh, (long)smp * a.Lq * HD + head * dh, HD, a.Lq, dh, LP, SD, lane, a);
+    const long e0 = (long)smp * a.Lq * HD + head * dh;
+    if (!(dh & 3) && !(HD & 3)) {
+      const float* const src[4] = {base, base + HD, base + 2 * HD, a.dout + e0};
+      const int lds[4] = {ld, ld, ld, HD};
+      stage1v<4, LP, 3>(Qs, src, lds, a.Lq, dh, SD, lane, &a, e0);
+    } else {
+      stage(Qs, base, ld, a.Lq, dh, LP, SD, lane);
+      stage(Ks, base + HD, ld, a.Lq, dh, LP, SD, lane);
+      stage(Vs, base + 2 * HD, ld, a.Lq, dh, LP, SD, lane);
+      stage_drop(Gs, a.dout + e0, e0, HD, a.Lq, dh, LP, SD, lane, a);
+    }
   }
   f32x16 p[NB][NB], dp[NB][NB];
   const unsigned long long live = key_bits(a, smp, lane);
