@@ -59,6 +59,8 @@ def join_extra_streams(dev=None):
     cur = torch.cuda.current_stream(dev)
     for st in EXTRA_STREAMS:
         cur.wait_stream(st)
+    _DEFER['keep'].clear()               # leaf_deferred: everything it issued is ordered before the caller's next launch now
+    _DEFER['queued'] = False             # (also the recovery path if a backward pass died before its end-of-pass callback ran)
 
 
 class leaf_scope:
@@ -97,7 +99,7 @@ class leaf_scope:
         self.keep = []                   # (dropped on the host after the join was ENQUEUED: later main-stream work is ordered behind it)
 
 
-_DEFER = {'keep': [], 'queued': False}
+_DEFER = {'keep': [], 'queued': False, 'calls': 0}     # calls: launches that went to the leaf stream (tests)
 
 
 LEAF_MIN_ROWS = 49152       # defer only when the step is big enough to be GPU-bound (Model.forward posts the history call's token
@@ -111,7 +113,7 @@ def leaf_deferred(dev, rows, fn, *tensors):
     behind the current stream's work, and join it when THIS backward pass ends (autograd's end-of-pass callback), so the data
     gradient chain on the main stream does not wait for it.  `tensors` (the inputs fn reads) are held until that join.
     NNR_LEAF_DEFER=0 runs fn inline."""
-    if _NO_DEFER or max(rows, STEP_ROWS[0]) < LEAF_MIN_ROWS:
+    if _NO_DEFER or _DEFER.get('off') or max(rows, STEP_ROWS[0]) < LEAF_MIN_ROWS:
         fn()
         return
     key = (dev.type, dev.index)
@@ -120,6 +122,7 @@ def leaf_deferred(dev, rows, fn, *tensors):
     leaf, main = _LEAF[key], torch.cuda.current_stream(dev)
     leaf.wait_stream(main)
     _DEFER['keep'].extend(tensors)
+    _DEFER['calls'] += 1
     with torch.cuda.stream(leaf):
         fn()
     if not _DEFER['queued']:

@@ -152,6 +152,41 @@ def test_mhsa_and_cnn_pairs_on_ragged_batch():
             assert float((p.grad.cpu().double() - rp[k].grad.double()).abs().max()) <= 1e-4 * max(1e-3, 0.05 * total), (ne, ue, k)
 
 
+def test_deferred_weight_gradients_match_inline():
+    """MHSA+MHSA and CNN+ATT on a GPU-bound step size (>= ops.LEAF_MIN_ROWS token rows): the weight-gradient GEMMs go to the
+    leaf stream (ops.leaf_deferred), with W_Q|W_K|W_V fused through the trainer's flat layout.  Same gradients as the inline,
+    per-projection sequence on a model that was not re-homed (f32 atomics reorder sums: relative 1e-5)."""
+    from nnr_amd import ops
+    from nnr_amd.model import Model, negative_log_softmax
+    from nnr_amd.trainer import FlatParams
+    for ne, ue in (('MHSA', 'MHSA'), ('CNN', 'ATT')):
+        cfg = make_config(['--news_encoder=' + ne, '--user_encoder=' + ue], corpus_sizes=dict(vocabulary_size=800), dropout_rate=0.0)
+        B = -(-ops.LEAF_MIN_ROWS // (cfg.max_history_num * cfg.max_title_length))
+        corpus = SynthCorpus(SynthSpec(vocabulary_size=800, news_pool=300, seed=5))
+        batch = corpus.batch(B, np.random.default_rng(8))
+        grads = []
+        for deferred in (False, True):
+            torch.manual_seed(9)
+            model = Model(cfg)
+            model.initialize()
+            model = model.cuda().eval()
+            if deferred:
+                FlatParams(model)                    # adjacent W_Q | W_K | W_V -> the fused projection path
+            ops._DEFER['off'] = not deferred
+            calls = ops._DEFER['calls']
+            try:
+                negative_log_softmax(model(*to_torch(batch, 'cuda'))).backward()
+            finally:
+                ops._DEFER['off'] = False
+            assert (ops._DEFER['calls'] > calls) == deferred
+            assert not ops._DEFER['keep'] and not ops._DEFER['queued']        # the end-of-pass callback ran
+            grads.append({k: p.grad.clone() for k, p in model.named_parameters()})   # same stream as the join: ordered
+        top = max(float(g.abs().max()) for g in grads[0].values())
+        for k in grads[0]:                           # (W_K.bias has a mathematically zero gradient: rounding noise only)
+            scale = max(1e-3 * top, float(grads[0][k].abs().max()))
+            assert float((grads[0][k] - grads[1][k]).abs().max()) <= 2e-5 * scale, (ne, ue, k)
+
+
 def test_large_vocabulary_config_parity_and_dropout_properties():
     """BASELINE.json config 5 (CNE+SUE 'large': vocabulary 130 000, per-GPU batch 16, dropout 0.1).  Dropout off: logits /
     loss / gradients against the oracle on a 2-impression shard (the oracle finishes in seconds).  Dropout on, full per-GPU
