@@ -49,6 +49,26 @@ class _NegLogSoftmaxFn(torch.autograd.Function):
         return dlogits * dloss
 
 
+class _JoinSideFn(torch.autograd.Function):
+    """Fork/join of the candidate encoder call that ran on a side HIP stream (autograd-based encoders, GPU-bound steps).
+    forward: the current (main) stream waits for the side stream.  backward: autograd runs the candidate call's backward nodes
+    on the side stream again (and orders them behind the producer of this gradient); the end-of-pass callback joins the side
+    stream back, because those nodes write parameter gradients out of autograd's sight."""
+
+    @staticmethod
+    def forward(ctx, x, side):
+        ctx.side, ctx.main = side, torch.cuda.current_stream(x.device)
+        ctx.main.wait_stream(side)
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        side = ctx.side
+        g.record_stream(side)                        # consumed by side-stream kernels after this node's buffer is released
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: ops.join_extra_streams(g.device))
+        return g, None
+
+
 def negative_log_softmax(logits):
     return _NegLogSoftmaxFn.apply(logits)
 
@@ -100,10 +120,26 @@ class Model(nn.Module):
         else:
             # size class of this step for ops.leaf_deferred: the token rows of the history call
             ops.STEP_ROWS[0] = user_title_text.shape[0] * user_title_text.shape[1] * user_title_text.shape[2]
-            news_representation = self.news_encoder(news_title_text, news_title_mask, news_title_entity, news_content_text, news_content_mask,
-                                                    news_content_entity, news_category, news_subCategory, user_embedding)
-            user_representation = self.user_encoder(user_title_text, user_title_mask, user_title_entity, user_content_text, user_content_mask,
-                                                    user_content_entity, user_category, user_subCategory, user_history_mask,
-                                                    user_history_graph, user_history_category_mask, user_history_category_indices,
-                                                    user_embedding, news_representation)
+            cand = (news_title_text, news_title_mask, news_title_entity, news_content_text, news_content_mask, news_content_entity,
+                    news_category, news_subCategory, user_embedding)
+            if news_title_text.is_cuda and ops.SIDE_CALL and ops.STEP_ROWS[0] >= ops.LEAF_MIN_ROWS and hasattr(self.user_encoder, 'encode_user'):
+                # GPU-bound step: the small candidate call runs on a side HIP stream next to the history call (same launches,
+                # same seeds, same order of the dropout counters as the sequential form below)
+                dev = news_title_text.device
+                side, main = newsEncoders._side_stream(dev), torch.cuda.current_stream(dev)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    news_representation = self.news_encoder(*cand)
+                history_embedding = self.news_encoder(user_title_text, user_title_mask, user_title_entity, user_content_text,
+                                                      user_content_mask, user_content_entity, user_category, user_subCategory, user_embedding)
+                news_representation = _JoinSideFn.apply(news_representation, side)
+                user_representation = self.user_encoder.encode_user(history_embedding, user_history_mask, user_history_graph,
+                                                                    user_history_category_mask, user_history_category_indices,
+                                                                    news_representation)
+            else:
+                news_representation = self.news_encoder(*cand)
+                user_representation = self.user_encoder(user_title_text, user_title_mask, user_title_entity, user_content_text,
+                                                        user_content_mask, user_content_entity, user_category, user_subCategory,
+                                                        user_history_mask, user_history_graph, user_history_category_mask,
+                                                        user_history_category_indices, user_embedding, news_representation)
         return _DotProductFn.apply(user_representation, news_representation)

@@ -43,6 +43,7 @@ def _s():
 # 14 ms or 50-67 ms per step -- measured when the 2.7 GB gate buffer was recorded.)
 _LEAF = {}
 _NO_DEFER = os.environ.get('NNR_LEAF_DEFER', '1') == '0'
+SIDE_CALL = os.environ.get('NNR_SIDE_CALL', '1') != '0'      # model.Model.forward: candidate encoder call on a side stream
 EXTRA_STREAMS = []          # every HIP stream this package created (side, title, leaf): see join_extra_streams()
 
 
@@ -127,15 +128,10 @@ def leaf_deferred(dev, rows, fn, *tensors):
         fn()
     if not _DEFER['queued']:
         _DEFER['queued'] = True
-
-        def done():
-            main.wait_stream(leaf)
-            _DEFER['keep'].clear()
-            _DEFER['queued'] = False
-        try:
-            torch.autograd.Variable._execution_engine.queue_callback(done)
+        try:                             # end-of-pass callbacks run on the stream that surrounded the caller's backward()
+            torch.autograd.Variable._execution_engine.queue_callback(lambda: join_extra_streams(dev))
         except RuntimeError:             # not inside a backward pass (a backward function called by hand): join right away
-            done()
+            join_extra_streams(dev)
 
 
 def split_for(m, n, k, tile_m=64, tile_n=80, target_blocks=2048, kmin=256):

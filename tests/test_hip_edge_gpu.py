@@ -154,8 +154,10 @@ def test_mhsa_and_cnn_pairs_on_ragged_batch():
 
 def test_deferred_weight_gradients_match_inline():
     """MHSA+MHSA and CNN+ATT on a GPU-bound step size (>= ops.LEAF_MIN_ROWS token rows): the weight-gradient GEMMs go to the
-    leaf stream (ops.leaf_deferred), with W_Q|W_K|W_V fused through the trainer's flat layout.  Same gradients as the inline,
-    per-projection sequence on a model that was not re-homed (f32 atomics reorder sums: relative 1e-5)."""
+    leaf stream (ops.leaf_deferred), with W_Q|W_K|W_V fused through the trainer's flat layout, and the candidate encoder call
+    runs on a side stream (model._JoinSideFn).  Same gradients as the inline, sequential, per-projection form on a model that
+    was not re-homed (f32 atomics reorder sums: relative 1e-5).  Gradients are read on the stream that called backward():
+    the end-of-pass callbacks must have joined every package stream into it."""
     from nnr_amd import ops
     from nnr_amd.model import Model, negative_log_softmax
     from nnr_amd.trainer import FlatParams
@@ -173,17 +175,18 @@ def test_deferred_weight_gradients_match_inline():
             if deferred:
                 FlatParams(model)                    # adjacent W_Q | W_K | W_V -> the fused projection path
             ops._DEFER['off'] = not deferred
+            side_call, ops.SIDE_CALL = ops.SIDE_CALL, deferred      # ... and the candidate call on a side stream or in sequence
             calls = ops._DEFER['calls']
             try:
                 negative_log_softmax(model(*to_torch(batch, 'cuda'))).backward()
             finally:
-                ops._DEFER['off'] = False
+                ops._DEFER['off'], ops.SIDE_CALL = False, side_call
             assert (ops._DEFER['calls'] > calls) == deferred
             assert not ops._DEFER['keep'] and not ops._DEFER['queued']        # the end-of-pass callback ran
             grads.append({k: p.grad.clone() for k, p in model.named_parameters()})   # same stream as the join: ordered
         top = max(float(g.abs().max()) for g in grads[0].values())
         for k in grads[0]:                           # (W_K.bias has a mathematically zero gradient: rounding noise only)
-            scale = max(1e-3 * top, float(grads[0][k].abs().max()))
+            scale = max(1e-2 * top, float(grads[0][k].abs().max()))
             assert float((grads[0][k] - grads[1][k]).abs().max()) <= 2e-5 * scale, (ne, ue, k)
 
 
