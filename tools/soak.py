@@ -12,7 +12,8 @@ from nnr_amd.synth import SynthSpec, SynthCorpus
 from nnr_amd.trainer import Trainer
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 BS = int(sys.argv[2]) if len(sys.argv) > 2 else 64
-cfg = make_config(['--news_encoder=CNE', '--user_encoder=SUE', '--dataset=200k', '--batch_size=%d' % BS], corpus_sizes=dict(vocabulary_size=60000))
+NE, UE = (sys.argv[3], sys.argv[4]) if len(sys.argv) > 4 else ('CNE', 'SUE')
+cfg = make_config(['--news_encoder=' + NE, '--user_encoder=' + UE, '--dataset=200k', '--batch_size=%d' % BS], corpus_sizes=dict(vocabulary_size=60000))
 torch.manual_seed(0)
 model = Model(cfg, torch.randn(cfg.vocabulary_size, cfg.word_embedding_dim) * 0.3)
 model.initialize()
@@ -32,6 +33,7 @@ for i in range(steps):
     timeouts += ops.lstm_sync_timeouts()
 l = torch.stack(losses).cpu().numpy()
 flat = tr.flat.flat
+print(NE, UE, 'reserved GB %.2f' % (torch.cuda.max_memory_reserved() / 2 ** 30))
 print('batch %d steps %d: loss first %.4f last-50 mean %.4f min %.4f max %.4f; finite loss %s; finite params %s; exchange timeouts %d' %
       (BS, steps, l[0], l[-50:].mean(), l.min(), l.max(), bool(np.isfinite(l).all()), bool(torch.isfinite(flat).all()), timeouts))
 ts = np.array(times[5:]) * 1e3
