@@ -9,9 +9,17 @@
 //   O^T[d][i] = sum_j V^T[d][j] P^T[j][i]
 // with the k-order of each MFMA step permuted to the accumulator's row map (row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)),
 // so P never leaves registers.  Sequence lengths 32 (news titles, NB=1) and 50 (user history, NB=2, padded to 64).
-// Backward recomputes nothing: it reloads P^T in the same register layout, forms dP^T = V dO^T and dS^T in registers,
-// uses dS^T as a register operand for dQ^T = K^T dS^T, and goes through one LDS tile for the two products that reduce
-// over the query (lane) index: dV = P^T dO and dK = dS^T Q.
+// Backward saves nothing but Q, K, V: it recomputes P^T with the forward's code (prob == NULL; a caller may still pass the
+// probabilities the forward stored), forms dP^T = V dO^T and dS^T in registers, uses dS^T as a register operand for
+// dQ^T = K^T dS^T, and goes through one LDS tile for the two products that reduce over the query (lane) index:
+// dV = P^T dO and dK = dS^T Q.
+//
+// Memory side (this is what bounds the kernel -- QK^T / PV are ~5 % of the encoder's FLOPs): a workgroup is 4 waves = 4
+// ADJACENT heads of one sample, so it moves [Lq] row segments of 4*dh floats (320 B) as float4, every load of every operand
+// issued before the first LDS write (one HBM latency per wave, not one per loop trip), and the results leave through the LDS
+// tiles the same way.  The key mask is one ballot word per wave.  The dropout that follows the attention in the news encoder
+// is applied in the output stage / while staging dO (same counter-based mask as nnr_dropout).  Shapes that do not fit the
+// 4-head grouping (heads % 4, dh % 4) take the one-head-per-wave path with the same batched loads.
 #include "common.h"
 
 namespace {
