@@ -481,6 +481,20 @@ def test_elementwise_and_optimizer():
     ops.small_embed_bwd(idx.to(d), 50, drep.to(d)[:, 800:], 900, dt, 0.0, 1)
     ref = torch.zeros(18, 50, dtype=torch.float64).index_add_(0, idx.long(), drep[:, 800:850].double())
     close(dt, ref, what='small embed bwd')
+    # history-shaped ids (every history ends in a run of padded slots = id 0), dropout on, every row-per-wave setting of the
+    # run-merging kernel, a ragged last wave; the mask is the forward's (keep = f(seed, row * dim + c))
+    for n in (3203, 17001, 50):
+        g = torch.Generator().manual_seed(n)
+        idx = torch.randint(0, 270, (n,), generator=g).int()
+        for u0 in range(0, n, 50):
+            idx[u0 + int(torch.randint(5, 50, (1,), generator=g)):u0 + 50] = 0
+        drep = rnd(n, 100, seed=n + 1)
+        mask = torch.zeros(n, 64, **f32)
+        ops.small_embed_fwd(torch.ones(270, 50, **f32), idx.to(d), mask, 64, 0.3, 77)
+        dt = torch.zeros(270, 50, **f32)
+        ops.small_embed_bwd(idx.to(d), 50, drep.to(d)[:, 40:], 100, dt, 0.3, 77)
+        ref = torch.zeros(270, 50, dtype=torch.float64).index_add_(0, idx.long(), drep[:, 40:90].double() * mask[:, :50].cpu().double())
+        close(dt, ref, what='small embed bwd, runs, n=%d' % n)
 
 
 # ------------------------------------------------------------------------------------------------ MFMA attention core
