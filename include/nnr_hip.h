@@ -153,9 +153,13 @@ int nnr_attn_pool_bwd(const nnr_pool_args* a, hipStream_t stream);
 int nnr_gate_bwd(const float* dHt, const float* H, const float* G, float* dH, float* dpre, const int* rows_dev, int rows, int cols,
                  hipStream_t stream);                                            /* newsEncoders.py:128-131 backward */
 int nnr_packed_seq_sum(const float* x, int D, const int* off, const int* slen, int n, float* out, hipStream_t stream);
-int nnr_tanh_score_bwd(float* th, const float* ds, const float* w2, float* dw2, const int* rows_dev, int rows, int A,
+/* `ws`: NULL, or a ZEROED workspace of nnr_slot_workspace_floats(N) floats owned by the calling stream: many workgroups adding
+ * into one short vector serialise on its few cache lines, so they add into 32 slots of the workspace first and a second tiny
+ * launch folds the slots into the destination and leaves the workspace zeroed (reusable by the next call on that stream). */
+int nnr_slot_workspace_floats(int N);
+int nnr_tanh_score_bwd(float* th, const float* ds, const float* w2, float* dw2, const int* rows_dev, int rows, int A, float* ws,
                        hipStream_t stream);                                      /* layers.py:168-169 backward */
-int nnr_colsum(const float* x, int ld, const int* rows_dev, int rows, int N, float* out_accum, hipStream_t stream);
+int nnr_colsum(const float* x, int ld, const int* rows_dev, int rows, int N, float* out_accum, float* ws, hipStream_t stream);
 int nnr_rowdot(const float* x, int ld, const float* w, const int* rows_dev, int rows, int N, float* out,
                hipStream_t stream);                                              /* out[row] = <x[row, :N], w>  (layers.py:168) */
 int nnr_small_embed_fwd(const float* table, const int* idx, int n, int dim, float* out, int ldo, float p, uint32_t seed,

@@ -41,11 +41,30 @@ __global__ __launch_bounds__(256) void packed_seq_sum_kernel(const float* __rest
 
 // ---- additive-attention score backward (layers.py:168-169): th = tanh(pre) saved; s = w2 . th
 //      dpre = ds * w2 * (1 - th^2)  (in place over th) ;  dw2[a] += sum_rows ds * th
+//
+// Column sums that many workgroups add into ONE short vector: f32 atomics into the same 128-B line retire at ~2.2 ns each in
+// L2 whatever the address within the line (measured: 1 600 workgroups x 200 columns = 93 us, 800 x 400 = 66 us, both far above
+// their HBM time), so with a workspace the workgroups add into slot (blockIdx.x % NNR_SLOTS) of `ws` [NNR_SLOTS, N] -- 32x
+// more lines -- and slot_reduce_kernel folds the slots into the destination and leaves the workspace zeroed for the next call.
+constexpr int NNR_SLOTS = 32;
+__global__ __launch_bounds__(256) void slot_reduce_kernel(float* __restrict__ ws, int N, float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= N) return;
+  float acc = 0.f;
+#pragma unroll 8
+  for (int s = 0; s < NNR_SLOTS; ++s) {
+    acc += ws[s * N + c];
+    ws[s * N + c] = 0.f;
+  }
+  atomicAdd(&out[c], acc);               // the destination is a parameter gradient other streams may add into
+}
+
 __global__ __launch_bounds__(256) void tanh_score_bwd_kernel(float* __restrict__ th, const float* __restrict__ ds,
                                                              const float* __restrict__ w2, float* __restrict__ dw2,
-                                                             const int* rows_dev, int rows, int A, int rows_per_block) {
+                                                             const int* rows_dev, int rows, int A, int rows_per_block, float* ws) {
   const int R = dyn_rows(rows_dev, rows);
   const int r0 = blockIdx.x * rows_per_block, r1 = min(R, r0 + rows_per_block);
+  if (ws) dw2 = ws + (blockIdx.x % NNR_SLOTS) * A;
   for (int a = threadIdx.x; a < A; a += blockDim.x) {
     const float w = w2[a];
     float acc = 0.f;
@@ -81,10 +100,11 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ x
 
 // ---- out[c] += sum_rows x[row, c]   (bias gradients)
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int ld, const int* rows_dev, int rows, int N,
-                                                     float* __restrict__ out, int rows_per_block) {
+                                                     float* __restrict__ out, int rows_per_block, float* ws) {
   const int R = dyn_rows(rows_dev, rows);
   const int r0 = blockIdx.x * rows_per_block, r1 = min(R, r0 + rows_per_block);
   if (r0 >= r1) return;
+  if (ws) out = ws + (blockIdx.x % NNR_SLOTS) * N;
   for (int c = blockIdx.y * blockDim.x + threadIdx.x; c < N; c += gridDim.y * blockDim.x) {
     float acc = 0.f;
     for (int row = r0; row < r1; ++row) acc += x[(long)row * ld + c];
@@ -549,11 +569,19 @@ extern "C" int nnr_packed_seq_sum(const float* x, int D, const int* off, const i
   return NNR_OK;
 }
 
+extern "C" int nnr_slot_workspace_floats(int N) { return NNR_SLOTS * N; }
+
 extern "C" int nnr_tanh_score_bwd(float* th, const float* ds, const float* w2, float* dw2, const int* rows_dev, int rows, int A,
-                                  hipStream_t stream) {
+                                  float* ws, hipStream_t stream) {
   const int rpb = 64;
-  hipLaunchKernelGGL(tanh_score_bwd_kernel, dim3((rows + rpb - 1) / rpb), dim3(256), 0, stream, th, ds, w2, dw2, rows_dev, rows, A, rpb);
+  const int blocks = (rows + rpb - 1) / rpb;
+  if (blocks < 4 * NNR_SLOTS) ws = nullptr;                     // few workgroups: the direct atomics are cheaper than a second launch
+  hipLaunchKernelGGL(tanh_score_bwd_kernel, dim3(blocks), dim3(256), 0, stream, th, ds, w2, dw2, rows_dev, rows, A, rpb, ws);
   NNR_CHECK_LAUNCH();
+  if (ws) {
+    hipLaunchKernelGGL(slot_reduce_kernel, dim3((A + 255) / 256), dim3(256), 0, stream, ws, A, dw2);
+    NNR_CHECK_LAUNCH();
+  }
   return NNR_OK;
 }
 
@@ -566,14 +594,20 @@ extern "C" int nnr_rowdot(const float* x, int ld, const float* w, const int* row
   return NNR_OK;
 }
 
-extern "C" int nnr_colsum(const float* x, int ld, const int* rows_dev, int rows, int N, float* out, hipStream_t stream) {
+extern "C" int nnr_colsum(const float* x, int ld, const int* rows_dev, int rows, int N, float* out, float* ws, hipStream_t stream) {
   if (rows <= 0 || N <= 0) return NNR_OK;
   // rows per workgroup: few enough that mid-size inputs (3 200 .. 6 080 rows here) still spread over the chip -- with 128 rows
   // per block a [3200, 200] bias gradient was 25 workgroups walking 128 rows each (43 us); many enough to bound the atomics
   int rpb = rows / 512;
   rpb = rpb < 8 ? 8 : (rpb > 128 ? 128 : rpb);
-  hipLaunchKernelGGL(colsum_kernel, dim3((rows + rpb - 1) / rpb, (N + 255) / 256), dim3(256), 0, stream, x, ld, rows_dev, rows, N, out, rpb);
+  const int blocks = (rows + rpb - 1) / rpb;
+  if (blocks < 4 * NNR_SLOTS) ws = nullptr;
+  hipLaunchKernelGGL(colsum_kernel, dim3(blocks, (N + 255) / 256), dim3(256), 0, stream, x, ld, rows_dev, rows, N, out, rpb, ws);
   NNR_CHECK_LAUNCH();
+  if (ws) {
+    hipLaunchKernelGGL(slot_reduce_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, ws, N, out);
+    NNR_CHECK_LAUNCH();
+  }
   return NNR_OK;
 }
 

@@ -264,9 +264,25 @@ def rowdot(x, w, out, dyn=None, rows=None):
     L.check(L.lib().nnr_rowdot(_p(x), x.stride(0), _p(w), _p(dyn), R, x.shape[1], _p(out), _s()), 'nnr_rowdot')
 
 
+_SLOT_WS = {}
+
+
+def _slot_ws(dev, n):
+    """Zeroed slot workspace of the CURRENT stream (see nnr_slot_workspace_floats): kernels of one stream run in order and each
+    call leaves it zeroed, so one buffer per stream serves every call; grown (fresh zeros) when a wider vector comes along."""
+    key = torch._C._cuda_getCurrentRawStream(dev.index if dev.index is not None else torch.cuda.current_device())
+    need = L.lib().nnr_slot_workspace_floats(int(n))
+    ws = _SLOT_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.zeros(max(need, 32 * 1024), device=dev, dtype=torch.float32)
+        _SLOT_WS[key] = ws
+    return ws
+
+
 def bias_grad(dy, db, dyn=None, rows=None):
     R = dy.shape[0] if rows is None else rows
-    L.check(L.lib().nnr_colsum(_p(dy), dy.stride(0), _p(dyn), R, db.numel(), _p(db), _s()), 'nnr_colsum')
+    ws = _slot_ws(dy.device, db.numel()) if R >= 1024 else None
+    L.check(L.lib().nnr_colsum(_p(dy), dy.stride(0), _p(dyn), R, db.numel(), _p(db), _p(ws), _s()), 'nnr_colsum')
 
 
 # ---------------------------------------------------------------------------------------------- planner / LSTM
@@ -422,8 +438,10 @@ def packed_seq_sum(x, D, plan, out):
 
 
 def tanh_score_bwd(th, ds, w2, dw2, plan, A):
-    L.check(L.lib().nnr_tanh_score_bwd(_p(th), _p(ds), _p(w2), _p(dw2), _p(plan.total) if plan is not None else None,
-                                       plan.cap if plan is not None else th.shape[0], A, _s()), 'nnr_tanh_score_bwd')
+    rows = plan.cap if plan is not None else th.shape[0]
+    ws = _slot_ws(th.device, A) if rows >= 8192 else None
+    L.check(L.lib().nnr_tanh_score_bwd(_p(th), _p(ds), _p(w2), _p(dw2), _p(plan.total) if plan is not None else None, rows, A, _p(ws),
+                                       _s()), 'nnr_tanh_score_bwd')
 
 
 def small_embed_fwd(table, idx, out_view, ldo, p, seed):

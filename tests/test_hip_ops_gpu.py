@@ -497,6 +497,41 @@ def test_elementwise_and_optimizer():
         close(dt, ref, what='small embed bwd, runs, n=%d' % n)
 
 
+def test_slot_spread_column_sums():
+    """Long reductions into a short vector (bias gradients, dw2 of the additive attention) go through the per-stream slot
+    workspace (nnr_slot_workspace_floats): same sums as the direct form, and the workspace is left zeroed -- the second call,
+    on the same stream and on a side stream with its own workspace, must be exact too."""
+    from nnr_amd import ops
+    d = dev()
+    f32 = dict(device=d, dtype=torch.float32)
+    x = rnd(20000, 400, seed=31)
+    dyn = torch.tensor([19001], dtype=torch.int32, device=d)
+    out = torch.zeros(400, **f32)
+    xd = x.to(d)
+    ops.bias_grad(xd, out, dyn=dyn)
+    ref = x[:19001].double().sum(0)
+    close(out, ref, what='colsum (slots)')
+    ops.bias_grad(xd, out, dyn=dyn)
+    close(out, 2 * ref, what='colsum (slots), second call')
+    th = torch.tanh(rnd(20000, 200, seed=32))
+    ds = rnd(20000, 1, seed=33).reshape(-1)
+    w2 = rnd(1, 200, seed=34)
+    dw2 = torch.zeros(1, 200, **f32)
+    ref_dw2 = (ds.double()[:, None] * th.double()).sum(0)
+    ref_dpre = ds.double()[:, None] * w2.double() * (1 - th.double() ** 2)
+    side = torch.cuda.Stream()
+    for k, stream in enumerate((torch.cuda.current_stream(), torch.cuda.current_stream(), side)):
+        t = th.to(d)
+        stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(stream):
+            ops.tanh_score_bwd(t, ds.to(d), w2.to(d), dw2, None, 200)
+        torch.cuda.current_stream().wait_stream(stream)
+        close(dw2.reshape(-1), (k + 1) * ref_dw2, what='tanh score bwd dw2 (slots), call %d' % k)
+        close(t, ref_dpre, what='tanh score bwd dpre')
+    for ws in ops._SLOT_WS.values():
+        assert float(ws.abs().max()) == 0.0
+
+
 # ------------------------------------------------------------------------------------------------ MFMA attention core
 @pytest.mark.parametrize('saved_prob', [True, False])
 @pytest.mark.parametrize('n,Lq,heads,dh', [(7, 32, 20, 20), (5, 50, 20, 20), (3, 5, 2, 4), (2, 20, 4, 8), (3, 17, 6, 10)])
