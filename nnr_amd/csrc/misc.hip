@@ -33,9 +33,19 @@ __global__ __launch_bounds__(256) void packed_seq_sum_kernel(const float* __rest
   for (int c0 = 0; c0 < nv; c0 += 64) {
     const int c = c0 + lane;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    if (c < nv)
-      for (int t = 0; t < len; ++t) acc += *reinterpret_cast<const f32x4*>(x + ((long)off[t] + s) * D + 4 * c);
-    if (c < nv) *reinterpret_cast<f32x4*>(out + (long)s * D + 4 * c) = acc;
+    if (c < nv) {
+      // 8 rows in flight: the row address depends on off[t], so a plain loop pays one memory round trip per token
+      int t = 0;
+      for (; t + 8 <= len; t += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(x + ((long)off[t + u] + s) * D + 4 * c);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+      }
+      for (; t < len; ++t) acc += *reinterpret_cast<const f32x4*>(x + ((long)off[t] + s) * D + 4 * c);
+      *reinterpret_cast<f32x4*>(out + (long)s * D + 4 * c) = acc;
+    }
   }
 }
 
@@ -68,7 +78,18 @@ __global__ __launch_bounds__(256) void tanh_score_bwd_kernel(float* __restrict__
   for (int a = threadIdx.x; a < A; a += blockDim.x) {
     const float w = w2[a];
     float acc = 0.f;
-    for (int row = r0; row < r1; ++row) {
+    int row = r0;
+    for (; row + 8 <= r1; row += 8) {            // 8 rows in flight per thread
+      float t[8], d[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { d[u] = ds[row + u]; t[u] = th[(long)(row + u) * A + a]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        acc += d[u] * t[u];
+        th[(long)(row + u) * A + a] = d[u] * w * (1.f - t[u] * t[u]);
+      }
+    }
+    for (; row < r1; ++row) {
       const float d = ds[row];
       const float t = th[(long)row * A + a];
       acc += d * t;
@@ -107,7 +128,15 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   if (ws) out = ws + (blockIdx.x % NNR_SLOTS) * N;
   for (int c = blockIdx.y * blockDim.x + threadIdx.x; c < N; c += gridDim.y * blockDim.x) {
     float acc = 0.f;
-    for (int row = r0; row < r1; ++row) acc += x[(long)row * ld + c];
+    int row = r0;
+    for (; row + 8 <= r1; row += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = x[(long)(row + u) * ld + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; row < r1; ++row) acc += x[(long)row * ld + c];
     atomicAdd(&out[c], acc);
   }
 }
