@@ -48,6 +48,7 @@ def parse():
                     'corpus (id-only batches: nnr_corpus_batch + nnr_history_graph) instead of re-using pre-built batches')
     ap.add_argument('--roofline_every', type=int, default=4, help='instrument every n-th timed step with HIP events (the two events per '
                     'launch cost ~5 %% of a step when all steps carry them)')
+    ap.add_argument('--zipf_s', type=float, default=None, help='diagnostic: exponent of the synthetic word-id distribution (default: SynthSpec)')
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--cpu_baseline_batch', type=int, default=8)
     ap.add_argument('--cpu_baseline_steps', type=int, default=2)
@@ -99,7 +100,7 @@ def main():
     cfg = make_config(['--news_encoder=' + a.news_encoder, '--user_encoder=' + a.user_encoder, '--dataset=200k',
                        '--batch_size=%d' % global_batch, '--world_size=%d' % world],
                       corpus_sizes=dict(vocabulary_size=a.vocabulary_size))
-    spec = SynthSpec(vocabulary_size=cfg.vocabulary_size, dense=a.dense)
+    spec = SynthSpec(vocabulary_size=cfg.vocabulary_size, dense=a.dense, **({} if a.zipf_s is None else dict(zipf_s=a.zipf_s)))
 
     torch.manual_seed(cfg.seed)
     table = torch.randn(cfg.vocabulary_size, cfg.word_embedding_dim) * 0.3
