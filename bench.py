@@ -1,31 +1,34 @@
 #!/usr/bin/env python3
-"""Headline benchmark of the hot path: training impressions/sec, CNE+SUE on MIND-200k-shaped synthetic data, global
-batch 64 (BASELINE.json), one process per GPU.
+"""Headline benchmark of the hot path: training impressions/sec, CNE+SUE on MIND-200k-shaped synthetic data, batch 64
+(BASELINE.json), one process per GPU.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+With N > 1 and no WORLD_SIZE in the environment this process is only a LAUNCHER: before anything touches the GPU it starts
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same flags>` as a child
+process and exits with the child's return code (a fresh child, never an exec of a GPU-touched process).  Started by torchrun
+(RANK / LOCAL_RANK / WORLD_SIZE set) it is one rank of the job.
 
 One "step" = one optimizer step of trainer.py:105-120 (forward, loss, backward, [RCCL all-reduce of the flat gradient],
-clip_grad_norm_(4), Adam) on one batch that is already resident in HBM; dropout is ON (0.2, the reference's 200k
-setting).
+clip_grad_norm_(4), Adam) on one batch that is already resident in HBM; dropout is ON (0.2, the reference's 200k setting).
 
-Scaling mode.  Impressions are independent units sharded over the ranks, so the default is WEAK scaling: every GPU
-processes the headline batch of 64 impressions per step (global batch 64*N) and `value` = impressions of all ranks / time.
-`--global_batch G` instead fixes the GLOBAL batch (the reference's `--batch_size` semantics: per-rank = G // world_size,
-trainer.py:218) = strong scaling; at G=64 on 8 GPUs that is 8 impressions per GPU, a regime bound by the 128-step
-dependent chain of the Bi-LSTM and by launch latency, not by throughput (measured on 1 GPU: 14.8 ms/step at batch 8 vs
-24.8 ms at batch 64).
+Scaling.  Impressions are independent units sharded over the ranks, so the headline line is WEAK scaling: every GPU
+processes the headline batch of 64 impressions per step (global batch 64*N), `value` = impressions of all ranks / time.
+For N > 1 the same run also times the reference's own flag semantics (`--batch_size` is the GLOBAL batch, per rank
+batch_size // world_size, trainer.py:218) = STRONG scaling at global batch 64, reported in the `strong_scaling` object of the
+same JSON line (per-GPU batch 8 at N = 8: a regime bound by the 128-step dependent chain of the Bi-LSTM and by launch
+latency, not by throughput).  `--global_batch G` makes the strong-scaling run the headline instead.
 
-Prints ONE JSON line (rank 0) with the throughput, the roofline of the dominant kernel measured live with HIP events
-on the launch stream, and a CPU baseline (the oracle, timed on this box's host cores on a bounded sample)."""
+Prints ONE JSON line (rank 0): throughput, the roofline of the dominant kernel measured live with HIP events on the launch
+stream, and a CPU baseline (the oracle with ATen's packed-sequence LSTM = the reference's nn.LSTM host path, timed on this
+box's cores on a bounded sample).  Exit code 3 if the CU-pair recurrence's exchange ever timed out (values poisoned)."""
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -33,7 +36,7 @@ sys.path.insert(0, ROOT)
 PEAK_F32_TFLOPS = 157.3          # MI355X_MICROARCH.md: fp32 vector = fp32 MFMA peak
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
@@ -41,7 +44,8 @@ def parse():
     ap.add_argument('--news_encoder', default='CNE')
     ap.add_argument('--user_encoder', default='SUE')
     ap.add_argument('--batch_size', type=int, default=64, help='impressions per GPU per step (weak scaling, the default)')
-    ap.add_argument('--global_batch', type=int, default=0, help='>0: strong scaling, this GLOBAL batch split over the GPUs')
+    ap.add_argument('--global_batch', type=int, default=0, help='>0: strong scaling as the headline, this GLOBAL batch split over the GPUs')
+    ap.add_argument('--no_strong', action='store_true', help='N > 1: skip the additional strong-scaling (global batch 64) leg')
     ap.add_argument('--vocabulary_size', type=int, default=60000)
     ap.add_argument('--dense', action='store_true', help='all titles/abstracts at full length (worst-case roofline variant)')
     ap.add_argument('--device_corpus', action='store_true', help='build every batch inside the timed step from the device-resident '
@@ -52,17 +56,38 @@ def parse():
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--cpu_baseline_batch', type=int, default=8)
     ap.add_argument('--cpu_baseline_steps', type=int, default=2)
-    return ap.parse_args()
+    ap.add_argument('--plumbing_check', action='store_true', help='CPU only (gloo): run the launcher + the product\'s flat-buffer / '
+                    'exchange plumbing (trainer.FlatParams, nnr_amd.dp) on a stand-in module and print one JSON line; no HIP call')
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(a):
+    """N > 1 and not yet inside a torchrun job: start the N ranks as a child process group and return its exit code.
+    Nothing in this process has touched the GPU (no HIP call, no torch.cuda.is_available())."""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(a.gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')        # dmabuf IPC: RCCL across processes needs it on this driver
+    return subprocess.call(cmd, env=env)
 
 
 def cpu_baseline(cfg, spec, batch_size, steps):
-    """Time the CPU oracle (oracle/nnr_oracle.py, pinned against the reference by tests/golden) on this box's host cores."""
+    """Time the CPU oracle (oracle/nnr_oracle.py, pinned against the reference by tests/golden) on this box's host cores.
+    The Bi-LSTM runs through ATen's own packed-sequence LSTM -- the code path the reference's nn.LSTM takes on the host
+    (newsEncoders.py:119-127) -- not through the oracle's explicit time loop (2.8x slower, kept as the parity checker)."""
+    import numpy as np
+    import torch
     from nnr_amd.synth import SynthCorpus, to_torch
     from oracle import nnr_oracle as O
-    # The oracle's explicit-time-loop LSTM is thousands of small ops: beyond ~16 threads intra-op parallelism stops helping
-    # (measured on the 256-core bench host: 8 / 16 / 32 threads -> 4.7 / 4.3 / 4.7 s per batch-4 step; 256 threads stall).
-    cores = min(os.cpu_count() or 1, 16)
-    torch.set_num_threads(cores)
+    O.BiLSTM.backend = 'aten'
     torch.manual_seed(0)
     model = O.Model(cfg)
     model.initialize()
@@ -70,9 +95,22 @@ def cpu_baseline(cfg, spec, batch_size, steps):
     opt = O.make_optimizer(model, cfg)
     corpus = SynthCorpus(spec)
     rng = np.random.default_rng(11)
-    O.train_step(model, opt, to_torch(corpus.batch(batch_size, rng)), cfg.gradient_clip_norm)          # warm-up
-    # bounded sample: at least `steps` optimizer steps, more (up to 60) until ~10 s of CPU work are timed (a CNE+SUE step at
-    # batch 8 takes ~10 s on 16 threads, an MHSA+MHSA step 0.2 s)
+    # thread count: the step is a chain of mid-size CPU GEMMs; probe a few intra-op thread counts with one step each (the
+    # first also warms up) and time the sample with the fastest
+    ncpu = os.cpu_count() or 1
+    cands = sorted({min(ncpu, c) for c in (8, 16, 32, 64)})
+    best, probe = None, {}
+    for c in cands:
+        torch.set_num_threads(c)
+        if best is None:
+            O.train_step(model, opt, to_torch(corpus.batch(batch_size, rng)), cfg.gradient_clip_norm)      # warm-up
+        t0 = time.perf_counter()
+        O.train_step(model, opt, to_torch(corpus.batch(batch_size, rng)), cfg.gradient_clip_norm)
+        probe[c] = time.perf_counter() - t0
+        if best is None or probe[c] < probe[best]:
+            best = c
+    torch.set_num_threads(best)
+    # bounded sample: at least `steps` optimizer steps, more (up to 60) until ~10 s of CPU work are timed
     done, dt = 0, 0.0
     while done < steps or (dt < 10.0 and done < 60):
         b = to_torch(corpus.batch(batch_size, rng))
@@ -80,13 +118,89 @@ def cpu_baseline(cfg, spec, batch_size, steps):
         O.train_step(model, opt, b, cfg.gradient_clip_norm)
         dt += time.perf_counter() - t0
         done += 1
-    return dict(value=round(done * batch_size / dt, 4), unit='impressions/s', cores=cores, kind='port',
-                sample='%d optimizer steps of the same workload at batch %d (%.1f s of CPU work), torch %s CPU ops, %d threads' %
-                       (done, batch_size, dt, torch.__version__, cores))
+    return dict(value=round(done * batch_size / dt, 4), unit='impressions/s', cores=best, kind='port',
+                sample='%d optimizer steps of the same workload at batch %d (%.1f s of CPU work), oracle with ATen packed-sequence LSTM '
+                       '(= the reference\'s nn.LSTM host path), torch %s, %d of %d cores (probe s/step: %s)' %
+                       (done, batch_size, dt, torch.__version__, best, ncpu, {k: round(v, 2) for k, v in probe.items()}))
+
+
+def plumbing_check(a):
+    """CPU stand-in run of everything around the HIP model: launcher -> torchrun env -> dp.init_from_env(gloo) ->
+    trainer.FlatParams -> dp.broadcast_parameters -> per-rank gradients -> dp.GradientExchange (bucketed all-reduce, 1/world)
+    -> a plain SGD update on the flat buffer; rank 0 prints one JSON line a test can check."""
+    import torch
+    from nnr_amd import dp
+    from nnr_amd.trainer import FlatParams
+    rank, local, world = dp.init_from_env('gloo')
+    assert world == a.gpus, 'world size %d != --gpus %d' % (world, a.gpus)
+    torch.manual_seed(1234 + rank)                               # different init per rank: the broadcast must fix it
+    head = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 3))
+    tail = torch.nn.Linear(3, 2)
+    model = torch.nn.ModuleDict(dict(news_encoder=head, user_encoder=tail))
+    flat = FlatParams(model)
+    dp.broadcast_parameters(flat.flat)
+    p0 = flat.flat.clone()
+    ex = dp.GradientExchange(flat, early_modules=[tail])
+    per_gpu = a.batch_size if a.global_batch <= 0 else a.global_batch // world
+    t0 = time.perf_counter()
+    for step in range(a.steps):
+        flat.zero_grad()
+        flat.grad += float(rank + 1) * (step + 1)                # rank r contributes (r + 1) * (step + 1) to every element
+        ex.early_ready()                                         # the tail bucket is final: its all-reduce may start
+        scale = ex.finish()
+        flat.flat -= 0.5 * scale * flat.grad
+    dt = time.perf_counter() - t0
+    mean = sum(r + 1 for r in range(world)) / world
+    expect = p0 - 0.5 * mean * sum(s + 1 for s in range(a.steps))
+    ok = bool(torch.allclose(flat.flat, expect, rtol=0, atol=1e-5))
+    same = [torch.zeros_like(flat.flat) for _ in range(world)]
+    if world > 1:
+        torch.distributed.all_gather(same, flat.flat)
+        ok = ok and all(torch.equal(same[0], s) for s in same)
+    if rank == 0:
+        print(json.dumps({'metric': 'plumbing check (CPU, gloo)', 'n_gpus': world, 'steps': a.steps, 'per_gpu_batch': per_gpu,
+                          'global_batch': per_gpu * world, 'scaling': 'weak' if a.global_batch <= 0 else 'strong',
+                          'buckets': ex.describe(), 'params_equal_on_all_ranks_and_expected': ok, 'seconds': round(dt, 4)}))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+    return 0 if ok else 4
+
+
+def timed_run(a, trainer, fresh, steps, warmup, prof, dp, torch, dev, world, instrument):
+    """W untimed + K timed steps bracketed by barrier + synchronize; returns the MAX over ranks of the elapsed seconds."""
+    for i in range(warmup):
+        trainer.train_step(fresh(i))
+    dp.barrier()
+    torch.cuda.synchronize()
+    if instrument:
+        prof.enable(every=a.roofline_every)     # live HIP-event spans on every `roofline_every`-th step of the timed region
+    from nnr_amd import _lib
+    calls0 = _lib.CALLS[0]
+    t0 = time.perf_counter()
+    for i in range(steps):
+        if instrument:
+            prof.begin_step(i)
+        trainer.train_step(fresh(warmup + i))
+    dp.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if instrument:
+        prof.disable()
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    return float(tmax), (_lib.CALLS[0] - calls0) / max(1, steps)
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(a))
+    if a.plumbing_check:
+        sys.exit(plumbing_check(a))
+
+    import numpy as np
+    import torch
     from nnr_amd import dp, ops
     from nnr_amd.config import make_config
     from nnr_amd.model import Model
@@ -95,11 +209,12 @@ def main():
     from nnr_amd import profile as prof
 
     rank, local, world = dp.init_from_env('nccl' if a.gpus > 1 else None)
-    assert world == a.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % a.gpus
+    assert world == a.gpus, 'world size %d != --gpus %d (launch with torch.distributed.run --nproc-per-node %d, or let bench.py do it)' % (world, a.gpus, a.gpus)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     weak = a.global_batch <= 0
     per_gpu = a.batch_size if weak else a.global_batch // world
+    assert per_gpu >= 1, 'global batch %d cannot be split over %d GPUs' % (a.global_batch, world)
     global_batch = per_gpu * world
     cfg = make_config(['--news_encoder=' + a.news_encoder, '--user_encoder=' + a.user_encoder, '--dataset=200k',
                        '--batch_size=%d' % global_batch, '--world_size=%d' % world],
@@ -117,43 +232,38 @@ def main():
     corpus = SynthCorpus(spec)
     rng = np.random.default_rng(100 + rank)
     nb = min(8, a.steps + a.warmup)
-    if a.device_corpus:
-        from nnr_amd.corpus import from_synth
-        dcorpus = from_synth(corpus, 4096, rng, dev, graph='build')
-        order = [torch.from_numpy(rng.permutation(4096)[:per_gpu].astype(np.int32)).to(dev) for _ in range(nb)]
 
-        def fresh(i):      # 256 bytes of behaviour ids per batch; the 21 tensors are gathered / built in HBM
-            return dcorpus.train_batch(order[i % nb])
-    else:
-        batches = [to_torch(corpus.batch(per_gpu, rng), dev) for _ in range(nb)]
+    def batch_source(per_rank):
+        if a.device_corpus:
+            from nnr_amd.corpus import from_synth
+            dcorpus = from_synth(corpus, 4096, rng, dev, graph='build')
+            order = [torch.from_numpy(rng.permutation(4096)[:per_rank].astype(np.int32)).to(dev) for _ in range(nb)]
+            return lambda i: dcorpus.train_batch(order[i % nb])      # 256 bytes of behaviour ids per batch; the 21 tensors are gathered / built in HBM
+        batches = [to_torch(corpus.batch(per_rank, rng), dev) for _ in range(nb)]
+        return lambda i: batches[i % nb]        # masks are mutated in place by the model; mutation is idempotent, so batches can be reused
 
-        def fresh(i):      # masks are mutated in place by the model; mutation is idempotent, so batches can be reused
-            return batches[i % nb]
-
-    for i in range(a.warmup):
-        trainer.train_step(fresh(i))
-    dp.barrier()
-    torch.cuda.synchronize()
-    prof.enable(every=a.roofline_every)     # live HIP-event spans on every `roofline_every`-th step of the timed region
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        prof.begin_step(i)
-        trainer.train_step(fresh(a.warmup + i))
-    dp.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    prof.disable()
-    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-    dt = float(tmax)
+    dt, calls = timed_run(a, trainer, batch_source(per_gpu), a.steps, a.warmup, prof, dp, torch, dev, world, True)
     sampled = len(range(0, a.steps, max(1, a.roofline_every)))
     roof = prof.roofline(PEAK_F32_TFLOPS, sampled_steps=sampled, ms_per_step=1000 * dt / a.steps)
     if roof and (a.news_encoder, a.user_encoder, per_gpu, a.dense) != ('CNE', 'SUE', 64, False):
         roof['traffic'] = None            # the committed PMC passes (profiles/pmc_traffic.json) are of the headline command only
-    exchange_timeouts = ops.lstm_sync_timeouts()      # the CU-pair recurrence's exchange must never time out (last launch's counter)
-    if exchange_timeouts:
-        print('WARNING: pair-recurrence exchange timed out %d times (values poisoned with NaN)' % exchange_timeouts, file=sys.stderr)
+
+    strong = None
+    if world > 1 and weak and not a.no_strong and a.batch_size % world == 0:
+        # the reference's semantics for the SAME command line on N GPUs: --batch_size 64 is the global batch (trainer.py:218)
+        sp = a.batch_size // world
+        sdt, scalls = timed_run(a, trainer, batch_source(sp), a.steps, max(2, a.warmup // 2), prof, dp, torch, dev, world, False)
+        strong = {'scaling': 'strong', 'global_batch': a.batch_size, 'per_gpu_batch': sp, 'value': round(a.steps * a.batch_size / sdt, 2),
+                  'unit': 'impressions/s', 'ms_per_step': round(1000 * sdt / a.steps, 3), 'abi_calls_per_step': round(scalls, 1)}
+
+    exchange_timeouts = ops.lstm_sync_timeouts()      # persistent device counter over EVERY pair-kernel launch of this process
+    tmo = torch.tensor([exchange_timeouts], device=dev, dtype=torch.int64)
+    if world > 1:
+        torch.distributed.all_reduce(tmo)
+    exchange_timeouts = int(tmo)
+    if exchange_timeouts and rank == 0:
+        print('ERROR: pair-recurrence exchange timed out %d times (values poisoned with NaN, optimizer steps skipped)' % exchange_timeouts,
+              file=sys.stderr)
 
     if rank == 0:
         out = {
@@ -168,14 +278,21 @@ def main():
                        'synth': {k: v for k, v in spec.describe().items() if k in ('vocabulary_size', 'title_len_mean', 'content_len_mean', 'news_pool', 'dense')},
                        'batches': 'device-resident corpus, id-only' if a.device_corpus else 'pre-built, resident in HBM',
                        'peak_hbm_reserved_gb': round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 2),
+                       'abi_calls_per_step': round(calls, 1),
+                       'gradient_exchange': trainer.exchange.describe() if world > 1 else 'none (1 GPU)',
                        'recurrence_exchange_timeouts': exchange_timeouts},
             'roofline': roof,
         }
+        if strong is not None:
+            out['strong_scaling'] = strong
         if not a.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(cfg, spec, a.cpu_baseline_batch, a.cpu_baseline_steps)
         print(json.dumps(out))
+        sys.stdout.flush()
     if world > 1:
         torch.distributed.destroy_process_group()
+    if exchange_timeouts:
+        sys.exit(3)
 
 
 if __name__ == '__main__':

@@ -120,10 +120,16 @@ typedef struct nnr_lstm_problem {
   const float* dcn;   /* bwd: dL/dc_n [n, 2*H] or NULL */
   unsigned* sync;     /* optional workspace of nnr_lstm_sync_bytes(n) bytes (zeroed by the library): when every problem of a
                        * launch has one and H = 200, each 16-sequence tile runs on a PAIR of CUs with W_hh resident in
-                       * registers/LDS, exchanging half of h_t per step; after the launch its last 64 bytes hold diagnostics
-                       * (word 0 = spin-wait timeouts, must be 0) */
+                       * registers/LDS, exchanging half of h_t per step; after the launch the 64 bytes at
+                       * nnr_lstm_sync_diag_offset(n) hold diagnostics (word 0 = spin-wait time-outs of that launch, must be 0) */
 } nnr_lstm_problem;
 size_t nnr_lstm_sync_bytes(int n);
+size_t nnr_lstm_sync_diag_offset(int n);   /* byte offset of the diagnostics block inside that workspace */
+/* Registers a caller-owned, zero-initialised device counter that every exchange time-out of every later launch adds to (NULL
+ * unregisters).  A time-out is a data-poisoning event, not a retry: the waiting lane continues with NaN, the step's loss and
+ * gradient norm become NaN, and nnr_clip_adam leaves parameters and moments untouched for such a step.  (The reference has no
+ * counterpart: cuDNN's nn.LSTM is one kernel, newsEncoders.py:119-127.) */
+int nnr_lstm_set_timeout_counter(unsigned* dev_counter);
 /* up to 4 problems (title + content streams of the candidate call and of the history call) run in ONE launch: the
  * recurrence is bound by its longest dependent chain, so independent streams are free to share it */
 int nnr_lstm_fwd(const nnr_lstm_problem* probs, int nprob, int H, hipStream_t stream);
@@ -214,8 +220,9 @@ int nnr_sue_intra_bwd(const float* kf, const float* qc, const float* g, const lo
  *                      (dtypes of the reference's DataLoader: int64 user ids / cluster indices, int32 ids, 1-byte bools, fp32 graph).
  *                      With graph_table == NULL the graph / cluster mask / cluster indices are left to nnr_history_graph.
  * nnr_history_graph  = MIND_Corpus.preprocess step 6 (MIND_corpus.py:162-221) for a batch, from the history's category ids:
- *                      norm 0 = none, 1 = symmetric D^-1/2 A D^-1/2, 2 = asymmetric D^-1 A; self connections always on
- *                      (the reference asserts normalisation needs them, config.py:111).  Bit-identical to the numpy result. */
+ *                      norm 0 = none, 1 = symmetric D^-1/2 A D^-1/2, 2 = asymmetric D^-1 A (self connections on), 3 = none and
+ *                      NO self connections (--no_self_connection; the reference asserts it excludes normalisation,
+ *                      config.py:56,111).  Bit-identical to the numpy result. */
 typedef struct nnr_corpus_tables {
   const int* news_category; const int* news_subCategory;                       /* [news] */
   const int* title_text; const uint8_t* title_mask; const int* title_entity;   /* [news, T] */
@@ -249,7 +256,8 @@ int nnr_logits_bwd(const float* dlogits, const float* user, const float* cand, i
                    int dcand_accumulate, hipStream_t stream);
 int nnr_sumsq(const float* g, long n, float* out_zeroed, hipStream_t stream);
 /* clip_grad_norm_(max_norm = clip) + torch.optim.Adam step on one flat buffer (trainer.py:118-120); grads are scaled by
- * grad_scale first (1/world_size after the RCCL sum all-reduce). */
+ * grad_scale first (1/world_size after the RCCL sum all-reduce).  A step whose squared gradient norm is not finite is
+ * skipped as a whole (parameters and moments untouched). */
 int nnr_clip_adam(float* p, const float* g, float* m, float* v, long n, const float* sumsq, float grad_scale, float clip, float lr,
                   float beta1, float beta2, float eps, float weight_decay, int step, hipStream_t stream);
 

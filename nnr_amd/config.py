@@ -14,7 +14,7 @@ _FLAGS = [
     ('world_size', int, 1), ('word_embedding_dim', int, 300), ('entity_embedding_dim', int, 100), ('context_embedding_dim', int, 100),
     ('cnn_method', str, 'naive'), ('cnn_kernel_num', int, 400), ('cnn_window_size', int, 3), ('attention_dim', int, 200),
     ('head_num', int, 20), ('head_dim', int, 20), ('user_embedding_dim', int, 50), ('category_embedding_dim', int, 50),
-    ('subCategory_embedding_dim', int, 50), ('dropout_rate', float, 0.2), ('gcn_layer_num', int, 4), ('hidden_dim', int, 200),
+    ('subCategory_embedding_dim', int, 50), ('dropout_rate', float, 0.2), ('gcn_normalization_type', str, 'symmetric'), ('gcn_layer_num', int, 4), ('hidden_dim', int, 200),
     ('click_predictor', str, 'dot_product'),
 ]
 _BOOL_FLAGS = ['no_self_connection', 'no_adjacent_normalization', 'no_gcn_residual', 'gcn_layer_norm']
@@ -26,7 +26,7 @@ USER_ENCODERS = ['SUE', 'MHSA', 'ATT']          # in scope; the reference lists 
 def build_parser():
     p = argparse.ArgumentParser(description='NNR hot path on MI355X (flag names follow the reference config.py)')
     for name, typ, default in _FLAGS:
-        p.add_argument('--' + name, type=typ, default=default)
+        p.add_argument('--' + name, type=typ, default=default, **({'choices': ['symmetric', 'asymmetric']} if name == 'gcn_normalization_type' else {}))
     for name in _BOOL_FLAGS:
         p.add_argument('--' + name, default=False, action='store_true')
     p.add_argument('--tie_order', type=str, default='stable', choices=['stable', 'torch'],
@@ -65,5 +65,7 @@ def make_config(argv=None, corpus_sizes=None, **over):
         setattr(cfg, k, v)
     for k, v in over.items():
         setattr(cfg, k, v)
+    # config.py:111 and :116
+    assert not (cfg.no_self_connection and not cfg.no_adjacent_normalization), 'Adjacent normalization of graph only can be set in case of self-connection'
     assert cfg.batch_size % cfg.world_size == 0, 'For multi-gpu training, batch size must be divisible by world size'
     return cfg

@@ -14,7 +14,19 @@ import torch
 from . import _lib as L
 from .ops import _p, _s
 
-NORM = {'none': 0, 'symmetric': 1, 'asymmetric': 2}
+NORM = {'none': 0, 'symmetric': 1, 'asymmetric': 2, 'none_noself': 3}
+
+
+def norm_from_config(config):
+    """The graph normalisation the reference's flags select (config.py:56-58,111; MIND_corpus.py:180-214):
+    --no_self_connection (only legal together with --no_adjacent_normalization) -> zero diagonal, no normalisation;
+    --no_adjacent_normalization -> none; else --gcn_normalization_type ('symmetric' | 'asymmetric')."""
+    if getattr(config, 'no_self_connection', False):
+        assert getattr(config, 'no_adjacent_normalization', False), 'Adjacent normalization of graph only can be set in case of self-connection'
+        return 'none_noself'
+    if getattr(config, 'no_adjacent_normalization', False):
+        return 'none'
+    return getattr(config, 'gcn_normalization_type', 'symmetric')
 
 _NEWS_KEYS = ('news_category', 'news_subCategory', 'news_title_text', 'news_title_mask', 'news_title_entity',
               'news_abstract_text', 'news_abstract_mask', 'news_abstract_entity')
@@ -47,7 +59,9 @@ class DeviceCorpus:
     indices, 0 = PAD news), beh_history_mask [n, H] bool, optionally beh_line [n] + train_user_history_graph /
     _category_mask / _category_indices (the reference's pre-built tables; used when graph='table')."""
 
-    def __init__(self, arrays, device, category_num, graph='build', norm='symmetric'):
+    def __init__(self, arrays, device, category_num, graph='build', norm='symmetric', config=None):
+        if config is not None:                       # the reference's flags decide (they cannot disagree with a separate argument)
+            norm = norm_from_config(config)
         assert graph in ('build', 'table') and norm in NORM
         dev = torch.device(device)
         if dev.type != 'cuda':

@@ -91,7 +91,8 @@ __global__ __launch_bounds__(256) void history_graph_kernel(const int* __restric
     cat[i] = cats[(long)b * H + i];
     if (hmask[(long)b * H + i]) atomicAdd(&nh, 1);        // the mask is a prefix (MIND_corpus.py:352-353): count = history length
   }
-  for (int i = tid; i < G * G; i += 256) A[i] = ((i / G) == (i % G)) ? 1.f : 0.f;            // :183 identity (self connections)
+  const float diag = norm == 3 ? 0.f : 1.f;                                                  // :180-183 --no_self_connection: zero diagonal
+  for (int i = tid; i < G * G; i += 256) A[i] = ((i / G) == (i % G)) ? diag : 0.f;           // :183 identity (self connections)
   __syncthreads();
   const int n = nh;
   for (int i = tid; i < K + 1; i += 256) cmask[(long)b * (K + 1) + i] = 0;
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256) void history_graph_kernel(const int* __restric
   }
   __syncthreads();
   float* out = graph + (long)b * G * G;
-  if (n == 0 || norm == 0) {                                                                 // :186 empty history stays un-normalised
+  if (n == 0 || norm == 0 || norm == 3) {                                                                 // :186 empty history stays un-normalised
     for (int i = tid; i < G * G; i += 256) out[i] = A[i];
     return;
   }

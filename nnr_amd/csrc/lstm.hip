@@ -89,7 +89,8 @@ __device__ __forceinline__ unsigned long long ld_tag_first(const unsigned long l
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // re-poll one word until its tag matches (bounded: never hang the GPU -- on timeout count it and return NaN)
-__device__ __forceinline__ float wait_tag(const unsigned long long* p, unsigned long long v, unsigned tag, bool same_xcd, unsigned* diag) {
+__device__ __forceinline__ float wait_tag(const unsigned long long* p, unsigned long long v, unsigned tag, bool same_xcd, unsigned* diag,
+                                          unsigned* total) {
   int spins = 0;
   while ((unsigned)(v >> 32) != tag) {
     __builtin_amdgcn_s_sleep(1);
@@ -98,7 +99,8 @@ __device__ __forceinline__ float wait_tag(const unsigned long long* p, unsigned 
     // count it, and poison the value so the step's loss becomes NaN instead of silently training on stale data
     if (++spins > SPIN_LIMIT || ((spins & 1023) == 0 && __hip_atomic_load(diag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
       atomicAdd(diag, 1u);
-      v = 0x7fc00000ull;
+      if (total) atomicAdd(total, 1u);      // persistent across launches (nnr_lstm_set_timeout_counter): a time-out is a DATA-POISONING
+      v = 0x7fc00000ull;                    // event (NaN), not a retry -- the optimizer skips a step whose gradient norm is not finite
       break;
     }
   }
@@ -108,7 +110,7 @@ __device__ __forceinline__ float wait_tag(const unsigned long long* p, unsigned 
   return __uint_as_float((unsigned)v);
 }
 
-struct LstmArgs { LstmProblem p[4]; int nprob; int H; int dbg; };   // dbg: timing-attribution mask (NNR_LSTM_DBG), 0 in production
+struct LstmArgs { LstmProblem p[4]; int nprob; int H; int dbg; unsigned* tmo_total; };   // dbg: timing-attribution mask (NNR_LSTM_DBG), 0 in production
 
 // ------------------------------------------------------------------------------------------------ forward
 template <int UB>
@@ -277,7 +279,7 @@ __device__ __forceinline__ void lstm_fwd_pair_body(const LstmArgs& a, float (*hb
   if (tid == 0) {
     const unsigned mine = xcc_id();
     st_tag(xmine + 2 * XT, __uint_as_float(mine), 0x7fffffffu, false);
-    const float theirs = wait_tag(xtheirs + 2 * XT, ld_tag(xtheirs + 2 * XT, false), 0x7fffffffu, false, diag);
+    const float theirs = wait_tag(xtheirs + 2 * XT, ld_tag(xtheirs + 2 * XT, false), 0x7fffffffu, false, diag, a.tmo_total);
     hbuf[0][0] = (__float_as_uint(theirs) == mine && !(a.dbg & 64)) ? 1.f : 0.f;
   }
   __syncthreads();
@@ -364,7 +366,7 @@ __device__ __forceinline__ void lstm_fwd_pair_body(const LstmArgs& a, float (*hb
 #pragma unroll
       for (int j = 0; j < MAXW; ++j) {
         const int i = tid + NT * j, row = i / XW, cc = i - row * XW;
-        if (row < nprev && cc < pw) hc[lds_off(row, pu0 + cc, HP)] = wait_tag(src + i, v[j], tag, same_xcd, diag);
+        if (row < nprev && cc < pw) hc[lds_off(row, pu0 + cc, HP)] = wait_tag(src + i, v[j], tag, same_xcd, diag, a.tmo_total);
       }
     }
     STAMP(2);
@@ -631,7 +633,7 @@ __device__ __forceinline__ void lstm_bwd_pair_body(const LstmArgs& a, float* dg,
   if (tid == 0) {
     const unsigned mine = xcc_id();
     st_tag(xmine + 2 * XT, __uint_as_float(mine), 0x7fffffffu, false);
-    const float theirs = wait_tag(xtheirs + 2 * XT, ld_tag(xtheirs + 2 * XT, false), 0x7fffffffu, false, diag);
+    const float theirs = wait_tag(xtheirs + 2 * XT, ld_tag(xtheirs + 2 * XT, false), 0x7fffffffu, false, diag, a.tmo_total);
     dg[0] = (__float_as_uint(theirs) == mine && !(a.dbg & 64)) ? 1.f : 0.f;
   }
   __syncthreads();
@@ -711,7 +713,7 @@ __device__ __forceinline__ void lstm_bwd_pair_body(const LstmArgs& a, float* dg,
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = ld_tag_first(src + e * 64, same_xcd);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) dhr[e] += wait_tag(src + e * 64, v[e], (unsigned)step, same_xcd, diag);
+        for (int e = 0; e < 4; ++e) dhr[e] += wait_tag(src + e * 64, v[e], (unsigned)step, same_xcd, diag, a.tmo_total);
       }
       if (stamp && step < 128) tbuf[step * 16 + 5] = wall_clock64() + (unsigned long long)(dhr[0] == 123.456f);
 #pragma unroll
@@ -897,6 +899,19 @@ extern "C" int nnr_lstm_dims(int H, int* UB, int* HP, int* NP) {
   return (ub == 1 || ub == 2 || ub == 13) ? NNR_OK : NNR_ERR_UNSUPPORTED;
 }
 
+static unsigned* g_tmo_total = nullptr;     // caller-owned persistent time-out counter (device memory), see nnr_lstm_set_timeout_counter
+
+extern "C" int nnr_lstm_set_timeout_counter(unsigned* dev_counter) {
+  g_tmo_total = dev_counter;
+  return NNR_OK;
+}
+
+extern "C" size_t nnr_lstm_sync_diag_offset(int n) {
+  // byte offset of the diagnostics block (word 0 = exchange time-outs of the LAST launch on this workspace) inside the
+  // workspace of nnr_lstm_sync_bytes(n): it sits behind the exchange slots, in front of the 128 x 16 stamp words
+  return nnr_lstm_sync_bytes(n) - SYNC_PAD * sizeof(unsigned) - 128 * 16 * 8;
+}
+
 extern "C" size_t nnr_lstm_sync_bytes(int n) {
   const size_t ntiles = (size_t)(n + 15) / 16;
   // [2 directions][ntiles][2 halves][2 step parities][16 rows][7 * 16 units] tagged 8-byte words + 64 bytes of diagnostics
@@ -933,6 +948,7 @@ static int lstm_run(const nnr_lstm_problem* probs, int nprob, int H, bool backwa
   a.nprob = nprob;
   a.H = H;
   { const char* e = getenv("NNR_LSTM_DBG"); a.dbg = e ? atoi(e) : 0; }
+  a.tmo_total = g_tmo_total;
   int max_tiles = 0;
   for (int i = 0; i < nprob; ++i) {
     const nnr_lstm_problem& q = probs[i];

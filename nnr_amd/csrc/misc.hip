@@ -594,6 +594,10 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
                             long n, const float* __restrict__ sumsq, float grad_scale, float clip, float lr, float b1, float b2,
                             float eps, float wd, float bc1, float bc2_sqrt) {
   // clip_grad_norm_: coef = clip / (norm + 1e-6), applied only when < 1 (torch clamps the coefficient to 1)
+  // a gradient whose norm is not finite (overflow, or the NaN poison of a timed-out recurrence exchange, lstm.hip) must not
+  // reach the parameters or the moments: the step is skipped as a whole (torch's clip_grad_norm_ + Adam would write NaN into
+  // all three, permanently)
+  if (!isfinite(*sumsq)) return;
   float coef = grad_scale;
   if (clip > 0.f) {
     const float norm = sqrtf(*sumsq) * grad_scale;

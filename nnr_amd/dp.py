@@ -96,6 +96,100 @@ def allreduce_gradients(flat_grads):
     return 1.0 / w
 
 
+class GradientExchange:
+    """The per-step gradient exchange of DistributedDataParallel (trainer.py:212-219,297) on the flat gradient buffer, in
+    two buckets so that the first overlaps the rest of the backward pass the way DDP's bucketed all-reduce does:
+
+      * EARLY bucket = the gradients of `early_modules` (the user encoder's own parameters: GCN, cluster attention, ...).
+        The user encoder is the FIRST thing the backward pass finishes (loss -> user encoder -> news encoder), so its
+        segment of the flat buffer is final while the whole news-encoder backward (several ms: recurrence + token GEMMs) is
+        still ahead.  `early_ready()` -- called by the user encoder's backward function once its weight-gradient launches
+        are ordered on the current stream -- starts an asynchronous all-reduce of that segment (torch.distributed: RCCL's
+        own stream, ordered behind the current stream; C-ABI binding: a dedicated comm stream).
+      * LATE bucket = everything else (word-embedding table, Bi-LSTM, attention / gate layers), all-reduced by `finish()`
+        after the backward pass has joined its streams; `finish()` also makes the optimizer's stream wait for the early one.
+
+    Both buckets are slices of ONE buffer: no packing copies.  The order of collectives (early, then late) is the same on
+    every rank by construction.  With world_size 1 nothing is exchanged unless NNR_DP_FORCE=1 (single-GPU ordering tests on a
+    one-rank communicator).  Returns the 1/world scale the fused clip+Adam kernel applies."""
+
+    def __init__(self, flat, early_modules=()):
+        self.flat = flat
+        self.grad = flat.grad
+        self.force = os.environ.get('NNR_DP_FORCE') == '1'
+        total = flat.grad.numel()
+        lo = hi = None
+        ids = {id(p) for m in early_modules for p in m.parameters()}
+        spans = sorted((o, o + (p.numel() + 3) // 4 * 4, id(p) in ids) for p, o in zip(flat.params, flat.offsets))
+        early = [(a, b) for a, b, e in spans if e]
+        if early:
+            lo, hi = early[0][0], early[-1][1]
+            if any(not e for a, b, e in spans if a >= lo and b <= hi):      # not contiguous in this layout: one bucket
+                lo = hi = None
+        self.early_span = (lo, hi) if lo is not None else None
+        self.late_spans = [(0, total)] if lo is None else [(a, b) for a, b in ((0, lo), (hi, total)) if b > a]
+        self._pending = None
+        self._comm = None
+        self.events = None            # tests: {'early_issued': Event, ...} recorded on the issuing stream when set to a dict
+
+    def active(self):
+        return world_size() > 1 or (self.force and dist.is_initialized())
+
+    def describe(self):
+        es = self.early_span
+        return {'buckets': ([{'name': 'early (user encoder)', 'floats': es[1] - es[0]}] if es else []) +
+                           [{'name': 'late', 'floats': sum(b - a for a, b in self.late_spans)}],
+                'binding': 'C-ABI nnr_dp_allreduce' if (os.environ.get('NNR_DP_NATIVE') == '1' and self.grad.is_cuda) else 'torch.distributed all_reduce',
+                'overlap': 'early bucket is reduced while the news-encoder backward runs' if es else 'none (single bucket)'}
+
+    def _reduce(self, view, async_op):
+        nx = _native_exchange() if view.is_cuda else None
+        if nx is None:
+            return dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=async_op)
+        if not async_op:
+            nx.allreduce(view)
+            return None
+        if self._comm is None:
+            self._comm = torch.cuda.Stream(device=view.device)
+        cur = torch.cuda.current_stream(view.device)
+        self._comm.wait_stream(cur)
+        with torch.cuda.stream(self._comm):
+            nx.allreduce(view)
+        return self._comm
+
+    def early_ready(self):
+        """The early bucket's gradients are final on the CURRENT stream: start reducing them."""
+        if self.early_span is None or self._pending is not None or not self.active():
+            return
+        a, b = self.early_span
+        if self.events is not None and self.grad.is_cuda:
+            self.events['early_issued'] = torch.cuda.Event(enable_timing=True)
+            self.events['early_issued'].record()
+        self._pending = self._reduce(self.grad[a:b], True)
+
+    def finish(self):
+        """All gradients are final on the current stream: reduce what is left, order the early bucket before the caller's next
+        launch, return 1/world."""
+        w = world_size()
+        if not self.active():
+            return 1.0 / w
+        pend, self._pending = self._pending, None
+        spans = list(self.late_spans)
+        if pend is None and self.early_span is not None:       # early_ready was never called this step
+            spans = [(0, self.grad.numel())]
+        for a, b in spans:
+            self._reduce(self.grad[a:b], False)
+        if pend is not None:
+            if isinstance(pend, torch.cuda.Stream):
+                torch.cuda.current_stream(self.grad.device).wait_stream(pend)
+            else:
+                pend.wait()                                    # NCCL: the current stream waits; gloo: the host waits
+        if self.events is not None and self.grad.is_cuda:
+            self.events['finished'] = torch.cuda.Event(enable_timing=True)
+            self.events['finished'].record()
+        return 1.0 / w
+
+
 def sampler_indices(n, rank, world, epoch, seed=0):
     """The behaviour indices rank `rank` visits in epoch `epoch`, exactly as torch's DistributedSampler(shuffle=True, seed)
     after set_epoch(epoch) -- the sampler of trainer.py:256-257,264: randperm(n) from Generator(seed + epoch), padded by

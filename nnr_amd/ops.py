@@ -343,12 +343,36 @@ def lstm_unpack_grads(dw_ihp, db_p, dw_hhp, H, E, grads):
 
 
 LSTM_PAIR = os.environ.get('NNR_LSTM_PAIR', '1') != '0'      # 2-CU weights-stationary recurrence (lstm.hip) when H = 200
-LAST_LSTM_SYNC = []                                           # step-counter workspaces of the last launch (diagnostics)
+LAST_LSTM_SYNC = []                                           # exchange workspaces of the last launch (diagnostics)
+_TMO = {}                                                     # per device: persistent exchange time-out counter (uint32 as int32)
 
 
-def lstm_sync_timeouts():
-    """Spin-wait timeouts recorded by the last pair-kernel launch (must be 0; synchronises)."""
-    return sum(int(t[-16].item()) for t in LAST_LSTM_SYNC)
+def _timeout_counter(dev):
+    """The device counter every pair-kernel launch of this process adds its exchange time-outs to (registered once with the
+    library: nnr_lstm_set_timeout_counter).  One process drives one GPU."""
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    t = _TMO.get(key)
+    if t is None:
+        t = torch.zeros(1, dtype=torch.int32, device=dev)
+        _TMO[key] = t
+        L.check(L.lib().nnr_lstm_set_timeout_counter(C.c_void_p(t.data_ptr())), 'nnr_lstm_set_timeout_counter')
+    return t
+
+
+def lstm_sync_timeouts(reset=False):
+    """Exchange time-outs of the CU-pair recurrence accumulated over EVERY launch since the process started (or since the
+    last reset); must be 0.  A time-out poisons the step with NaN (the optimizer then skips it).  Synchronises."""
+    n = sum(int(t.item()) for t in _TMO.values())
+    if reset:
+        for t in _TMO.values():
+            t.zero_()
+    return n
+
+
+def lstm_last_launch_timeouts():
+    """Time-outs recorded by the LAST pair-kernel launch only, read from the diagnostics block of its workspaces at the offset
+    the library reports (nnr_lstm_sync_diag_offset).  Synchronises."""
+    return sum(int(t[off // 4].item()) for t, off in LAST_LSTM_SYNC)
 
 
 def _lstm_probs(items, H=0):
@@ -357,8 +381,9 @@ def _lstm_probs(items, H=0):
     for a, it in zip(arr, items):
         pl = it['plan']
         if LSTM_PAIR and H == 200:
+            _timeout_counter(it['gates'].device)
             it['sync'] = torch.empty(L.lib().nnr_lstm_sync_bytes(pl.n) // 4, dtype=torch.int32, device=it['gates'].device)
-            LAST_LSTM_SYNC.append(it['sync'])
+            LAST_LSTM_SYNC.append((it['sync'], L.lib().nnr_lstm_sync_diag_offset(pl.n)))
         a.sync = _p(it.get('sync'))
         a.bs, a.off, a.slen, a.prev_f, a.prev_r = _p(pl.bs), _p(pl.off), _p(pl.slen), _p(pl.prev_f), _p(pl.prev_r)
         a.n, a.L = pl.n, pl.L

@@ -40,9 +40,23 @@ class FlatParams:
             p.data = self.flat[o:o + n].view(p.shape)
             p.grad = self.grad[o:o + n].view(p.shape)
         self.numel = total
+        self.offsets = offs
 
     def zero_grad(self):
         self.grad.zero_()
+
+
+class _Own:
+    """The parameters a user encoder owns itself: its direct parameters and its children except the shared news encoder."""
+
+    def __init__(self, ue, children):
+        self.ue, self.children = ue, children
+
+    def parameters(self):
+        for p in self.ue.parameters(recurse=False):
+            yield p
+        for m in self.children:
+            yield from m.parameters()
 
 
 class Trainer:
@@ -57,6 +71,12 @@ class Trainer:
         self.gradient_clip_norm = float(config.gradient_clip_norm)
         self.lr, self.weight_decay = float(config.lr), float(config.weight_decay)
         dp.broadcast_parameters(self.flat.flat)
+        # bucketed exchange: the user encoder's own gradients are final first (its backward runs before the news encoder's)
+        ue = getattr(model, 'user_encoder', None)
+        own = [m for name, m in ue.named_children() if name != 'news_encoder'] if ue is not None else []
+        self.exchange = dp.GradientExchange(self.flat, early_modules=[_Own(ue, own)] if ue is not None else [])
+        if ue is not None:
+            ue.__dict__['_grads_ready_hook'] = self.exchange.early_ready
 
     def train_step(self, batch):
         """One optimizer step on `batch` (21 device tensors, Model.forward order).  Returns (logits, loss) as device
@@ -67,7 +87,7 @@ class Trainer:
         loss = negative_log_softmax(logits)
         loss.backward()
         ops.join_extra_streams()
-        scale = dp.allreduce_gradients(self.flat.grad)
+        scale = self.exchange.finish()
         self.optimizer_step(scale)
         return logits.detach(), loss.detach()
 

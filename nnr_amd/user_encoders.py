@@ -118,7 +118,13 @@ def sue_backward(mod, sv, dout):
     dout = dout.view(B * N, D)
     ia = mod.interClusterAttention
     with ops.leaf_scope(dev) as leaf:
-        return _sue_backward_body(mod, sv, dout, leaf, B, Hn, D, N, Kc, G, Cn, A, p, seed, dev, f32, cand2, ia)
+        res = _sue_backward_body(mod, sv, dout, leaf, B, Hn, D, N, Kc, G, Cn, A, p, seed, dev, f32, cand2, ia)
+    # every parameter gradient of this encoder is now ordered on the current stream (the leaf stream was joined on exit):
+    # a data-parallel trainer starts reducing them while the news encoder's backward is still to come (dp.GradientExchange)
+    hook = mod.__dict__.get('_grads_ready_hook')
+    if hook is not None:
+        hook()
+    return res
 
 
 def _sue_backward_body(mod, sv, dout, leaf, B, Hn, D, N, Kc, G, Cn, A, p, seed, dev, f32, cand2, ia):

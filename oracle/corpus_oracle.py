@@ -17,6 +17,8 @@ def history_graph(cats, n_hist, max_history_num, category_num, norm='symmetric',
     G = max_history_num + category_num.  MIND_corpus.py:179-216."""
     H, K = max_history_num, category_num
     G = H + K
+    if norm == 'none_noself':                          # --no_self_connection: zero diagonal, never normalised (config.py:56,111)
+        self_connection = False
     graph = np.identity(G, dtype=np.float32) if self_connection else np.zeros([G, G], dtype=np.float32)   # :180-183
     mask = np.zeros(K + 1, dtype=bool)                                                                      # :184
     indices = np.full([H], K, dtype=np.int64)                                                               # :185

@@ -180,9 +180,28 @@ class BiLSTM(nn.Module):
             outs[t] = torch.cat([h_new, xw.new_zeros(n - nt, hd)], dim=0)
         return torch.stack(outs, dim=1), c
 
+    # 'loop': the explicit time loop below (independent of ATen's fused LSTM: the parity checker).
+    # 'aten': ATen's own CPU LSTM on a PackedSequence -- the very code path the reference's nn.LSTM takes on the host
+    #         (newsEncoders.py:119-127); same results (tests/test_oracle_golden.py runs both), several times faster, so this
+    #         is what bench.py times as the CPU baseline.
+    backend = 'loop'
+
+    def _forward_aten(self, x, lengths):
+        n, L, _ = x.shape
+        packed = nn.utils.rnn.pack_padded_sequence(x, lengths.cpu(), batch_first=True, enforce_sorted=False)
+        flat = [getattr(self, k + sfx) for sfx in ('', '_reverse') for k in ('weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0')]
+        zeros = x.new_zeros(2, n, self.hidden_dim)
+        out, _, c_n = torch._VF.lstm(packed.data, packed.batch_sizes, (zeros, zeros), flat, True, 1, 0.0, self.training, True)
+        H, _ = nn.utils.rnn.pad_packed_sequence(nn.utils.rnn.PackedSequence(out, packed.batch_sizes, packed.sorted_indices, packed.unsorted_indices),
+                                                batch_first=True, total_length=L)
+        c_n = c_n.index_select(1, packed.unsorted_indices)            # back to the caller's row order (nn.LSTM.permute_hidden)
+        return H, torch.cat([c_n[0], c_n[1]], dim=1)
+
     def forward(self, x, lengths):
         """x [n, L, E] (values past length ignored), lengths [n] >= 1.
         Returns H [n, L, 2h] and c_n [n, 2h] = [c_fwd ; c_rev], both in the caller's row order."""
+        if self.backend == 'aten':
+            return self._forward_aten(x, lengths)
         order = torch.argsort(lengths, descending=True, stable=True)
         inv = torch.argsort(order)
         xs, ls = x[order], lengths[order]

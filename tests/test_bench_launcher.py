@@ -1,0 +1,70 @@
+"""`python bench.py --gpus N` must work as typed: with N > 1 and no torchrun environment it launches the N ranks itself (a
+child `python -m torch.distributed.run`, before anything touches the GPU).  The CPU form of the run (`--plumbing_check`,
+gloo) drives the PRODUCT's flat-buffer and exchange plumbing -- trainer.FlatParams, dp.init_from_env, dp.broadcast_parameters,
+dp.GradientExchange (early + late bucket, 1/world scale) -- on a stand-in module; rank 0 prints one JSON line.
+Reference semantics: trainer.py:212-220 (per-rank batch = batch_size // world_size, averaged gradients), :256-258."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env_extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, capture_output=True, text=True, env=env, timeout=300)
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+@pytest.mark.parametrize('n', [1, 2])
+def test_bench_self_launches_ranks_and_exchanges_gradients(n):
+    r, out = _run(['--gpus', str(n), '--plumbing_check', '--steps', '3'])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert out is not None and out['n_gpus'] == n and out['params_equal_on_all_ranks_and_expected'] is True
+    assert out['scaling'] == 'weak' and out['global_batch'] == 64 * n
+    names = [b['name'] for b in out['buckets']['buckets']]
+    assert names == ['early (user encoder)', 'late']
+
+
+def test_bench_strong_scaling_flag_follows_the_reference_batch_semantics():
+    """--global_batch G == the reference's `--batch_size G --world_size N`: per-rank batch G // N (trainer.py:218)."""
+    r, out = _run(['--gpus', '2', '--plumbing_check', '--steps', '1', '--global_batch', '64'])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert out['scaling'] == 'strong' and out['per_gpu_batch'] == 32 and out['global_batch'] == 64
+
+
+def test_gradient_exchange_buckets_cover_the_flat_buffer_exactly_once():
+    from nnr_amd import dp
+    from nnr_amd.trainer import FlatParams, _Own
+    from nnr_amd.config import make_config
+    from oracle import nnr_oracle as O          # any module tree with the reference's names: news_encoder shared by user_encoder
+    cfg = make_config(['--news_encoder=CNE', '--user_encoder=SUE'], corpus_sizes=dict(vocabulary_size=50), hidden_dim=16, attention_dim=8,
+                      word_embedding_dim=12, category_embedding_dim=4, subCategory_embedding_dim=4, gcn_layer_num=2, category_num=5,
+                      subCategory_num=7)
+    model = O.Model(cfg)
+    flat = FlatParams(model)
+    ue = model.user_encoder
+    own = [m for name, m in ue.named_children() if name != 'news_encoder']
+    ex = dp.GradientExchange(flat, early_modules=[_Own(ue, own)])
+    assert ex.early_span is not None
+    a, b = ex.early_span
+    own_ids = {id(p) for p in _Own(ue, own).parameters()}
+    shared_ids = {id(p) for p in model.news_encoder.parameters()}
+    assert own_ids and not (own_ids & shared_ids)
+    covered = torch.zeros(flat.numel, dtype=torch.int32)
+    covered[a:b] += 1
+    for x, y in ex.late_spans:
+        covered[x:y] += 1
+    assert bool((covered == 1).all())
+    for p, o in zip(flat.params, flat.offsets):          # the early span holds exactly the user encoder's own parameters
+        assert (a <= o < b) == (id(p) in own_ids)
+    # world size 1, not forced: nothing to exchange, scale 1
+    flat.grad.fill_(2.0)
+    ex.early_ready()
+    assert ex.finish() == 1.0 and float(flat.grad.min()) == 2.0

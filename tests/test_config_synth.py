@@ -73,3 +73,19 @@ def test_device_corpus_refuses_cpu_and_negative_sampling_rules():
     s = negative_sampling([(9, [4]), (8, [1, 2, 3, 5, 6, 7])], 4, rs.randint)
     assert s.dtype == np.int32 and s[0].tolist() == [9, 4, 4, 4, 4]
     assert s[1, 0] == 8 and len(set(s[1, 1:].tolist())) == 4 and set(s[1, 1:].tolist()) <= {1, 2, 3, 5, 6, 7}
+
+
+def test_gcn_graph_flags_follow_the_reference():
+    """config.py:56-58,111: --gcn_normalization_type {symmetric, asymmetric}; --no_self_connection only with
+    --no_adjacent_normalization; the device corpus derives its graph normalisation from these flags."""
+    import pytest
+    from nnr_amd.config import make_config
+    from nnr_amd.corpus import norm_from_config
+    assert make_config([]).gcn_normalization_type == 'symmetric'
+    assert norm_from_config(make_config(['--gcn_normalization_type=asymmetric'])) == 'asymmetric'
+    assert norm_from_config(make_config(['--no_adjacent_normalization'])) == 'none'
+    assert norm_from_config(make_config(['--no_adjacent_normalization', '--no_self_connection'])) == 'none_noself'
+    with pytest.raises(AssertionError):
+        make_config(['--no_self_connection'])
+    with pytest.raises(SystemExit):
+        make_config(['--gcn_normalization_type=bogus'])

@@ -8,7 +8,7 @@ import pytest
 from oracle import corpus_oracle as CO
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
-TAGS = ['tiny_h50_sym', 'tiny_h8_asym', 'tiny_h8_none']
+TAGS = ['tiny_h50_sym', 'tiny_h8_asym', 'tiny_h8_none', 'tiny_h8_noself']
 
 
 def load(tag):

@@ -9,7 +9,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
-TAGS = ['tiny_h50_sym', 'tiny_h8_asym', 'tiny_h8_none']
+TAGS = ['tiny_h50_sym', 'tiny_h8_asym', 'tiny_h8_none', 'tiny_h8_noself']
 
 
 def load(tag):
@@ -58,7 +58,7 @@ def test_history_graph_equals_reference_preprocess(tag):
     np.testing.assert_array_equal(ci.cpu().numpy(), c['train_user_history_category_indices'])
 
 
-@pytest.mark.parametrize('norm', ['symmetric', 'asymmetric', 'none'])
+@pytest.mark.parametrize('norm', ['symmetric', 'asymmetric', 'none', 'none_noself'])
 def test_history_graph_mind_shape_random_vs_oracle(norm):
     """H = 50, 18 categories (G = 68), 512 random histories incl. empty / single / full ones, against the numpy restatement."""
     from nnr_amd.corpus import history_graph

@@ -224,6 +224,48 @@ def test_seq_plan_matches_stable_sort():
     assert torch.equal(plan2.order.cpu(), perm)
 
 
+def test_pair_recurrence_timeout_is_counted_and_skips_the_optimizer(monkeypatch):
+    """The CU-pair exchange must fail LOUDLY: with the tagged stores switched off (debug bit 2 of NNR_LSTM_DBG) every partner
+    wait runs into its bound, the per-launch diagnostics word AND the persistent counter become non-zero, h is poisoned with
+    NaN, and clip+Adam leaves parameters and moments untouched for a gradient whose norm is not finite."""
+    from nnr_amd import ops
+    from nnr_amd.layers import LSTMParams
+    monkeypatch.setattr(ops, 'LSTM_PAIR', True)
+    d = dev()
+    n, Lx, E, H = 32, 6, 300, 200
+    lens = torch.full((n,), Lx)
+    mask = torch.arange(Lx)[None, :] < lens[:, None]
+    ids = torch.arange(n * Lx, dtype=torch.int32).view(n, Lx)
+    plan = ops.SeqPlan(mask.clone().to(d), ids.to(d))
+    holder = LSTMParams(E, H).to(d)
+    w = ops.LstmPacked(holder.param_list(), H, E)
+    f32 = dict(device=d, dtype=torch.float32)
+    cap = plan.cap
+    st = dict(plan=plan, w=w, gates=torch.randn((cap, 2 * w.NP), **f32) * 0.1, cell=torch.empty((cap, 2 * w.HP), **f32),
+              hout=torch.zeros((cap, 2 * H), **f32), cn=torch.empty((n, 2 * H), **f32))
+    ops.lstm_sync_timeouts(reset=True)
+    ops.lstm_fwd([st], H)
+    torch.cuda.synchronize()
+    assert ops.lstm_sync_timeouts() == 0 and ops.lstm_last_launch_timeouts() == 0 and bool(torch.isfinite(st['hout']).all())
+    monkeypatch.setenv('NNR_LSTM_DBG', '2')
+    ops.lstm_fwd([st], H)
+    torch.cuda.synchronize()
+    monkeypatch.delenv('NNR_LSTM_DBG')
+    assert ops.lstm_last_launch_timeouts() > 0
+    total = ops.lstm_sync_timeouts()
+    assert total > 0 and not bool(torch.isfinite(st['hout']).all())
+    ops.lstm_fwd([st], H)                                   # a clean launch: its own diagnostics are 0, the total stays
+    torch.cuda.synchronize()
+    assert ops.lstm_last_launch_timeouts() == 0 and ops.lstm_sync_timeouts(reset=True) == total and ops.lstm_sync_timeouts() == 0
+    # the poisoned step never reaches the parameters
+    p = torch.randn(1000, **f32); g = torch.randn(1000, **f32); g[7] = float('nan')
+    m = torch.zeros(1000, **f32); v = torch.zeros(1000, **f32); ss = torch.zeros(1, **f32)
+    p0 = p.clone()
+    ops.sumsq(g, ss)
+    ops.clip_adam(p, g, m, v, ss, 1.0, 4.0, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1)
+    assert torch.equal(p, p0) and float(m.abs().max()) == 0.0 and float(v.abs().max()) == 0.0
+
+
 @pytest.mark.parametrize('n,Lx,E,H,variant', [(37, 12, 16, 8, 'one'), (100, 32, 300, 200, 'one'), (45, 128, 300, 200, 'one'),
                                               (100, 32, 300, 200, 'pair'), (45, 128, 300, 200, 'pair'), (200, 128, 300, 200, 'pair'),
                                               (45, 128, 300, 200, 'pair_fabric')])

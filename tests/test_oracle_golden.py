@@ -44,8 +44,18 @@ def check_params_after_adam(case, model, steps, tight=5e-5):
         assert d.max(initial=0.0) <= steps * lr * 1.01 + tight, k
 
 
+@pytest.fixture(params=['loop', 'aten'])
+def lstm_backend(request, monkeypatch):
+    """Both restatements of the Bi-LSTM are pinned: the explicit time loop (the parity checker) and ATen's own packed-sequence
+    LSTM (what the reference's nn.LSTM runs on the host; bench.py's CPU baseline times this one)."""
+    monkeypatch.setattr(O.BiLSTM, 'backend', request.param)
+    return request.param
+
+
 @pytest.mark.parametrize('tag', ALL_CASES)
-def test_oracle_matches_reference_golden(tag):
+def test_oracle_matches_reference_golden(tag, lstm_backend):
+    if lstm_backend == 'aten' and 'CNE' not in tag:
+        pytest.skip('no LSTM in this model')
     case = GoldenCase(tag)
     steps = int(case.meta['adam_steps'])
     model, res = _run(case, steps)

@@ -9,7 +9,7 @@ os.environ['NNR_LSTM_DBG'] = '32'
 for _ in range(3):
     which([crit], H)
 torch.cuda.synchronize()
-sync = ops.LAST_LSTM_SYNC[0]
+sync, _diag_off = ops.LAST_LSTM_SYNC[0]
 tb = sync[-(128 * 16 * 2):].view(torch.int64).view(128, 16).cpu().numpy().astype(np.float64)
 tb = tb[8:120]
 base = tb[:, 4:5]                      # compute wave: step start

@@ -80,8 +80,8 @@ def run(tag, max_history_num, norm):
             import MIND_dataset                     # /root/reference/MIND_dataset.py
             cfg = SimpleNamespace(dataset='tiny', tokenizer='MIND', word_threshold=1, max_title_length=8, max_abstract_length=16,
                                   word_embedding_dim=50, entity_embedding_dim=100, context_embedding_dim=100,
-                                  max_history_num=max_history_num, negative_sample_num=4, no_self_connection=False,
-                                  no_adjacent_normalization=(norm == 'none'), gcn_normalization_type=(norm if norm != 'none' else 'symmetric'),
+                                  max_history_num=max_history_num, negative_sample_num=4, no_self_connection=(norm == 'none_noself'),
+                                  no_adjacent_normalization=norm.startswith('none'), gcn_normalization_type=(norm if not norm.startswith('none') else 'symmetric'),
                                   train_root='../MIND-tiny/train', dev_root='../MIND-tiny/dev', test_root='../MIND-tiny/test')
             torch.manual_seed(0)
             corpus = MIND_corpus.MIND_Corpus(cfg)
@@ -129,3 +129,4 @@ if __name__ == '__main__':
     run('tiny_h50_sym', 50, 'symmetric')
     run('tiny_h8_asym', 8, 'asymmetric')
     run('tiny_h8_none', 8, 'none')
+    run('tiny_h8_noself', 8, 'none_noself')     # --no_self_connection (config.py:56; requires --no_adjacent_normalization, config.py:111)
