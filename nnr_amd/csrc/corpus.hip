@@ -159,7 +159,7 @@ extern "C" int nnr_corpus_batch(const nnr_corpus_tables* t, const nnr_batch_out*
 extern "C" int nnr_history_graph(const int* cats, const uint8_t* hmask, int B, int H, int K, int norm, float* graph, uint8_t* cmask,
                                  long* cidx, hipStream_t stream) {
   if (!cats || !hmask || !graph || !cmask || !cidx || B <= 0) return NNR_ERR_ARG;
-  if (H + K > GMAX || norm < 0 || norm > 2) return NNR_ERR_UNSUPPORTED;
+  if (H + K > GMAX || norm < 0 || norm > 3) return NNR_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(history_graph_kernel, dim3(B), dim3(256), 0, stream, cats, hmask, B, H, K, norm, graph, cmask, cidx);
   NNR_CHECK_LAUNCH();
   return NNR_OK;

@@ -16,6 +16,7 @@
 //   (embedding gradient), split-K with atomics for the token-reduction GEMMs, dynamic token count read from
 //   device memory (no host sync).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -24,6 +25,134 @@ __device__ __forceinline__ int swz(int r16) {  // chunk XOR for row r (0..15) of
   // BK=16 (4 chunks / row): f(r>>2) = {0,3,2,1};  BK=32 (8 chunks / row): (r>>1)&7;  BK=64 (16 chunks = one 256-B bank row
   // per row): r itself.  Each makes the four ds_read_b128 lane groups hit 16 distinct 16-B slots (brute-force checked).
   return BK == 16 ? ((4 - (r16 >> 2)) & 3) : BK == 32 ? ((r16 >> 1) & 7) : (r16 & 15);
+}
+
+// ---------------------------------------------------------------- shared epilogue (all tiled kernels of this file)
+// Wave w of the 4-wave workgroup holds rows [(w*TM + m)*16, +16) of the block tile in acc[m][*]; `stage` is LDS of at least
+// 64 * (16*TN + 4) floats that no wave still reads.
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(const nnr_gemm_args& g, f32x4 (&acc)[TM][TN], float* lds, float* __restrict__ C, int m0,
+                                              int n0, int M, int N, int z) {
+  constexpr int BN = 16 * TN, E_LD = BN + 4;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int r = lane & 15, kk = lane >> 4;
+  const uint32_t dthr = g.drop_thresh;
+  const float dscale = g.drop_scale;
+  // ---------------------------------------------------------------- epilogue
+  // Accumulators go through LDS in TM passes of 64 rows (tiny fully-unrolled store loop: the MFMA registers are only
+  // ever indexed statically), then a rolled, runtime-flagged loop applies the epilogue with consecutive lanes on
+  // consecutive columns: every global access (C, aux, mul, resid, atomics) is a contiguous 256-B wave access.
+  const bool use_atomic = g.atomic || g.split_k > 1 || g.k_chunk > 0;
+  float* aux = g.aux_out;
+  const float* res = g.resid;
+  const float* mulp = g.mul;
+  if (g.batch > 1 && g.split_k <= 1 && g.k_chunk <= 0) {
+    if (aux) aux += (long)z * g.stride_aux;
+    if (res) res += (long)z * g.stride_res;
+  }
+  float* stage = lds;
+#pragma unroll
+  for (int m = 0; m < TM; ++m) {
+    if (m > 0) __syncthreads();
+#pragma unroll
+    for (int n = 0; n < TN; ++n)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) stage[(w * 16 + kk * 4 + reg) * E_LD + n * 16 + r] = acc[m][n][reg];
+    __syncthreads();
+    if (g.rowdot_w) {
+      // one wave per row: lanes stride the columns, wave-reduce the w2-weighted sum (needs the whole row in this tile)
+      for (int lr = w; lr < 64; lr += 4) {
+        const int row = m0 + (lr >> 4) * (TM * 16) + m * 16 + (lr & 15);
+        float dot = 0.f;
+        if (row < M) {
+          for (int c = lane; c < BN; c += 64) {
+            const int col = n0 + c;
+            if (col < N) {
+              float x = stage[lr * E_LD + c] * g.alpha;
+              if (g.bias) x += g.bias[col];
+              if (g.act == 1) x = fmaxf(x, 0.f);
+              else if (g.act == 2) x = fast_tanh(x);
+              else if (g.act == 3) x = fast_sigmoid(x);
+              if (aux) aux[(long)row * g.ldaux + col] = x;
+              dot += g.rowdot_w[col] * x;
+              if (C) C[(long)row * g.ldc + col] = x;
+            }
+          }
+        }
+        dot = wave_sum(dot);
+        if (row < M && lane == 0) g.rowdot_out[row] = dot;
+      }
+    } else if (g.vec_epi) {
+      // float4 path (all operands 16-B aligned, no scatter / atomics): a wave writes 1 KiB contiguous pieces of C rows
+      constexpr int NV = BN / 4;
+      for (int idx = tid; idx < 64 * NV; idx += 256) {
+        const int lr = idx / NV, c4 = idx - lr * NV;
+        const int row = m0 + (lr >> 4) * (TM * 16) + m * 16 + (lr & 15);
+        const int col = n0 + 4 * c4;
+        if (row >= M || col >= N) continue;
+        f32x4 x = *reinterpret_cast<const f32x4*>(&stage[lr * E_LD + 4 * c4]) * g.alpha;
+        if (g.accumulate == 2) x += *reinterpret_cast<const f32x4*>(C + (long)row * g.ldc + col);
+        if (g.bias) x += *reinterpret_cast<const f32x4*>(g.bias + col);
+        if (g.rowvec) x += *reinterpret_cast<const f32x4*>(g.rowvec + (long)(g.rowvec_map ? g.rowvec_map[row] : row) * g.ldrv + col);
+        if (g.act == 1) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) x[e] = fmaxf(x[e], 0.f);
+        } else if (g.act == 2) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) x[e] = fast_tanh(x[e]);
+        } else if (g.act == 3) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) x[e] = fast_sigmoid(x[e]);
+        }
+        if (aux) *reinterpret_cast<f32x4*>(aux + (long)row * g.ldaux + col) = x;
+        if (mulp) x *= *reinterpret_cast<const f32x4*>(mulp + (long)row * g.ldmul + col);
+        if (res) x += *reinterpret_cast<const f32x4*>(res + (long)row * g.ldres + col);
+        if (g.drop_target == 3) {
+          bool kp[4];
+          nnr_keep4(g.drop_seed, (uint64_t)(row + (long)z * g.M) * g.drop_cols + col, dthr, kp);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) x[e] = kp[e] ? x[e] * dscale : 0.f;
+        }
+        if (C) {
+          f32x4* cp = reinterpret_cast<f32x4*>(C + (long)row * g.ldc + col);
+          if (g.accumulate == 1) x += *cp;
+          *cp = x;
+        }
+      }
+    } else {
+      for (int idx = tid; idx < 64 * BN; idx += 256) {
+        const int lr = idx / BN, c = idx - lr * BN;
+        const int row = m0 + (lr >> 4) * (TM * 16) + m * 16 + (lr & 15);
+        const int col = n0 + c;
+        if (row >= M || col >= N) continue;
+        int crow = row;
+        if (g.c_idx) { crow = g.c_idx[row]; if (crow < 0) continue; }
+        float x = stage[lr * E_LD + c] * g.alpha;
+        if (g.accumulate == 2) x += C[(long)crow * g.ldc + col];      // running sum BEFORE bias / activation
+        if (g.bias) x += g.bias[col];
+        if (g.rowvec) x += g.rowvec[(long)(g.rowvec_map ? g.rowvec_map[row] : row) * g.ldrv + col];
+        if (g.act == 1) x = fmaxf(x, 0.f);
+        else if (g.act == 2) x = fast_tanh(x);
+        else if (g.act == 3) x = fast_sigmoid(x);
+        if (aux) aux[(long)row * g.ldaux + col] = x;
+        if (mulp) x *= mulp[(long)row * g.ldmul + col];
+        if (res) x += res[(long)row * g.ldres + col];
+        if (g.drop_target == 3)
+          x = nnr_keep(g.drop_seed, (uint64_t)(row + (long)z * g.M) * g.drop_cols + col, dthr) ? x * dscale : 0.f;
+        if (C) {
+          float* cp = C + (long)crow * g.ldc + col;
+          if (use_atomic) {
+            if (g.drop_target == 4)   // scatter of d(dropout(emb)) : mask keyed by the token row
+              x = nnr_keep(g.drop_seed, (uint64_t)row * g.drop_cols + col, dthr) ? x * dscale : 0.f;
+            atomicAdd(cp, x);
+          } else {
+            if (g.accumulate == 1) x += *cp;
+            *cp = x;
+          }
+        }
+      }
+    }
+  }
 }
 
 template <int TM, int TN, bool TA, bool TB, int BK>
@@ -311,121 +440,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(nnr_gemm_args g) {
     __syncthreads();
   }
 
-  // ---------------------------------------------------------------- epilogue
-  // Accumulators go through LDS in TM passes of 64 rows (tiny fully-unrolled store loop: the MFMA registers are only
-  // ever indexed statically), then a rolled, runtime-flagged loop applies the epilogue with consecutive lanes on
-  // consecutive columns: every global access (C, aux, mul, resid, atomics) is a contiguous 256-B wave access.
-  const bool use_atomic = g.atomic || g.split_k > 1 || g.k_chunk > 0;
-  float* aux = g.aux_out;
-  const float* res = g.resid;
-  const float* mulp = g.mul;
-  if (g.batch > 1 && g.split_k <= 1 && g.k_chunk <= 0) {
-    if (aux) aux += (long)z * g.stride_aux;
-    if (res) res += (long)z * g.stride_res;
-  }
-  float* stage = lds;
-#pragma unroll
-  for (int m = 0; m < TM; ++m) {
-    if (m > 0) __syncthreads();
-#pragma unroll
-    for (int n = 0; n < TN; ++n)
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) stage[(w * 16 + kk * 4 + reg) * E_LD + n * 16 + r] = acc[m][n][reg];
-    __syncthreads();
-    if (g.rowdot_w) {
-      // one wave per row: lanes stride the columns, wave-reduce the w2-weighted sum (needs the whole row in this tile)
-      for (int lr = w; lr < 64; lr += 4) {
-        const int row = m0 + (lr >> 4) * (TM * 16) + m * 16 + (lr & 15);
-        float dot = 0.f;
-        if (row < M) {
-          for (int c = lane; c < BN; c += 64) {
-            const int col = n0 + c;
-            if (col < N) {
-              float x = stage[lr * E_LD + c] * g.alpha;
-              if (g.bias) x += g.bias[col];
-              if (g.act == 1) x = fmaxf(x, 0.f);
-              else if (g.act == 2) x = fast_tanh(x);
-              else if (g.act == 3) x = fast_sigmoid(x);
-              if (aux) aux[(long)row * g.ldaux + col] = x;
-              dot += g.rowdot_w[col] * x;
-              if (C) C[(long)row * g.ldc + col] = x;
-            }
-          }
-        }
-        dot = wave_sum(dot);
-        if (row < M && lane == 0) g.rowdot_out[row] = dot;
-      }
-    } else if (g.vec_epi) {
-      // float4 path (all operands 16-B aligned, no scatter / atomics): a wave writes 1 KiB contiguous pieces of C rows
-      constexpr int NV = BN / 4;
-      for (int idx = tid; idx < 64 * NV; idx += 256) {
-        const int lr = idx / NV, c4 = idx - lr * NV;
-        const int row = m0 + (lr >> 4) * (TM * 16) + m * 16 + (lr & 15);
-        const int col = n0 + 4 * c4;
-        if (row >= M || col >= N) continue;
-        f32x4 x = *reinterpret_cast<const f32x4*>(&stage[lr * E_LD + 4 * c4]) * g.alpha;
-        if (g.accumulate == 2) x += *reinterpret_cast<const f32x4*>(C + (long)row * g.ldc + col);
-        if (g.bias) x += *reinterpret_cast<const f32x4*>(g.bias + col);
-        if (g.rowvec) x += *reinterpret_cast<const f32x4*>(g.rowvec + (long)(g.rowvec_map ? g.rowvec_map[row] : row) * g.ldrv + col);
-        if (g.act == 1) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) x[e] = fmaxf(x[e], 0.f);
-        } else if (g.act == 2) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) x[e] = fast_tanh(x[e]);
-        } else if (g.act == 3) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) x[e] = fast_sigmoid(x[e]);
-        }
-        if (aux) *reinterpret_cast<f32x4*>(aux + (long)row * g.ldaux + col) = x;
-        if (mulp) x *= *reinterpret_cast<const f32x4*>(mulp + (long)row * g.ldmul + col);
-        if (res) x += *reinterpret_cast<const f32x4*>(res + (long)row * g.ldres + col);
-        if (g.drop_target == 3) {
-          bool kp[4];
-          nnr_keep4(g.drop_seed, (uint64_t)(row + (long)z * g.M) * g.drop_cols + col, dthr, kp);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) x[e] = kp[e] ? x[e] * dscale : 0.f;
-        }
-        if (C) {
-          f32x4* cp = reinterpret_cast<f32x4*>(C + (long)row * g.ldc + col);
-          if (g.accumulate == 1) x += *cp;
-          *cp = x;
-        }
-      }
-    } else {
-      for (int idx = tid; idx < 64 * BN; idx += 256) {
-        const int lr = idx / BN, c = idx - lr * BN;
-        const int row = m0 + (lr >> 4) * (TM * 16) + m * 16 + (lr & 15);
-        const int col = n0 + c;
-        if (row >= M || col >= N) continue;
-        int crow = row;
-        if (g.c_idx) { crow = g.c_idx[row]; if (crow < 0) continue; }
-        float x = stage[lr * E_LD + c] * g.alpha;
-        if (g.accumulate == 2) x += C[(long)crow * g.ldc + col];      // running sum BEFORE bias / activation
-        if (g.bias) x += g.bias[col];
-        if (g.rowvec) x += g.rowvec[(long)(g.rowvec_map ? g.rowvec_map[row] : row) * g.ldrv + col];
-        if (g.act == 1) x = fmaxf(x, 0.f);
-        else if (g.act == 2) x = fast_tanh(x);
-        else if (g.act == 3) x = fast_sigmoid(x);
-        if (aux) aux[(long)row * g.ldaux + col] = x;
-        if (mulp) x *= mulp[(long)row * g.ldmul + col];
-        if (res) x += res[(long)row * g.ldres + col];
-        if (g.drop_target == 3)
-          x = nnr_keep(g.drop_seed, (uint64_t)(row + (long)z * g.M) * g.drop_cols + col, dthr) ? x * dscale : 0.f;
-        if (C) {
-          float* cp = C + (long)crow * g.ldc + col;
-          if (use_atomic) {
-            if (g.drop_target == 4)   // scatter of d(dropout(emb)) : mask keyed by the token row
-              x = nnr_keep(g.drop_seed, (uint64_t)row * g.drop_cols + col, dthr) ? x * dscale : 0.f;
-            atomicAdd(cp, x);
-          } else {
-            if (g.accumulate == 1) x += *cp;
-            *cp = x;
-          }
-        }
-      }
-    }
-  }
+  gemm_epilogue<TM, TN>(g, acc, lds, C, m0, n0, M, N, z);
 }
 
 template <int TM, int TN, int BK>
@@ -443,6 +458,405 @@ int launch_cfg(const nnr_gemm_args& g, hipStream_t s) {
   return NNR_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------ pipelined NT GEMM (LDS-DMA)
+// C[M,N] = epilogue(A[M,K] . B[N,K]^T), both operands K-contiguous -- the forward GEMMs, and every data-gradient GEMM once the
+// (small) weight has been transposed.  Same tile / wave / fragment layout as gemm_kernel, different staging:
+//  * global -> LDS by LDS-DMA (`global_load_lds_dwordx4`: 64 lanes x 16 B = 1 KiB straight into LDS, no staging registers,
+//    no ds_write pass).  The LDS image of a stage is LINEAR in (row, 16-byte position); the XOR swizzle that makes the
+//    fragment reads conflict-free is applied to the per-lane SOURCE address (position p of row r holds k-chunk p ^ swz(r))
+//    and again on the ds_read_b128 side -- the same involution on both sides.
+//  * NS stage buffers; the loads of stage s + NS - 1 are issued right after the barrier that opens stage s, so NS - 1
+//    stages (2-3 us of MFMA work) cover the L2 / HBM round trip even when only one or two workgroups share the CU -- the
+//    regime of the mid-size GEMMs (SUE: 4 352 x 900 x 900) and of the tail of every launch, where the two-buffer
+//    register-staged kernel exposes one round trip per 16-deep stage.
+//  * one `s_waitcnt vmcnt(n)` + one raw `s_barrier` per stage: the wait retires this wave's own DMAs of the stage about to
+//    be read (the newer stages stay in flight ACROSS the barrier), the barrier makes every wave's DMAs of that stage visible
+//    and doubles as the write-after-read fence for the buffer that is refilled next.
+//  * rows beyond M / N and k-chunks beyond K read a zero page instead (the source address is per lane), so the tile needs
+//    no bounds logic in the loop.  Requirements (checked by the dispatcher): K, lda, ldb multiples of 4, 16-byte aligned bases.
+__device__ __attribute__((aligned(16))) float nnr_zero_page[4] = {0.f, 0.f, 0.f, 0.f};
+
+__device__ __forceinline__ void lds_dma16(const float* gsrc, unsigned lds_dst) {
+  unsigned keep;      // M0 carries the wave-uniform LDS base of the instruction; it is compiler-reserved: saved and restored here
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void set_prio_dyn(unsigned p) {      // s_setprio takes an immediate
+  switch (p & 3) {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// wait until at most AHEAD stages of CNT instructions each (this wave's own DMAs) are outstanding, AHEAD = min(MAXA, ahead)
+template <int CNT, int MAXA>
+__device__ __forceinline__ void wait_stages(int ahead) {
+  if constexpr (MAXA == 0) wait_vmcnt<0>();
+  else {
+    if (ahead >= MAXA) wait_vmcnt<CNT * MAXA>();
+    else wait_stages<CNT, MAXA - 1>(ahead);
+  }
+}
+
+template <int TM, int TN, int BK, int NS, int OCC, int PRIO = 0>
+__global__ __launch_bounds__(256, OCC) void gemm_nt_pipe_kernel(nnr_gemm_args g) {
+  // PRIO 1: static, distinct wave priorities for the workgroups that (most likely) share a CU.  With equal priorities the SIMD
+  // interleaves the MFMAs of its resident waves instruction by instruction, so they all reach their per-stage wait + barrier +
+  // fragment-read phase together and the matrix pipe idles through it; with distinct priorities one wave runs its stage at full
+  // rate while the others queue, and the phases stay staggered.
+  if (PRIO == 1) set_prio_dyn(blockIdx.x >> 8);
+  if (PRIO == 2) set_prio_dyn(blockIdx.x >> 5);
+  if (PRIO == 3) set_prio_dyn(blockIdx.x);
+  constexpr int BM = 64 * TM, BN = 16 * TN, ROWS = BM + BN;
+  constexpr int KQ = BK / 4, NKG = BK / 16;             // 16-byte chunks per row; 16-deep k-groups per stage
+  constexpr int RPI = 64 / KQ;                          // tile rows one DMA instruction covers (1 KiB)
+  constexpr int NI = ROWS / RPI;                        // DMA instructions per stage
+  constexpr int NPW = (NI + 3) / 4;                     // ... per wave (wave w issues instructions w, w + 4, ...)
+  constexpr int STAGE = ROWS * BK;                      // floats
+  constexpr int E_LD = BN + 4;
+  constexpr int LDS_FLOATS = (NS * STAGE > 64 * E_LD) ? NS * STAGE : 64 * E_LD;
+  static_assert(ROWS % RPI == 0, "tile rows must fill whole DMA instructions");
+  __shared__ __attribute__((aligned(1024))) float lds[LDS_FLOATS];
+
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, kk = lane >> 4;
+
+  int M = g.M;
+  if (g.dyn_dim == 1) M = min(M, *g.dyn_dev);
+  const int N = g.N, K = g.K;
+  const int nbm = (M + BM - 1) / BM, nbn = (N + BN - 1) / BN;
+  const int nblk = nbm * nbn;
+  if ((int)blockIdx.x >= nblk) return;
+  int v;
+  {
+    const int b = blockIdx.x, q = nblk >> 3, rem = nblk & 7, x = b & 7, slot = b >> 3;
+    v = x * q + min(x, rem) + slot;
+  }
+  const int bm = v / nbn, bn = v - bm * nbn;
+  const int m0 = bm * BM, n0 = bn * BN;
+  const int z = blockIdx.z;
+  const float* __restrict__ A = g.A;
+  const float* __restrict__ B = g.B;
+  float* __restrict__ C = g.C;
+  if (g.batch > 1) {
+    A += (long)z * g.strideA;
+    B += (long)z * g.strideB;
+    C += (long)z * g.strideC;
+  }
+
+  // ---- per-lane DMA sources: instruction q covers tile rows [q*RPI, +RPI) (A rows first, then B rows); this lane feeds
+  //      position (lane % KQ) of row q*RPI + lane / KQ, i.e. k-chunk (lane % KQ) ^ swz(row & 15) of that row
+  const float* rowp[NPW];
+  int kch[NPW];
+#pragma unroll
+  for (int i = 0; i < NPW; ++i) {
+    const int q = w + 4 * i;
+    const int tr = q * RPI + lane / KQ;
+    const int c = (lane % KQ) ^ swz<BK>(tr & 15);
+    kch[i] = 4 * c;
+    const float* p = nullptr;
+    if (q < NI) {
+      if (tr < BM) {
+        const int gm = m0 + tr;
+        if (gm < M) {
+          const int src = g.a_idx ? g.a_idx[gm] : gm;
+          if (src >= 0) p = A + (long)src * g.lda + 4 * c;
+        }
+      } else {
+        const int gn = n0 + (tr - BM);
+        if (gn < N) p = B + (long)gn * g.ldb + 4 * c;
+      }
+    }
+    rowp[i] = p;
+  }
+  const float* zero = nnr_zero_page;
+  asm volatile("" : "+s"(zero));                       // pinned in SGPRs: the compiler would re-fetch the symbol's address per use
+  const unsigned lds_base = (unsigned)(uintptr_t)lds;      // low 32 bits of a flat LDS address = the LDS byte offset
+  const int S = (K + BK - 1) / BK;
+
+  auto issue = [&](int s) {
+    const int k0 = s * BK;
+    const unsigned sb = lds_base + (unsigned)((s % NS) * STAGE * 4);
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+      const int q = w + 4 * i;
+      if (q < NI) {
+        const float* src = (rowp[i] != nullptr && k0 + kch[i] < K) ? rowp[i] + k0 : zero;
+        lds_dma16(src, sb + (unsigned)(q * 1024));
+      }
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int m = 0; m < TM; ++m)
+#pragma unroll
+    for (int n = 0; n < TN; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < S) issue(s);
+
+  for (int s = 0; s < S; ++s) {
+    // this wave's DMAs of stage s have landed once at most `ahead` newer stages of its own are still outstanding
+    const int ahead = S - 1 - s;
+    if (NI % 4 == 0 || w < NI % 4) wait_stages<NPW, NS - 2>(ahead);
+    else wait_stages<NPW - 1, NS - 2>(ahead);
+    __builtin_amdgcn_s_barrier();
+    if (s + NS - 1 < S) issue(s + NS - 1);              // into the buffer every wave finished reading before that barrier
+
+    const float* As = lds + (s % NS) * STAGE;
+    const float* Bs = As + BM * BK;
+#pragma unroll
+    for (int kg = 0; kg < NKG; ++kg) {
+      f32x4 af[TM], bf[TN];
+#pragma unroll
+      for (int m = 0; m < TM; ++m)
+        af[m] = *reinterpret_cast<const f32x4*>(&As[((w * TM + m) * 16 + r) * BK + 4 * ((kg * 4 + kk) ^ swz<BK>(r))]);
+#pragma unroll
+      for (int n = 0; n < TN; ++n)
+        bf[n] = *reinterpret_cast<const f32x4*>(&Bs[(n * 16 + r) * BK + 4 * ((kg * 4 + kk) ^ swz<BK>(r))]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+          for (int n = 0; n < TN; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][i], bf[n][i], acc[m][n], 0, 0, 0);
+    }
+  }
+  __syncthreads();        // every wave is done with the stage buffers: the epilogue reuses them
+  gemm_epilogue<TM, TN>(g, acc, lds, C, m0, n0, M, N, z);
+}
+
+template <int TM, int TN, int BK, int NS, int OCC, int PRIO = 0>
+int launch_pipe(const nnr_gemm_args& g, hipStream_t s) {
+  constexpr int BM = 64 * TM, BN = 16 * TN;
+  const int nbm = (g.M + BM - 1) / BM, nbn = (g.N + BN - 1) / BN;
+  dim3 grid(nbm * nbn, 1, g.batch > 1 ? g.batch : 1), block(256);
+  hipLaunchKernelGGL((gemm_nt_pipe_kernel<TM, TN, BK, NS, OCC, PRIO>), grid, block, 0, s, g);
+  NNR_CHECK_LAUNCH();
+  return NNR_OK;
+}
+
+// what the pipelined NT kernel accepts (everything else stays on gemm_kernel)
+static bool pipe_ok(const nnr_gemm_args& g) {
+  auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+  return !g.trans_a && !g.trans_b && !g.b_idx && g.split_k <= 1 && g.k_chunk <= 0 && !g.rowdot_w && !g.colsum_out &&
+         (g.drop_target == 0 || g.drop_target == 3 || g.drop_target == 4) && (g.K & 3) == 0 && (g.lda & 3) == 0 && (g.ldb & 3) == 0 &&
+         al(g.A) && al(g.B) && (g.batch <= 1 || (((g.strideA | g.strideB) & 3) == 0)) && (g.dyn_dim == 0 || g.dyn_dim == 1);
+}
+
+// ------------------------------------------------------------------------------------------------ pipelined TN GEMM (LDS-DMA)
+// C[M,N] += A[K,M]^T . B[K,N] over a slice of the (device-side) reduction range -- the weight-gradient GEMMs: both operands
+// are ACTIVATIONS stored row-major by token, i.e. K-major for this product, and K is the token count (10^5).
+//  * a stage is 16 token rows of the A tile and of the B tile; a token row's tile columns are contiguous in memory, so one
+//    LDS-DMA instruction (1 KiB) moves 256 / PA whole row segments: full cache lines, no register staging, no ds_write pass.
+//  * LDS image [16][PA] / [16][PB] (PA = 64*TM, PB = 16*TN rounded up to 64 / 128 / 256 floats; columns past the tile edge
+//    read the zero page).  Lane (r, kk) of MFMA step i reads row 4*kk + i: four rows per lane at immediate offsets.  Rows k
+//    and k + 4 would hit the same banks, so position p of row k holds column p ^ 16*((k >> 2) & 1) -- applied to the DMA's
+//    per-lane SOURCE address and to the ds_read_b32 address alike.
+//  * B's token rows may be gathered (b_idx: the previous time step's packed row for dW_hh; negative = zero row).  The row
+//    index of an instruction's segments is wave-uniform, so it is fetched with SCALAR loads one stage ahead (vector loads
+//    would share vmcnt with the DMAs and drain the pipeline every stage).
+//  * NS stage buffers, one counted vmcnt wait + one raw barrier per stage (as gemm_nt_pipe_kernel).
+//  * split-K over blockIdx.z, f32 atomics in the epilogue; the fused bias gradient (column sums of A) of the column-block-0
+//    workgroups is one extra MFMA per row tile and step against a fragment of ones -- no LDS traffic, no extra pass over A.
+template <int TM, int TN, int NS, int OCC, int PRIO = 0>
+__global__ __launch_bounds__(256, OCC) void gemm_tn_pipe_kernel(nnr_gemm_args g) {
+  if (PRIO == 1) set_prio_dyn((blockIdx.x + gridDim.x * blockIdx.z) >> 8);
+  constexpr int BK = 16, BM = 64 * TM, BN = 16 * TN;
+  constexpr int PA = BM, PB = BN <= 64 ? 64 : (BN <= 128 ? 128 : 256);
+  constexpr int RA = 256 / PA, RB = 256 / PB;          // token rows per DMA instruction
+  constexpr int NIA = BK / RA, NIB = BK / RB, NI = NIA + NIB;
+  constexpr int NPW = (NI + 3) / 4;
+  constexpr int STAGE = BK * (PA + PB);
+  constexpr int E_LD = BN + 4;
+  constexpr int LDS_FLOATS = (NS * STAGE > 64 * E_LD) ? NS * STAGE : 64 * E_LD;
+  static_assert(BN <= 256 && NI % 4 == 0, "tile shape");
+  __shared__ __attribute__((aligned(1024))) float lds[LDS_FLOATS];
+
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, kk = lane >> 4;
+  const int M = g.M, N = g.N;
+  int K = g.K;
+  if (g.dyn_dim == 2) K = min(K, *g.dyn_dev);
+  const int nbm = (M + BM - 1) / BM, nbn = (N + BN - 1) / BN;
+  const int nblk = nbm * nbn;
+  int v;
+  {
+    const int b = blockIdx.x, q = nblk >> 3, rem = nblk & 7, x = b & 7, slot = b >> 3;
+    v = x * q + min(x, rem) + slot;
+  }
+  const int bm = v / nbn, bn = v - bm * nbn;
+  const int m0 = bm * BM, n0 = bn * BN;
+  const int z = blockIdx.z;
+  int kbeg = 0, kend = K;
+  if (g.split_k > 1) {
+    const int ktiles = (K + BK - 1) / BK;
+    const int per = (ktiles + g.split_k - 1) / g.split_k;
+    kbeg = z * per * BK;
+    kend = min(K, kbeg + per * BK);
+    if (kbeg >= kend) return;
+  }
+  const float* __restrict__ A = g.A;
+  const float* __restrict__ B = g.B;
+  const int* __restrict__ bidx = g.b_idx;
+  const float* zero = nnr_zero_page;
+  asm volatile("" : "+s"(zero));
+
+  // ---- per-lane DMA geometry.  Instruction q < NIA: A rows [q*RA, +RA); else B rows [(q-NIA)*RB, +RB)
+  long coloff[NPW];          // column offset (floats) of this lane's 16-byte chunk, or -1 (beyond the matrix edge: zero page)
+  int krow[NPW];             // token row inside the stage this lane feeds
+#pragma unroll
+  for (int i = 0; i < NPW; ++i) {
+    const int q = w + 4 * i;
+    if (q < NIA) {
+      const int kl = q * RA + lane / (PA / 4), p4 = lane % (PA / 4);
+      const int col = (4 * p4) ^ (16 * ((kl >> 2) & 1));
+      krow[i] = kl;
+      coloff[i] = (m0 + col < M) ? (long)(m0 + col) : -1;
+    } else {
+      const int kl = (q - NIA) * RB + lane / (PB / 4), p4 = lane % (PB / 4);
+      const int col = (4 * p4) ^ (16 * ((kl >> 2) & 1));
+      krow[i] = kl;
+      coloff[i] = (col < BN && n0 + col < N) ? (long)(n0 + col) : -1;
+    }
+  }
+  const unsigned lds_base = (unsigned)(uintptr_t)lds;
+  const int S = (kend - kbeg + BK - 1) / BK;
+
+  // gathered B rows: the RB row indices of each of this wave's B instructions for one stage, in SGPRs
+  int bsrc[NPW][RB];
+  auto fetch_idx = [&](int s) {
+    if (bidx == nullptr) return;
+    const int k0 = kbeg + s * BK;
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+      const int q = w + 4 * i;
+      if (q >= NIA) {
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+          const int k = min(k0 + (q - NIA) * RB + j, kend - 1);
+          // SCALAR load (the compiler picks a vector load here: it cannot prove the table is never written by this kernel;
+          // a vector load would share vmcnt with the DMAs and its wait would drain them).  Consumed one stage later, behind the
+          // s_waitcnt lgkmcnt(0) in front of issue().
+          asm volatile("s_load_dword %0, %1, %2" : "=s"(bsrc[i][j]) : "s"(bidx), "s"(k * 4) : "memory");
+        }
+      }
+    }
+  };
+  auto issue = [&](int s) {
+    const int k0 = kbeg + s * BK;
+    const unsigned sb = lds_base + (unsigned)((s % NS) * STAGE * 4);
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+      const int q = w + 4 * i;
+      const int k = k0 + krow[i];
+      const float* src = zero;
+      if (q < NIA) {
+        if (coloff[i] >= 0 && k < kend) src = A + (long)k * g.lda + coloff[i];
+        lds_dma16(src, sb + (unsigned)(q * 1024));
+      } else {
+        long row = k;
+        if (bidx != nullptr) {
+          int sel = bsrc[i][0];
+#pragma unroll
+          for (int j = 1; j < RB; ++j) sel = (lane / (PB / 4) == j) ? bsrc[i][j] : sel;
+          row = sel;
+        }
+        if (coloff[i] >= 0 && k < kend && row >= 0) src = B + row * g.ldb + coloff[i];
+        lds_dma16(src, sb + (unsigned)(NIA * 1024 + (q - NIA) * 1024));
+      }
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int m = 0; m < TM; ++m)
+#pragma unroll
+    for (int n = 0; n < TN; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool do_colsum = g.colsum_out != nullptr && bn == 0;
+  f32x4 cs[TM];
+#pragma unroll
+  for (int m = 0; m < TM; ++m) cs[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < S) {
+      fetch_idx(s);
+      if (bidx != nullptr) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      issue(s);
+    }
+  if (NS - 1 < S) fetch_idx(NS - 1);
+
+  const int xo = 16 * (kk & 1);                         // this lane's rows 4*kk + i all have ((k >> 2) & 1) == kk & 1
+  for (int s = 0; s < S; ++s) {
+    wait_stages<NPW, NS - 2>(S - 1 - s);
+    __builtin_amdgcn_s_barrier();
+    if (s + NS - 1 < S) {
+      if (bidx != nullptr) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the gather indices fetched a stage ago
+      issue(s + NS - 1);
+    }
+    const float* As = lds + (s % NS) * STAGE;
+    const float* Bs = As + BK * PA;
+    float af[4][TM];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float bf[TN];
+#pragma unroll
+      for (int m = 0; m < TM; ++m) af[i][m] = As[(4 * kk + i) * PA + (((w * TM + m) * 16 + r) ^ xo)];
+#pragma unroll
+      for (int n = 0; n < TN; ++n) bf[n] = Bs[(4 * kk + i) * PB + ((n * 16 + r) ^ xo)];
+#pragma unroll
+      for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][m], bf[n], acc[m][n], 0, 0, 0);
+    }
+    // the gather indices of the stage issued NEXT iteration: behind this stage's fragment reads, so the compiler's lgkmcnt
+    // waits for those do not also wait for the scalar loads; they land while the wave sits in the next barrier
+    if (s + NS < S) fetch_idx(s + NS);
+    if (do_colsum) {      // (one branch per stage: inside the step loop it would cut the block the compiler pipelines reads over)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int m = 0; m < TM; ++m) cs[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][m], 1.f, cs[m], 0, 0, 0);
+    }
+  }
+  if (do_colsum && r == 0) {      // every column of cs[m] holds the column sums of A for rows kk*4 + reg of row tile m
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int row = m0 + (w * TM + m) * 16 + kk * 4 + reg;
+        if (row < M) atomicAdd(&g.colsum_out[row], cs[m][reg]);
+      }
+  }
+  __syncthreads();
+  gemm_epilogue<TM, TN>(g, acc, lds, g.C, m0, n0, M, N, z);
+}
+
+template <int TM, int TN, int NS, int OCC, int PRIO = 0>
+int launch_tn_pipe(const nnr_gemm_args& g, hipStream_t s) {
+  constexpr int BM = 64 * TM, BN = 16 * TN;
+  const int nbm = (g.M + BM - 1) / BM, nbn = (g.N + BN - 1) / BN;
+  dim3 grid(nbm * nbn, 1, g.split_k > 1 ? g.split_k : 1), block(256);
+  hipLaunchKernelGGL((gemm_tn_pipe_kernel<TM, TN, NS, OCC, PRIO>), grid, block, 0, s, g);
+  NNR_CHECK_LAUNCH();
+  return NNR_OK;
+}
+
+static bool tn_pipe_ok(const nnr_gemm_args& g) {
+  auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+  return g.trans_a && g.trans_b && !g.a_idx && !g.c_idx && g.k_chunk <= 0 && !g.rowdot_w && g.drop_target == 0 && g.batch <= 1 &&
+         (g.M & 3) == 0 && (g.N & 3) == 0 && (g.lda & 3) == 0 && (g.ldb & 3) == 0 && al(g.A) && al(g.B) && (g.dyn_dim == 0 || g.dyn_dim == 2) &&
+         (g.atomic || g.split_k > 1 || g.accumulate == 1 || g.accumulate == 0);
+}
 
 // ------------------------------------------------------------------------------------------------ skinny GEMM (small launches)
 // For launches that cannot fill the chip (M of a few hundred to a few thousand rows: per-news vectors, SUE heads) the tiled
@@ -590,16 +1004,20 @@ extern "C" int nnr_gemm_f32(const nnr_gemm_args* a, hipStream_t stream) {
     const long wg64 = (long)((g.M + 63) / 64) * ((g.N + 79) / 80) * (g.split_k > 1 ? g.split_k : (g.batch > 1 ? g.batch : 1));
     const bool plain = !g.trans_a && !g.a_idx && !g.b_idx && !g.c_idx && !g.dyn_dev && g.split_k <= 1 && g.k_chunk <= 0 && !g.rowdot_w &&
                        !g.colsum_out && !g.atomic && (g.drop_target == 0 || g.drop_target == 3);
+    static const bool use_pipe = [] { const char* e = getenv("NNR_GEMM_PIPE"); return !(e && atoi(e) == 0); }();   // A/B switch
     if (g.rowdot_w) tile = 3;
     else if (plain && wg64 <= 512 && g.K >= 64) tile = 7;   // small row-parallel launch: 16 x 80 tiles, K split over the 4 waves
+    else if (use_pipe && pipe_ok(g) && (g.dyn_dev || wg128 >= 640)) tile = 15;   // GPU-filling NT: LDS-DMA staged 128 x 80, BK 16, 4 workgroups / CU
+                             // (112 vs 98 TF on the 131 072-row CNE shapes, tools/gemm_pipe_bench.py)
+    else if (use_pipe && pipe_ok(g) && wg64 > 512 && g.K >= 128) tile = 16;      // mid-size NT (SUE: 4 352 x 900 x 900): same tile, two 13 KB stages,
+                             // 5-6 workgroups / CU cover the round trips (79 vs 65-72 TF)
     else if (wg64 <= 512 && !g.dyn_dev && g.k_chunk <= 0 && g.K >= 128) tile = 6;   // at most 2 workgroups per CU: nothing hides the
                              // memory round trip each k-stage pays with a one-stage prefetch -> BK = 64, 4x fewer stages
     else if (g.M <= 512 || (wg128 < 640 && !g.dyn_dev)) tile = 2;   // too few 128-row tiles to fill 256 CUs x 4: use 64-row tiles
-    else if (g.trans_a) tile = 2;   // TN (token-reduction dW): 64 x 80 measured 5-10 % faster than 128 x 80 on every in-step shape
-                                    // (84.7 vs 81.0, 81.0 vs 75.1, 66.7 vs 60.2, 53.7 vs 48.7 TF; tools/gemm_tn_shapes.py)
-    else if (!g.trans_a && !g.trans_b) tile = 5;   // NT: BK = 32 measured +7 % (97.7 vs 90.9 TF); the K-major operands of NN / TN lose with it
-    else tile = 4;           // 128 x 80: 117 VGPRs -> 4 waves/SIMD, 4 workgroups per CU hide barriers, prologue and epilogue
-                             // (measured 84-96 TF vs 63-79 TF for the 256 x 80 tile on the CNE shapes)
+    else if (g.trans_a) tile = 2;   // TN (token-reduction dW): callers pick the LDS-DMA tiles 20 / 24 explicitly (their split-K factor
+                                    // depends on the tile); this is the register-staged fallback
+    else if (!g.trans_a && !g.trans_b) tile = 5;   // NT that the pipelined kernel cannot take (unaligned operands)
+    else tile = 4;           // NN with a K-major B (activations on both sides, or a weight the caller did not transpose)
   }
   switch (tile) {
     case 1: return launch_cfg<4, 5, 16>(g, stream);    // 256 x 80
@@ -608,6 +1026,24 @@ extern "C" int nnr_gemm_f32(const nnr_gemm_args* a, hipStream_t stream) {
     case 4: return launch_cfg<2, 5, 16>(g, stream);    // 128 x 80 (4 waves/SIMD: more workgroups in flight per CU)
     case 5: return launch_cfg<2, 5, 32>(g, stream);   // 128 x 80, BK = 32: half the barriers per FLOP, 3 workgroups per CU
     case 6: return launch_cfg<1, 5, 64>(g, stream);   //  64 x 80, BK = 64: latency-bound small launches (few stages, 74 KB LDS)
+    case 8:  if (!pipe_ok(g)) return NNR_ERR_ARG; return launch_pipe<2, 5, 32, 3, 2>(g, stream);   // 128 x 80, 3 x 26 KB stages, 2 workgroups / CU
+    case 9:  if (!pipe_ok(g)) return NNR_ERR_ARG; return launch_pipe<2, 5, 32, 4, 1>(g, stream);   // 128 x 80, 4 stages, 1 workgroup / CU
+    case 10: if (!pipe_ok(g)) return NNR_ERR_ARG; return launch_pipe<2, 5, 16, 3, 4, 2>(g, stream);   // t15 + priority by blockIdx >> 5
+    case 11: if (!pipe_ok(g)) return NNR_ERR_ARG; return launch_pipe<2, 5, 16, 3, 4, 3>(g, stream);   // t15 + priority by blockIdx & 3
+    case 12: if (!pipe_ok(g)) return NNR_ERR_ARG; return launch_pipe<2, 5, 16, 4, 3, 1>(g, stream);   // t13 + priority by blockIdx >> 8
+    case 13: if (!pipe_ok(g)) return NNR_ERR_ARG; return launch_pipe<2, 5, 16, 4, 3>(g, stream);   // 128 x 80, BK 16, 4 x 13 KB stages, 3 workgroups / CU
+    case 14: if (!pipe_ok(g)) return NNR_ERR_ARG; return launch_pipe<2, 5, 32, 3, 2, 1>(g, stream);   // t8 + priority by blockIdx >> 8
+    case 15: if (!pipe_ok(g)) return NNR_ERR_ARG; return launch_pipe<2, 5, 16, 3, 4>(g, stream);   // 128 x 80, BK 16, 3 x 13 KB stages, 4 workgroups / CU
+    case 16: if (!pipe_ok(g)) return NNR_ERR_ARG; return launch_pipe<2, 5, 16, 2, 5>(g, stream);   // 128 x 80, BK 16, 2 stages, 5-6 workgroups / CU
+    case 17: if (!pipe_ok(g)) return NNR_ERR_ARG; return launch_pipe<1, 5, 16, 4, 4>(g, stream);   //  64 x 80, BK 16, 4 x 9 KB stages
+    case 18: if (!pipe_ok(g)) return NNR_ERR_ARG; return launch_pipe<4, 5, 16, 3, 2>(g, stream);   // 256 x 80, BK 16, 3 x 21 KB stages
+    case 19: if (!pipe_ok(g)) return NNR_ERR_ARG; return launch_pipe<2, 10, 16, 3, 2>(g, stream);  // 128 x 160, BK 16, 3 x 18 KB stages
+    case 20: if (!tn_pipe_ok(g)) return NNR_ERR_ARG; return launch_tn_pipe<2, 5, 3, 3>(g, stream);   // TN 128 x 80, 3 x 16 KB stages
+    case 21: if (!tn_pipe_ok(g)) return NNR_ERR_ARG; return launch_tn_pipe<2, 5, 3, 3, 1>(g, stream);   // t20 + static priorities
+    case 22: if (!tn_pipe_ok(g)) return NNR_ERR_ARG; return launch_tn_pipe<1, 5, 3, 4>(g, stream);   // TN  64 x 80, 3 x 12 KB stages, 4 workgroups / CU
+    case 23: if (!tn_pipe_ok(g)) return NNR_ERR_ARG; return launch_tn_pipe<4, 5, 3, 2>(g, stream);   // TN 256 x 80, 3 x 24 KB stages
+    case 24: if (!tn_pipe_ok(g)) return NNR_ERR_ARG; return launch_tn_pipe<2, 13, 3, 2>(g, stream);  // TN 128 x 208, 3 x 24 KB stages
+    case 25: if (!tn_pipe_ok(g)) return NNR_ERR_ARG; return launch_tn_pipe<2, 8, 3, 2>(g, stream);   // TN 128 x 128
     case 7:
       if (g.trans_a || g.a_idx || g.b_idx || g.c_idx || g.dyn_dev || g.split_k > 1 || g.k_chunk > 0 || g.rowdot_w || g.colsum_out || g.atomic ||
           (g.drop_target != 0 && g.drop_target != 3)) return NNR_ERR_ARG;

@@ -96,9 +96,12 @@ class QKVFn(torch.autograd.Function):
         if gw is not None:
             # dW (+ the bias gradient, fused into the same launch) is a leaf: own stream, joined at the end of the pass
             ops.leaf_deferred(x.device, M, lambda: ops.gemm(dqkv, x, gw, M=3 * HD, N=K, K=M, lda=3 * HD, ldb=K, ldc=K, trans_a=True,
-                                                         trans_b=True, split_k=ops.split_for(3 * HD, K, M), atomic=True,
-                                                         colsum_out=gb), dqkv, x)
-            ops.gemm(dqkv, w, dx, M=M, N=K, K=3 * HD, lda=3 * HD, ldb=K, ldc=K, trans_b=True)
+                                                         trans_b=True, split_k=ops.split_for(3 * HD, K, M, *ops.tn_tile(3 * HD, K, M)[1:]), atomic=True,
+                                                         colsum_out=gb, tile=ops.tn_tile(3 * HD, K, M)[0]), dqkv, x)
+            if ops.USE_WT and M >= 1024 and w.is_contiguous():
+                ops.gemm(dqkv, ops.wt(w), dx, M=M, N=K, K=3 * HD, lda=3 * HD, ldb=3 * HD, ldc=K)          # NT on [W_Q; W_K; W_V]^T
+            else:
+                ops.gemm(dqkv, w, dx, M=M, N=K, K=3 * HD, lda=3 * HD, ldb=K, ldc=K, trans_b=True)
             return dx, None
         for s, lin in enumerate((mha.W_Q, mha.W_K, mha.W_V)):
             d = dqkv[:, s * HD:]

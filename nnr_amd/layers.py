@@ -87,7 +87,10 @@ class _AttentionFn(torch.autograd.Function):
         ops.tanh_score_bwd(th, ds, mod.affine2.weight, grad_of(mod.affine2.weight), None, A)
         gw, gb = grad_of(mod.affine1.weight), grad_of(mod.affine1.bias)
         ops.leaf_deferred(x.device, n * Lx, lambda: ops.linear_bwd_weight(th, x, gw, db=gb), th, x)      # leaf: own stream (ops.leaf_deferred)
-        ops.gemm(th, mod.affine1.weight, dx, M=n * Lx, N=F, K=A, lda=A, ldb=F, ldc=F, trans_b=True, accumulate=True)
+        if ops.USE_WT and n * Lx >= 1024 and (A & 3) == 0:
+            ops.gemm(th, ops.wt(mod.affine1.weight), dx, M=n * Lx, N=F, K=A, lda=A, ldb=A, ldc=F, accumulate=True)      # NT on W1^T
+        else:
+            ops.gemm(th, mod.affine1.weight, dx, M=n * Lx, N=F, K=A, lda=A, ldb=F, ldc=F, trans_b=True, accumulate=True)
         return dx.view(n, Lx, F), None, None
 
 

@@ -356,14 +356,14 @@ def _cne_bwd_pre(mod, sv, drep, par=False, leaf=None):
                      dout=drep[:, col0:], lddo=D, dout2=st['dself_x'], lddo2=H2, dx=st['dHt'], lddx=H2, dx_accumulate=True, dscore=ds)
         th = st['th']
         ops.tanh_score_bwd(th, ds, sa.affine2.weight, grad_of(sa.affine2.weight), plan, A)    # th := dpre
-        ops.gemm(th, sa.affine1.weight, st['dHt'], M=cap, N=H2, K=A, lda=A, ldb=H2, ldc=H2, trans_b=True, accumulate=True,
+        ops.gemm(th, ops.wt(sa.affine1.weight), st['dHt'], M=cap, N=H2, K=A, lda=A, ldb=A, ldc=H2, accumulate=True,      # NT on W1^T
                  dyn=plan.total, dyn_dim=1)
         leaf(lambda: ops.linear_bwd_weight(th, st['Ht'], grad_of(sa.affine1.weight), dyn=plan.total, db=grad_of(sa.affine1.bias)), th, st['Ht'])
         # gate: Ht = hout * G
         st['dH'] = torch.empty((cap, H2), **f32)
         dpre = torch.empty((cap, H2), **f32)             # (not Ht's buffer: the deferred weight-gradient GEMM above still reads it)
         ops.gate_bwd(st['dHt'], st['hout'], st['G'], st['dH'], dpre, plan, H2)
-        ops.gemm(dpre, st['Hlin'].weight, st['dH'], M=cap, N=H2, K=H2, lda=H2, ldb=H2, ldc=H2, trans_b=True, accumulate=True,
+        ops.gemm(dpre, ops.wt(st['Hlin'].weight), st['dH'], M=cap, N=H2, K=H2, lda=H2, ldb=H2, ldc=H2, accumulate=True,   # NT on W_H^T
                  dyn=plan.total, dyn_dim=1)
         leaf(lambda: ops.linear_bwd_weight(dpre, st['hout'], grad_of(st['Hlin'].weight), dyn=plan.total), dpre, st['hout'])
         dP = torch.empty((n, H2), **f32)                  # d mproj[rank]
@@ -396,16 +396,20 @@ def _cne_bwd_post(mod, sv, st, leaf=None):
     dw_hhp = torch.zeros((2, NP, H), **f32)
 
     def dw_ih():
+        t, bm, bn, target = ops.tn_tile(2 * NP, E, cap)
         ops.gemm(dg, st['xd'], dw_ihp, M=2 * NP, N=E, K=cap, lda=2 * NP, ldb=E, ldc=E, trans_a=True, trans_b=True,
-                 split_k=ops.split_for(2 * NP, E, cap), atomic=True, dyn=plan.total, dyn_dim=2, colsum_out=db_p)
+                 split_k=ops.split_for(2 * NP, E, cap, bm, bn, target), atomic=True, dyn=plan.total, dyn_dim=2, colsum_out=db_p, tile=t)
 
     def dw_hh(d):
+        t, bm, bn, target = ops.tn_tile(NP, H, cap)
         ops.gemm(dg[:, d * NP:], st['hout'][:, d * H:], dw_hhp[d], M=NP, N=H, K=cap, lda=2 * NP, ldb=H2, ldc=H, trans_a=True,
-                 trans_b=True, b_idx=(plan.prev_f, plan.prev_r)[d], split_k=ops.split_for(NP, H, cap), atomic=True, dyn=plan.total, dyn_dim=2)
+                 trans_b=True, b_idx=(plan.prev_f, plan.prev_r)[d], split_k=ops.split_for(NP, H, cap, bm, bn, target), atomic=True,
+                 dyn=plan.total, dyn_dim=2, tile=t)
 
     def dx_scatter():
-        # d(embedding rows): dX = dgates . W_ihp, scattered (atomic) into the table gradient through the dropout mask
-        ops.gemm(dg, w.w_ihp, grad_of(emb), M=cap, N=E, K=2 * NP, lda=2 * NP, ldb=E, ldc=E, trans_b=True, c_idx=plan.tok, atomic=True,
+        # d(embedding rows): dX = dgates . W_ihp (NT on the transposed packed weight), scattered (atomic) into the table
+        # gradient through the dropout mask
+        ops.gemm(dg, w.w_ihp_t, grad_of(emb), M=cap, N=E, K=2 * NP, lda=2 * NP, ldb=2 * NP, ldc=E, c_idx=plan.tok, atomic=True,
                  drop=(4, p, st['seed'], E), dyn=plan.total, dyn_dim=1)
 
     if leaf is None:

@@ -3,6 +3,7 @@ Tensors are only used as (device pointer, size) carriers; views are fine as long
 import ctypes as C
 import math
 import os
+import weakref
 
 import torch
 
@@ -134,6 +135,55 @@ def leaf_deferred(dev, rows, fn, *tensors):
             join_extra_streams(dev)
 
 
+_WT = {}
+USE_WT = os.environ.get('NNR_WT', '1') != '0'      # A/B switch: data-gradient GEMMs as NT products on cached W^T
+
+
+def wt(w):
+    """W^T (contiguous [cols, rows]) of a 2-D contiguous PARAMETER, cached until the parameter changes (optimizer step:
+    layers.PARAM_EPOCH; in-place edits: the tensor's version counter).  With it every data-gradient GEMM dX = dY . W becomes
+    an NT product (both operands K-contiguous) and runs on the LDS-DMA staged kernel; the transposes are a few hundred KB per
+    step against GBs of activations.  The copy is made on the stream of the first user; a user on another HIP stream (the
+    candidate call's side stream, the title stream) waits for the producer's event."""
+    from .layers import PARAM_EPOCH
+    # identity of the cached object: the tensor OBJECT (weak reference) + its pointer.  A pointer alone is not an identity --
+    # the caching allocator hands a freed parameter's address to the next model's parameter of the same shape.
+    key = id(w)
+    ver = (w.data_ptr(), PARAM_EPOCH[0], w._version)
+    hit = _WT.get(key)
+    cur = torch._C._cuda_getCurrentRawStream(w.device.index if w.device.index is not None else torch.cuda.current_device())
+    if hit is None or hit[0] != ver or hit[4]() is not w:
+        rows, cols = w.shape
+        t = torch.empty((cols, rows), device=w.device, dtype=torch.float32)
+        transpose2d(w, t, rows, cols)
+        ev = torch.cuda.Event()
+        ev.record()
+        if len(_WT) > 256:                                   # entries of dead tensors (temporary views, discarded models)
+            for k in [k for k, v in _WT.items() if v[4]() is None]:
+                del _WT[k]
+        hit = (ver, t, ev, cur, weakref.ref(w))
+        _WT[key] = hit
+    elif hit[3] != cur:
+        torch.cuda.current_stream(w.device).wait_event(hit[2])
+    return hit[1]
+
+
+# LDS-DMA staged weight-gradient tiles (csrc/gemm.hip: gemm_tn_pipe_kernel): (tile id, rows, cols, workgroups to aim for)
+TN_PIPE = os.environ.get('NNR_TN_PIPE', '1') != '0'
+
+
+def tn_tile(M, N, K):
+    """Tile of a token-reduction (weight-gradient) GEMM C[M,N] += A[K,M]^T B[K,N] and the tile dims its split-K factor is sized
+    for.  Measured on the step's shapes (tools/gemm_pipe_bench.py tn, TFLOP/s old -> new): 1664x300 82 -> 96 (128x80),
+    832x200 with gathered rows 68 -> 86, 400x400 75 -> 82, 200x400 62 -> 73 (128x208); short reductions and the 900x900 SUE
+    layers stay on the register-staged 64x80 tile."""
+    if not TN_PIPE or K < 8192 or (M & 3) or (N & 3) or (M >= 512 and N >= 512):
+        return 0, 64, 80, 2048
+    if N <= 208 or (N > 320 and N <= 416):
+        return 24, 128, 208, 640
+    return 20, 128, 80, 2048
+
+
 def split_for(m, n, k, tile_m=64, tile_n=80, target_blocks=2048, kmin=256):
     """split-K factor for the token-reduction (weight-gradient) GEMMs: enough blocks to fill 256 CUs x ~3.  (Cutting short
     reductions finer, kmin 64, measured no better.)"""
@@ -198,6 +248,8 @@ def gemm(A, B, C_=None, *, M, N, K, lda, ldb, ldc=0, trans_a=False, trans_b=Fals
     if not _prof.active():
         L.check(L.lib().nnr_gemm_f32(C.byref(g), _s()), 'nnr_gemm_f32')
         return
+    pipe_nt = (not trans_a and not trans_b and b_idx is None and split_k <= 1 and k_chunk <= 0 and rowdot_w is None and colsum_out is None
+               and (drop is None or drop[0] in (3, 4) or drop[1] <= 0.0) and (K | lda | ldb) & 3 == 0 and (A.data_ptr() | B.data_ptr()) & 15 == 0)
     wg128 = ((M + 127) // 128) * ((N + 79) // 80) * (split_k if split_k > 1 else max(1, batch)) * (1 if k_chunk <= 0 else max(1, K // k_chunk))
     # mirror of the library's tile choice (csrc/gemm.hip:nnr_gemm_f32), only to NAME the kernel family in the live profile
     wg64 = ((M + 63) // 64) * ((N + 79) // 80) * (split_k if split_k > 1 else max(1, batch))
@@ -208,6 +260,10 @@ def gemm(A, B, C_=None, *, M, N, K, lda, ldb, ldc=0, trans_a=False, trans_b=Fals
     elif (not trans_a and a_idx is None and b_idx is None and c_idx is None and dyn is None and split_k <= 1 and k_chunk <= 0
           and colsum_out is None and not atomic and wg64 <= 512 and K >= 64 and drop is None):
         t = 7
+    elif pipe_nt and (dyn is not None or wg128 >= 640):
+        t = 15
+    elif pipe_nt and wg64 > 512 and K >= 128:
+        t = 16
     elif wg64 <= 512 and dyn is None and k_chunk <= 0 and K >= 128:
         t = 6
     elif M <= 512 or (wg128 < 640 and dyn is None) or trans_a:
@@ -215,7 +271,8 @@ def gemm(A, B, C_=None, *, M, N, K, lda, ldb, ldc=0, trans_a=False, trans_b=Fals
     else:
         t = 5 if not trans_b else 4
     fam = 'gemm_%s_%s' % ('tn' if trans_a else ('nn' if trans_b else 'nt'),
-                          {1: '256x80', 2: '64x80', 3: '128x208', 4: '128x80', 5: '128x80k32', 6: '64x80k64', 7: '16x80skinny'}[t])
+                          {1: '256x80', 2: '64x80', 3: '128x208', 4: '128x80', 5: '128x80k32', 6: '64x80k64', 7: '16x80skinny', 8: 'pipe128x80k32', 13: 'pipe128x80s4',
+                           15: 'pipe128x80', 16: 'pipe128x80s2', 20: 'pipe128x80', 22: 'pipe64x80', 23: 'pipe256x80', 24: 'pipe128x208', 25: 'pipe128x128'}.get(t, 'tile%d' % t))
 
     def flops(M=M, N=N, K=K, dyn=dyn, dyn_dim=dyn_dim, batch=batch):
         m, k = M, K
@@ -244,7 +301,10 @@ def linear_bwd_data(dy, w, out=None, accumulate=False, **kw):
     K = w.shape[1]
     if out is None:
         out = torch.empty((M, K), device=dy.device, dtype=torch.float32)
-    gemm(dy, w, out, M=M, N=K, K=N, lda=dy.stride(0), ldb=w.stride(0), ldc=out.stride(0), trans_b=True, accumulate=accumulate, **kw)
+    if USE_WT and M >= 1024 and w.is_contiguous() and (N & 3) == 0:
+        gemm(dy, wt(w), out, M=M, N=K, K=N, lda=dy.stride(0), ldb=N, ldc=out.stride(0), accumulate=accumulate, **kw)      # NT on W^T
+    else:
+        gemm(dy, w, out, M=M, N=K, K=N, lda=dy.stride(0), ldb=w.stride(0), ldc=out.stride(0), trans_b=True, accumulate=accumulate, **kw)
     return out
 
 
@@ -253,9 +313,11 @@ def linear_bwd_weight(dy, x, dw, dyn=None, rows=None, db=None, **kw):
     db[N] += column sums of dy, fused into the same launch."""
     R = dy.shape[0] if rows is None else rows
     N, K = dw.shape
-    sk = dict(split_k=split_for(N, K, R))      # (k_chunk slices measured no better than a static split at these sizes)
+    t, bm, bn, target = tn_tile(N, K, R)
+    if t and ((dy.stride(0) | x.stride(0)) & 3 or (dy.data_ptr() | x.data_ptr()) & 15):
+        t, bm, bn, target = 0, 64, 80, 2048
     gemm(dy, x, dw, M=N, N=K, K=R, lda=dy.stride(0), ldb=x.stride(0), ldc=dw.stride(0), trans_a=True, trans_b=True,
-         atomic=True, dyn=dyn, dyn_dim=2, colsum_out=db, **sk, **kw)
+         atomic=True, dyn=dyn, dyn_dim=2, colsum_out=db, split_k=split_for(N, K, R, bm, bn, target), tile=t, **kw)
 
 
 def rowdot(x, w, out, dyn=None, rows=None):
@@ -333,6 +395,8 @@ class LstmPacked:
         self.wb = torch.empty(2 * ub * (np_ // 16) * 256, **f)
         L.check(L.lib().nnr_lstm_pack_weights(*[_p(t) for t in p], H, E, _p(self.w_ihp), _p(self.b_p), _p(self.wf), _p(self.wb), _s()),
                 'nnr_lstm_pack_weights')
+        self.w_ihp_t = torch.empty((E, 2 * np_), **f)             # [E, 2*NP]: K-contiguous B operand of the dX GEMM (NT form)
+        transpose2d(self.w_ihp, self.w_ihp_t, 2 * np_, E)
 
 
 def lstm_unpack_grads(dw_ihp, db_p, dw_hhp, H, E, grads):

@@ -524,7 +524,14 @@ class MHSAUser(UserEncoder):
         N = a['candidate_news_representation'].shape[1]
         hist = self.encode_history(a)
         h = self.multiheadAttention(hist, hist, hist, a['user_history_mask'])
-        h = torch.relu(F.dropout(self.affine(h), 0.5, self.training))
+        forced = getattr(self, 'forced_dropout_keep', None)
+        if forced is not None and self.training:
+            # parity tests: the keep-mask of the HIP path's counter-based generator for this call, injected so that the
+            # train-mode arithmetic of userEncoders.py:171 (p = 0.5, scale 2) can be compared element for element
+            y = self.affine(h)
+            h = torch.relu(y * forced.to(y.dtype).view_as(y) * 2.0)
+        else:
+            h = torch.relu(F.dropout(self.affine(h), 0.5, self.training))
         return self.attention(h).unsqueeze(1).repeat(1, N, 1)        # unmasked pool, :172
 
 

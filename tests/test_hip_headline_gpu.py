@@ -1,0 +1,111 @@
+"""Parity at the HEADLINE size (BASELINE.json: batch 64, MIND-200k-shaped synthetic batches, vocabulary 60 000, full model
+dimensions): the HIP path driven by the product Trainer -- every HIP stream, the leaf-stream weight gradients, the CU-pair
+recurrence on a full chip, the flat-buffer clip+Adam -- against the CPU oracle on the SAME batch.  This is the only size at
+which all four streams, leaf deferral and ~880 pair-recurrence workgroups are active at once; a cross-stream race that needs
+hundreds of tiles in flight would not show at the batch 2-8 fixtures.  Dropout 0 (masks are generator-specific), train mode,
+tie_order 'stable'.  Bars: logits 1e-4 (BASELINE.json north_star), loss 2e-5, every parameter gradient within 1e-4 of the
+gradient scale, gradient norms 1e-4 relative, parameters after the Adam step as in tests/test_oracle_golden.py.
+Reference sites: trainer.py:105-120, model.py:120-133, newsEncoders.py:102-141, userEncoders.py:68-98 / 164-173."""
+import numpy as np
+import pytest
+import torch
+
+from nnr_amd.config import make_config
+from nnr_amd.synth import SynthSpec, SynthCorpus, to_torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(cfg, seed, train=True):
+    from nnr_amd.model import Model
+    from oracle import nnr_oracle as O
+    O.BiLSTM.backend = 'aten'                          # ATen's packed LSTM: pinned to the goldens like the time loop, 3x faster
+    torch.manual_seed(seed)
+    table = torch.randn(cfg.vocabulary_size, cfg.word_embedding_dim) * 0.3
+    table[0] = 0
+    ref = O.Model(cfg, table)
+    ref.initialize()
+    with torch.no_grad():
+        for p in ref.parameters():                     # zero-initialised tensors (proxy nodes, biases) carry signal too
+            if float(p.abs().max()) == 0.0:
+                p.normal_(0, 0.05)
+    model = Model(cfg)
+    model.load_state_dict(ref.state_dict())
+    model = model.cuda()
+    (ref.train(), model.train()) if train else (ref.eval(), model.eval())
+    return model, ref
+
+
+def _check_step(model, ref, cfg, batch, lr_steps=1):
+    from nnr_amd import ops
+    from nnr_amd.trainer import Trainer
+    from oracle import nnr_oracle as O
+    trainer = Trainer(model, cfg)
+    ops.lstm_sync_timeouts(reset=True)
+    logits, loss = trainer.train_step(to_torch(batch, 'cuda'))
+    torch.cuda.synchronize()
+    assert ops.lstm_sync_timeouts() == 0
+    got_grads = {k: p.grad.detach().cpu().double() for k, p in model.named_parameters()}
+    got_norm = trainer.grad_total_norm()
+    # oracle: the same step
+    opt = O.make_optimizer(ref, cfg)
+    rl = ref(*to_torch(batch))
+    rloss = O.negative_log_softmax(rl)
+    opt.zero_grad()
+    rloss.backward()
+    ref_grads = {k: p.grad.detach().double().clone() for k, p in ref.named_parameters()}
+    rnorm = float(torch.nn.utils.clip_grad_norm_(ref.parameters(), cfg.gradient_clip_norm))
+    opt.step()
+    err = float((logits.cpu() - rl.detach()).abs().max())
+    assert err <= 1e-4, 'logits differ by %.3e' % err
+    assert abs(float(loss) - float(rloss)) <= 2e-5, (float(loss), float(rloss))
+    assert abs(got_norm - rnorm) <= 1e-4 * max(1.0, rnorm), (got_norm, rnorm)
+    worst = 0.0
+    for k, rg in ref_grads.items():
+        g = got_grads[k]
+        scale = max(1e-3, 0.05 * rnorm, float(rg.norm()))
+        d = float((g - rg).abs().max())
+        worst = max(worst, d / scale)
+        assert d <= 1e-4 * scale, 'grad %s: %.3e vs scale %.3e' % (k, d, scale)
+        assert abs(float(g.norm()) - float(rg.norm())) <= 1e-4 * scale, 'grad norm ' + k
+    # one Adam step: elements with a well-resolved gradient move identically; the rest move by -+lr each (the first Adam step
+    # is lr * sign(g) and the sign of a gradient at the fp32 noise floor is noise): at most 2 * lr apart
+    lr = float(cfg.lr)
+    rp = dict(ref.named_parameters())
+    for k, p in model.named_parameters():
+        a, e = p.detach().cpu().numpy(), rp[k].detach().numpy()
+        gabs = ref_grads[k].abs().numpy()
+        resolved = gabs > 0.05 * max(float(gabs.max()), 1e-30)
+        d = np.abs(a - e)
+        assert d[resolved].max(initial=0.0) <= 5e-5, 'param ' + k
+        assert d.max(initial=0.0) <= 2 * lr * 1.01 + 5e-5, 'param ' + k
+    return err, worst
+
+
+def test_cne_sue_batch64_vocab60000_matches_oracle():
+    cfg = make_config(['--news_encoder=CNE', '--user_encoder=SUE', '--dataset=200k', '--batch_size=64'],
+                      corpus_sizes=dict(vocabulary_size=60000), dropout_rate=0.0, tie_order='stable')
+    model, ref = _pair(cfg, seed=0)
+    batch = SynthCorpus(SynthSpec(vocabulary_size=cfg.vocabulary_size)).batch(64, np.random.default_rng(100))
+    err, worst = _check_step(model, ref, cfg, batch)
+    print('CNE+SUE batch 64: logits max|diff| %.2e, worst gradient deviation %.2e of its scale' % (err, worst))
+
+
+def test_mhsa_mhsa_batch64_train_mode_with_injected_user_dropout_mask():
+    """MHSA-user's hard-wired F.dropout(p = 0.5) (userEncoders.py:171) in TRAIN mode: the keep-mask of the HIP path's
+    counter-based generator for this call is computed on the GPU and injected into the oracle, so the whole train-mode step is
+    compared (news-encoder dropout_rate 0)."""
+    from nnr_amd import ops
+    cfg = make_config(['--news_encoder=MHSA', '--user_encoder=MHSA', '--dataset=200k', '--batch_size=64'],
+                      corpus_sizes=dict(vocabulary_size=60000), dropout_rate=0.0)
+    model, ref = _pair(cfg, seed=1)
+    B, Hn, D = 64, cfg.max_history_num, model.news_embedding_dim
+    ue = model.user_encoder
+    ue._calls = 0
+    seed = (ue._seed_base + 15485863 * 1) & 0x7FFFFFFF                     # UserEncoder._next_seed() of the first call
+    keep = ops.dropout(torch.ones(B * Hn * D, device='cuda'), 0.5, seed) > 0
+    assert 0.45 < float(keep.float().mean()) < 0.55
+    ref.user_encoder.forced_dropout_keep = keep.cpu().view(B, Hn, D)
+    batch = SynthCorpus(SynthSpec(vocabulary_size=cfg.vocabulary_size)).batch(64, np.random.default_rng(101))
+    err, worst = _check_step(model, ref, cfg, batch)
+    print('MHSA+MHSA batch 64 (train, p=0.5 mask injected): logits max|diff| %.2e, worst gradient deviation %.2e' % (err, worst))

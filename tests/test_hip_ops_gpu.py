@@ -83,6 +83,65 @@ def test_gemm_skinny_tile_all_epilogues(M, N, K):
     close(ob, ab.double() @ bb.double(), what='skinny batched NN')
 
 
+PIPE_TILES = [8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19]
+
+
+@pytest.mark.parametrize('tile', PIPE_TILES)
+@pytest.mark.parametrize('M,N,K', [(37, 83, 68), (700, 300, 404), (3200, 200, 400), (1, 80, 4), (500, 228, 900), (1111, 1664, 300)])
+def test_gemm_pipelined_nt_tiles(tile, M, N, K):
+    """The LDS-DMA staged NT kernel (csrc/gemm.hip: gemm_nt_pipe_kernel), every tile shape: ragged M / N (rows and columns beyond
+    the edge come from the zero page), K not a multiple of the stage depth (k-chunks beyond K come from the zero page), K
+    shorter than one stage, fewer stages than buffers, every element-wise epilogue, dynamic M, row gather, atomic row
+    scatter, batched."""
+    from nnr_amd import ops
+    d = dev()
+    a, b = rnd(M, K, seed=1), rnd(N, K, seed=2)
+    out = torch.empty(M, N, device=d)
+    ops.gemm(a.to(d), b.to(d), out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, tile=tile)
+    close(out, a.double() @ b.double().t(), what='pipe NT tile %d' % tile)
+    if M < 37:
+        return
+    bias, resid, mul, base = rnd(N, seed=4), rnd(M, N, seed=5), rnd(M, N, seed=6), rnd(M, N, seed=7)
+    rv, rmap = rnd(5, N, seed=8), torch.randint(0, 5, (M,), generator=torch.Generator().manual_seed(9)).int()
+    aux = torch.empty(M, N, device=d)
+    out = base.to(d).clone()
+    ops.gemm(a.to(d), b.to(d), out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, alpha=0.5, bias=bias.to(d), rowvec=rv.to(d), ldrv=N, rowvec_map=rmap.to(d),
+             act=ops.ACT_TANH, aux_out=aux, ldaux=N, mul=mul.to(d), ldmul=N, resid=resid.to(d), ldres=N, accumulate=True, tile=tile)
+    pre = torch.tanh(0.5 * (a.double() @ b.double().t()) + bias.double() + rv.double()[rmap.long()])
+    etol = 2e-5 * max(1.0, math.sqrt(K / 100.0))          # the pre-activation is an fp32 sum of K products of magnitude ~1
+    close(aux, pre, tol=etol, what='pipe aux')
+    close(out, base.double() + pre * mul.double() + resid.double(), tol=etol, what='pipe full epilogue')
+    # dynamic M + row gather (negative index = zero row) + rows beyond the live count untouched
+    used = max(1, (M * 2) // 3)
+    V = 97
+    tab = rnd(V, K, seed=11)
+    idx = torch.randint(0, V, (M,), generator=torch.Generator().manual_seed(12)).int()
+    idx[min(5, used - 1)] = -1
+    out = torch.full((M, N), 7.0, device=d)
+    dyn = torch.tensor([used], dtype=torch.int32, device=d)
+    ops.gemm(tab.to(d), b.to(d), out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, a_idx=idx.to(d), dyn=dyn, dyn_dim=1, bias=bias.to(d), tile=tile)
+    g = tab.double()[idx.long().clamp_min(0)] * (idx >= 0).double()[:, None]
+    exp = g @ b.double().t() + bias.double()
+    close(out[:used], exp[:used], what='pipe gather dyn')
+    assert bool((out[used:] == 7.0).all())
+    # atomic row scatter (embedding-gradient shape): C[c_idx[m]] += row m
+    rows = 50
+    cidx = torch.randint(0, rows, (M,), generator=torch.Generator().manual_seed(13)).int()
+    cidx[0] = -1
+    acc = torch.zeros(rows, N, device=d)
+    ops.gemm(a.to(d), b.to(d), acc, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, c_idx=cidx.to(d), atomic=True, tile=tile)
+    full = a.double() @ b.double().t()
+    exp = torch.zeros(rows, N, dtype=torch.double)
+    keep = cidx >= 0
+    exp.index_add_(0, cidx[keep].long(), full[keep])
+    close(acc, exp, tol=5e-5, what='pipe scatter')
+    if M <= 700:
+        ab, bb = rnd(3, M, K, seed=20), rnd(3, N, K, seed=21)
+        ob = torch.empty(3, M, N, device=d)
+        ops.gemm(ab.to(d), bb.to(d), ob, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, batch=3, strideA=M * K, strideB=N * K, strideC=M * N, tile=tile)
+        close(ob, ab.double() @ bb.double().transpose(1, 2), what='pipe batched')
+
+
 def test_gemm_nn_accumulate_and_tn_splitk_dyn():
     from nnr_amd import ops
     dy, w = rnd(300, 225, seed=1), rnd(225, 900, seed=2)
@@ -645,3 +704,38 @@ def test_gemm_fused_bias_gradient():
     ops.linear_bwd_weight(dy.to(d), x.to(d), dw, dyn=dyn, db=db)
     close(dw, dy[:used].double().t() @ x[:used].double(), tol=5e-5, what='dw')
     close(db, 0.25 + dy[:used].double().sum(0), tol=5e-5, what='fused db')
+
+
+TN_PIPE_TILES = [20, 21, 22, 23, 24, 25]
+
+
+@pytest.mark.parametrize('tile', TN_PIPE_TILES)
+@pytest.mark.parametrize('M,N,K,split', [(832, 300, 5000, 4), (400, 400, 777, 1), (200, 400, 3333, 3), (1664, 300, 20000, 7), (900, 900, 4352, 2),
+                                         (36, 20, 50, 2), (128, 80, 16, 1), (132, 84, 40, 3)])
+def test_gemm_pipelined_tn_tiles(tile, M, N, K, split):
+    """The LDS-DMA staged weight-gradient kernel (gemm_tn_pipe_kernel): ragged tile edges (zero page), reduction lengths that
+    are not multiples of the stage depth, fewer stages than buffers, split-K slices that come out empty, device-side K,
+    gathered B rows with negative (= zero) entries, fused column sums, accumulation into a running gradient."""
+    from nnr_amd import ops
+    d = dev()
+    at, bt = rnd(K, M, seed=4), rnd(K, N, seed=3)
+    base = rnd(M, N, seed=5)
+    o = base.to(d).clone()
+    ops.gemm(at.to(d), bt.to(d), o, M=M, N=N, K=K, lda=M, ldb=N, ldc=N, trans_a=True, trans_b=True, split_k=split, atomic=True, tile=tile)
+    close(o, base.double() + at.double().t() @ bt.double(), tol=5e-5, what='TN pipe tile %d' % tile)
+    # device-side K + gathered B rows + fused column sums, operands as column slices of wider buffers (the dW_hh shape)
+    used = max(1, (K * 3) // 4)
+    lda, ldb = M + 64, N + 8
+    A2 = rnd(K, lda, seed=6); B2 = rnd(K, ldb, seed=7)
+    bidx = torch.randint(0, K, (K,), generator=torch.Generator().manual_seed(8)).int()
+    bidx[::7] = -1
+    dyn = torch.tensor([used], dtype=torch.int32, device=d)
+    o = torch.zeros(M, N, device=d)
+    cs = torch.zeros(M, device=d)
+    A2d, B2d = A2.to(d), B2.to(d)
+    ops.gemm(A2d[:, 64:], B2d[:, 8:], o, M=M, N=N, K=K, lda=lda, ldb=ldb, ldc=N, trans_a=True, trans_b=True, split_k=split, atomic=True,
+             b_idx=bidx.to(d), dyn=dyn, dyn_dim=2, colsum_out=cs, tile=tile)
+    a_ = A2[:used, 64:].double()
+    b_ = B2[:, 8:].double()[bidx[:used].long().clamp_min(0)] * (bidx[:used] >= 0).double()[:, None]
+    close(o, a_.t() @ b_, tol=5e-5, what='TN pipe gather dyn')
+    close(cs, a_.sum(dim=0), tol=5e-5, what='TN pipe column sums')
