@@ -17,6 +17,7 @@
 //   device memory (no host sync).
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -475,7 +476,7 @@ int launch_cfg(const nnr_gemm_args& g, hipStream_t s) {
 //    and doubles as the write-after-read fence for the buffer that is refilled next.
 //  * rows beyond M / N and k-chunks beyond K read a zero page instead (the source address is per lane), so the tile needs
 //    no bounds logic in the loop.  Requirements (checked by the dispatcher): K, lda, ldb multiples of 4, 16-byte aligned bases.
-__device__ __attribute__((aligned(16))) float nnr_zero_page[4] = {0.f, 0.f, 0.f, 0.f};
+__device__ __attribute__((aligned(1024))) float nnr_zero_page[512] = {};      // 2 KiB: a whole (gathered) tile row of zeros
 
 __device__ __forceinline__ void lds_dma16(const float* gsrc, unsigned lds_dst) {
   unsigned keep;      // M0 carries the wave-uniform LDS base of the instruction; it is compiler-reserved: saved and restored here
@@ -632,6 +633,215 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_pipe_kernel(nnr_gemm_args g)
   }
   __syncthreads();        // every wave is done with the stage buffers: the epilogue reuses them
   gemm_epilogue<TM, TN>(g, acc, lds, C, m0, n0, M, N, z);
+}
+
+// ---- lean LDS-DMA issue: N loads of one operand in ONE statement.  The global address is SGPR base (advanced by the caller per
+// stage) + a per-lane 32-bit byte offset that never changes, so a stage costs no vector ALU work at all; M0 (the LDS base) is
+// saved once, stepped by `step` bytes between the loads and restored.  (s_nop 0: the wait state between an M0 write and its use.)
+template <int N>
+__device__ __forceinline__ void lds_dma16_block(const float* sbase, unsigned lds_dst, const unsigned (&voff)[8]) {
+  unsigned keep;
+  static_assert(N >= 1 && N <= 8, "1..8 loads per block");
+#define NNR_DMA_HEAD "s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[dst]\n\t"
+#define NNR_DMA_LD(I) "s_nop 0\n\tglobal_load_lds_dwordx4 %[v" #I "], %[sb]\n\ts_add_u32 m0, m0, 0x1000\n\t"
+#define NNR_DMA_TAIL "s_mov_b32 m0, %[keep]"
+#define NNR_DMA_OPS : [keep] "=&s"(keep) : [dst] "s"(lds_dst), [sb] "s"(sbase), [v0] "v"(voff[0]), [v1] "v"(voff[1]), [v2] "v"(voff[2]), [v3] "v"(voff[3]), \
+                      [v4] "v"(voff[4]), [v5] "v"(voff[5]), [v6] "v"(voff[6]), [v7] "v"(voff[7]) : "memory", "scc"
+  if constexpr (N == 1) asm volatile(NNR_DMA_HEAD NNR_DMA_LD(0) NNR_DMA_TAIL NNR_DMA_OPS);
+  if constexpr (N == 2) asm volatile(NNR_DMA_HEAD NNR_DMA_LD(0) NNR_DMA_LD(1) NNR_DMA_TAIL NNR_DMA_OPS);
+  if constexpr (N == 3) asm volatile(NNR_DMA_HEAD NNR_DMA_LD(0) NNR_DMA_LD(1) NNR_DMA_LD(2) NNR_DMA_TAIL NNR_DMA_OPS);
+  if constexpr (N == 4) asm volatile(NNR_DMA_HEAD NNR_DMA_LD(0) NNR_DMA_LD(1) NNR_DMA_LD(2) NNR_DMA_LD(3) NNR_DMA_TAIL NNR_DMA_OPS);
+  if constexpr (N == 5) asm volatile(NNR_DMA_HEAD NNR_DMA_LD(0) NNR_DMA_LD(1) NNR_DMA_LD(2) NNR_DMA_LD(3) NNR_DMA_LD(4) NNR_DMA_TAIL NNR_DMA_OPS);
+  if constexpr (N == 6) asm volatile(NNR_DMA_HEAD NNR_DMA_LD(0) NNR_DMA_LD(1) NNR_DMA_LD(2) NNR_DMA_LD(3) NNR_DMA_LD(4) NNR_DMA_LD(5) NNR_DMA_TAIL NNR_DMA_OPS);
+  if constexpr (N == 7) asm volatile(NNR_DMA_HEAD NNR_DMA_LD(0) NNR_DMA_LD(1) NNR_DMA_LD(2) NNR_DMA_LD(3) NNR_DMA_LD(4) NNR_DMA_LD(5) NNR_DMA_LD(6) NNR_DMA_TAIL NNR_DMA_OPS);
+  if constexpr (N == 8) asm volatile(NNR_DMA_HEAD NNR_DMA_LD(0) NNR_DMA_LD(1) NNR_DMA_LD(2) NNR_DMA_LD(3) NNR_DMA_LD(4) NNR_DMA_LD(5) NNR_DMA_LD(6) NNR_DMA_LD(7) NNR_DMA_TAIL NNR_DMA_OPS);
+#undef NNR_DMA_HEAD
+#undef NNR_DMA_LD
+#undef NNR_DMA_TAIL
+#undef NNR_DMA_OPS
+}
+
+// ---- second-generation NT loop: the same LDS-DMA staging, BK = 32, with the fragment reads software-pipelined ACROSS the stage
+// barrier.  A stage is two 16-deep k-groups; the fragments of group 1 are read while group 0's MFMAs run, and the wait + barrier
+// + DMA issue + fragment reads of the NEXT stage's group 0 sit between the two MFMA blocks of the current stage -- so a single
+// wave keeps the matrix pipe fed (no read latency in front of any MFMA block, the barrier costs only the skew between the
+// four waves).  The first-generation loop above needs 3-4 co-resident workgroups per CU to hide those gaps; this one is
+// meant for 1-2 (bigger tiles, deeper prefetch).
+template <int TM, int TN, int NS, int OCC>
+__global__ __launch_bounds__(256, OCC) void gemm_nt_pipe2_kernel(nnr_gemm_args g) {
+  constexpr int BK = 32, BM = 64 * TM, BN = 16 * TN, ROWS = BM + BN;
+  constexpr int KQ = BK / 4, RPI = 64 / KQ, NI = ROWS / RPI, NPW = (NI + 3) / 4, STAGE = ROWS * BK, E_LD = BN + 4;
+  constexpr int LDS_FLOATS = (NS * STAGE > 64 * E_LD) ? NS * STAGE : 64 * E_LD;
+  static_assert(ROWS % RPI == 0 && NS >= 3, "tile shape");
+  __shared__ __attribute__((aligned(1024))) float lds[LDS_FLOATS];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, kk = lane >> 4;
+  int M = g.M;
+  if (g.dyn_dim == 1) M = min(M, *g.dyn_dev);
+  const int N = g.N, K = g.K;
+  const int nbm = (M + BM - 1) / BM, nbn = (N + BN - 1) / BN;
+  const int nblk = nbm * nbn;
+  if ((int)blockIdx.x >= nblk) return;
+  int v;
+  {
+    const int b = blockIdx.x, q = nblk >> 3, rem = nblk & 7, x = b & 7, slot = b >> 3;
+    v = x * q + min(x, rem) + slot;
+  }
+  const int bm = v / nbn, bn = v - bm * nbn;
+  const int m0 = bm * BM, n0 = bn * BN;
+  const int z = blockIdx.z;
+  const float* __restrict__ A = g.A;
+  const float* __restrict__ B = g.B;
+  float* __restrict__ C = g.C;
+  if (g.batch > 1) {
+    A += (long)z * g.strideA;
+    B += (long)z * g.strideB;
+    C += (long)z * g.strideC;
+  }
+  // ---- DMA geometry.  Instruction q covers tile rows [q*8, +8): A rows for q < NIA, then B rows; wave w issues q = w, w + 4, ...
+  // i.e. its i-th A instruction is q = w + 4i (all waves have NIA / 4 of them) and its j-th B instruction q = NIA + w + 4j.
+  // Per lane and instruction a constant byte offset from the operand's stage base: (row * ld + chunk) -- rows past the matrix
+  // edge are CLAMPED to the last valid row: they only feed output rows / columns that are never stored.  Only the k-tail needs
+  // real zeros; it goes through the per-lane-pointer path with the zero page (last stage, K % 32 != 0 only).
+  constexpr int NIA = BM / RPI, NIB = BN / RPI, NA = NIA / 4, NBMAX = (NIB + 3) / 4;
+  static_assert(NIA % 4 == 0 && NA <= 8 && NBMAX <= 8, "tile shape");
+  unsigned voffA[8], voffB[8];
+  int kchA[NA], kchB[NBMAX];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) voffA[i] = voffB[i] = 0;
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int tr = (w + 4 * i) * RPI + lane / KQ;
+    const int c = (lane % KQ) ^ swz<BK>(tr & 15);
+    kchA[i] = 4 * c;
+    voffA[i] = (unsigned)(((long)min(tr, M - 1 - m0) * g.lda + 4 * c) * 4);
+  }
+#pragma unroll
+  for (int j = 0; j < NBMAX; ++j) {
+    const int tr = (w + 4 * j) * RPI + lane / KQ;           // row inside the B part of the tile
+    const int c = (lane % KQ) ^ swz<BK>(tr & 15);
+    kchB[j] = 4 * c;
+    voffB[j] = (unsigned)(((long)min(tr, N - 1 - n0) * g.ldb + 4 * c) * 4);
+  }
+  const float* zero = nnr_zero_page;
+  asm volatile("" : "+s"(zero));
+  const unsigned lds_base = (unsigned)(uintptr_t)lds;
+  const int S = (K + BK - 1) / BK;
+  const float* Abase = A + (long)m0 * g.lda;               // wave-uniform (SGPR) stage bases, advanced by BK floats per stage
+  const float* Bbase = B + (long)n0 * g.ldb;
+  const bool ktail = (K % BK) != 0;
+  const bool nb_hi = (NIB % 4 == 0) || (w < NIB % 4);      // this wave has NBMAX (else NBMAX - 1) B instructions
+  auto issue_lean = [&](int s) {                             // any stage but a k-tail one: no vector ALU work
+    const int k0 = s * BK;
+    const unsigned sb = lds_base + (unsigned)((s % NS) * STAGE * 4) + (unsigned)(w * 1024);
+    lds_dma16_block<NA>(Abase + k0, sb, voffA);
+    if (nb_hi) lds_dma16_block<NBMAX>(Bbase + k0, sb + NIA * 1024, voffB);
+    else if constexpr (NBMAX > 1) lds_dma16_block<NBMAX - 1>(Bbase + k0, sb + NIA * 1024, voffB);
+  };
+  auto issue = [&](int s) {
+    if (!(ktail && s == S - 1)) { issue_lean(s); return; }
+    const int k0 = s * BK;                                     // zero the k-chunks beyond K (per-lane source select)
+    const unsigned sb = lds_base + (unsigned)((s % NS) * STAGE * 4) + (unsigned)(w * 1024);
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+      lds_dma16((k0 + kchA[i] < K) ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(Abase + k0) + voffA[i]) : zero, sb + i * 4096);
+#pragma unroll
+    for (int j = 0; j < NBMAX; ++j)
+      if (j < NBMAX - 1 || nb_hi)
+        lds_dma16((k0 + kchB[j] < K) ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(Bbase + k0) + voffB[j]) : zero,
+                  sb + NIA * 1024 + j * 4096);
+  };
+  auto wait_landed = [&](int ahead) {       // this wave's DMAs of the stage about to be read: at most `ahead` newer stages stay in flight
+    if (NI % 4 == 0 || w < NI % 4) wait_stages<NPW, NS - 3>(ahead);
+    else wait_stages<NPW - 1, NS - 3>(ahead);
+  };
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int m = 0; m < TM; ++m)
+#pragma unroll
+    for (int n = 0; n < TN; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+  auto rd = [&](int s, int kg, f32x4 (&a)[TM], f32x4 (&b)[TN]) {
+    const float* As = lds + (s % NS) * STAGE;
+    const float* Bs = As + BM * BK;
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+      a[m] = *reinterpret_cast<const f32x4*>(&As[((w * TM + m) * 16 + r) * BK + 4 * ((kg * 4 + kk) ^ swz<BK>(r))]);
+#pragma unroll
+    for (int n = 0; n < TN; ++n)
+      b[n] = *reinterpret_cast<const f32x4*>(&Bs[(n * 16 + r) * BK + 4 * ((kg * 4 + kk) ^ swz<BK>(r))]);
+  };
+  auto mm = [&](const f32x4 (&a)[TM], const f32x4 (&b)[TN]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][i], b[n][i], acc[m][n], 0, 0, 0);
+  };
+
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < S) issue(s);
+  // stage 0 must be complete: with min(NS - 1, S) stages issued, the newer ones (at most NS - 2) may stay in flight
+  if (NI % 4 == 0 || w < NI % 4) wait_stages<NPW, NS - 2>(S - 1); else wait_stages<NPW - 1, NS - 2>(S - 1);
+  __builtin_amdgcn_s_barrier();
+  rd(0, 0, fa0, fb0);
+  // Three loops, so that the steady-state body is branch-free between the fragment reads and the MFMA blocks (any branch that
+  // merges there makes the compiler's lgkmcnt bookkeeping wait for the NEWEST reads): (1) stages whose refill is an ordinary
+  // stage, (2) the one whose refill is the last stage (possibly a k-tail), (3) the drain, no refill; the last stage is peeled.
+  // lgkmcnt(0), visible to the compiler (a builtin, not asm): scalar loads of kernel arguments still pending at the loop header
+  // would otherwise force EVERY in-loop LDS wait to lgkmcnt(0) (scalar loads return out of order), i.e. to wait for the reads
+  // just issued instead of the older ones the MFMAs need.
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  // After every MFMA block an lgkmcnt(0) the compiler can see: the reads it covers were issued a whole MFMA block earlier, so it
+  // never stalls, and it empties the compiler's pending-read list before the barrier / DMA / branch section -- where that list
+  // otherwise degrades to "wait for everything" at the next use.
+#define NNR_LGKM0() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0xC07F); } while (0)
+  int s = 0;
+  for (; s + NS < S; ++s) {                                   // refill = stage s + NS - 1 <= S - 2
+    rd(s, 1, fa1, fb1);
+    __builtin_amdgcn_sched_barrier(0);                        // keep the reads AHEAD of the MFMA block that hides them
+    mm(fa0, fb0);
+    NNR_LGKM0();
+    wait_landed(NS);                                          // stage s + 1: up to NS - 3 newer stages stay in flight
+    __builtin_amdgcn_s_barrier();
+    issue_lean(s + NS - 1);                                   // into the buffer of stage s - 1: free since the previous barrier
+    rd(s + 1, 0, fa0, fb0);
+    __builtin_amdgcn_sched_barrier(0);
+    mm(fa1, fb1);
+    NNR_LGKM0();
+  }
+  for (; s + 1 < S; ++s) {                                    // at most NS - 1 iterations
+    rd(s, 1, fa1, fb1);
+    __builtin_amdgcn_sched_barrier(0);
+    mm(fa0, fb0);
+    NNR_LGKM0();
+    wait_landed(S - 1 - (s + 1));
+    __builtin_amdgcn_s_barrier();
+    if (s + NS - 1 < S) issue(s + NS - 1);
+    rd(s + 1, 0, fa0, fb0);
+    __builtin_amdgcn_sched_barrier(0);
+    mm(fa1, fb1);
+    NNR_LGKM0();
+  }
+#undef NNR_LGKM0
+  rd(S - 1, 1, fa1, fb1);
+  __builtin_amdgcn_sched_barrier(0);
+  mm(fa0, fb0);
+  mm(fa1, fb1);
+  __syncthreads();
+  gemm_epilogue<TM, TN>(g, acc, lds, C, m0, n0, M, N, z);
+}
+
+template <int TM, int TN, int NS, int OCC>
+int launch_pipe2(const nnr_gemm_args& g, hipStream_t s) {
+  constexpr int BM = 64 * TM, BN = 16 * TN;
+  const int nbm = (g.M + BM - 1) / BM, nbn = (g.N + BN - 1) / BN;
+  dim3 grid(nbm * nbn, 1, g.batch > 1 ? g.batch : 1), block(256);
+  hipLaunchKernelGGL((gemm_nt_pipe2_kernel<TM, TN, NS, OCC>), grid, block, 0, s, g);
+  NNR_CHECK_LAUNCH();
+  return NNR_OK;
 }
 
 template <int TM, int TN, int BK, int NS, int OCC, int PRIO = 0>
@@ -851,6 +1061,241 @@ int launch_tn_pipe(const nnr_gemm_args& g, hipStream_t s) {
   return NNR_OK;
 }
 
+// ---- second-generation TN loop (see gemm_nt_pipe2_kernel): the four MFMA steps of a 16-row stage are software-pipelined -- the
+// fragments of step i + 1 are read while step i's MFMAs run, the wait + barrier + DMA issue + the next stage's first reads sit
+// between steps 2 and 3 -- and the DMA issue is lean: an SGPR row base per stage (or per gathered token row) plus per-lane
+// offsets that never change.  Restrictions on top of gemm_tn_pipe_kernel's: a gathered B (b_idx) needs the 256-float pitch
+// (TN > 8: one token row per instruction, so the row's base is a scalar).  A reduction tail (rows beyond kend in the last
+// stage) is issued through per-lane pointers with the zero page.
+template <int N>
+__device__ __forceinline__ void lds_dma16_rows(const float* const (&sbase)[4], unsigned lds_dst, const unsigned (&voff)[8]) {
+  unsigned keep;      // N loads, each with ITS OWN scalar base (one gathered token row per instruction) and lane offset (the swizzle depends on the row)
+  static_assert(N >= 1 && N <= 4, "1..4 rows");
+#define NNR_ROW_HEAD "s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[dst]\n\t"
+#define NNR_ROW_LD(I) "s_nop 0\n\tglobal_load_lds_dwordx4 %[v" #I "], %[b" #I "]\n\ts_add_u32 m0, m0, 0x1000\n\t"
+#define NNR_ROW_OPS : [keep] "=&s"(keep) : [dst] "s"(lds_dst), [v0] "v"(voff[0]), [v1] "v"(voff[1]), [v2] "v"(voff[2]), [v3] "v"(voff[3]), [b0] "s"(sbase[0]), [b1] "s"(sbase[1]), [b2] "s"(sbase[2]), [b3] "s"(sbase[3]) : "memory", "scc"
+  if constexpr (N == 1) asm volatile(NNR_ROW_HEAD NNR_ROW_LD(0) "s_mov_b32 m0, %[keep]" NNR_ROW_OPS);
+  if constexpr (N == 2) asm volatile(NNR_ROW_HEAD NNR_ROW_LD(0) NNR_ROW_LD(1) "s_mov_b32 m0, %[keep]" NNR_ROW_OPS);
+  if constexpr (N == 3) asm volatile(NNR_ROW_HEAD NNR_ROW_LD(0) NNR_ROW_LD(1) NNR_ROW_LD(2) "s_mov_b32 m0, %[keep]" NNR_ROW_OPS);
+  if constexpr (N == 4) asm volatile(NNR_ROW_HEAD NNR_ROW_LD(0) NNR_ROW_LD(1) NNR_ROW_LD(2) NNR_ROW_LD(3) "s_mov_b32 m0, %[keep]" NNR_ROW_OPS);
+#undef NNR_ROW_HEAD
+#undef NNR_ROW_LD
+#undef NNR_ROW_OPS
+}
+
+template <int TM, int TN, int NS, int OCC>
+__global__ __launch_bounds__(256, OCC) void gemm_tn_pipe2_kernel(nnr_gemm_args g) {
+  constexpr int BK = 16, BM = 64 * TM, BN = 16 * TN;
+  constexpr int PA = BM, PB = BN <= 64 ? 64 : (BN <= 128 ? 128 : 256);
+  constexpr int RA = 256 / PA, RB = 256 / PB;
+  constexpr int NIA = BK / RA, NIB = BK / RB, NA = NIA / 4, NB = NIB / 4, NPW = NA + NB;
+  constexpr int STAGE = BK * (PA + PB);
+  constexpr int E_LD = BN + 4;
+  constexpr int LDS_FLOATS = (NS * STAGE > 64 * E_LD) ? NS * STAGE : 64 * E_LD;
+  static_assert(BN <= 256 && NIA % 4 == 0 && NIB % 4 == 0 && NA <= 8 && NB <= 8 && NS >= 3, "tile shape");
+  __shared__ __attribute__((aligned(1024))) float lds[LDS_FLOATS];
+
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, kk = lane >> 4;
+  const int M = g.M, N = g.N;
+  int K = g.K;
+  if (g.dyn_dim == 2) K = min(K, *g.dyn_dev);
+  const int nbm = (M + BM - 1) / BM, nbn = (N + BN - 1) / BN;
+  const int nblk = nbm * nbn;
+  int v;
+  {
+    const int b = blockIdx.x, q = nblk >> 3, rem = nblk & 7, x = b & 7, slot = b >> 3;
+    v = x * q + min(x, rem) + slot;
+  }
+  const int bm = v / nbn, bn = v - bm * nbn;
+  const int m0 = bm * BM, n0 = bn * BN;
+  const int z = blockIdx.z;
+  int kbeg = 0, kend = K;
+  if (g.split_k > 1) {
+    const int ktiles = (K + BK - 1) / BK;
+    const int per = (ktiles + g.split_k - 1) / g.split_k;
+    kbeg = z * per * BK;
+    kend = min(K, kbeg + per * BK);
+    if (kbeg >= kend) return;
+  }
+  const float* __restrict__ A = g.A;
+  const float* __restrict__ B = g.B;
+  const int* __restrict__ bidx = g.b_idx;
+  const bool gather = bidx != nullptr;                       // (RB == 1 guaranteed by the dispatcher)
+  const float* zero = nnr_zero_page;
+  asm volatile("" : "+s"(zero));
+  const unsigned lds_base = (unsigned)(uintptr_t)lds;
+  const int S = (kend - kbeg + BK - 1) / BK;
+  const bool ktail = ((kend - kbeg) % BK) != 0;
+
+  // ---- DMA geometry: wave w issues A instructions q = w + 4i (i < NA) and B instructions q = w + 4j (j < NB); instruction q
+  // of A covers token rows [q*RA, +RA) of the stage.  Lane offsets (bytes) from the stage's row base; columns past the matrix
+  // edge are CLAMPED to column 0 of the tile (they only feed outputs that are never stored).
+  unsigned voffA[8], voffB[8];
+  int krA[NA], colA[NA], krB[NB], colB[NB];                  // for the reduction-tail stage (per-lane pointers)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) voffA[i] = voffB[i] = 0;
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int q = w + 4 * i;
+    const int kl = q * RA + lane / (PA / 4), p4 = lane % (PA / 4);
+    int col = (4 * p4) ^ (16 * ((kl >> 2) & 1));
+    if (m0 + col >= M) col = 0;
+    krA[i] = kl; colA[i] = col;
+    voffA[i] = (unsigned)(((long)kl * g.lda + col) * 4);
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int q = w + 4 * j;
+    const int kl = q * RB + lane / (PB / 4), p4 = lane % (PB / 4);
+    int col = (4 * p4) ^ (16 * ((kl >> 2) & 1));
+    if (col >= BN || n0 + col >= N) col = 0;
+    krB[j] = kl; colB[j] = col;
+    voffB[j] = gather ? (unsigned)(col * 4) : (unsigned)(((long)kl * g.ldb + col) * 4);
+  }
+  const float* Abase = A + (long)kbeg * g.lda + m0;          // + s * BK * lda per stage
+  const float* Bbase = B + (long)kbeg * g.ldb + n0;
+
+  // gathered B: the NB token-row indices of this wave's B instructions for one stage, fetched (scalar) one stage ahead
+  int bsrc[NB > 0 ? NB : 1];
+  auto fetch_idx = [&](int s) {
+    const int k0 = kbeg + s * BK;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int k = min(k0 + (w + 4 * j) * RB, kend - 1);
+      asm volatile("s_load_dword %0, %1, %2" : "=s"(bsrc[j]) : "s"(bidx), "s"(k * 4) : "memory");
+    }
+  };
+  auto issue = [&](int s, bool tail) {
+    const unsigned sb = lds_base + (unsigned)((s % NS) * STAGE * 4) + (unsigned)(w * 1024);
+    const int k0 = kbeg + s * BK;
+    if (tail) {                                              // rows >= kend of the last stage: zeros (per-lane source select)
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+        lds_dma16((k0 + krA[i] < kend) ? A + (long)(k0 + krA[i]) * g.lda + m0 + colA[i] : zero, sb + i * 4096);
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const int k = k0 + krB[j];
+        long row = k;
+        if (gather) row = bsrc[j];
+        lds_dma16((k < kend && row >= 0) ? B + row * g.ldb + n0 + colB[j] : zero, sb + NIA * 1024 + j * 4096);
+      }
+      return;
+    }
+    lds_dma16_block<NA>(Abase + (long)s * BK * g.lda, sb, voffA);
+    if (!gather) {
+      lds_dma16_block<NB>(Bbase + (long)s * BK * g.ldb, sb + NIA * 1024, voffB);
+    } else {
+      if constexpr (RB == 1 && NB <= 4) {
+        const float* rows[4] = {zero, zero, zero, zero};
+#pragma unroll
+        for (int j = 0; j < NB; ++j) rows[j] = bsrc[j] >= 0 ? B + (long)bsrc[j] * g.ldb + n0 : zero;
+        lds_dma16_rows<NB>(rows, sb + NIA * 1024, voffB);
+      }
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int m = 0; m < TM; ++m)
+#pragma unroll
+    for (int n = 0; n < TN; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool do_colsum = g.colsum_out != nullptr && bn == 0;
+  f32x4 cs[TM];
+#pragma unroll
+  for (int m = 0; m < TM; ++m) cs[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int xo = 16 * (kk & 1);
+  float fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+  auto rd = [&](int s, int i, float (&a)[TM], float (&b)[TN]) {
+    const float* As = lds + (s % NS) * STAGE;
+    const float* Bs = As + BK * PA;
+#pragma unroll
+    for (int m = 0; m < TM; ++m) a[m] = As[(4 * kk + i) * PA + (((w * TM + m) * 16 + r) ^ xo)];
+#pragma unroll
+    for (int n = 0; n < TN; ++n) b[n] = Bs[(4 * kk + i) * PB + ((n * 16 + r) ^ xo)];
+  };
+  auto wait_landed = [&](int ahead) { wait_stages<NPW, NS - 3>(ahead); };
+#define NNR_LGKM0() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0xC07F); } while (0)
+#define NNR_PIN() __builtin_amdgcn_sched_barrier(0)
+
+  // one pass over the stages; CS: also accumulate the column sums of A (the column-block-0 workgroups of a launch that asks
+  // for the fused bias gradient) -- a separate instantiation so that the common loop carries no branch
+  auto run = [&](auto cs_tag) {
+    constexpr bool CS = decltype(cs_tag)::value;
+    auto mm = [&](const float (&a)[TM], const float (&b)[TN]) {
+#pragma unroll
+      for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[n], acc[m][n], 0, 0, 0);
+      if constexpr (CS) {
+#pragma unroll
+        for (int m = 0; m < TM; ++m) cs[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], 1.f, cs[m], 0, 0, 0);
+      }
+    };
+    // prologue
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+      if (s < S) {
+        if (gather) { fetch_idx(s); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+        issue(s, ktail && s == S - 1);
+      }
+    if (gather && NS - 1 < S) fetch_idx(NS - 1);
+    wait_stages<NPW, NS - 2>(S - 1);
+    __builtin_amdgcn_s_barrier();
+    rd(0, 0, fa0, fb0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    auto stage = [&](int s, int refill /* 0 none, 1 ordinary stage, 2 possibly the tail stage */) {
+      rd(s, 1, fa1, fb1); NNR_PIN(); mm(fa0, fb0);
+      rd(s, 2, fa0, fb0); NNR_PIN(); mm(fa1, fb1);
+      rd(s, 3, fa1, fb1); NNR_PIN(); mm(fa0, fb0);
+      NNR_LGKM0();
+      wait_landed(S - 1 - (s + 1));
+      __builtin_amdgcn_s_barrier();
+      if (refill) {
+        if (gather) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the row indices fetched a stage ago
+        issue(s + NS - 1, refill == 2 && ktail && s + NS - 1 == S - 1);
+        if (gather && s + NS < S) fetch_idx(s + NS);
+      }
+      rd(s + 1, 0, fa0, fb0); NNR_PIN(); mm(fa1, fb1);
+      NNR_LGKM0();
+    };
+    int s = 0;
+    for (; s + NS < S; ++s) stage(s, 1);                    // refill = stage s + NS - 1 <= S - 2: never the tail
+    for (; s + 1 < S; ++s) stage(s, s + NS - 1 < S ? 2 : 0);
+    rd(S - 1, 1, fa1, fb1); NNR_PIN(); mm(fa0, fb0);
+    rd(S - 1, 2, fa0, fb0); NNR_PIN(); mm(fa1, fb1);
+    rd(S - 1, 3, fa1, fb1); NNR_PIN(); mm(fa0, fb0);
+    mm(fa1, fb1);
+  };
+  if (do_colsum) run(std::true_type{});
+  else run(std::false_type{});
+#undef NNR_LGKM0
+#undef NNR_PIN
+
+  if (do_colsum && r == 0) {
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int row = m0 + (w * TM + m) * 16 + kk * 4 + reg;
+        if (row < M) atomicAdd(&g.colsum_out[row], cs[m][reg]);
+      }
+  }
+  __syncthreads();
+  gemm_epilogue<TM, TN>(g, acc, lds, g.C, m0, n0, M, N, z);
+}
+
+template <int TM, int TN, int NS, int OCC>
+int launch_tn_pipe2(const nnr_gemm_args& g, hipStream_t s) {
+  constexpr int BM = 64 * TM, BN = 16 * TN;
+  const int nbm = (g.M + BM - 1) / BM, nbn = (g.N + BN - 1) / BN;
+  dim3 grid(nbm * nbn, 1, g.split_k > 1 ? g.split_k : 1), block(256);
+  hipLaunchKernelGGL((gemm_tn_pipe2_kernel<TM, TN, NS, OCC>), grid, block, 0, s, g);
+  NNR_CHECK_LAUNCH();
+  return NNR_OK;
+}
+
 static bool tn_pipe_ok(const nnr_gemm_args& g) {
   auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
   return g.trans_a && g.trans_b && !g.a_idx && !g.c_idx && g.k_chunk <= 0 && !g.rowdot_w && g.drop_target == 0 && g.batch <= 1 &&
@@ -1007,6 +1452,8 @@ extern "C" int nnr_gemm_f32(const nnr_gemm_args* a, hipStream_t stream) {
     static const bool use_pipe = [] { const char* e = getenv("NNR_GEMM_PIPE"); return !(e && atoi(e) == 0); }();   // A/B switch
     if (g.rowdot_w) tile = 3;
     else if (plain && wg64 <= 512 && g.K >= 64) tile = 7;   // small row-parallel launch: 16 x 80 tiles, K split over the 4 waves
+    else if (use_pipe && pipe_ok(g) && !g.a_idx && g.K >= 800 && wg64 > 512) tile = 9;   // long reductions (dX: K = 1664, SUE: K = 900): the
+                             // software-pipelined loop with the lean DMA issue, 2 workgroups / CU (130 vs 112 TF, 93 vs 79 TF)
     else if (use_pipe && pipe_ok(g) && (g.dyn_dev || wg128 >= 640)) tile = 15;   // GPU-filling NT: LDS-DMA staged 128 x 80, BK 16, 4 workgroups / CU
                              // (112 vs 98 TF on the 131 072-row CNE shapes, tools/gemm_pipe_bench.py)
     else if (use_pipe && pipe_ok(g) && wg64 > 512 && g.K >= 128) tile = 16;      // mid-size NT (SUE: 4 352 x 900 x 900): same tile, two 13 KB stages,
@@ -1027,12 +1474,12 @@ extern "C" int nnr_gemm_f32(const nnr_gemm_args* a, hipStream_t stream) {
     case 5: return launch_cfg<2, 5, 32>(g, stream);   // 128 x 80, BK = 32: half the barriers per FLOP, 3 workgroups per CU
     case 6: return launch_cfg<1, 5, 64>(g, stream);   //  64 x 80, BK = 64: latency-bound small launches (few stages, 74 KB LDS)
     case 8:  if (!pipe_ok(g)) return NNR_ERR_ARG; return launch_pipe<2, 5, 32, 3, 2>(g, stream);   // 128 x 80, 3 x 26 KB stages, 2 workgroups / CU
-    case 9:  if (!pipe_ok(g)) return NNR_ERR_ARG; return launch_pipe<2, 5, 32, 4, 1>(g, stream);   // 128 x 80, 4 stages, 1 workgroup / CU
-    case 10: if (!pipe_ok(g)) return NNR_ERR_ARG; return launch_pipe<2, 5, 16, 3, 4, 2>(g, stream);   // t15 + priority by blockIdx >> 5
-    case 11: if (!pipe_ok(g)) return NNR_ERR_ARG; return launch_pipe<2, 5, 16, 3, 4, 3>(g, stream);   // t15 + priority by blockIdx & 3
-    case 12: if (!pipe_ok(g)) return NNR_ERR_ARG; return launch_pipe<2, 5, 16, 4, 3, 1>(g, stream);   // t13 + priority by blockIdx >> 8
+    case 9:  if (!pipe_ok(g) || g.a_idx) return NNR_ERR_ARG; return launch_pipe2<2, 5, 3, 2>(g, stream);    // gen-2 loop, 128 x 80, 3 x 26 KB stages, 2 workgroups / CU
+    case 10: if (!pipe_ok(g) || g.a_idx) return NNR_ERR_ARG; return launch_pipe2<2, 5, 4, 1>(g, stream);   // gen-2 loop, 128 x 80, 4 stages, 1 workgroup / CU
+    case 11: if (!pipe_ok(g) || g.a_idx) return NNR_ERR_ARG; return launch_pipe2<2, 10, 3, 1>(g, stream);  // gen-2 loop, 128 x 160, 3 x 36 KB stages
+    case 12: if (!pipe_ok(g) || g.a_idx) return NNR_ERR_ARG; return launch_pipe2<4, 5, 3, 1>(g, stream);   // gen-2 loop, 256 x 80, 3 x 42 KB stages
     case 13: if (!pipe_ok(g)) return NNR_ERR_ARG; return launch_pipe<2, 5, 16, 4, 3>(g, stream);   // 128 x 80, BK 16, 4 x 13 KB stages, 3 workgroups / CU
-    case 14: if (!pipe_ok(g)) return NNR_ERR_ARG; return launch_pipe<2, 5, 32, 3, 2, 1>(g, stream);   // t8 + priority by blockIdx >> 8
+    case 14: if (!pipe_ok(g) || g.a_idx) return NNR_ERR_ARG; return launch_pipe2<2, 10, 4, 1>(g, stream);  // gen-2 loop, 128 x 160, 4 stages
     case 15: if (!pipe_ok(g)) return NNR_ERR_ARG; return launch_pipe<2, 5, 16, 3, 4>(g, stream);   // 128 x 80, BK 16, 3 x 13 KB stages, 4 workgroups / CU
     case 16: if (!pipe_ok(g)) return NNR_ERR_ARG; return launch_pipe<2, 5, 16, 2, 5>(g, stream);   // 128 x 80, BK 16, 2 stages, 5-6 workgroups / CU
     case 17: if (!pipe_ok(g)) return NNR_ERR_ARG; return launch_pipe<1, 5, 16, 4, 4>(g, stream);   //  64 x 80, BK 16, 4 x 9 KB stages
@@ -1044,6 +1491,10 @@ extern "C" int nnr_gemm_f32(const nnr_gemm_args* a, hipStream_t stream) {
     case 23: if (!tn_pipe_ok(g)) return NNR_ERR_ARG; return launch_tn_pipe<4, 5, 3, 2>(g, stream);   // TN 256 x 80, 3 x 24 KB stages
     case 24: if (!tn_pipe_ok(g)) return NNR_ERR_ARG; return launch_tn_pipe<2, 13, 3, 2>(g, stream);  // TN 128 x 208, 3 x 24 KB stages
     case 25: if (!tn_pipe_ok(g)) return NNR_ERR_ARG; return launch_tn_pipe<2, 8, 3, 2>(g, stream);   // TN 128 x 128
+    case 26: if (!tn_pipe_ok(g) || g.b_idx) return NNR_ERR_ARG; return launch_tn_pipe2<2, 5, 3, 3>(g, stream);    // gen-2 TN 128 x 80 (no gather)
+    case 27: if (!tn_pipe_ok(g)) return NNR_ERR_ARG; return launch_tn_pipe2<2, 13, 3, 2>(g, stream);              // gen-2 TN 128 x 208
+    case 28: if (!tn_pipe_ok(g) || g.b_idx) return NNR_ERR_ARG; return launch_tn_pipe2<2, 5, 4, 2>(g, stream);    // gen-2 TN 128 x 80, 4 stages
+    case 29: if (!tn_pipe_ok(g) || g.b_idx) return NNR_ERR_ARG; return launch_tn_pipe2<4, 5, 3, 2>(g, stream);    // gen-2 TN 256 x 80
     case 7:
       if (g.trans_a || g.a_idx || g.b_idx || g.c_idx || g.dyn_dev || g.split_k > 1 || g.k_chunk > 0 || g.rowdot_w || g.colsum_out || g.atomic ||
           (g.drop_target != 0 && g.drop_target != 3)) return NNR_ERR_ARG;

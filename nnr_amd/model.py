@@ -108,6 +108,8 @@ class Model(nn.Module):
                 user_history_category_indices, news_category, news_subCategory, news_title_text, news_title_mask, news_title_entity,
                 news_content_text, news_content_mask, news_content_entity):
         user_embedding = None
+        if self.training and torch.is_grad_enabled() and news_title_text.is_cuda:
+            ops.wt_prefetch(news_title_text.device)      # W^T copies the backward pass will want, off the critical chain
         if hasattr(self.news_encoder, 'forward_pair'):
             # same arithmetic as the two encoder calls of model.py:123-125, issued in lock-step so that launch-latency-bound
             # stages (the Bi-LSTM recurrences) of the candidate call and of the history call share one launch

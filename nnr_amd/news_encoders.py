@@ -27,6 +27,7 @@ from . import ops
 from .layers import Attention, ScaledDotProduct_CandidateAttention, MultiHeadAttention, Conv1D, LSTMParams, grad_of, PARAM_EPOCH
 
 _SITE = dict(title=1, content=2, cat=3, sub=4)
+_POST_SERIAL = os.environ.get('NNR_POST_SERIAL', '0') == '1'
 
 
 class NewsEncoder(nn.Module):
@@ -114,7 +115,7 @@ def _side_stream(dev):
     """One extra HIP stream per device for the small (candidate) encoder call."""
     key = (dev.type, dev.index)
     if key not in _SIDE:
-        _SIDE[key] = ops.new_stream(dev)
+        _SIDE[key] = ops.new_stream(dev, critical=True)
     return _SIDE[key]
 
 
@@ -130,7 +131,7 @@ def _two_chains(dev, enable, title_fn, content_fn):
     main = torch.cuda.current_stream(dev)
     key = (dev.type, dev.index, 2)
     if key not in _SIDE:
-        _SIDE[key] = ops.new_stream(dev)
+        _SIDE[key] = ops.new_stream(dev, critical=True)
     s2 = _SIDE[key]
     s2.wait_stream(main)
     with torch.cuda.stream(s2):
@@ -412,7 +413,11 @@ def _cne_bwd_post(mod, sv, st, leaf=None):
         ops.gemm(dg, w.w_ihp_t, grad_of(emb), M=cap, N=E, K=2 * NP, lda=2 * NP, ldb=2 * NP, ldc=E, c_idx=plan.tok, atomic=True,
                  drop=(4, p, st['seed'], E), dyn=plan.total, dyn_dim=1)
 
-    if leaf is None:
+    if leaf is None or _POST_SERIAL:
+        # one stream: every launch here fills the chip on its own (LDS-DMA staged tiles at 1-3 workgroups per CU); side by side
+        # they fight for LDS and CU slots instead of filling each other's gaps
+        if leaf is not None:
+            dx_scatter()
         dw_ih(); dw_hh(0); dw_hh(1)
     else:
         # two balanced halves: leaf stream dW_ih + dW_hh(reverse), this stream the scatter GEMM + dW_hh(forward)

@@ -84,6 +84,7 @@ def test_gemm_skinny_tile_all_epilogues(M, N, K):
 
 
 PIPE_TILES = [8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19]
+PIPE2_TILES = [9, 10, 11, 12, 14]
 
 
 @pytest.mark.parametrize('tile', PIPE_TILES)
@@ -119,9 +120,13 @@ def test_gemm_pipelined_nt_tiles(tile, M, N, K):
     idx[min(5, used - 1)] = -1
     out = torch.full((M, N), 7.0, device=d)
     dyn = torch.tensor([used], dtype=torch.int32, device=d)
-    ops.gemm(tab.to(d), b.to(d), out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, a_idx=idx.to(d), dyn=dyn, dyn_dim=1, bias=bias.to(d), tile=tile)
-    g = tab.double()[idx.long().clamp_min(0)] * (idx >= 0).double()[:, None]
-    exp = g @ b.double().t() + bias.double()
+    if tile in PIPE2_TILES:                                 # the gen-2 loop takes no row gather: dynamic M only
+        ops.gemm(a.to(d), b.to(d), out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, dyn=dyn, dyn_dim=1, bias=bias.to(d), tile=tile)
+        exp = a.double() @ b.double().t() + bias.double()
+    else:
+        ops.gemm(tab.to(d), b.to(d), out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, a_idx=idx.to(d), dyn=dyn, dyn_dim=1, bias=bias.to(d), tile=tile)
+        g = tab.double()[idx.long().clamp_min(0)] * (idx >= 0).double()[:, None]
+        exp = g @ b.double().t() + bias.double()
     close(out[:used], exp[:used], what='pipe gather dyn')
     assert bool((out[used:] == 7.0).all())
     # atomic row scatter (embedding-gradient shape): C[c_idx[m]] += row m
@@ -706,7 +711,8 @@ def test_gemm_fused_bias_gradient():
     close(db, 0.25 + dy[:used].double().sum(0), tol=5e-5, what='fused db')
 
 
-TN_PIPE_TILES = [20, 21, 22, 23, 24, 25]
+TN_PIPE_TILES = [20, 21, 22, 23, 24, 25, 26, 27, 28, 29]
+TN_NO_GATHER = [26, 28, 29]          # gen-2 loop: gathered B rows only with the 256-float pitch (tile 27)
 
 
 @pytest.mark.parametrize('tile', TN_PIPE_TILES)
@@ -733,8 +739,10 @@ def test_gemm_pipelined_tn_tiles(tile, M, N, K, split):
     o = torch.zeros(M, N, device=d)
     cs = torch.zeros(M, device=d)
     A2d, B2d = A2.to(d), B2.to(d)
+    if tile in TN_NO_GATHER:
+        bidx = torch.arange(K).int()
     ops.gemm(A2d[:, 64:], B2d[:, 8:], o, M=M, N=N, K=K, lda=lda, ldb=ldb, ldc=N, trans_a=True, trans_b=True, split_k=split, atomic=True,
-             b_idx=bidx.to(d), dyn=dyn, dyn_dim=2, colsum_out=cs, tile=tile)
+             b_idx=None if tile in TN_NO_GATHER else bidx.to(d), dyn=dyn, dyn_dim=2, colsum_out=cs, tile=tile)
     a_ = A2[:used, 64:].double()
     b_ = B2[:, 8:].double()[bidx[:used].long().clamp_min(0)] * (bidx[:used] >= 0).double()[:, None]
     close(o, a_.t() @ b_, tol=5e-5, what='TN pipe gather dyn')

@@ -42,8 +42,10 @@ def tn_main():
             pass
         fns = {}
         for t in tiles:
-            bm = {2: 64, 4: 128, 20: 128, 21: 128, 22: 64, 23: 256, 24: 128, 25: 128}[t]
-            bn = {24: 208, 25: 128}.get(t, 80)
+            bm = {2: 64, 4: 128, 20: 128, 21: 128, 22: 64, 23: 256, 24: 128, 25: 128, 26: 128, 27: 128, 28: 128, 29: 256}[t]
+            bn = {24: 208, 25: 128, 27: 208}.get(t, 80)
+            if gather and t in (26, 28, 29):
+                continue
             for target in (512, 1024, 2048):
                 sk = ops.split_for(M, N, K, tile_m=bm, tile_n=bn, target_blocks=target)
                 fns['t%d/%d' % (t, target)] = (lambda t=t, sk=sk: ops.gemm(a, b, c, M=M, N=N, K=K, lda=M, ldb=N, ldc=N, trans_a=True, trans_b=True, split_k=sk, atomic=True, tile=t, b_idx=bidx, dyn=dyn, dyn_dim=2))
