@@ -254,6 +254,14 @@ int nnr_logits_fwd(const float* user, const float* cand, int B, int N, int D, fl
 int nnr_nls_loss(const float* logits, int B, int N, float* loss, float* dlogits, hipStream_t stream);               /* trainer.py:64-66 */
 int nnr_logits_bwd(const float* dlogits, const float* user, const float* cand, int B, int N, int D, float* duser, float* dcand,
                    int dcand_accumulate, hipStream_t stream);
+/* --gcn_layer_norm (config.py:61; layers.py:273-274,287-288): nn.LayerNorm([D]) between the graph convolution and the ReLU,
+ * fused with the rest of GCNLayer.forward / GCN.forward:  y = dropout(relu(LN(u) * gamma + beta) + resid)  (resid may be NULL,
+ * p may be 0).  xhat [rows, D], rstd [rows] and r_out = relu(.) [rows, D] are saved for the backward pass; D <= 1024.
+ * Backward: du = d(LN input) from dv = d(LN output); dgamma / dbeta are ACCUMULATED (f32 atomics). */
+int nnr_layernorm_fwd(const float* u, const float* gamma, const float* beta, float eps, long rows, int D, float* xhat, float* rstd,
+                      float* r_out, const float* resid, float* y, float p, uint32_t seed, hipStream_t stream);
+int nnr_layernorm_bwd(const float* dv, const float* xhat, const float* rstd, const float* gamma, long rows, int D, float* du,
+                      float* dgamma, float* dbeta, hipStream_t stream);
 int nnr_sumsq(const float* g, long n, float* out_zeroed, hipStream_t stream);
 /* clip_grad_norm_(max_norm = clip) + torch.optim.Adam step on one flat buffer (trainer.py:118-120); grads are scaled by
  * grad_scale first (1/world_size after the RCCL sum all-reduce).  A step whose squared gradient norm is not finite is

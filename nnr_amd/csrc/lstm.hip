@@ -896,7 +896,7 @@ extern "C" int nnr_lstm_dims(int H, int* UB, int* HP, int* NP) {
   if (UB) *UB = ub;
   if (HP) *HP = ub * 16;
   if (NP) *NP = ub * 64;
-  return (ub == 1 || ub == 2 || ub == 13) ? NNR_OK : NNR_ERR_UNSUPPORTED;
+  return (ub >= 1 && ub <= 16) ? NNR_OK : NNR_ERR_UNSUPPORTED;      // any hidden size up to 256 (padded to a multiple of 16)
 }
 
 static unsigned* g_tmo_total = nullptr;     // caller-owned persistent time-out counter (device memory), see nnr_lstm_set_timeout_counter
@@ -973,9 +973,23 @@ static int lstm_run(const nnr_lstm_problem* probs, int nprob, int H, bool backwa
     return launch_pair<13>(a, backward, max_tiles, stream);
   }
   switch (UB) {
+    // one-CU kernel for every unit-block count (hidden_dim <= 256, config.py:62); H = 200 normally takes the CU-pair kernel above
     case 1: return launch_rec<1>(a, backward, max_tiles, stream);
     case 2: return launch_rec<2>(a, backward, max_tiles, stream);
+    case 3: return launch_rec<3>(a, backward, max_tiles, stream);
+    case 4: return launch_rec<4>(a, backward, max_tiles, stream);
+    case 5: return launch_rec<5>(a, backward, max_tiles, stream);
+    case 6: return launch_rec<6>(a, backward, max_tiles, stream);
+    case 7: return launch_rec<7>(a, backward, max_tiles, stream);
+    case 8: return launch_rec<8>(a, backward, max_tiles, stream);
+    case 9: return launch_rec<9>(a, backward, max_tiles, stream);
+    case 10: return launch_rec<10>(a, backward, max_tiles, stream);
+    case 11: return launch_rec<11>(a, backward, max_tiles, stream);
+    case 12: return launch_rec<12>(a, backward, max_tiles, stream);
     case 13: return launch_rec<13>(a, backward, max_tiles, stream);
+    case 14: return launch_rec<14>(a, backward, max_tiles, stream);
+    case 15: return launch_rec<15>(a, backward, max_tiles, stream);
+    case 16: return launch_rec<16>(a, backward, max_tiles, stream);
   }
   return NNR_ERR_UNSUPPORTED;
 }

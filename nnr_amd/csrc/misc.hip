@@ -615,6 +615,102 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   }
 }
 
+
+// ---- LayerNorm over the last dimension for --gcn_layer_norm (layers.py:273-274,287-288: nn.LayerNorm([out_dim]) between the
+// graph convolution and the ReLU), fused with what follows it in GCNLayer.forward / GCN.forward:
+//   y = dropout(relu(LN(u) * gamma + beta) + resid).   One wave per row (D <= 1024), the row lives in registers; biased variance,
+//   1 / sqrt(var + eps) exactly as ATen.  Saved for backward: xhat = (u - mean) * rstd, rstd, and r = relu(.) (as the GEMM
+//   epilogue of the LayerNorm-free path saves it).
+constexpr int LN_MAXPL = 16;      // elements per lane
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ u, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float eps, long rows, int D, float* __restrict__ xhat, float* __restrict__ rstd_out,
+                                                     float* __restrict__ r_out, const float* __restrict__ resid, float* __restrict__ y,
+                                                     uint32_t seed, uint32_t thr, float scale) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* x = u + row * D;
+  float v[LN_MAXPL];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXPL; ++i) {
+    const int c = lane + 64 * i;
+    v[i] = c < D ? x[c] : 0.f;
+    s += v[i];
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXPL; ++i) {
+    const int c = lane + 64 * i;
+    const float d = c < D ? v[i] - mean : 0.f;
+    q += d * d;
+  }
+  const float rstd = 1.f / sqrtf(wave_sum(q) / (float)D + eps);
+  if (lane == 0) rstd_out[row] = rstd;
+#pragma unroll
+  for (int i = 0; i < LN_MAXPL; ++i) {
+    const int c = lane + 64 * i;
+    if (c < D) {
+      const float xh = (v[i] - mean) * rstd;
+      const float r = fmaxf(xh * gamma[c] + beta[c], 0.f);
+      xhat[row * D + c] = xh;
+      r_out[row * D + c] = r;
+      float o = r + (resid ? resid[row * D + c] : 0.f);
+      if (thr) o = nnr_keep(seed, (uint64_t)(row * D + c), thr) ? o * scale : 0.f;
+      y[row * D + c] = o;
+    }
+  }
+}
+
+// du = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dv * gamma;   dgamma += sum_rows dv * xhat;  dbeta += sum_rows dv
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dv, const float* __restrict__ xhat, const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma, long rows, int D, float* __restrict__ du,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ float red[2][LN_MAXPL * 64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 2 * LN_MAXPL * 64; i += 256) (&red[0][0])[i] = 0.f;
+  __syncthreads();
+  float ag[LN_MAXPL], ab[LN_MAXPL];
+#pragma unroll
+  for (int i = 0; i < LN_MAXPL; ++i) ag[i] = ab[i] = 0.f;
+  for (int k = 0; k < 4; ++k) {                        // 16 rows per workgroup: 4 per wave
+    const long row = (long)blockIdx.x * 16 + w * 4 + k;
+    if (row >= rows) break;
+    float g[LN_MAXPL], xh[LN_MAXPL];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXPL; ++i) {
+      const int c = lane + 64 * i;
+      const float d = c < D ? dv[row * D + c] : 0.f;
+      xh[i] = c < D ? xhat[row * D + c] : 0.f;
+      g[i] = c < D ? d * gamma[c] : 0.f;
+      s1 += g[i];
+      s2 += g[i] * xh[i];
+      ag[i] += d * xh[i];
+      ab[i] += d;
+    }
+    s1 = wave_sum(s1) / (float)D;
+    s2 = wave_sum(s2) / (float)D;
+    const float rs = rstd[row];
+#pragma unroll
+    for (int i = 0; i < LN_MAXPL; ++i) {
+      const int c = lane + 64 * i;
+      if (c < D) du[row * D + c] = rs * (g[i] - s1 - xh[i] * s2);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < LN_MAXPL; ++i) {
+    atomicAdd(&red[0][lane + 64 * i], ag[i]);
+    atomicAdd(&red[1][lane + 64 * i], ab[i]);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += 256) {
+    atomicAdd(&dgamma[c], red[0][c]);
+    atomicAdd(&dbeta[c], red[1][c]);
+  }
+}
+
 }  // namespace
 
 #define EW_LAUNCH(kern, n, ...)                                                             \
@@ -756,6 +852,23 @@ extern "C" int nnr_relu_drop_bwd(const float* dy, const float* r, float* ds, flo
 extern "C" int nnr_dropout(const float* x, float* y, long n, float p, uint32_t seed, hipStream_t stream) {
   const float sc = p > 0.f ? 1.f / (1.f - p) : 1.f;
   EW_LAUNCH(dropout_kernel, n, x, y, n, seed, nnr_drop_thresh(p), sc);
+}
+
+extern "C" int nnr_layernorm_fwd(const float* u, const float* gamma, const float* beta, float eps, long rows, int D, float* xhat, float* rstd,
+                                 float* r_out, const float* resid, float* y, float p, uint32_t seed, hipStream_t stream) {
+  if (D > LN_MAXPL * 64 || rows <= 0) return D > LN_MAXPL * 64 ? NNR_ERR_UNSUPPORTED : NNR_OK;
+  const float sc = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, u, gamma, beta, eps, rows, D, xhat, rstd, r_out, resid, y,
+                     seed, nnr_drop_thresh(p), sc);
+  NNR_CHECK_LAUNCH();
+  return NNR_OK;
+}
+extern "C" int nnr_layernorm_bwd(const float* dv, const float* xhat, const float* rstd, const float* gamma, long rows, int D, float* du,
+                                 float* dgamma, float* dbeta, hipStream_t stream) {
+  if (D > LN_MAXPL * 64 || rows <= 0) return D > LN_MAXPL * 64 ? NNR_ERR_UNSUPPORTED : NNR_OK;
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, stream, dv, xhat, rstd, gamma, rows, D, du, dgamma, dbeta);
+  NNR_CHECK_LAUNCH();
+  return NNR_OK;
 }
 extern "C" int nnr_relu_bwd(const float* dy, const float* y, float* dx, long n, hipStream_t stream) {
   EW_LAUNCH(relu_bwd_kernel, n, dy, y, dx, n);

@@ -125,6 +125,46 @@ class ScaledDotProduct_CandidateAttention(nn.Module):
         nn.init.xavier_uniform_(self.Q.weight)
         nn.init.zeros_(self.Q.bias)
 
+    def forward(self, feature, query, mask=None):
+        """layers.py:196-203 on its own: feature [n, L, F], query [n, Qd], mask [n, L] -> [n, F].  GEMV form: the score of
+        position t is <feature_t, K^T (Q query + b)> / sqrt(A), so K is never applied to the L x F features."""
+        return _CandidateAttentionFn.apply(feature, query, self, mask)
+
+
+class _CandidateAttentionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feature, query, mod, mask):
+        n, Lx, F = feature.shape
+        A = mod.K.weight.shape[0]
+        x = feature.contiguous().view(n * Lx, F)
+        q = query.contiguous()
+        f32 = dict(device=x.device, dtype=torch.float32)
+        qv = ops.linear_fwd(q, mod.Q.weight, mod.Q.bias)                                       # [n, A]
+        v = torch.empty((n, F), **f32)
+        ops.gemm(qv, mod.K.weight, v, M=n, N=F, K=A, lda=A, ldb=F, ldc=F, trans_b=True)         # K^T (Q q + b)
+        alpha = torch.empty(n * Lx, **f32)
+        out = torch.empty((n, F), **f32)
+        ops.pool_fwd(x=x, ldx=F, D=F, n=n, Lx=Lx, mask=mask, v=v, ldv=F, scale=1.0 / math.sqrt(A), alpha=alpha, out=out, ldo=F)
+        ctx.mod, ctx.mask, ctx.saved = mod, mask, (x, q, qv, v, alpha, n, Lx, F, A)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        mod = ctx.mod
+        x, q, qv, v, alpha, n, Lx, F, A = ctx.saved
+        f32 = dict(device=x.device, dtype=torch.float32)
+        dx = torch.empty((n * Lx, F), **f32)
+        dv = torch.empty((n, F), **f32)
+        ops.pool_bwd(x=x, ldx=F, D=F, n=n, Lx=Lx, mask=ctx.mask, v=v, ldv=F, scale=1.0 / math.sqrt(A), alpha=alpha, dout=dout.contiguous(),
+                     lddo=F, dx=dx, lddx=F, dv=dv, lddv=F)
+        dqv = torch.empty((n, A), **f32)
+        ops.gemm(dv, mod.K.weight, dqv, M=n, N=A, K=F, lda=F, ldb=F, ldc=A)                     # dqv = dv . K^T
+        ops.linear_bwd_weight(qv, dv, grad_of(mod.K.weight))                                    # dK[A, F] += qv^T dv
+        ops.linear_bwd_weight(dqv, q, grad_of(mod.Q.weight))
+        ops.bias_grad(dqv, grad_of(mod.Q.bias))
+        dq = ops.linear_bwd_data(dqv, mod.Q.weight)
+        return dx.view(n, Lx, F), dq, None, None
+
 
 class MultiHeadAttention(nn.Module):
     """layers.py:102-148 (parameter holder + forward over the MFMA attention kernel, see news_encoders.MHSA)."""
@@ -171,12 +211,13 @@ class GCNLayer(nn.Module):
 
     def __init__(self, in_dim, out_dim, residual=False, layer_norm=False):
         super().__init__()
-        if layer_norm:
-            raise NotImplementedError('--gcn_layer_norm is off on the BASELINE configs; not implemented on the HIP path')
         if residual and in_dim != out_dim:
             raise Exception('To facilitate residual connection, in_dim must equal to out_dim')
         self.residual = residual
+        self.layer_norm = layer_norm
         self.W = nn.Linear(in_dim, out_dim, bias=True)
+        if self.layer_norm:
+            self.layer_normalization = nn.LayerNorm(normalized_shape=[out_dim])       # layers.py:273-274
 
     def initialize(self):
         nn.init.xavier_uniform_(self.W.weight, gain=nn.init.calculate_gain('relu'))
@@ -197,3 +238,8 @@ class GCN(nn.Module):
     def initialize(self):
         for gcn_layer in self.gcn_layers:
             gcn_layer.initialize()
+
+    def forward(self, feature, graph):
+        """layers.py:318-323 on its own (the SUE pipeline drives the same kernels directly): feature [B, G, D], graph [B, G, G]."""
+        from .user_encoders import _GCNFunction
+        return _GCNFunction.apply(feature, self, graph)

@@ -582,6 +582,19 @@ def dropout(x, p, seed, out=None):
     return out
 
 
+def layernorm_fwd(u, gamma, beta, eps, xhat, rstd, r_out, resid, y, p, seed):
+    """y = dropout(relu(LayerNorm(u) * gamma + beta) + resid) over the last dimension of a contiguous [rows, D] u."""
+    rows, D = u.numel() // u.shape[-1], u.shape[-1]
+    L.check(L.lib().nnr_layernorm_fwd(_p(u), _p(gamma), _p(beta), C.c_float(eps), C.c_long(rows), D, _p(xhat), _p(rstd), _p(r_out), _p(resid),
+                                      _p(y), C.c_float(p), C.c_uint32(seed & 0xFFFFFFFF), _s()), 'nnr_layernorm_fwd')
+
+
+def layernorm_bwd(dv, xhat, rstd, gamma, du, dgamma, dbeta):
+    rows, D = dv.numel() // dv.shape[-1], dv.shape[-1]
+    L.check(L.lib().nnr_layernorm_bwd(_p(dv), _p(xhat), _p(rstd), _p(gamma), C.c_long(rows), D, _p(du), _p(dgamma), _p(dbeta), _s()),
+            'nnr_layernorm_bwd')
+
+
 def relu_bwd(dy, y, dx=None):
     if dx is None:
         dx = torch.empty_like(dy)

@@ -54,6 +54,88 @@ class _SUEFunction(torch.autograd.Function):
         return dhist, dcand, None, None, None, None
 
 
+def gcn_forward(gcn, x0, graph, seed0, training):
+    """GCN.forward (layers.py:318-323) over GCNLayer.forward (:285-292):  X <- dropout(relu(LN?((A X) W^T + b)) + X).  The dense
+    product runs first (X W^T on all B*G rows), then the per-user G x G aggregate as a batched GEMM whose epilogue applies bias /
+    relu / residual / dropout -- or, with --gcn_layer_norm, only the bias, followed by the fused LayerNorm kernel."""
+    B, G, D = x0.shape
+    f32 = dict(device=x0.device, dtype=torch.float32)
+    Lg = gcn.num_layers
+    xs, rs, lns = [x0], [], []
+    x = x0
+    for l, layer in enumerate(gcn.gcn_layers):
+        z = ops.linear_fwd(x.view(B * G, D), layer.W.weight)                       # X W^T  (bias goes after the aggregate)
+        y = torch.empty((B, G, D), **f32)
+        r = torch.empty((B, G, D), **f32)
+        pl = (gcn.dropout_rate if training else 0.0) if l + 1 < Lg else 0.0
+        if getattr(layer, 'layer_norm', False):
+            u = torch.empty((B, G, D), **f32)
+            ops.gemm(graph, z, u, M=G, N=D, K=G, lda=G, ldb=D, ldc=D, trans_b=True, bias=layer.W.bias, batch=B, strideA=G * G, strideB=G * D,
+                     strideC=G * D, tile=2)
+            xhat = torch.empty((B, G, D), **f32)
+            rstd = torch.empty(B * G, **f32)
+            ln = layer.layer_normalization
+            ops.layernorm_fwd(u, ln.weight, ln.bias, ln.eps, xhat, rstd, r, x if gcn.residual else None, y, pl, seed0 + l)
+            lns.append((xhat, rstd))
+        else:
+            ops.gemm(graph, z, y, M=G, N=D, K=G, lda=G, ldb=D, ldc=D, trans_b=True, bias=layer.W.bias, act=ops.ACT_RELU, aux_out=r,
+                     ldaux=D, resid=x if gcn.residual else None, ldres=D, drop=(3, pl, seed0 + l, D), batch=B, strideA=G * G,
+                     strideB=G * D, strideC=G * D, stride_aux=G * D, stride_res=G * D, tile=2)
+            lns.append(None)
+        xs.append(y)
+        rs.append(r)
+        x = y
+    return x, dict(xs=xs, rs=rs, lns=lns, seed0=seed0, training=training)
+
+
+def gcn_backward(gcn, gsv, dy, graph, leaf):
+    """Gradient of gcn_forward wrt its input; parameter gradients are accumulated (the weight-gradient GEMMs through `leaf`)."""
+    B, G, D = dy.shape
+    f32 = dict(device=dy.device, dtype=torch.float32)
+    Lg = gcn.num_layers
+    for l in range(Lg - 1, -1, -1):
+        layer = gcn.gcn_layers[l]
+        pl = (gcn.dropout_rate if gsv['training'] else 0.0) if l + 1 < Lg else 0.0
+        dS = torch.empty((B, G, D), **f32)
+        dx = torch.empty((B, G, D), **f32)
+        ops.relu_drop_bwd(dy, gsv['rs'][l], dS, dx, pl, gsv['seed0'] + l)        # dx = masked dy (residual branch)
+        if not gcn.residual:
+            dx.zero_()
+        if gsv['lns'][l] is not None:                                              # through the LayerNorm: dS := d(A z + b)
+            xhat, rstd = gsv['lns'][l]
+            ln = layer.layer_normalization
+            du = torch.empty((B, G, D), **f32)
+            ops.layernorm_bwd(dS, xhat, rstd, ln.weight, du, grad_of(ln.weight), grad_of(ln.bias))
+            dS = du
+        dz = torch.empty((B, G, D), **f32)                                   # dZ_b = A_b^T dS_b
+        ops.gemm(graph, dS, dz, M=G, N=D, K=G, lda=G, ldb=D, ldc=D, trans_a=True, trans_b=True, batch=B, strideA=G * G, strideB=G * D,
+                 strideC=G * D, tile=2)
+        ops.linear_bwd_data(dz.view(B * G, D), layer.W.weight, out=dx.view(B * G, D), accumulate=True)
+        leaf(lambda dS=dS, dz=dz, l=l, layer=layer: (ops.bias_grad(dS.view(B * G, D), grad_of(layer.W.bias)),
+                                                     ops.linear_bwd_weight(dz.view(B * G, D), gsv['xs'][l].view(B * G, D), grad_of(layer.W.weight))), dS, dz)
+        dy = dx
+    return dy
+
+
+class _GCNFunction(torch.autograd.Function):
+    """GCN.forward as a standalone layer (layers.GCN.forward)."""
+
+    @staticmethod
+    def forward(ctx, feature, gcn, graph):
+        seed = (getattr(gcn, '_calls', 0) * 7919 + 101) & 0x7FFFFFFF
+        gcn.__dict__['_calls'] = getattr(gcn, '_calls', 0) + 1
+        out, gsv = gcn_forward(gcn, feature.contiguous(), graph.contiguous(), seed, gcn.training)
+        ctx.gcn, ctx.gsv, ctx.graph = gcn, gsv, graph.contiguous()
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        with ops.leaf_scope(dy.device, enable=False) as leaf:
+            dx = gcn_backward(ctx.gcn, ctx.gsv, dy.contiguous(), ctx.graph, leaf)
+        ctx.gsv = None
+        return dx, None, None
+
+
 def sue_forward(mod, hist, cand, graph, cmask, cidx):
     B, Hn, D = hist.shape
     N = cand.shape[1]
@@ -68,21 +150,8 @@ def sue_forward(mod, hist, cand, graph, cmask, cidx):
     x0 = torch.empty((B, G, D), **f32)
     ops.sue_x0_fwd(hist, mod.proxy_node_embedding, x0, B, Hn, Kc, D, p, seed + 1)
     # ---- GCN
-    Lg = mod.gcn.num_layers
-    xs, rs = [x0], []
-    x = x0
-    for l, layer in enumerate(mod.gcn.gcn_layers):
-        z = ops.linear_fwd(x.view(B * G, D), layer.W.weight)                       # X W^T  (bias goes after the aggregate)
-        y = torch.empty((B, G, D), **f32)
-        r = torch.empty((B, G, D), **f32)
-        pl = (mod.gcn.dropout_rate if mod.training else 0.0) if l + 1 < Lg else 0.0
-        ops.gemm(graph, z, y, M=G, N=D, K=G, lda=G, ldb=D, ldc=D, trans_b=True, bias=layer.W.bias, act=ops.ACT_RELU, aux_out=r,
-                 ldaux=D, resid=x if mod.gcn.residual else None, ldres=D, drop=(3, pl, seed + 10 + l, D), batch=B, strideA=G * G,
-                 strideB=G * D, strideC=G * D, stride_aux=G * D, stride_res=G * D, tile=2)
-        xs.append(y)
-        rs.append(r)
-        x = y
-    sv['xs'], sv['rs'] = xs, rs
+    x, gsv = gcn_forward(mod.gcn, x0, graph, seed + 10, mod.training)
+    sv['gcn'] = gsv
     gfeat = torch.empty((B, Hn, D), **f32)
     ops.sue_slice_fwd(x, x0, gfeat, B, Hn, G, D)
     # ---- intra-cluster attention
@@ -157,24 +226,7 @@ def _sue_backward_body(mod, sv, dout, leaf, B, Hn, D, N, Kc, G, Cn, A, p, seed, 
     # ---- GCN (+ outer residual)
     dpad = torch.empty((B, G, D), **f32)
     ops.sue_slice_bwd(dg, dpad, B, Hn, G, D)
-    Lg = mod.gcn.num_layers
-    dy = dpad
-    graph = sv['graph']
-    for l in range(Lg - 1, -1, -1):
-        layer = mod.gcn.gcn_layers[l]
-        pl = (mod.gcn.dropout_rate if mod.training else 0.0) if l + 1 < Lg else 0.0
-        dS = torch.empty((B, G, D), **f32)
-        dx = torch.empty((B, G, D), **f32)
-        ops.relu_drop_bwd(dy, sv['rs'][l], dS, dx, pl, seed + 10 + l)        # dx = masked dy (residual branch)
-        if not mod.gcn.residual:
-            dx.zero_()
-        dz = torch.empty((B, G, D), **f32)                                   # dZ_b = A_b^T dS_b
-        ops.gemm(graph, dS, dz, M=G, N=D, K=G, lda=G, ldb=D, ldc=D, trans_a=True, trans_b=True, batch=B, strideA=G * G, strideB=G * D,
-                 strideC=G * D, tile=2)
-        ops.linear_bwd_data(dz.view(B * G, D), layer.W.weight, out=dx.view(B * G, D), accumulate=True)
-        leaf(lambda dS=dS, dz=dz, l=l, layer=layer: (ops.bias_grad(dS.view(B * G, D), grad_of(layer.W.bias)),
-                                                     ops.linear_bwd_weight(dz.view(B * G, D), sv['xs'][l].view(B * G, D), grad_of(layer.W.weight))), dS, dz)
-        dy = dx
+    dy = gcn_backward(mod.gcn, sv['gcn'], dpad, sv['graph'], leaf)
     ops.add_(dy, dpad)                                                       # gcn(X0) + X0
     dhist = torch.empty((B, Hn, D), **f32)
     ops.sue_x0_bwd(dy, dhist, grad_of(mod.proxy_node_embedding), B, Hn, Kc, D, p, seed + 1)

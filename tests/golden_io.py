@@ -11,7 +11,9 @@ from nnr_amd.synth import BATCH_FIELDS
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 ALL_CASES = ['tiny_CNE_SUE', 'tiny_CNE_SUE_scaled', 'tiny_MHSA_MHSA', 'tiny_CNN_ATT',
              'tiny_CNE_SUE_stable', 'full_CNE_SUE_g1p0', 'full_CNE_SUE_g1p6', 'full_CNE_SUE_g1p0_stable',
-             'full_MHSA_MHSA_g1p0', 'full_CNN_ATT_g1p0']
+             'full_MHSA_MHSA_g1p0', 'full_CNN_ATT_g1p0',
+             # round 2 (tools/make_goldens.py extra): --gcn_layer_norm, with / without residual; hidden_dim 48 and 112
+             'tiny_CNE_SUE_ln_stable', 'tiny_CNE_SUE_ln_nores_stable', 'tiny_CNE_SUE_h48_stable', 'tiny_CNE_SUE_h112_stable']
 
 
 def _parse(v):

@@ -38,7 +38,9 @@ def check_params_after_adam(case, model, steps, tight=5e-5):
     for k, p in model.named_parameters():
         e, a = case.expect_param(steps, k, p)
         g = np.abs(case.expect('grad/' + k)).reshape(e.shape)
-        resolved = g > 0.05 * max(float(g.max()), 1e-30)
+        # resolved = well above the tensor's own scale AND above the fp32 noise floor of the whole backward pass (a tensor whose
+        # largest gradient is 1e-6 of the total norm is noise everywhere: Adam's g / (|g| + eps) turns that noise into +-lr)
+        resolved = (g > 0.05 * max(float(g.max()), 1e-30)) & (g > 1e-4 * float(case.expect('grad_total_norm')))
         d = np.abs(a - e)
         assert d[resolved].max(initial=0.0) <= tight, k
         assert d.max(initial=0.0) <= steps * lr * 1.01 + tight, k

@@ -160,7 +160,27 @@ def full_spec(cfg, seed):
     return SynthSpec(vocabulary_size=cfg.vocabulary_size, news_pool=300, seed=seed)
 
 
+def extra_cases():
+    """Cases added after round 1 (run with `python tools/make_goldens.py extra`; main() still rewrites the round-1 fixtures
+    bit for bit): --gcn_layer_norm (layers.py:273-274,287-288) with and without the GCN residual (one Adam step: with LayerNorm and
+    lr 1e-2 the fp32 noise of step 1 is amplified past any useful tolerance by step 3), and hidden sizes that are
+    other multiples of 16 than the default 200's 13 unit blocks (config.py:62)."""
+    with stable_sort_patch():
+        cfg = tiny_cfg('CNE', 'SUE', gcn_layer_norm=True)
+        run_case('tiny_CNE_SUE_ln_stable', cfg, tiny_spec(cfg, 3), batch_size=4, seed=23, mode='train', gain=2.0, adam_steps=1)
+        cfg = tiny_cfg('CNE', 'SUE', gcn_layer_norm=True, no_gcn_residual=True)
+        run_case('tiny_CNE_SUE_ln_nores_stable', cfg, tiny_spec(cfg, 4), batch_size=4, seed=29, mode='train', gain=2.0, adam_steps=1)
+        for hd in (48, 112):
+            cfg = tiny_cfg('CNE', 'SUE')
+            cfg.hidden_dim = hd
+            run_case('tiny_CNE_SUE_h%d_stable' % hd, cfg, tiny_spec(cfg, 5), batch_size=3, seed=31 + hd, mode='train', gain=1.0 if hd > 64 else 1.5,
+                     full_arrays=False)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'extra':
+        torch.set_num_threads(8)
+        return extra_cases()
     torch.set_num_threads(8)
     # tiny dims, reference's own initialisation, every array stored
     for news, user, mode in (('CNE', 'SUE', 'train'), ('MHSA', 'MHSA', 'eval'), ('CNN', 'ATT', 'train')):
