@@ -67,6 +67,7 @@ class DeviceCorpus:
         if dev.type != 'cuda':
             raise L.NnrHipError('DeviceCorpus needs a GPU: the batch kernels live in libnnr_hip.so (no CPU path)')
         self.device, self.graph_mode, self.norm, self.category_num = dev, graph, NORM[norm], int(category_num)
+        self.norm_name = norm
         up = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dt).to(dev)
         t = {}
         for k in _NEWS_KEYS:

@@ -19,9 +19,71 @@ def dev_corpus(arrays, device, category_num, graph='build', norm='symmetric'):
     return dc
 
 
+LAST_STATS = {}          # filled by compute_scores: how many news rows the news encoder processed (cached vs per-sample form)
+
+
+def news_reps_cacheable(model):
+    """A news representation may be cached (encoded once per evaluation, gathered by id) only if it does not depend on the
+    other news of its encoder call.  True for the MHSA / CNN encoders; NOT for CNE: the reference gates the title at
+    title-rank r with the content memory at content-rank r of the SAME call (newsEncoders.py:112-115,128-129), so its
+    representations depend on their batch-mates and caching would change the reference's scores."""
+    return getattr(model.news_encoder, 'batch_independent', False) and hasattr(model.user_encoder, 'encode_user')
+
+
 @torch.no_grad()
-def compute_scores(model, corpus, batch_size):
-    """One score per dev sample, in dataset order (util.py:13-49): float32 [n] on the device."""
+def encode_news_table(model, corpus, ids, chunk=4096):
+    """Representations [len(ids), D] of the news `ids` (int64 device tensor of news indices), chunk by chunk, eval mode."""
+    t = corpus.t
+    ne = model.news_encoder
+    out = torch.empty((ids.numel(), ne.news_embedding_dim), device=corpus.device, dtype=torch.float32)
+    for s in range(0, ids.numel(), chunk):
+        sel = ids[s:s + chunk]
+        f = lambda k: t[k][sel].unsqueeze(1).contiguous()          # [n, 1, ...]: one news per "sample"
+        rep = ne(f('news_title_text'), f('news_title_mask'), f('news_title_entity'), f('news_abstract_text'), f('news_abstract_mask'),
+                 f('news_abstract_entity'), f('news_category'), f('news_subCategory'), None)
+        out[s:s + sel.numel()] = rep.view(sel.numel(), -1)
+    return out
+
+
+@torch.no_grad()
+def compute_scores_cached(model, corpus, batch_size):
+    """compute_scores for encoders with batch-independent news representations (the reference's README
+    lists the missing cache as a known cost, README.md:125): every DISTINCT news of the split is encoded once, a sample's history
+    / candidate representations are gathered by news id, and only the user encoder + click predictor run per sample."""
+    assert news_reps_cacheable(model)
+    was_training = model.training
+    model.eval()
+    t, dev = corpus.t, corpus.device
+    hist, cand = t['beh_history'].long(), corpus.samples[:, 0].long()
+    used, inv = torch.unique(torch.cat([hist.reshape(-1), cand]), return_inverse=True)
+    reps = encode_news_table(model, corpus, used)
+    slot_h, slot_c = inv[:hist.numel()].view_as(hist), inv[hist.numel():]
+    scores = torch.zeros(corpus.num, device=dev, dtype=torch.float32)
+    ue = model.user_encoder
+    from .model import _DotProductFn
+    need_graph = type(ue).__name__ == 'SUE'
+    for start in range(0, corpus.num, batch_size):
+        idx = torch.arange(start, min(start + batch_size, corpus.num), device=dev)
+        h = reps[slot_h[idx]]                                  # [B, H, D]
+        c = reps[slot_c[idx]].unsqueeze(1)                     # [B, 1, D]
+        hmask = t['beh_history_mask'][idx]
+        graph = cmask = cidx = None
+        if need_graph:
+            from .corpus import history_graph
+            graph, cmask, cidx = history_graph(t['news_category'][hist[idx]].contiguous(), hmask.contiguous(), corpus.category_num, corpus.norm_name)
+        user = ue.encode_user(h, hmask, graph, cmask, cidx, c)
+        scores[start:start + idx.numel()] = _DotProductFn.apply(user, c).squeeze(dim=1)
+    model.train(was_training)
+    LAST_STATS.update(mode='cached', encoder_rows=int(used.numel()), per_sample_rows=int(corpus.num * (hist.shape[1] + 1)))
+    return scores
+
+
+@torch.no_grad()
+def compute_scores(model, corpus, batch_size, cache='auto'):
+    """One score per dev sample, in dataset order (util.py:13-49): float32 [n] on the device.  cache: 'auto' (cache the news
+    representations when the encoder allows it, see news_reps_cacheable), True, False (the reference's per-sample form)."""
+    if cache is True or (cache == 'auto' and news_reps_cacheable(model)):
+        return compute_scores_cached(model, corpus, batch_size)
     was_training = model.training
     model.eval()
     scores = torch.zeros(corpus.num, device=corpus.device, dtype=torch.float32)
@@ -30,6 +92,7 @@ def compute_scores(model, corpus, batch_size):
         batch = corpus.train_batch(idx)                       # candidate fields are [B, 1, ...] = the unsqueeze of util.py:43-48
         scores[start:start + idx.numel()] = model(*batch).squeeze(dim=1)
     model.train(was_training)
+    LAST_STATS.update(mode='per-sample', encoder_rows=int(corpus.num * (corpus.H + 1)), per_sample_rows=int(corpus.num * (corpus.H + 1)))
     return scores
 
 

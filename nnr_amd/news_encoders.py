@@ -497,6 +497,7 @@ class CNE(NewsEncoder):
 class MHSA(NewsEncoder):
     """newsEncoders.py:173-200: title only; embedding gather -> QKV GEMMs -> MFMA attention core -> dropout ->
     additive attention pool -> feature fusion."""
+    batch_independent = True          # a news representation does not depend on the other news of the call (evaluate.py cache)
 
     def __init__(self, config, word_table=None):
         super().__init__(config, word_table)
@@ -530,6 +531,7 @@ class MHSA(NewsEncoder):
 class CNN(NewsEncoder):
     """newsEncoders.py:144-170: title only; embedding gather -> Conv1d(k=3)+ReLU as shifted GEMMs -> dropout_ ->
     additive attention pool -> feature fusion."""
+    batch_independent = True
 
     def __init__(self, config, word_table=None):
         super().__init__(config, word_table)

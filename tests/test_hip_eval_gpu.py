@@ -67,3 +67,60 @@ def test_compute_scores_and_metrics_match_reference(tag, graph):
     r2, _, m2 = rank_metrics(torch.from_numpy(z['scores']).cuda(), torch.from_numpy(z['labels']), z['sizes'])
     np.testing.assert_array_equal(r2.cpu().numpy(), z['ranks'])
     np.testing.assert_allclose(m2.cpu().numpy(), z['metrics'], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize('tag', ['tiny_MHSA_MHSA', 'tiny_CNN_ATT'])
+def test_cached_news_representations_give_the_reference_scores(tag):
+    """f-3 (results-preserving part): for the MHSA / CNN encoders every distinct news is encoded ONCE per evaluation and gathered
+    by id.  Same scores as the reference's per-sample util.compute_scores (goldens) and as this package's own per-sample form;
+    the encoder processes several times fewer news rows.  CNE must refuse (rank-pairing quirk)."""
+    from nnr_amd import evaluate as E
+    from nnr_amd.model import Model
+    z = np.load(os.path.join(GOLD, 'eval_%s.npz' % tag))
+    cast = {'int': int, 'float': float, 'str': str, 'bool': lambda v: v == 'True'}
+    cfg = SimpleNamespace(**{k: cast[t](v) for k, v, t in zip(z['cfg_keys'], z['cfg_vals'], z['cfg_types'])})
+    cfg.tie_order = str(z['tie_order'])
+    model = Model(cfg, torch.zeros(cfg.vocabulary_size, cfg.word_embedding_dim))
+    model.load_state_dict({k[len('state/'):]: torch.from_numpy(z[k].copy()) for k in z.files if k.startswith('state/')})
+    model = model.cuda().train()
+    dc = E.dev_corpus({k: z[k] for k in z.files}, 'cuda', int(z['category_num']))
+    assert E.news_reps_cacheable(model)
+    cached = E.compute_scores(model, dc, batch_size=8)                    # 'auto' -> cached
+    st = dict(E.LAST_STATS)
+    plain = E.compute_scores(model, dc, batch_size=8, cache=False)
+    assert st['mode'] == 'cached' and E.LAST_STATS['mode'] == 'per-sample' and model.training
+    assert float((cached - plain).abs().max()) <= 2e-6
+    assert float(np.abs(cached.cpu().numpy() - z['scores']).max()) <= 2e-5
+    assert st['encoder_rows'] * 2 <= st['per_sample_rows']               # tiny fixture: 60 news vs 6-7 rows per sample; MIND dev: > 10x
+    print('%s: cached %d encoder rows vs %d per-sample rows' % (tag, st['encoder_rows'], st['per_sample_rows']))
+
+
+def test_cne_representations_are_not_cacheable():
+    from nnr_amd import evaluate as E
+    from nnr_amd.config import make_config
+    from nnr_amd.model import Model
+    m = Model(make_config(['--news_encoder=CNE', '--user_encoder=SUE'], corpus_sizes=dict(vocabulary_size=50)))
+    assert not E.news_reps_cacheable(m)
+
+
+def test_cached_evaluation_on_a_mind_shaped_dev_split():
+    """MIND-shaped sizes: 20 000 news, 8 000 (impression, candidate) samples with up to 50-news histories (MIND-small's dev split
+    has 2.7 M samples over 42 k news): >= 10x fewer encoder rows, same scores."""
+    from nnr_amd import evaluate as E
+    from nnr_amd.config import make_config
+    from nnr_amd.corpus import from_synth
+    from nnr_amd.model import Model
+    from nnr_amd.synth import SynthSpec, SynthCorpus
+    cfg = make_config(['--news_encoder=MHSA', '--user_encoder=MHSA'], corpus_sizes=dict(vocabulary_size=5000))
+    torch.manual_seed(0)
+    model = Model(cfg)
+    model.initialize()
+    model = model.cuda()
+    synth = SynthCorpus(SynthSpec(vocabulary_size=5000, news_pool=20000, seed=2))
+    dc = from_synth(synth, 8000, np.random.default_rng(1), 'cuda')
+    dc.set_samples(dc.samples[:, :1].cpu().numpy())          # dev / test samples carry ONE candidate (util.py:43-48)
+    a = E.compute_scores(model, dc, 256)
+    st = dict(E.LAST_STATS)
+    b = E.compute_scores(model, dc, 256, cache=False)
+    assert st['encoder_rows'] * 10 <= st['per_sample_rows'], st
+    assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(b.abs().max()))
