@@ -20,13 +20,21 @@ struct Api {
 Api* api() {
   static Api a = [] {
     Api x{};
-    void* h = nullptr;
-    for (const char* name : {"librccl.so", "librccl.so.1"}) {
-      h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);          // the copy the process already has (torch's)
-      if (h) break;
+    // 1. symbols of an RCCL the process ALREADY has, under whatever file name it was loaded (torch bundles its own copy; a
+    //    hashed or versioned soname would defeat a dlopen(name, RTLD_NOLOAD) probe): the global symbol scope
+    void* h = RTLD_DEFAULT;
+    if (!dlsym(h, "ncclAllReduce")) {
+      // 2. loaded, but with local visibility (dlopen'ed by torch): probe the known names without loading anything
+      h = nullptr;
+      for (const char* name : {"librccl.so", "librccl.so.1"}) {
+        h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+        if (h) break;
+      }
+      // 3. no RCCL in the process at all: load the system one.  (Never reached next to PyTorch-ROCm; a second copy beside
+      //    torch's would have its own communicator state.)
+      if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+      if (!h) return x;
     }
-    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) return x;
     x.GetUniqueId = reinterpret_cast<decltype(x.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
     x.CommInitRank = reinterpret_cast<decltype(x.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
     x.AllReduce = reinterpret_cast<decltype(x.AllReduce)>(dlsym(h, "ncclAllReduce"));

@@ -33,14 +33,14 @@ __global__ __launch_bounds__(256) void plan_len_kernel(uint8_t* __restrict__ mas
 __global__ __launch_bounds__(PLAN_THREADS) void plan_rank_kernel(const int* __restrict__ len_in, int n, int L,
                                                                  const int* __restrict__ perm_in, int* __restrict__ order,
                                                                  int* __restrict__ rank, int* __restrict__ slen,
-                                                                 int* __restrict__ bs, int* __restrict__ off) {
+                                                                 int* __restrict__ bs, int* __restrict__ off, int fast_ok) {
   extern __shared__ int sm[];          // [L+1] hist/gt, [L+1] offs, then fast path: [nseg][L+1] segment counts
   int* hist = sm;
   int* offs = sm + (L + 1);
   int* seg = offs + (L + 1);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int nseg = (n + 63) >> 6;
-  const bool fast = (perm_in == nullptr) && nseg <= MAX_SEG;
+  const bool fast = (perm_in == nullptr) && nseg <= MAX_SEG && fast_ok;
   for (int t = tid; t <= L; t += PLAN_THREADS) hist[t] = 0;
   if (fast) for (int t = tid; t < nseg * (L + 1); t += PLAN_THREADS) seg[t] = 0;
   __syncthreads();
@@ -119,14 +119,18 @@ extern "C" int nnr_seq_plan(uint8_t* mask, const int* ids, int n, int L, const i
                             hipStream_t stream) {
   if (!mask || n <= 0 || L <= 0 || L > MAX_L) return NNR_ERR_ARG;
   const int nseg = (n + 63) / 64;
-  const bool fast = !perm_in && nseg <= MAX_SEG;
-  const size_t shm = (size_t)(2 * (L + 1) + (fast ? nseg * (L + 1) : 0)) * sizeof(int);
-  if (shm > 160 * 1024) return NNR_ERR_UNSUPPORTED;
+  bool fast = !perm_in && nseg <= MAX_SEG;
+  size_t shm = (size_t)(2 * (L + 1) + (fast ? nseg * (L + 1) : 0)) * sizeof(int);
+  if (shm > 160 * 1024) {          // the per-segment histograms do not fit the LDS: the O(n^2) rank path needs only 2 * (L + 1) ints
+    fast = false;
+    shm = (size_t)(2 * (L + 1)) * sizeof(int);
+  }
   hipLaunchKernelGGL(plan_len_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, mask, n, L, len_out);
   NNR_CHECK_LAUNCH();
-  if (shm > 64 * 1024)
-    hipFuncSetAttribute(reinterpret_cast<const void*>(plan_rank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-  hipLaunchKernelGGL(plan_rank_kernel, dim3(1), dim3(PLAN_THREADS), shm, stream, len_out, n, L, perm_in, order, rank, slen, bs, off);
+  if (shm > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(plan_rank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
+    return NNR_ERR_LAUNCH;
+  hipLaunchKernelGGL(plan_rank_kernel, dim3(1), dim3(PLAN_THREADS), shm, stream, len_out, n, L, perm_in, order, rank, slen, bs, off, fast ? 1 : 0);
   NNR_CHECK_LAUNCH();
   const long total = (long)n * L;
   const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);

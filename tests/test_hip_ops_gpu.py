@@ -288,6 +288,21 @@ def test_seq_plan_matches_stable_sort():
     assert torch.equal(plan2.order.cpu(), perm)
 
 
+def test_seq_plan_long_sequences_take_the_small_lds_path():
+    """L = 512 with n near 8 192: the fast ranking's per-segment histograms (128 x 513 ints = 263 KB) exceed the 160 KB of LDS; the
+    planner must fall back to the ranking that needs 2 * (L + 1) ints instead of refusing the call (ADVICE, round 1)."""
+    from nnr_amd import ops
+    n, Lx = 8000, 512
+    g = torch.Generator().manual_seed(3)
+    lens = torch.randint(1, Lx + 1, (n,), generator=g)
+    mask = torch.arange(Lx)[None, :] < lens[:, None]
+    plan = ops.SeqPlan(mask.clone().to(dev()), None)
+    order = torch.argsort(lens, descending=True, stable=True)
+    assert torch.equal(plan.order.cpu().long(), order)
+    assert torch.equal(plan.slen.cpu().long(), lens[order])
+    assert int(plan.off.cpu()[-1]) == int(lens.sum())
+
+
 def test_pair_recurrence_timeout_is_counted_and_skips_the_optimizer(monkeypatch):
     """The CU-pair exchange must fail LOUDLY: with the tagged stores switched off (debug bit 2 of NNR_LSTM_DBG) every partner
     wait runs into its bound, the per-launch diagnostics word AND the persistent counter become non-zero, h is poisoned with
