@@ -908,8 +908,14 @@ __global__ __launch_bounds__(256, OCC) void gemm_tn_pipe_kernel(nnr_gemm_args g)
   const int z = blockIdx.z;
   int kbeg = 0, kend = K;
   if (g.split_k > 1) {
+    // The host sizes split_k for the CAPACITY of the token buffers; the live reduction length (device side) is typically a
+    // fifth of it.  Use only as many slices as keep a slice long enough to amortise its prologue and its atomic epilogue
+    // (~96 stages) while still giving every CU a workgroup or two; the surplus slices exit.
     const int ktiles = (K + BK - 1) / BK;
-    const int per = (ktiles + g.split_k - 1) / g.split_k;
+    const int want = (512 + nblk - 1) / nblk;
+    const int eff = max(1, min(min(g.split_k, max(want, ktiles / 96)), max(1, ktiles / 12)));
+    if (z >= eff) return;
+    const int per = (ktiles + eff - 1) / eff;
     kbeg = z * per * BK;
     kend = min(K, kbeg + per * BK);
     if (kbeg >= kend) return;
@@ -1112,8 +1118,14 @@ __global__ __launch_bounds__(256, OCC) void gemm_tn_pipe2_kernel(nnr_gemm_args g
   const int z = blockIdx.z;
   int kbeg = 0, kend = K;
   if (g.split_k > 1) {
+    // The host sizes split_k for the CAPACITY of the token buffers; the live reduction length (device side) is typically a
+    // fifth of it.  Use only as many slices as keep a slice long enough to amortise its prologue and its atomic epilogue
+    // (~96 stages) while still giving every CU a workgroup or two; the surplus slices exit.
     const int ktiles = (K + BK - 1) / BK;
-    const int per = (ktiles + g.split_k - 1) / g.split_k;
+    const int want = (512 + nblk - 1) / nblk;
+    const int eff = max(1, min(min(g.split_k, max(want, ktiles / 96)), max(1, ktiles / 12)));
+    if (z >= eff) return;
+    const int per = (ktiles + eff - 1) / eff;
     kbeg = z * per * BK;
     kend = min(K, kbeg + per * BK);
     if (kbeg >= kend) return;

@@ -51,6 +51,8 @@ EXTRA_STREAMS = []          # every HIP stream this package created (side, title
 def new_stream(dev, critical=False):
     """critical: a stream that carries a piece of the dependent chain (candidate call, title chain) rather than leaf work.
     (Measured and rejected: giving the critical streams a high HIP stream priority -- 13.43 vs 13.05 ms/step.)"""
+    if os.environ.get('NNR_ONE_STREAM') == '1':          # diagnostic: every launch on the caller's stream (solo kernel durations)
+        return torch.cuda.current_stream(dev)
     st = torch.cuda.Stream(device=dev)
     EXTRA_STREAMS.append(st)
     return st

@@ -189,7 +189,9 @@ def sue_backward(mod, sv, dout):
     with ops.leaf_scope(dev) as leaf:
         res = _sue_backward_body(mod, sv, dout, leaf, B, Hn, D, N, Kc, G, Cn, A, p, seed, dev, f32, cand2, ia)
     # every parameter gradient of this encoder is now ordered on the current stream (the leaf stream was joined on exit):
-    # a data-parallel trainer starts reducing them while the news encoder's backward is still to come (dp.GradientExchange)
+    # a data-parallel trainer starts reducing them while the news encoder's backward is still to come (dp.GradientExchange).
+    # (Measured and rejected: issuing this encoder's weight-gradient GEMMs only after its data-gradient chain, so that they
+    # overlap the news encoder's backward prologue instead of slowing the 4 352-row chain: 13.05 vs 12.84 ms/step.)
     hook = mod.__dict__.get('_grads_ready_hook')
     if hook is not None:
         hook()
