@@ -1461,16 +1461,19 @@ extern "C" int nnr_gemm_f32(const nnr_gemm_args* a, hipStream_t stream) {
     const long wg64 = (long)((g.M + 63) / 64) * ((g.N + 79) / 80) * (g.split_k > 1 ? g.split_k : (g.batch > 1 ? g.batch : 1));
     const bool plain = !g.trans_a && !g.a_idx && !g.b_idx && !g.c_idx && !g.dyn_dev && g.split_k <= 1 && g.k_chunk <= 0 && !g.rowdot_w &&
                        !g.colsum_out && !g.atomic && (g.drop_target == 0 || g.drop_target == 3);
+    static const bool use_t9 = [] { const char* e = getenv("NNR_NT9"); return !(e && atoi(e) == 0); }();   // A/B
     static const bool use_pipe = [] { const char* e = getenv("NNR_GEMM_PIPE"); return !(e && atoi(e) == 0); }();   // A/B switch
     if (g.rowdot_w) tile = 3;
     else if (plain && wg64 <= 512 && g.K >= 64) tile = 7;   // small row-parallel launch: 16 x 80 tiles, K split over the 4 waves
-    else if (use_pipe && pipe_ok(g) && !g.a_idx && g.K >= 800 && wg64 > 512) tile = 9;   // long reductions (dX: K = 1664, SUE: K = 900): the
+    else if (use_pipe && use_t9 && pipe_ok(g) && !g.a_idx && g.K >= 800 && wg64 > 512) tile = 9;   // long reductions (dX: K = 1664, SUE: K = 900): the
                              // software-pipelined loop with the lean DMA issue, 2 workgroups / CU (130 vs 112 TF, 93 vs 79 TF)
     else if (use_pipe && pipe_ok(g) && (g.dyn_dev || wg128 >= 640)) tile = 15;   // GPU-filling NT: LDS-DMA staged 128 x 80, BK 16, 4 workgroups / CU
                              // (112 vs 98 TF on the 131 072-row CNE shapes, tools/gemm_pipe_bench.py)
     else if (use_pipe && pipe_ok(g) && wg64 > 512 && g.K >= 128) tile = 16;      // mid-size NT (SUE: 4 352 x 900 x 900): same tile, two 13 KB stages,
                              // 5-6 workgroups / CU cover the round trips (79 vs 65-72 TF)
-    else if (wg64 <= 512 && !g.dyn_dev && g.k_chunk <= 0 && g.K >= 128) tile = 6;   // at most 2 workgroups per CU: nothing hides the
+    else if (wg64 <= 512 && !g.dyn_dev && g.k_chunk <= 0 && g.K >= 128 && !g.trans_a) tile = 6;   // (not for TN: the small weight-gradient
+                             // launches run on the leaf stream BESIDE the recurrence, whose workgroups hold 98 KB of LDS per CU; a 74 KB tile cannot
+                             // move in next to them and waits for free CUs, the 19 KB tile can: 12.60 vs 12.70 ms/step)   // at most 2 workgroups per CU: nothing hides the
                              // memory round trip each k-stage pays with a one-stage prefetch -> BK = 64, 4x fewer stages
     else if (g.M <= 512 || (wg128 < 640 && !g.dyn_dev)) tile = 2;   // too few 128-row tiles to fill 256 CUs x 4: use 64-row tiles
     else if (g.trans_a) tile = 2;   // TN (token-reduction dW): callers pick the LDS-DMA tiles 20 / 24 explicitly (their split-K factor

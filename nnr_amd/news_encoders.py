@@ -402,7 +402,7 @@ def _cne_bwd_post(mod, sv, st, leaf=None):
                  split_k=ops.split_for(2 * NP, E, cap, bm, bn, target), atomic=True, dyn=plan.total, dyn_dim=2, colsum_out=db_p, tile=t)
 
     def dw_hh(d):
-        t, bm, bn, target = ops.tn_tile(NP, H, cap)
+        t, bm, bn, target = ops.tn_tile(NP, H, cap, gather=True)
         ops.gemm(dg[:, d * NP:], st['hout'][:, d * H:], dw_hhp[d], M=NP, N=H, K=cap, lda=2 * NP, ldb=H2, ldc=H, trans_a=True,
                  trans_b=True, b_idx=(plan.prev_f, plan.prev_r)[d], split_k=ops.split_for(NP, H, cap, bm, bn, target), atomic=True,
                  dyn=plan.total, dyn_dim=2, tile=t)

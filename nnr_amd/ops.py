@@ -201,15 +201,20 @@ def wt_prefetch(dev):
 
 # LDS-DMA staged weight-gradient tiles (csrc/gemm.hip: gemm_tn_pipe_kernel): (tile id, rows, cols, workgroups to aim for)
 TN_PIPE = os.environ.get('NNR_TN_PIPE', '1') != '0'
+_TN_SMALL_LDS = os.environ.get('NNR_TN_SMALL_LDS', '1') == '1'      # 53 KB tiles everywhere: they fit beside a recurrence workgroup (98 KB)
+                                                                    # and beside each other; the 78 KB 128 x 208 tile is faster alone (83 vs 70 TF
+                                                                    # on 400 x 400) but the step is 12.35 vs 12.52 ms with the small ones
 
 
-def tn_tile(M, N, K):
+def tn_tile(M, N, K, gather=False):
     """Tile of a token-reduction (weight-gradient) GEMM C[M,N] += A[K,M]^T B[K,N] and the tile dims its split-K factor is sized
     for.  Measured on the step's shapes (tools/gemm_pipe_bench.py tn, TFLOP/s old -> new): 1664x300 82 -> 96 (128x80),
     832x200 with gathered rows 68 -> 86, 400x400 75 -> 82, 200x400 62 -> 73 (128x208); short reductions and the 900x900 SUE
     layers stay on the register-staged 64x80 tile."""
     if not TN_PIPE or K < 8192 or (M & 3) or (N & 3) or (M >= 512 and N >= 512):
         return 0, 64, 80, 2048
+    if _TN_SMALL_LDS:
+        return (20 if gather else 26), 128, 80, 2048
     if N <= 208 or (N > 320 and N <= 416):
         return 27, 128, 208, 640          # gen-2 loop, 128 x 208 (one token row per DMA instruction: takes gathered rows)
     return 26, 128, 80, 2048             # gen-2 loop, 128 x 80
