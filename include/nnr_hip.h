@@ -179,6 +179,10 @@ int nnr_embed_gather(const float* table, const int* idx, long n, const int* n_de
 int nnr_embed_scatter(const float* dout, const int* idx, long n, int dim, float* dtable_accum, float p, uint32_t seed,
                       hipStream_t stream);
 int nnr_transpose2d(const float* in, float* out, long rows, int cols, int accumulate, hipStream_t stream);
+/* `count` independent transposes out[c][r] = in[r][c] in ONE launch; the descriptors live in device memory (the host side keeps
+ * them for the W^T copies of the weights that the data-gradient GEMMs multiply by: refreshed once per optimizer step). */
+typedef struct nnr_transpose_desc { const float* in; float* out; int rows, cols; } nnr_transpose_desc;
+int nnr_transpose_batch(const nnr_transpose_desc* descs_dev, int count, hipStream_t stream);
 int nnr_add(float* y, const float* x, long n, float alpha, hipStream_t stream);
 int nnr_add_atomic(float* y, const float* x, long n, float alpha, hipStream_t stream);   /* y += alpha*x with f32 atomics */
 int nnr_add2d(float* y, int ldy, const float* x, int ldx, int rows, int cols, float alpha, int accumulate, hipStream_t stream);

@@ -251,6 +251,28 @@ __global__ void transpose2d_kernel(const float* __restrict__ in, float* __restri
   }
 }
 
+// ---- several transposes in one launch (the W^T copies of every weight the backward pass multiplies by: ~20 small matrices
+// per step; blockIdx.y selects the matrix, tiles of 32 x 32 go through LDS so that reads and writes are both coalesced)
+__global__ __launch_bounds__(256) void transpose_batch_kernel(const nnr_transpose_desc* __restrict__ descs) {
+  __shared__ float tile[32][33];
+  const nnr_transpose_desc d = descs[blockIdx.y];
+  const int tr = (d.rows + 31) / 32, tc = (d.cols + 31) / 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8 threads
+  for (int t = blockIdx.x; t < tr * tc; t += gridDim.x) {
+    const int r0 = (t / tc) * 32, c0 = (t % tc) * 32;
+    for (int j = ty; j < 32; j += 8) {
+      const int r = r0 + j, c = c0 + tx;
+      tile[j][tx] = (r < d.rows && c < d.cols) ? d.in[(long)r * d.cols + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+      const int c = c0 + j, r = r0 + tx;
+      if (r < d.rows && c < d.cols) d.out[(long)c * d.rows + r] = tile[tx][j];
+    }
+    __syncthreads();
+  }
+}
+
 // ---- generic y (op)= x
 __global__ void add_kernel(float* __restrict__ y, const float* __restrict__ x, long n, float alpha) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] += alpha * x[i];
@@ -814,6 +836,14 @@ extern "C" int nnr_embed_scatter(const float* dout, const int* idx, long n, int 
 }
 extern "C" int nnr_transpose2d(const float* in, float* out, long rows, int cols, int accumulate, hipStream_t stream) {
   EW_LAUNCH(transpose2d_kernel, rows * cols, in, out, rows, cols, accumulate);
+}
+
+extern "C" int nnr_transpose_batch(const nnr_transpose_desc* descs_dev, int count, hipStream_t stream) {
+  if (count <= 0) return NNR_OK;
+  if (!descs_dev) return NNR_ERR_ARG;
+  hipLaunchKernelGGL(transpose_batch_kernel, dim3(64, count), dim3(256), 0, stream, descs_dev);
+  NNR_CHECK_LAUNCH();
+  return NNR_OK;
 }
 
 extern "C" int nnr_add(float* y, const float* x, long n, float alpha, hipStream_t stream) { EW_LAUNCH(add_kernel, n, y, x, n, alpha); }

@@ -143,60 +143,78 @@ _WT = {}
 USE_WT = os.environ.get('NNR_WT', '1') != '0'      # A/B switch: data-gradient GEMMs as NT products on cached W^T
 
 
+class _WtEntry:
+    __slots__ = ('ref', 'ptr', 'epoch', 'version', 't', 'event', 'stream')
+
+
+_WT_TABLE = {'ids': None, 'dev': None, 'count': 0}      # device-resident descriptor table of the registered transposes
+
+
 def wt(w):
     """W^T (contiguous [cols, rows]) of a 2-D contiguous PARAMETER, cached until the parameter changes (optimizer step:
     layers.PARAM_EPOCH; in-place edits: the tensor's version counter).  With it every data-gradient GEMM dX = dY . W becomes
-    an NT product (both operands K-contiguous) and runs on the LDS-DMA staged kernel; the transposes are a few hundred KB per
-    step against GBs of activations.  The copy is made on the stream of the first user; a user on another HIP stream (the
-    candidate call's side stream, the title stream) waits for the producer's event."""
+    an NT product (both operands K-contiguous) and runs on the LDS-DMA staged kernels; the transposes are a few hundred KB per
+    step against GBs of activations.  A stale copy is refreshed on the stream of the first user; a user on another HIP stream
+    waits for the producer's event.  In training, Model.forward refreshes ALL registered copies in one launch on the leaf
+    stream (wt_prefetch), so the backward pass only ever finds fresh ones."""
     from .layers import PARAM_EPOCH
     # identity of the cached object: the tensor OBJECT (weak reference) + its pointer.  A pointer alone is not an identity --
     # the caching allocator hands a freed parameter's address to the next model's parameter of the same shape.
-    key = id(w)
-    ver = (w.data_ptr(), PARAM_EPOCH[0], w._version)
-    hit = _WT.get(key)
-    cur = torch._C._cuda_getCurrentRawStream(w.device.index if w.device.index is not None else torch.cuda.current_device())
-    if hit is None or hit[0] != ver or hit[4]() is not w:
-        rows, cols = w.shape
-        t = torch.empty((cols, rows), device=w.device, dtype=torch.float32)
-        transpose2d(w, t, rows, cols)
-        ev = torch.cuda.Event()
-        ev.record()
+    e = _WT.get(id(w))
+    cur = torch._C._cuda_getCurrentRawStream(_DEV_INDEX[0] if _DEV_INDEX else torch.cuda.current_device())
+    if e is not None and e.epoch == PARAM_EPOCH[0] and e.version == w._version and e.ptr == w.data_ptr() and e.ref() is w:
+        if e.stream != cur:
+            torch.cuda.current_stream(w.device).wait_event(e.event)
+        return e.t
+    rows, cols = w.shape
+    if e is None or e.ref() is not w or e.ptr != w.data_ptr() or e.t.shape != (cols, rows):
         if len(_WT) > 256:                                   # entries of dead tensors (temporary views, discarded models)
-            for k in [k for k, v in _WT.items() if v[4]() is None]:
+            for k in [k for k, v in _WT.items() if v.ref() is None]:
                 del _WT[k]
-        hit = (ver, t, ev, cur, weakref.ref(w))
-        _WT[key] = hit
-    elif hit[3] != cur:
-        torch.cuda.current_stream(w.device).wait_event(hit[2])
-    return hit[1]
+        e = _WtEntry()
+        e.ref, e.ptr = weakref.ref(w), w.data_ptr()
+        e.t = torch.empty((cols, rows), device=w.device, dtype=torch.float32)      # kept across refreshes: stable address
+        _WT[id(w)] = e
+        _WT_TABLE['ids'] = None
+    transpose2d(w, e.t, rows, cols)
+    e.event = torch.cuda.Event()
+    e.event.record()
+    e.epoch, e.version, e.stream = PARAM_EPOCH[0], w._version, cur
+    return e.t
 
 
 def wt_prefetch(dev):
-    """Refresh, on the leaf stream, the transposes of every parameter that wt() has served before and that changed since
-    (i.e. after an optimizer step).  Called at the start of a training forward pass: the copies are needed by the BACKWARD
-    pass only, so they leave the critical chain -- made lazily, the first user's stream does the copy and users on the other
-    streams wait for it (measured: a 383 us stall of the history call's backward behind the candidate call's)."""
+    """Refresh, on the leaf stream and in ONE launch (nnr_transpose_batch over a device-resident descriptor table), the
+    transposes of every parameter wt() has served before and that changed since (i.e. after an optimizer step).  Called at the
+    start of a training forward pass: the copies are needed by the BACKWARD pass only, so they leave the critical chain --
+    made lazily, the first user's stream does the copy and users on the other streams wait for it (measured: a 383 us stall
+    of the history call's backward behind the candidate call's)."""
     if not USE_WT or not _WT:
         return
     from .layers import PARAM_EPOCH
-    stale = []
-    for k, v in list(_WT.items()):
-        w = v[4]()
-        if w is None:
-            del _WT[k]
-        elif v[0] != (w.data_ptr(), PARAM_EPOCH[0], w._version) and isinstance(w, torch.nn.Parameter):
-            stale.append(w)
-    if not stale:
+    live = [(k, e, e.ref()) for k, e in _WT.items()]
+    live = [(k, e, w) for k, e, w in live if w is not None and isinstance(w, torch.nn.Parameter) and e.ptr == w.data_ptr()]
+    if not live or all(e.epoch == PARAM_EPOCH[0] and e.version == w._version for _, e, w in live):
         return
+    ids = tuple(k for k, _, _ in live)
+    if _WT_TABLE['ids'] != ids:
+        arr = (L.TransposeDesc * len(live))()
+        for d, (_, e, w) in zip(arr, live):
+            d.inp, d.out, d.rows, d.cols = w.data_ptr(), e.t.data_ptr(), w.shape[0], w.shape[1]
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        _WT_TABLE.update(ids=ids, dev=host.to(dev), count=len(live))
     key = (dev.type, dev.index)
     if key not in _LEAF:
         _LEAF[key] = new_stream(dev)
     leaf = _LEAF[key]
     leaf.wait_stream(torch.cuda.current_stream(dev))       # behind the optimizer step that changed the parameters
     with torch.cuda.stream(leaf):
-        for w in stale:
-            wt(w)
+        L.check(L.lib().nnr_transpose_batch(_p(_WT_TABLE['dev']), _WT_TABLE['count'], _s()), 'nnr_transpose_batch')
+        ev = torch.cuda.Event()
+        ev.record()
+        cur = torch._C._cuda_getCurrentRawStream(_DEV_INDEX[0] if _DEV_INDEX else torch.cuda.current_device())
+    for _, e, w in live:
+        e.epoch, e.version, e.event, e.stream = PARAM_EPOCH[0], w._version, ev, cur
 
 
 # LDS-DMA staged weight-gradient tiles (csrc/gemm.hip: gemm_tn_pipe_kernel): (tile id, rows, cols, workgroups to aim for)

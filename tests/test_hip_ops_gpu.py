@@ -762,3 +762,36 @@ def test_gemm_pipelined_tn_tiles(tile, M, N, K, split):
     b_ = B2[:, 8:].double()[bidx[:used].long().clamp_min(0)] * (bidx[:used] >= 0).double()[:, None]
     close(o, a_.t() @ b_, tol=5e-5, what='TN pipe gather dyn')
     close(cs, a_.sum(dim=0), tol=5e-5, what='TN pipe column sums')
+
+
+def test_transpose_batch_and_weight_transpose_cache():
+    """nnr_transpose_batch: several transposes in one launch (ragged sizes, not multiples of the 32 x 32 tile); ops.wt / wt_prefetch:
+    the cached W^T follows the parameter through optimizer steps (PARAM_EPOCH), in-place edits (version counter) and is never
+    served for a different tensor that happens to reuse the pointer."""
+    import ctypes as C
+    from nnr_amd import _lib as L, ops
+    from nnr_amd.layers import PARAM_EPOCH
+    d = dev()
+    shapes = [(900, 900), (225, 900), (37, 5), (1, 64), (400, 200)]
+    ins = [rnd(r, c, seed=i).to(d) for i, (r, c) in enumerate(shapes)]
+    outs = [torch.empty(c, r, device=d) for r, c in shapes]
+    arr = (L.TransposeDesc * len(shapes))()
+    for k, (a, o) in enumerate(zip(ins, outs)):
+        arr[k].inp, arr[k].out, arr[k].rows, arr[k].cols = a.data_ptr(), o.data_ptr(), a.shape[0], a.shape[1]
+    tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(d)
+    L.check(L.lib().nnr_transpose_batch(C.c_void_p(tab.data_ptr()), len(shapes), ops._s()), 'nnr_transpose_batch')
+    for a, o in zip(ins, outs):
+        assert torch.equal(o, a.t().contiguous())
+    w = torch.nn.Parameter(rnd(300, 200, seed=9).to(d))
+    t1 = ops.wt(w)
+    assert torch.equal(t1, w.detach().t().contiguous()) and ops.wt(w) is t1
+    with torch.no_grad():
+        w.mul_(2.0)                                        # in-place edit: version counter
+    assert torch.equal(ops.wt(w), w.detach().t().contiguous())
+    w.data.add_(1.0)                                       # raw-pointer style update (as the fused Adam kernel): only PARAM_EPOCH tells
+    PARAM_EPOCH[0] += 1
+    ops.wt_prefetch(d)
+    torch.cuda.synchronize()
+    assert torch.equal(ops.wt(w), w.detach().t().contiguous())
+    w2 = torch.nn.Parameter(rnd(300, 200, seed=10).to(d))
+    assert torch.equal(ops.wt(w2), w2.detach().t().contiguous())
