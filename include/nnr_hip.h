@@ -103,10 +103,11 @@ int nnr_lstm_dims(int H, int* UB, int* HP, int* NP);
 int nnr_lstm_pack_weights(const float* w_ih_f, const float* w_hh_f, const float* b_ih_f, const float* b_hh_f, const float* w_ih_r,
                           const float* w_hh_r, const float* b_ih_r, const float* b_hh_r, int H, int E, float* w_ihp, float* b_p,
                           float* wf, float* wb, hipStream_t stream);
-/* dw_ihp [2*NP, E], db_p [2*NP], dw_hhp [2, NP, H] -> gradients in nn.LSTM's parameter layout (overwritten) */
-int nnr_lstm_unpack_grads(const float* dw_ihp, const float* db_p, const float* dw_hhp, int H, int E, float* dw_ih_f, float* dw_hh_f,
+/* dw_ihp [2*NP, E], db_p [2*NP], dw_hhp [2, NP, H] -> gradients in nn.LSTM's parameter layout.  zero_src != 0: the packed buffers are
+ * returned all-zero (a persistent workspace the next step's split-K GEMMs accumulate into again: no per-step fill launches). */
+int nnr_lstm_unpack_grads(float* dw_ihp, float* db_p, float* dw_hhp, int H, int E, float* dw_ih_f, float* dw_hh_f,
                           float* db_ih_f, float* db_hh_f, float* dw_ih_r, float* dw_hh_r, float* db_ih_r, float* db_hh_r,
-                          int accumulate /* 0: overwrite, 1: atomic += */, hipStream_t stream);
+                          int accumulate /* 0: overwrite, 1: atomic += */, int zero_src, hipStream_t stream);
 typedef struct nnr_lstm_problem {
   const int* bs; const int* off; const int* slen; const int* prev_f; const int* prev_r;   /* from nnr_seq_plan */
   int n, L;

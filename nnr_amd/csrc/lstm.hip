@@ -835,12 +835,14 @@ __global__ void lstm_pack_kernel(const float* __restrict__ w_ih_f, const float* 
 }
 
 // dW_ihp [2*NP, E], db_p [2*NP], dW_hhp [2][NP][H]  ->  reference-layout gradients (overwrite)
-__global__ void lstm_unpack_kernel(const float* __restrict__ dw_ihp, const float* __restrict__ db_p,
-                                   const float* __restrict__ dw_hhp, int H, int E, int UB, float* __restrict__ dw_ih_f,
+__global__ void lstm_unpack_kernel(float* __restrict__ dw_ihp, float* __restrict__ db_p,
+                                   float* __restrict__ dw_hhp, int H, int E, int UB, float* __restrict__ dw_ih_f,
                                    float* __restrict__ dw_hh_f, float* __restrict__ db_ih_f, float* __restrict__ db_hh_f,
                                    float* __restrict__ dw_ih_r, float* __restrict__ dw_hh_r, float* __restrict__ db_ih_r,
-                                   float* __restrict__ db_hh_r, int accumulate) {
+                                   float* __restrict__ db_hh_r, int accumulate, int zero_src) {
   // accumulate: atomic += into the running parameter gradients (several token streams / HIP streams add concurrently)
+  // zero_src: the packed buffers are a PERSISTENT workspace that the next step's split-K GEMMs add into again: every element
+  // is zeroed by the thread that consumed it (the padded ones, which nothing reads, by the loop at the end)
   auto put = [&](float* p, float v) __attribute__((always_inline)) { if (accumulate) atomicAdd(p, v); else *p = v; };
   const int NP = UB * 64;
   const long n_ih = (long)2 * 4 * H * E, n_hh = (long)2 * 4 * H * H, n_b = 2 * 4 * H;
@@ -850,14 +852,18 @@ __global__ void lstm_unpack_kernel(const float* __restrict__ dw_ihp, const float
     if (i < n_ih) {
       const int e = i % E; long q = i / E; const int row = q % (4 * H); const int d = q / (4 * H);
       const int g = row / H, unit = row % H, p = (unit / 16) * 64 + (unit % 16) * 4 + g;
-      put(&(d ? dw_ih_r : dw_ih_f)[(long)row * E + e], dw_ihp[(long)(d * NP + p) * E + e]);
+      float* src = &dw_ihp[(long)(d * NP + p) * E + e];
+      put(&(d ? dw_ih_r : dw_ih_f)[(long)row * E + e], *src);
+      if (zero_src) *src = 0.f;
       continue;
     }
     i -= n_ih;
     if (i < n_hh) {
       const int k = i % H; long q = i / H; const int row = q % (4 * H); const int d = q / (4 * H);
       const int g = row / H, unit = row % H, p = (unit / 16) * 64 + (unit % 16) * 4 + g;
-      put(&(d ? dw_hh_r : dw_hh_f)[(long)row * H + k], dw_hhp[((long)d * NP + p) * H + k]);
+      float* src = &dw_hhp[((long)d * NP + p) * H + k];
+      put(&(d ? dw_hh_r : dw_hh_f)[(long)row * H + k], *src);
+      if (zero_src) *src = 0.f;
       continue;
     }
     i -= n_hh;
@@ -867,6 +873,18 @@ __global__ void lstm_unpack_kernel(const float* __restrict__ dw_ihp, const float
       const float v = db_p[d * NP + p];
       put(&(d ? db_ih_r : db_ih_f)[row], v);
       put(&(d ? db_hh_r : db_hh_f)[row], v);
+      if (zero_src) db_p[d * NP + p] = 0.f;
+    }
+  }
+  if (zero_src && (UB * 16 != H)) {          // padded gate columns (unit >= H): never read above, but the GEMMs add into them
+    const long n1 = (long)2 * NP * E, n2 = (long)2 * NP * H, n3 = 2 * NP;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < n1 + n2 + n3; idx += (long)gridDim.x * blockDim.x) {
+      long i = idx;
+      float* base = dw_ihp; int width = E;
+      if (i >= n1) { i -= n1; base = dw_hhp; width = H; if (i >= n2) { i -= n2; base = db_p; width = 1; } }
+      const int p = (int)((i / width) % NP);
+      const int unit = (p / 64) * 16 + ((p % 64) / 4);
+      if (unit >= H) base[i] = 0.f;
     }
   }
 }
@@ -929,13 +947,13 @@ extern "C" int nnr_lstm_pack_weights(const float* w_ih_f, const float* w_hh_f, c
   return NNR_OK;
 }
 
-extern "C" int nnr_lstm_unpack_grads(const float* dw_ihp, const float* db_p, const float* dw_hhp, int H, int E,
+extern "C" int nnr_lstm_unpack_grads(float* dw_ihp, float* db_p, float* dw_hhp, int H, int E,
                                      float* dw_ih_f, float* dw_hh_f, float* db_ih_f, float* db_hh_f, float* dw_ih_r,
-                                     float* dw_hh_r, float* db_ih_r, float* db_hh_r, int accumulate, hipStream_t stream) {
+                                     float* dw_hh_r, float* db_ih_r, float* db_hh_r, int accumulate, int zero_src, hipStream_t stream) {
   int UB;
   if (nnr_lstm_dims(H, &UB, nullptr, nullptr) != NNR_OK) return NNR_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(lstm_unpack_kernel, dim3(1024), dim3(256), 0, stream, dw_ihp, db_p, dw_hhp, H, E, UB, dw_ih_f,
-                     dw_hh_f, db_ih_f, db_hh_f, dw_ih_r, dw_hh_r, db_ih_r, db_hh_r, accumulate);
+                     dw_hh_f, db_ih_f, db_hh_f, dw_ih_r, dw_hh_r, db_ih_r, db_hh_r, accumulate, zero_src);
   NNR_CHECK_LAUNCH();
   return NNR_OK;
 }

@@ -27,7 +27,8 @@ from . import ops
 from .layers import Attention, ScaledDotProduct_CandidateAttention, MultiHeadAttention, Conv1D, LSTMParams, grad_of, PARAM_EPOCH
 
 _SITE = dict(title=1, content=2, cat=3, sub=4)
-_POST_SERIAL = os.environ.get('NNR_POST_SERIAL', '0') == '1'
+_TITLE_DX_FIRST = os.environ.get('NNR_TITLE_DX_FIRST', '0') == '1'       # measured: no gain either way (12.39 vs 12.42-12.58 ms/step)
+_TITLE_DX_TILE = int(os.environ.get('NNR_TITLE_DX_TILE', '0'))
 
 
 class NewsEncoder(nn.Module):
@@ -392,9 +393,13 @@ def _cne_bwd_post(mod, sv, st, leaf=None):
     dg = st['gates']                                  # now d(pre-activation gates), p-order
     NP = w.NP
 
-    dw_ihp = torch.zeros((2 * NP, E), **f32)
-    db_p = torch.zeros(2 * NP, **f32)
-    dw_hhp = torch.zeros((2, NP, H), **f32)
+    # packed LSTM weight-gradient accumulators: one persistent, zeroed workspace per (token stream, encoder call); the unpack
+    # kernel hands it back zeroed (three fill launches per stream and step otherwise -- 0.5 ms of kernel time in round 1)
+    ws = mod.__dict__.setdefault('_dw_ws', {})
+    key = (st['name'], sv['n'])
+    if key not in ws or ws[key][0].shape != (2 * NP, E) or ws[key][0].device != dg.device:
+        ws[key] = (torch.zeros((2 * NP, E), **f32), torch.zeros(2 * NP, **f32), torch.zeros((2, NP, H), **f32))
+    dw_ihp, db_p, dw_hhp = ws[key]
 
     def dw_ih():
         t, bm, bn, target = ops.tn_tile(2 * NP, E, cap)
@@ -409,14 +414,16 @@ def _cne_bwd_post(mod, sv, st, leaf=None):
 
     def dx_scatter():
         # d(embedding rows): dX = dgates . W_ihp (NT on the transposed packed weight), scattered (atomic) into the table
-        # gradient through the dropout mask
+        # gradient through the dropout mask.  The title streams' launch runs BESIDE the content recurrence, whose workgroups
+        # hold 98 KB of LDS per CU: there the 40 KB tile (tile 15) can move in next to them, the 80 KB one (the automatic
+        # choice for this long reduction) cannot and crawls (384 us for 4 GFLOP, measured).
         ops.gemm(dg, w.w_ihp_t, grad_of(emb), M=cap, N=E, K=2 * NP, lda=2 * NP, ldb=2 * NP, ldc=E, c_idx=plan.tok, atomic=True,
-                 drop=(4, p, st['seed'], E), dyn=plan.total, dyn_dim=1)
+                 drop=(4, p, st['seed'], E), dyn=plan.total, dyn_dim=1, tile=0 if leaf is not None else _TITLE_DX_TILE)
 
-    if leaf is None or _POST_SERIAL:
-        # one stream: every launch here fills the chip on its own (LDS-DMA staged tiles at 1-3 workgroups per CU); side by side
-        # they fight for LDS and CU slots instead of filling each other's gaps
-        if leaf is not None:
+    if leaf is None:
+        # title streams (side stream, beside the content recurrence): the scatter GEMM first -- it is the largest launch and the
+        # one the tail of the step would otherwise still be waiting for
+        if _TITLE_DX_FIRST:
             dx_scatter()
         dw_ih(); dw_hh(0); dw_hh(1)
     else:
@@ -425,8 +432,8 @@ def _cne_bwd_post(mod, sv, st, leaf=None):
         dx_scatter()
         dw_hh(0)
         leaf.sync()
-    ops.lstm_unpack_grads(dw_ihp, db_p, dw_hhp, H, E, [grad_of(q) for q in st['lstm'].param_list()])
-    if leaf is None:
+    ops.lstm_unpack_grads(dw_ihp, db_p, dw_hhp, H, E, [grad_of(q) for q in st['lstm'].param_list()], zero_src=True)
+    if leaf is None and not _TITLE_DX_FIRST:
         dx_scatter()
 
 

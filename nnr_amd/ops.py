@@ -455,10 +455,10 @@ class LstmPacked:
         transpose2d(self.w_ihp, self.w_ihp_t, 2 * np_, E)
 
 
-def lstm_unpack_grads(dw_ihp, db_p, dw_hhp, H, E, grads):
+def lstm_unpack_grads(dw_ihp, db_p, dw_hhp, H, E, grads, zero_src=False):
     """grads: 8 tensors in nn.LSTM order (w_ih, w_hh, b_ih, b_hh, then *_reverse); accumulated into with f32 atomics
-    (parameter gradients may be accumulated from several HIP streams at once)."""
-    L.check(L.lib().nnr_lstm_unpack_grads(_p(dw_ihp), _p(db_p), _p(dw_hhp), H, E, *[_p(t) for t in grads], 1, _s()),
+    (parameter gradients may be accumulated from several HIP streams at once).  zero_src: leave the packed buffers zeroed."""
+    L.check(L.lib().nnr_lstm_unpack_grads(_p(dw_ihp), _p(db_p), _p(dw_hhp), H, E, *[_p(t) for t in grads], 1, int(zero_src), _s()),
             'nnr_lstm_unpack_grads')
 
 

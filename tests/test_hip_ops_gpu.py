@@ -415,6 +415,11 @@ def test_bilstm_forward_backward_matches_oracle(n, Lx, E, H, variant, monkeypatc
                  trans_b=True, b_idx=prev, split_k=ops.split_for(NP, H, cap), atomic=True, dyn=plan.total, dyn_dim=2)
     grads = [torch.zeros_like(q) for q in holder.param_list()]
     ops.lstm_unpack_grads(dw_ihp, db_p, dw_hhp, H, E, grads)
+    # the consuming form (persistent workspace): same gradients, packed buffers handed back all-zero incl. the padded gate columns
+    grads2 = [torch.zeros_like(q) for q in holder.param_list()]
+    ops.lstm_unpack_grads(dw_ihp, db_p, dw_hhp, H, E, grads2, zero_src=True)
+    assert all(torch.equal(a, b) for a, b in zip(grads, grads2))
+    assert float(dw_ihp.abs().max()) == 0.0 and float(db_p.abs().max()) == 0.0 and float(dw_hhp.abs().max()) == 0.0
     names = ['weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0']
     names = names + [k + '_reverse' for k in names]
     for k, g in zip(names, grads):
