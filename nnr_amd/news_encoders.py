@@ -215,7 +215,8 @@ def _cne_fwd_pre(mod, title_text, title_mask, content_text, content_mask, catego
         # dropout(embedding rows) materialised ONCE per token (6 TB/s gather): fused into the GEMM's A loader the counter hash
         # is recomputed by each of the 21 column blocks (-16 % on this GEMM and on the dW_ih GEMM of the backward)
         st['xd'] = ops.embed_gather(emb, plan.tok, p, st['seed'], dyn=plan.total)
-        ops.gemm(st['xd'], w.w_ihp, st['gates'], M=cap, N=2 * w.NP, K=E, lda=E, ldb=E, ldc=2 * w.NP, dyn=plan.total, dyn_dim=1, bias=w.b_p)
+        ops.gemm(st['xd'], w.w_ihp, st['gates'], M=cap, N=2 * w.NP, K=E, lda=E, ldb=E, ldc=2 * w.NP, dyn=plan.total, dyn_dim=1, bias=w.b_p,
+                 flop_scale=4.0 * H / w.NP)
         st['cell'] = torch.empty((cap, 2 * w.HP), **f32)
         st['hout'] = torch.empty((cap, H2), **f32)
         st['cn'] = torch.empty((n, H2), **f32)
@@ -404,13 +405,14 @@ def _cne_bwd_post(mod, sv, st, leaf=None):
     def dw_ih():
         t, bm, bn, target = ops.tn_tile(2 * NP, E, cap)
         ops.gemm(dg, st['xd'], dw_ihp, M=2 * NP, N=E, K=cap, lda=2 * NP, ldb=E, ldc=E, trans_a=True, trans_b=True,
-                 split_k=ops.split_for(2 * NP, E, cap, bm, bn, target), atomic=True, dyn=plan.total, dyn_dim=2, colsum_out=db_p, tile=t)
+                 split_k=ops.split_for(2 * NP, E, cap, bm, bn, target), atomic=True, dyn=plan.total, dyn_dim=2, colsum_out=db_p, tile=t,
+                 flop_scale=4.0 * H / NP)
 
     def dw_hh(d):
         t, bm, bn, target = ops.tn_tile(NP, H, cap, gather=True)
         ops.gemm(dg[:, d * NP:], st['hout'][:, d * H:], dw_hhp[d], M=NP, N=H, K=cap, lda=2 * NP, ldb=H2, ldc=H, trans_a=True,
                  trans_b=True, b_idx=(plan.prev_f, plan.prev_r)[d], split_k=ops.split_for(NP, H, cap, bm, bn, target), atomic=True,
-                 dyn=plan.total, dyn_dim=2, tile=t)
+                 dyn=plan.total, dyn_dim=2, tile=t, flop_scale=4.0 * H / NP)
 
     def dx_scatter():
         # d(embedding rows): dX = dgates . W_ihp (NT on the transposed packed weight), scattered (atomic) into the table
@@ -418,7 +420,7 @@ def _cne_bwd_post(mod, sv, st, leaf=None):
         # hold 98 KB of LDS per CU: there the 40 KB tile (tile 15) can move in next to them, the 80 KB one (the automatic
         # choice for this long reduction) cannot and crawls (384 us for 4 GFLOP, measured).
         ops.gemm(dg, w.w_ihp_t, grad_of(emb), M=cap, N=E, K=2 * NP, lda=2 * NP, ldb=2 * NP, ldc=E, c_idx=plan.tok, atomic=True,
-                 drop=(4, p, st['seed'], E), dyn=plan.total, dyn_dim=1, tile=0 if leaf is not None else _TITLE_DX_TILE)
+                 drop=(4, p, st['seed'], E), dyn=plan.total, dyn_dim=1, tile=0 if leaf is not None else _TITLE_DX_TILE, flop_scale=4.0 * H / NP)
 
     if leaf is None:
         # title streams (side stream, beside the content recurrence): the scatter GEMM first -- it is the largest launch and the

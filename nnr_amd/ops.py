@@ -248,7 +248,9 @@ def split_for(m, n, k, tile_m=64, tile_n=80, target_blocks=2048, kmin=256):
 def gemm(A, B, C_=None, *, M, N, K, lda, ldb, ldc=0, trans_a=False, trans_b=False, dyn=None, dyn_dim=0, a_idx=None, b_idx=None,
          drop=None, alpha=1.0, bias=None, rowvec=None, ldrv=0, rowvec_map=None, act=0, aux_out=None, ldaux=0, mul=None, ldmul=0,
          resid=None, ldres=0, accumulate=False, atomic=False, c_idx=None, split_k=1, rowdot_w=None, rowdot_out=None, batch=1,
-         strideA=0, strideB=0, strideC=0, stride_aux=0, stride_res=0, tile=0, colsum_out=None, k_chunk=0):
+         strideA=0, strideB=0, strideC=0, stride_aux=0, stride_res=0, tile=0, colsum_out=None, k_chunk=0, flop_scale=1.0):
+    # flop_scale: algorithmic / padded work of this launch (the LSTM gate columns are padded 800 -> 832 per direction; the live
+    # profile counts the true 8H columns, not the padded 2*NP)
     # ctypes zero-initialises the struct: only the fields a call actually uses are written (a field store costs ~0.2 us of host
     # time and a step issues ~130 GEMMs; writing all ~50 fields was the largest single item of the host-side enqueue time)
     g = L.GemmArgs()
@@ -335,7 +337,7 @@ def gemm(A, B, C_=None, *, M, N, K, lda, ldb, ldc=0, trans_a=False, trans_b=Fals
         if dyn is not None:
             d = int(dyn.item())
             m, k = (min(M, d), K) if dyn_dim == 1 else (M, min(K, d))
-        return 2.0 * m * N * k * max(1, batch)
+        return 2.0 * m * N * k * max(1, batch) * flop_scale
     flops.tag = 'M%d N%d K%d%s%s%s' % (M, N, K, ' b%d' % batch if batch > 1 else '', (' sk%d' % split_k if split_k > 1 else '') + (' kc%d' % k_chunk if k_chunk > 0 else ''), ' dyn' if dyn is not None else '')
     with _prof.span(fam, flops):
         L.check(L.lib().nnr_gemm_f32(C.byref(g), _s()), 'nnr_gemm_f32')

@@ -118,7 +118,8 @@ def roofline(peak_tflops, sampled_steps=None, ms_per_step=None):
     ach = d['flops'] / (d['ms'] * 1e-3) / 1e12 if d['ms'] > 0 else 0.0
     return {
         'bound': 'mfma', 'achieved': round(ach, 3), 'peak': peak_tflops, 'unit': 'TFLOP/s', 'frac': round(ach / peak_tflops, 4),
-        'traffic': pmc_traffic(KERNEL_OF.get(name, name)), 'kernel': KERNEL_OF.get(name, name), 'launches': d['launches'],
+        'traffic': pmc_traffic(KERNEL_OF.get(name, name)), 'traffic_source': 'profiles/pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes '
+        'of this command on the same build (PMC cannot be collected inside the timed run), FETCH_SIZE x2 per the gfx950 note', 'kernel': KERNEL_OF.get(name, name), 'launches': d['launches'],
         'avg_launch_us': round(1000 * d['ms'] / max(1, d['launches']), 2),
         'share_of_instrumented_time': round(d['ms'] / total_ms, 3),
         'families': {k: {'ms': round(v['ms'], 3), 'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2) if v['ms'] > 0 else 0.0,
