@@ -95,6 +95,21 @@ int nnr_gemm_f32(const nnr_gemm_args* args, hipStream_t stream);
 int nnr_seq_plan(uint8_t* mask, const int* ids, int n, int L, const int* perm_in, int* len_out, int* order, int* rank, int* slen,
                  int* bs, int* off, int* row_seq, int* tok, int* prev_f, int* prev_r, hipStream_t stream);
 
+/* The candidate call and the history call of one training step (model.py:123-125: the same news encoder applied to
+ * [B, 1+neg] and to [B, max_history] news) planned as ONE packed token stream of n0 + n1 sequences, so that every per-token
+ * kernel of the step runs once over both calls.  Rows [0, n0) of every per-sequence array come from mask0 / ids0, rows
+ * [n0, n0+n1) from mask1 / ids1; both masks get the mask[:,0]=1 fix in place.  Other arguments as nnr_seq_plan. */
+int nnr_seq_plan_pair(uint8_t* mask0, const int* ids0, int n0, uint8_t* mask1, const int* ids1, int n1, int L, const int* perm_in,
+                      int* len_out, int* order, int* rank, int* slen, int* bs, int* off, int* row_seq, int* tok, int* prev_f,
+                      int* prev_r, hipStream_t stream);
+
+/* CNE's rank pairing (newsEncoders.py:112-115,128-129: the title sequence at sorted position r of a call is gated by the cell
+ * state of the CONTENT sequence at sorted position r of the same call, and vice versa) for two calls planned as one union
+ * stream: order_t / order_c = nnr_seq_plan_pair's `order` of the title / content stream; pm_t[s] = position in the content
+ * stream's union order of the partner of the title sequence at position s, pm_c[s] the reverse (pm_c = pm_t^-1).
+ * tmp: 4 * n ints of scratch. */
+int nnr_cne_pair_map(const int* order_t, const int* order_c, int n0, int n, int* pm_t, int* pm_c, int* tmp, hipStream_t stream);
+
 /* ------------------------------------------------------------------------------------------------ Bi-LSTM
  * Replaces nn.LSTM(bidirectional) on a PackedSequence (newsEncoders.py:66-67, 119-127) and its backward.
  * Gate columns are kept in "p-order": p = (unit/16)*64 + (unit%16)*4 + gate, padded to NP = ceil(H/16)*64 per direction. */

@@ -17,10 +17,11 @@ constexpr int MAX_L = 512;
 constexpr int MAX_SEG = 128;          // 64-item segments handled by the fast stable ranking (n <= 8192)
 
 // ---- A. one wave per row: mask[:,0] = 1 in place (newsEncoders.py:108-109), length = popcount(mask row)
-__global__ __launch_bounds__(256) void plan_len_kernel(uint8_t* __restrict__ mask, int n, int L, int* __restrict__ len_out) {
+__global__ __launch_bounds__(256) void plan_len_kernel(uint8_t* __restrict__ mask, uint8_t* __restrict__ mask1, int n0, int n, int L,
+                                                       int* __restrict__ len_out) {
   const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n) return;
-  uint8_t* row = mask + (long)i * L;
+  uint8_t* row = (i < n0) ? mask + (long)i * L : mask1 + (long)(i - n0) * L;      // rows >= n0: the second encoder call's tensor
   int c = 0;
   for (int t = lane; t < L; t += 64) c += (t == 0 || row[t]) ? 1 : 0;
   c = (int)wave_sum((float)c);
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void plan_rank_kernel(const int* __re
 }
 
 // ---- C. one thread per (sorted position s, time t): per-row maps of the packed layout
-__global__ void plan_rows_kernel(const int* __restrict__ ids, int n, int L, const int* __restrict__ order,
+__global__ void plan_rows_kernel(const int* __restrict__ ids, const int* __restrict__ ids1, int n0, int n, int L, const int* __restrict__ order,
                                  const int* __restrict__ slen, const int* __restrict__ off, int* __restrict__ row_seq,
                                  int* __restrict__ tok, int* __restrict__ prev_f, int* __restrict__ prev_r) {
   const long total = (long)n * L;
@@ -106,17 +107,73 @@ __global__ void plan_rows_kernel(const int* __restrict__ ids, int n, int L, cons
     if (t >= l) continue;
     const int row = off[t] + s;
     row_seq[row] = s;
-    if (tok) tok[row] = ids ? ids[(long)order[s] * L + t] : 0;
+    if (tok) {
+      const int i = order[s];
+      tok[row] = !ids ? 0 : (i < n0 ? ids[(long)i * L + t] : ids1[(long)(i - n0) * L + t]);
+    }
     prev_f[row] = (t > 0) ? off[t - 1] + s : -1;
     prev_r[row] = (t + 1 < l) ? off[t + 1] + s : -1;
   }
 }
 
+// ---- D. CNE rank pairing over a UNION of two encoder calls (newsEncoders.py:112-115,128-129 applied per call).  The reference
+// pairs the title stream's sorted position r with the content stream's sorted position r INSIDE one call.  With the candidate
+// call (rows [0, n0)) and the history call (rows [n0, n)) planned as one packed stream, "position inside the call" is the
+// number of same-call sequences in front in the union order (the union order restricted to a call IS that call's order).
+//   pm_t[s] = union position, in the content stream, of the partner of the title sequence at union position s; pm_c likewise.
+// One workgroup; tmp = 4 n ints.
+__global__ __launch_bounds__(PLAN_THREADS) void pair_map_kernel(const int* __restrict__ order_t, const int* __restrict__ order_c, int n0, int n,
+                                                                int* __restrict__ pm_t, int* __restrict__ pm_c, int* __restrict__ tmp) {
+  __shared__ int scan[2][PLAN_THREADS];
+  const int tid = threadIdx.x;
+  const int chunk = (n + PLAN_THREADS - 1) / PLAN_THREADS;
+  const int lo = min(n, tid * chunk), hi = min(n, lo + chunk);
+  int* key[2] = {tmp, tmp + n};                 // key_x[s] = slot of (call, position inside the call) of stream x's union position s
+  int* inv[2] = {tmp + 2 * (long)n, tmp + 3 * (long)n};   // inv_x[slot] = s
+  const int* order[2] = {order_t, order_c};
+  int c0[2] = {0, 0};
+  for (int x = 0; x < 2; ++x)
+    for (int s = lo; s < hi; ++s) c0[x] += order[x][s] < n0 ? 1 : 0;
+  scan[0][tid] = c0[0];
+  scan[1][tid] = c0[1];
+  __syncthreads();
+  for (int d = 1; d < PLAN_THREADS; d <<= 1) {  // inclusive Hillis-Steele scan of the per-thread counts
+    const int a = tid >= d ? scan[0][tid - d] : 0, b = tid >= d ? scan[1][tid - d] : 0;
+    __syncthreads();
+    scan[0][tid] += a;
+    scan[1][tid] += b;
+    __syncthreads();
+  }
+  for (int x = 0; x < 2; ++x) {
+    int before0 = scan[x][tid] - c0[x];         // call-0 sequences in front of this thread's chunk
+    for (int s = lo; s < hi; ++s) {
+      const bool first = order[x][s] < n0;
+      const int slot = first ? before0 : n0 + (s - before0);
+      before0 += first ? 1 : 0;
+      key[x][s] = slot;
+      inv[x][slot] = s;
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  for (int s = tid; s < n; s += PLAN_THREADS) {
+    pm_t[s] = inv[1][key[0][s]];
+    pm_c[s] = inv[0][key[1][s]];
+  }
+}
+
 }  // namespace
 
-extern "C" int nnr_seq_plan(uint8_t* mask, const int* ids, int n, int L, const int* perm_in, int* len_out, int* order,
-                            int* rank, int* slen, int* bs, int* off, int* row_seq, int* tok, int* prev_f, int* prev_r,
-                            hipStream_t stream) {
+extern "C" int nnr_cne_pair_map(const int* order_t, const int* order_c, int n0, int n, int* pm_t, int* pm_c, int* tmp, hipStream_t stream) {
+  if (!order_t || !order_c || !pm_t || !pm_c || !tmp || n <= 0 || n0 < 0 || n0 > n) return NNR_ERR_ARG;
+  hipLaunchKernelGGL(pair_map_kernel, dim3(1), dim3(PLAN_THREADS), 0, stream, order_t, order_c, n0, n, pm_t, pm_c, tmp);
+  NNR_CHECK_LAUNCH();
+  return NNR_OK;
+}
+
+static int seq_plan_impl(uint8_t* mask, const int* ids, int n0, uint8_t* mask1, const int* ids1, int n, int L, const int* perm_in, int* len_out,
+                         int* order, int* rank, int* slen, int* bs, int* off, int* row_seq, int* tok, int* prev_f, int* prev_r,
+                         hipStream_t stream) {
   if (!mask || n <= 0 || L <= 0 || L > MAX_L) return NNR_ERR_ARG;
   const int nseg = (n + 63) / 64;
   bool fast = !perm_in && nseg <= MAX_SEG;
@@ -125,7 +182,7 @@ extern "C" int nnr_seq_plan(uint8_t* mask, const int* ids, int n, int L, const i
     fast = false;
     shm = (size_t)(2 * (L + 1)) * sizeof(int);
   }
-  hipLaunchKernelGGL(plan_len_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, mask, n, L, len_out);
+  hipLaunchKernelGGL(plan_len_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, mask, mask1, n0, n, L, len_out);
   NNR_CHECK_LAUNCH();
   if (shm > 64 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(plan_rank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
@@ -134,7 +191,22 @@ extern "C" int nnr_seq_plan(uint8_t* mask, const int* ids, int n, int L, const i
   NNR_CHECK_LAUNCH();
   const long total = (long)n * L;
   const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
-  hipLaunchKernelGGL(plan_rows_kernel, dim3(blocks), dim3(256), 0, stream, ids, n, L, order, slen, off, row_seq, tok, prev_f, prev_r);
+  hipLaunchKernelGGL(plan_rows_kernel, dim3(blocks), dim3(256), 0, stream, ids, ids1, n0, n, L, order, slen, off, row_seq, tok, prev_f, prev_r);
   NNR_CHECK_LAUNCH();
   return NNR_OK;
+}
+
+extern "C" int nnr_seq_plan(uint8_t* mask, const int* ids, int n, int L, const int* perm_in, int* len_out, int* order,
+                            int* rank, int* slen, int* bs, int* off, int* row_seq, int* tok, int* prev_f, int* prev_r,
+                            hipStream_t stream) {
+  return seq_plan_impl(mask, ids, n, nullptr, nullptr, n, L, perm_in, len_out, order, rank, slen, bs, off, row_seq, tok, prev_f, prev_r, stream);
+}
+
+// Two encoder calls (candidates: n0 sequences, history: n1) planned as ONE packed stream of n0 + n1 sequences: rows [0, n0) of
+// every per-sequence array belong to the first call's tensors, rows [n0, n0 + n1) to the second's.
+extern "C" int nnr_seq_plan_pair(uint8_t* mask0, const int* ids0, int n0, uint8_t* mask1, const int* ids1, int n1, int L, const int* perm_in,
+                                 int* len_out, int* order, int* rank, int* slen, int* bs, int* off, int* row_seq, int* tok, int* prev_f,
+                                 int* prev_r, hipStream_t stream) {
+  if (!mask1 || n0 <= 0 || n1 <= 0 || (ids0 && !ids1)) return NNR_ERR_ARG;
+  return seq_plan_impl(mask0, ids0, n0, mask1, ids1, n0 + n1, L, perm_in, len_out, order, rank, slen, bs, off, row_seq, tok, prev_f, prev_r, stream);
 }

@@ -72,18 +72,31 @@ def _i32(t):
 
 # ================================================================================================== CNE
 class _CNEPairFunction(torch.autograd.Function):
-    """Candidate call + history call of the SAME encoder in lock-step (one recurrence launch forward, one backward)."""
+    """Candidate call + history call of the SAME encoder in one pass.  Default: both calls planned as ONE packed token stream
+    (cne union: every per-token kernel runs once over both calls; the rank pairing of newsEncoders.py:128-129 stays per call
+    through nnr_cne_pair_map).  NNR_CNE_UNION=0: two lock-step calls that only share the recurrence launches."""
 
     @staticmethod
     def forward(ctx, anchor, mod, *tensors):
+        ctx.mod = mod
+        if _CNE_UNION:
+            ((rep_a, rep_b), sv), = cne_forward_many(mod, [tuple(zip(tensors[:6], tensors[6:]))])
+            ctx.saved = (sv,)
+            return rep_a, rep_b
         (rep_a, sv_a), (rep_b, sv_b) = cne_forward_many(mod, [tensors[:6], tensors[6:]])
-        ctx.mod, ctx.saved = mod, (sv_a, sv_b)
+        ctx.saved = (sv_a, sv_b)
         return rep_a, rep_b
 
     @staticmethod
     def backward(ctx, drep_a, drep_b):
-        sv_a, sv_b = ctx.saved
-        cne_backward_many(ctx.mod, [(sv_a, drep_a.contiguous()), (sv_b, drep_b.contiguous())])
+        if len(ctx.saved) == 1:
+            sv, = ctx.saved
+            D = drep_a.shape[-1]
+            drep = torch.cat([drep_a.reshape(-1, D), drep_b.reshape(-1, D)])
+            cne_backward_many(ctx.mod, [(sv, drep)])
+        else:
+            sv_a, sv_b = ctx.saved
+            cne_backward_many(ctx.mod, [(sv_a, drep_a.contiguous()), (sv_b, drep_b.contiguous())])
         ctx.saved = None
         return (None,) * 14
 
@@ -110,6 +123,7 @@ def cne_forward(mod, title_text, title_mask, content_text, content_mask, categor
 
 
 _SIDE = {}
+_CNE_UNION = os.environ.get('NNR_CNE_UNION', '1') != '0'      # A/B switch: candidate + history call as one packed token stream
 
 
 def _side_stream(dev):
@@ -177,7 +191,7 @@ def cne_forward_many(mod, calls):
     launch over all streams of all calls (it is latency-bound by its longest sequence, not throughput-bound).  The per-call
     phases of the first (small) call run on a second HIP stream, filling the gaps of the big call's kernels."""
     H = mod.hidden_dim
-    dev = calls[0][0].device
+    dev = (calls[0][0][0] if isinstance(calls[0][0], tuple) else calls[0][0]).device
     mod._packed_weights('title', mod.title_lstm)        # (re)pack on the main stream BEFORE forking: both calls read them
     mod._packed_weights('content', mod.content_lstm)
     pre = _fork_join(len(calls), dev, lambda i, on_main: _cne_fwd_pre(mod, *calls[i], par=on_main))
@@ -187,10 +201,34 @@ def cne_forward_many(mod, calls):
     return _fork_join(len(calls), dev, lambda i, on_main: _cne_fwd_post(mod, pre[i], on_main))
 
 
+def _torch_tie_perm(masks):
+    """tie_order='torch': the installed torch's CPU sort decides the order of equal lengths, per call (as the reference's
+    torch.sort calls do); for a union of calls, any length-descending order that keeps each call's own order."""
+    perms, lens = [], []
+    base = 0
+    for m in masks:
+        l = (m.sum(dim=1).long() + (~m[:, 0]).long()).cpu()      # lengths after the mask[:,0]=1 fix
+        q = torch.sort(l, descending=True)[1]
+        perms.append(q + base)
+        lens.append(l[q])
+        base += m.shape[0]
+    if len(perms) == 1:
+        return perms[0].to(torch.int32)
+    q, l = torch.cat(perms), torch.cat(lens)
+    return q[torch.sort(l, descending=True, stable=True)[1]].to(torch.int32)
+
+
 def _cne_fwd_pre(mod, title_text, title_mask, content_text, content_mask, category, subCategory, par=False):
-    B, N = title_text.shape[:2]
-    n = B * N
-    dev = title_text.device
+    union = isinstance(title_text, tuple)            # (candidate call's tensor, history call's tensor) per argument
+    if union:
+        B, N = title_text[0].shape[:2]
+        n0 = B * N
+        n = n0 + B * title_text[1].shape[1]
+        dev = title_text[0].device
+    else:
+        B, N = title_text.shape[:2]
+        n = n0 = B * N
+        dev = title_text.device
     H, E, A = mod.hidden_dim, mod.word_embedding_dim, mod.attention_dim
     H2 = 2 * H
     f32 = dict(device=dev, dtype=torch.float32)
@@ -201,13 +239,11 @@ def _cne_fwd_pre(mod, title_text, title_mask, content_text, content_mask, catego
     streams = [None, None]
 
     def prepare(slot, name, ids, mask, Lx, lstm, Hlin, Mlin, satt, catt):
-        ids2 = _i32(ids).reshape(n, Lx).contiguous()
-        mask2 = mask.view(n, Lx)                        # a view: the in-place mask[:,0]=1 must reach the caller's tensor
-        perm = None
-        if mod.tie_order == 'torch':
-            lens = mask2.sum(dim=1).long() + (~mask2[:, 0]).long()      # lengths after the mask[:,0]=1 fix
-            perm = torch.sort(lens.cpu(), descending=True)[1].to(torch.int32).to(dev)
-        plan = ops.SeqPlan(mask2, ids2, perm)
+        parts = list(zip(ids, mask)) if union else [(ids, mask)]
+        ids2 = [_i32(i).reshape(-1, Lx).contiguous() for i, _ in parts]
+        mask2 = [m.view(-1, Lx) for _, m in parts]      # views: the in-place mask[:,0]=1 must reach the caller's tensors
+        perm = _torch_tie_perm(mask2).to(dev) if mod.tie_order == 'torch' else None
+        plan = ops.SeqPlan(mask2[0], ids2[0], perm, *((mask2[1], ids2[1]) if union else ()))
         w = mod._packed_weights(name, lstm)
         cap = plan.cap
         st = dict(name=name, L=Lx, plan=plan, w=w, lstm=lstm, Hlin=Hlin, Mlin=Mlin, satt=satt, catt=catt, seed=seed + _SITE[name])
@@ -229,7 +265,7 @@ def _cne_fwd_pre(mod, title_text, title_mask, content_text, content_mask, catego
                                 mod.title_self_attention, mod.title_cross_attention),
                 lambda: prepare(1, 'content', content_text, content_mask, mod.max_content_length, mod.content_lstm, mod.content_H,
                                 mod.content_M, mod.content_self_attention, mod.content_cross_attention))
-    return dict(streams=streams, n=n, B=B, N=N, p=p, seed=seed, category=category, subCategory=subCategory)
+    return dict(streams=streams, n=n, n0=n0, union=union, B=B, N=N, p=p, seed=seed, category=category, subCategory=subCategory)
 
 
 def _cne_fwd_post(mod, sv, par=False):
@@ -241,10 +277,14 @@ def _cne_fwd_post(mod, sv, par=False):
     D = mod.news_embedding_dim
     f32 = dict(device=dev, dtype=torch.float32)
 
+    # rank pairing (newsEncoders.py:128-129): inside ONE call the partner of sorted position r is the other stream's position r;
+    # in a union of two calls it is the other stream's position with the same (call, position inside the call)
+    t_['pm'], c_['pm'] = ops.cne_pair_map(t_['plan'], c_['plan']) if sv['union'] else (None, None)
+
     def gate_and_self(st, other):
         plan, cap = st['plan'], st['plan'].cap
         # title_M(sorted_content_m): both indexed by sorted RANK (newsEncoders.py:128-129)
-        st['mproj'] = ops.linear_fwd(other['cn'], st['Mlin'].weight, st['Mlin'].bias)
+        st['mproj'] = ops.linear_fwd(other['cn'], st['Mlin'].weight, st['Mlin'].bias, **({} if st['pm'] is None else {'a_idx': st['pm']}))
         st['G'] = torch.empty((cap, H2), **f32)
         st['Ht'] = torch.empty((cap, H2), **f32)
         ops.gemm(st['hout'], st['Hlin'].weight, st['Ht'], M=cap, N=H2, K=H2, lda=H2, ldb=H2, ldc=H2, dyn=plan.total, dyn_dim=1,
@@ -275,14 +315,21 @@ def _cne_fwd_post(mod, sv, par=False):
                      alpha=st['alpha_c'], out=rep[:, col0:], ldo=D, add_in=st['selfv'], ldadd=H2)
 
     _two_chains(dev, par, lambda: cross(t_, c_, 0), lambda: cross(c_, t_, H2))
-    cat = _i32(sv.pop('category')).reshape(n).contiguous()
-    sub = _i32(sv.pop('subCategory')).reshape(n).contiguous()
+    if sv['union']:
+        cat = torch.cat([_i32(x).reshape(-1) for x in sv.pop('category')])
+        sub = torch.cat([_i32(x).reshape(-1) for x in sv.pop('subCategory')])
+    else:
+        cat = _i32(sv.pop('category')).reshape(n).contiguous()
+        sub = _i32(sv.pop('subCategory')).reshape(n).contiguous()
     cd, sd = mod.category_embedding.weight.shape[1], mod.subCategory_embedding.weight.shape[1]
     ops.small_embed_fwd(mod.category_embedding.weight, cat, rep[:, 2 * H2:], D, p, seed + _SITE['cat'])
     ops.small_embed_fwd(mod.subCategory_embedding.weight, sub, rep[:, 2 * H2 + cd:], D, p, seed + _SITE['sub'])
     sv.update(cat=cat, sub=sub, cd=cd, sd=sd)
     for st in sv['streams']:                             # not needed by backward
         st.pop('score'); st.pop('mproj')
+    if sv['union']:
+        n0 = sv['n0']
+        return (rep[:n0].view(B, N, D), rep[n0:].view(B, (n - n0) // B, D)), sv
     return rep.view(B, N, D), sv
 
 
@@ -371,8 +418,10 @@ def _cne_bwd_pre(mod, sv, drep, par=False, leaf=None):
         leaf(lambda: ops.linear_bwd_weight(dpre, st['hout'], grad_of(st['Hlin'].weight), dyn=plan.total), dpre, st['hout'])
         dP = torch.empty((n, H2), **f32)                  # d mproj[rank]
         ops.packed_seq_sum(dpre, H2, plan, dP)
-        leaf(lambda: (ops.linear_bwd_weight(dP, other['cn'], grad_of(st['Mlin'].weight)), ops.bias_grad(dP, grad_of(st['Mlin'].bias))), dP)
-        other['dcn'] = ops.linear_bwd_data(dP, st['Mlin'].weight)                             # [n, H2], rank-indexed
+        pm, opm = st['pm'], other['pm']                   # union of two calls: mproj[s] = M(cn_other[pm[s]])  (pm^-1 = other's pm)
+        leaf(lambda: (ops.linear_bwd_weight(dP, other['cn'], grad_of(st['Mlin'].weight), **({} if pm is None else {'b_idx': pm})),
+                      ops.bias_grad(dP, grad_of(st['Mlin'].bias))), dP)
+        other['dcn'] = ops.linear_bwd_data(dP, st['Mlin'].weight, **({} if opm is None else {'a_idx': opm}))   # [n, H2], rank-indexed
         st['dHt'] = None
 
     _two_chains(dev, par, lambda: self_gate_bwd(t_, c_, 0), lambda: self_gate_bwd(c_, t_, H2))

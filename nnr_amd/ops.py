@@ -407,12 +407,14 @@ def bias_grad(dy, db, dyn=None, rows=None):
 
 # ---------------------------------------------------------------------------------------------- planner / LSTM
 class SeqPlan:
-    """Device-resident plan of one token stream (see csrc/seq_plan.hip)."""
+    """Device-resident plan of one token stream (see csrc/seq_plan.hip).  With mask1 / ids1 given the stream is the UNION of two
+    encoder calls: sequences [0, n0) from (mask, ids), [n0, n0 + n1) from (mask1, ids1)."""
 
-    def __init__(self, mask, ids, perm=None):
-        n, Lx = mask.shape
+    def __init__(self, mask, ids, perm=None, mask1=None, ids1=None):
+        n0, Lx = mask.shape
+        n = n0 + (mask1.shape[0] if mask1 is not None else 0)
         dev = mask.device
-        self.n, self.L = n, Lx
+        self.n, self.L, self.n0 = n, Lx, n0
         i32 = dict(device=dev, dtype=torch.int32)
         self.len = torch.empty(n, **i32)
         self.order = torch.empty(n, **i32)
@@ -428,9 +430,25 @@ class SeqPlan:
         self.cap = n * Lx
         m8 = mask.view(torch.uint8) if mask.dtype == torch.bool else mask
         assert m8.is_contiguous() and (ids is None or (ids.is_contiguous() and ids.dtype == torch.int32))
-        L.check(L.lib().nnr_seq_plan(_p(m8), _p(ids), n, Lx, _p(perm), _p(self.len), _p(self.order), _p(self.rank), _p(self.slen),
-                                     _p(self.bs), _p(self.off), _p(self.row_seq), _p(self.tok), _p(self.prev_f), _p(self.prev_r),
-                                     _s()), 'nnr_seq_plan')
+        outs = (_p(self.len), _p(self.order), _p(self.rank), _p(self.slen), _p(self.bs), _p(self.off), _p(self.row_seq), _p(self.tok),
+                _p(self.prev_f), _p(self.prev_r), _s())
+        if mask1 is None:
+            L.check(L.lib().nnr_seq_plan(_p(m8), _p(ids), n, Lx, _p(perm), *outs), 'nnr_seq_plan')
+        else:
+            m81 = mask1.view(torch.uint8) if mask1.dtype == torch.bool else mask1
+            assert m81.is_contiguous() and m81.shape[1] == Lx and (ids is None) == (ids1 is None)
+            assert ids1 is None or (ids1.is_contiguous() and ids1.dtype == torch.int32)
+            L.check(L.lib().nnr_seq_plan_pair(_p(m8), _p(ids), n0, _p(m81), _p(ids1), n - n0, Lx, _p(perm), *outs), 'nnr_seq_plan_pair')
+
+
+def cne_pair_map(plan_t, plan_c):
+    """(pm_t, pm_c): per-call rank pairing of two union plans (csrc/seq_plan.hip, section D)."""
+    n, n0 = plan_t.n, plan_t.n0
+    assert plan_c.n == n and plan_c.n0 == n0
+    buf = torch.empty(6 * n, device=plan_t.order.device, dtype=torch.int32)
+    pm_t, pm_c = buf[:n], buf[n:2 * n]
+    L.check(L.lib().nnr_cne_pair_map(_p(plan_t.order), _p(plan_c.order), n0, n, _p(pm_t), _p(pm_c), _p(buf[2 * n:]), _s()), 'nnr_cne_pair_map')
+    return pm_t, pm_c
 
 
 def lstm_dims(H):

@@ -288,6 +288,42 @@ def test_seq_plan_matches_stable_sort():
     assert torch.equal(plan2.order.cpu(), perm)
 
 
+@pytest.mark.parametrize('n0,n1', [(37, 203), (320, 3200), (5, 1)])
+def test_seq_plan_pair_and_per_call_rank_pairing(n0, n1):
+    """Two encoder calls planned as one packed stream: the union plan equals the plan of the concatenated inputs, both masks
+    get the mask[:,0]=1 fix, and nnr_cne_pair_map pairs title position r of a call with content position r of the SAME call
+    (newsEncoders.py:112-115,128-129 applied per call)."""
+    from nnr_amd import ops
+    n = n0 + n1
+    Lt, Lc = 12, 40
+    lt, lc = _lengths(n, Lt, 11), _lengths(n, Lc, 12)
+    mt = torch.arange(Lt)[None, :] < lt[:, None]
+    mt[3] = False
+    lt[3] = 1
+    ids = torch.randint(2, 1000, (n, Lt), generator=torch.Generator().manual_seed(13)).int() * mt.int()
+    m0, m1 = mt[:n0].clone().to(dev()), mt[n0:].clone().to(dev())
+    plan_t = ops.SeqPlan(m0, ids[:n0].contiguous().to(dev()), None, m1, ids[n0:].contiguous().to(dev()))
+    ref = ops.SeqPlan(mt.clone().to(dev()), ids.to(dev()))
+    for k in ('len', 'order', 'rank', 'slen', 'bs', 'off'):
+        assert torch.equal(getattr(plan_t, k), getattr(ref, k)), k
+    tot = int(plan_t.off[-1])
+    for k in ('row_seq', 'tok', 'prev_f', 'prev_r'):
+        assert torch.equal(getattr(plan_t, k)[:tot], getattr(ref, k)[:tot]), k
+    assert bool(m0[3, 0]) and int(m0.sum()) + int(m1.sum()) == int(lt.sum())
+    mc = torch.arange(Lc)[None, :] < lc[:, None]
+    plan_c = ops.SeqPlan(mc[:n0].clone().to(dev()), None, None, mc[n0:].clone().to(dev()), None)
+    pm_t, pm_c = [x.cpu().long() for x in ops.cne_pair_map(plan_t, plan_c)]
+    # expected: per call, stable descending order of each stream; partner of title position r = content position r
+    rank_t, rank_c = plan_t.rank.cpu().long(), plan_c.rank.cpu().long()
+    exp_t = torch.empty(n, dtype=torch.long)
+    for lo, hi in ((0, n0), (n0, n)):
+        ot = torch.argsort(lt[lo:hi], descending=True, stable=True) + lo
+        oc = torch.argsort(lc[lo:hi], descending=True, stable=True) + lo
+        exp_t[rank_t[ot]] = rank_c[oc]
+    assert torch.equal(pm_t, exp_t)
+    assert torch.equal(pm_c[pm_t], torch.arange(n))
+
+
 def test_seq_plan_long_sequences_take_the_small_lds_path():
     """L = 512 with n near 8 192: the fast ranking's per-segment histograms (128 x 513 ints = 263 KB) exceed the 160 KB of LDS; the
     planner must fall back to the ranking that needs 2 * (L + 1) ints instead of refusing the call (ADVICE, round 1)."""
