@@ -242,7 +242,7 @@ __global__ __launch_bounds__((UB > 4 ? 16 : 4) * 64) void lstm_fwd_kernel(LstmAr
 
 
 // ------------------------------------------------------------------------------------------------ forward, 2 CUs per tile
-// Weights-stationary variant: a tile's gate columns are split over a PAIR of workgroups (pair_tile / pair_half) on two CUs
+// Weights-stationary variant: a tile's gate columns are split over a PAIR of workgroups (pair_id / pair_half) on two CUs
 // of one XCD.  Half 0 owns unit blocks [0, UB0), half 1 owns [UB0, UB).  Each of a workgroup's compute waves keeps the W_hh
 // fragments of its unit block RESIDENT for the whole sequence -- 3 gates in registers (3*KG f32x4 = 156 VGPRs at H = 200),
 // the 4th in LDS -- so nothing is streamed from L2 inside the time loop (the one-CU kernel re-reads 640 KB per step), and
@@ -254,18 +254,28 @@ __global__ __launch_bounds__((UB > 4 ? 16 : 4) * 64) void lstm_fwd_kernel(LstmAr
 // spin loops are bounded anyway.
 // Pairing: workgroups x and x + 8 of a dispatch share an XCD (round-robin placement), so within every group of 16
 // consecutive workgroups the first 8 are halves 0 and the next 8 the matching halves 1 of 8 tiles.
-__device__ __forceinline__ int pair_tile(int bx) { return (bx >> 4) * 8 + (bx & 7); }
+// Dispatch order = longest first over ALL token streams and directions (LPT): the 1-D grid walks groups of 16 workgroups
+// (8 tiles x 2 halves); group G holds tiles [8g, 8g + 8) of stream (problem, direction) = G % (2 nprob), g = G / (2 nprob).  (A
+// (tiles, direction, problem) grid dispatched every tile of direction 0 before the 128-step tiles of direction 1 got a CU:
+// 1.19 ms for a 1.0 ms chain.)
 __device__ __forceinline__ int pair_half(int bx) { return (bx >> 3) & 1; }
+struct PairId { int prob, d, tile; };
+__device__ __forceinline__ PairId pair_id(int nprob) {
+  const int bx = blockIdx.x, G = bx >> 4, per = 2 * nprob;
+  const int g = G / per, rem = G - g * per;
+  return PairId{rem >> 1, rem & 1, g * 8 + (bx & 7)};
+}
 
 template <int UB, int hv>
 __device__ __forceinline__ void lstm_fwd_pair_body(const LstmArgs& a, float (*hbuf)[16 * UB * 16], f32x4 (*wl)[UB][64]) {
   constexpr int HP = UB * 16, NP = UB * 64, KG = UB, UB0 = (UB + 1) / 2, NW = 8, NT = NW * 64;
-  const LstmProblem& P = a.p[blockIdx.z];
+  const PairId id = pair_id(a.nprob);
+  const LstmProblem& P = a.p[id.prob];
   const int H = a.H;
-  const int tile = pair_tile(blockIdx.x);
+  const int tile = id.tile;
   const int s0 = tile * 16;
   if (s0 >= P.n) return;
-  const int d = blockIdx.y;
+  const int d = id.d;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, kk = lane >> 4;
   constexpr int ub_lo = hv ? UB0 : 0, nb = hv ? UB - UB0 : UB0;
   const int tmax = P.slen[s0];
@@ -287,7 +297,7 @@ __device__ __forceinline__ void lstm_fwd_pair_body(const LstmArgs& a, float (*hb
   __syncthreads();
   for (int i = tid; i < 2 * 16 * HP; i += NT) (&hbuf[0][0])[i] = 0.f;
   unsigned long long* tbuf = reinterpret_cast<unsigned long long*>(diag + SYNC_PAD);
-  const bool stamp = (a.dbg & 32) && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0;
+  const bool stamp = (a.dbg & 32) && blockIdx.x == 0 && tid == 0;
 #define STAMP(slot) do { if (stamp && step < 128) tbuf[step * 16 + (slot)] = wall_clock64(); } while (0)
 
   // the partner's REAL units (its padded ones stay 0 in LDS)
@@ -617,12 +627,13 @@ __device__ __forceinline__ void lstm_bwd_pair_body(const LstmArgs& a, float* dg,
   constexpr int KR = KO / 2, KL = KO - KR;                               // partner-tile fragments in registers / in LDS
   constexpr int DLD = nb * 64 + 16;                                      // row stride = 4 (mod 16) 16-byte chunks (swizzle)
   static_assert((DLD / 4) % 16 == 4, "dgates tile stride must keep the ds_read_b128 swizzle conflict-free");
-  const LstmProblem& P = a.p[blockIdx.z];
+  const PairId id = pair_id(a.nprob);
+  const LstmProblem& P = a.p[id.prob];
   const int H = a.H;
-  const int tile = pair_tile(blockIdx.x);
+  const int tile = id.tile;
   const int s0 = tile * 16;
   if (s0 >= P.n) return;
-  const int d = blockIdx.y;
+  const int d = id.d;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, kk = lane >> 4;
   const int tmax = P.slen[s0];
   const int ntiles = (P.n + 15) >> 4;
@@ -641,7 +652,7 @@ __device__ __forceinline__ void lstm_bwd_pair_body(const LstmArgs& a, float* dg,
   __syncthreads();
 
   unsigned long long* tbuf = reinterpret_cast<unsigned long long*>(diag + SYNC_PAD);
-  const bool stamp = (a.dbg & 32) && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0;
+  const bool stamp = (a.dbg & 32) && blockIdx.x == 0 && tid == 0;
 #define STAMP(slot) do { if (stamp && step < 128) tbuf[step * 16 + (slot)] = wall_clock64(); } while (0)
   const bool own = w < nb;                               // this wave owns unit block ub_lo + w (gate gradients + own output tile)
   const bool par = w < npb;                              // ... and computes the partner's output tile pb_lo + w
@@ -891,7 +902,7 @@ __global__ void lstm_unpack_kernel(float* __restrict__ dw_ihp, float* __restrict
 
 template <int UB>
 int launch_pair(const LstmArgs& a, bool backward, int max_tiles, hipStream_t s) {
-  dim3 grid(((max_tiles + 7) / 8) * 16, 2, a.nprob), block(512);       // groups of 8 tiles x 2 halves (pair_tile / pair_half)
+  dim3 grid(((max_tiles + 7) / 8) * 16 * 2 * a.nprob), block(512);     // groups of 8 tiles x 2 halves, see pair_id()
   if (backward) hipLaunchKernelGGL((lstm_bwd_pair_kernel<UB>), grid, block, 0, s, a);
   else hipLaunchKernelGGL((lstm_fwd_pair_kernel<UB>), grid, block, 0, s, a);
   NNR_CHECK_LAUNCH();

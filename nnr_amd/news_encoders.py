@@ -123,6 +123,7 @@ def cne_forward(mod, title_text, title_mask, content_text, content_mask, categor
 
 
 _SIDE = {}
+_BWD_SPLIT = os.environ.get('NNR_LSTM_BWD_SPLIT', '1') == '1'      # batch 8: 4.68 (split) vs 4.93 ms; batch 64: no difference
 _CNE_UNION = os.environ.get('NNR_CNE_UNION', '1') != '0'      # A/B switch: candidate + history call as one packed token stream
 
 
@@ -350,20 +351,31 @@ def cne_backward_many(mod, pairs):
 def _cne_bwd_rest(mod, pairs, H, dev, leaf):
     _fork_join(len(pairs), dev, lambda i, on_main: _cne_bwd_pre(mod, pairs[i][0], pairs[i][1], on_main, leaf))
 
-    # recurrence backward + token-reduction GEMMs, per token stream kind: the content recurrence is one long dependent chain
-    # (128 steps) that leaves most CUs idle in its tail; the title recurrence (32 steps) and the title GEMMs run on the side
-    # stream and fill them.  All parameter-gradient accumulation below is atomic.
-    def run_kind(kind):
-        ops.lstm_bwd([sv['streams'][kind] for sv, _ in pairs], H)
-        for sv, _ in pairs:
-            _cne_bwd_post(mod, sv, sv['streams'][kind], leaf if kind == 1 else None)
-
+    # recurrence backward: ONE launch over every token stream (longest tiles of all streams first, lstm.hip pair_id), then the
+    # token-reduction GEMMs per stream kind -- the title streams' on the side stream next to the content streams'.  All
+    # parameter-gradient accumulation below is atomic.  NNR_LSTM_BWD_SPLIT=1: one launch per stream kind on two HIP streams
+    # (round 1's layout: the title recurrence then queues behind the content stream's GEMMs for CUs).
     main = torch.cuda.current_stream(dev)
     side = _side_stream(dev)
+    if _BWD_SPLIT:
+        def run_kind(kind):
+            ops.lstm_bwd([sv['streams'][kind] for sv, _ in pairs], H)
+            for sv, _ in pairs:
+                _cne_bwd_post(mod, sv, sv['streams'][kind], leaf if kind == 1 else None)
+
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            run_kind(0)
+        run_kind(1)
+        main.wait_stream(side)
+        return
+    ops.lstm_bwd([sv['streams'][1] for sv, _ in pairs] + [sv['streams'][0] for sv, _ in pairs], H)
     side.wait_stream(main)
     with torch.cuda.stream(side):
-        run_kind(0)
-    run_kind(1)
+        for sv, _ in pairs:
+            _cne_bwd_post(mod, sv, sv['streams'][0], None)
+    for sv, _ in pairs:
+        _cne_bwd_post(mod, sv, sv['streams'][1], leaf)
     main.wait_stream(side)
 
 
