@@ -110,7 +110,7 @@ __device__ __forceinline__ float wait_tag(const unsigned long long* p, unsigned 
   return __uint_as_float((unsigned)v);
 }
 
-struct LstmArgs { LstmProblem p[4]; int nprob; int H; int dbg; unsigned* tmo_total; };   // dbg: timing-attribution mask (NNR_LSTM_DBG), 0 in production
+struct LstmArgs { LstmProblem p[4]; int nprob; int H; int dbg; unsigned* tmo_total; int quad_T; };   // dbg: timing-attribution mask (NNR_LSTM_DBG), 0 in production
 
 // ------------------------------------------------------------------------------------------------ forward
 template <int UB>
@@ -266,20 +266,43 @@ __device__ __forceinline__ PairId pair_id(int nprob) {
   return PairId{rem >> 1, rem & 1, g * 8 + (bx & 7)};
 }
 
+// QUAD tiles.  A tile's chain of dependent steps is bound by the MFMA work of a step (5.6 of 8.6 us with 16 rows), and the launch by
+// its longest chain (128 steps), not by throughput.  Sequences longer than quad_T steps are therefore run in tiles of FOUR rows on
+// v_mfma_f32_4x4x1_16B_f32 (16 blocks of 4 rows x 4 columns x 1 k per instruction, same FLOP rate, a quarter of the work per
+// step: tools/micro/mfma4.hip checks the operand layout and the 8.6-clock issue rate): ~3 us per step instead of 8.6 / 9.8.
+// Sorted positions [0, 4 nq) are quad tiles (nq from the plan's batch sizes, on the device: bs[T] sequences are longer than T),
+// positions from 4 nq on are 16-row tiles.  Tile ids: quads 0 .. nq-1 (dispatched first: longest), 16-row tiles nq + j.
+constexpr int MAXQ = 64;
+__device__ __forceinline__ int quad_count(const LstmArgs& a, const LstmProblem& P) {
+  const int T = a.quad_T;
+  if (T <= 0 || T >= P.L) return 0;
+  return min((P.bs[T] + 3) >> 2, MAXQ);
+}
+__host__ __device__ inline int sync_tiles(int n) { return (n + 15) / 16 + MAXQ; }     // exchange slots per (stream, direction)
+#define MFMA4_BCAST(a, b, c, abid) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 4, (abid), 0)   /* A of block `abid` for all 16 blocks */
+#define MFMA4_OWN(a, b, c) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 0, 0, 0)                /* every block its own A */
+__device__ __forceinline__ float quad_bcast(float v, int g) {     // value of lane (quad, g) in all four lanes of the quad
+  const int x = __float_as_int(v);
+  int r;
+  switch (g) {
+    case 0: r = __builtin_amdgcn_mov_dpp(x, 0x00, 0xf, 0xf, true); break;
+    case 1: r = __builtin_amdgcn_mov_dpp(x, 0x55, 0xf, 0xf, true); break;
+    case 2: r = __builtin_amdgcn_mov_dpp(x, 0xaa, 0xf, 0xf, true); break;
+    default: r = __builtin_amdgcn_mov_dpp(x, 0xff, 0xf, 0xf, true); break;
+  }
+  return __int_as_float(r);
+}
+
 template <int UB, int hv>
-__device__ __forceinline__ void lstm_fwd_pair_body(const LstmArgs& a, float (*hbuf)[16 * UB * 16], f32x4 (*wl)[UB][64]) {
+__device__ __forceinline__ void lstm_fwd_pair_body(const LstmArgs& a, const LstmProblem& P, const int d, const int tile, const int s0,
+                                                   float (*hbuf)[16 * UB * 16], f32x4 (*wl)[UB][64]) {
   constexpr int HP = UB * 16, NP = UB * 64, KG = UB, UB0 = (UB + 1) / 2, NW = 8, NT = NW * 64;
-  const PairId id = pair_id(a.nprob);
-  const LstmProblem& P = a.p[id.prob];
   const int H = a.H;
-  const int tile = id.tile;
-  const int s0 = tile * 16;
   if (s0 >= P.n) return;
-  const int d = id.d;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, kk = lane >> 4;
   constexpr int ub_lo = hv ? UB0 : 0, nb = hv ? UB - UB0 : UB0;
   const int tmax = P.slen[s0];
-  const int ntiles = (P.n + 15) >> 4;
+  const int ntiles = sync_tiles(P.n);
   // exchange slots: [d][tile][half][step parity][16 rows][XW] tagged words, written by `half`, read by its partner
   constexpr int XW = UB0 * 16, XT = 16 * XW, XS = 2 * XT + 8;        // + one line for the placement handshake
   unsigned long long* xmine = reinterpret_cast<unsigned long long*>(P.sync) + ((long)(d * ntiles + tile) * 2 + hv) * XS;
@@ -456,13 +479,152 @@ __device__ __forceinline__ void lstm_fwd_pair_body(const LstmArgs& a, float (*hb
   }
 }
 
+// ---- forward, quad tile (4 sequences) on a CU pair.  Same split of the unit blocks, same exchange slots (rows 0..3 of a
+// 16-row slot) as the 16-row body.  A compute wave owns the 64 gate columns of its unit block, one column per lane
+// (lane = 4 * unit + gate): per k one v_mfma_f32_4x4x1 with h_{t-1}[4 rows][k] broadcast from one block (ABID) -- a single
+// ds_read_b32 of the k-major h tile (hq[k][row]) feeds 16 instructions.  W_hh: 156 of the 208 k in registers, 52 in LDS
+// (the budget of the 16-row body).  After the MFMAs a lane holds ONE gate of four rows; a 4 x 4 transpose inside each quad of
+// lanes (DPP) gives lane (unit, row) the four gates of its (row, unit): the cell update stays lane-local, one cell per lane.
+template <int UB, int hv>
+__device__ __forceinline__ void lstm_fwd_quad_body(const LstmArgs& a, const LstmProblem& P, const int d, const int q, float* hq, float* wlq) {
+  constexpr int HP = UB * 16, NP = UB * 64, KG = UB, UB0 = (UB + 1) / 2, NT = 512;
+  constexpr int RK = 12 * KG, QL = HP - RK;              // k < RK: W_hh column in registers; the rest in LDS
+  static_assert(QL * 64 * 4 * UB0 <= (int)sizeof(f32x4) * UB0 * UB * 64, "quad weights must fit the 16-row body's LDS array");
+  const int H = a.H;
+  const int s0 = q * 4;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int ub_lo = hv ? UB0 : 0, nb = hv ? UB - UB0 : UB0;
+  const int tmax = P.slen[s0];
+  __builtin_amdgcn_s_setprio(3);
+  const int ntl = sync_tiles(P.n);
+  constexpr int XW = UB0 * 16, XT = 16 * XW, XS = 2 * XT + 8;
+  unsigned long long* xmine = reinterpret_cast<unsigned long long*>(P.sync) + ((long)(d * ntl + q) * 2 + hv) * XS;
+  const unsigned long long* xtheirs = reinterpret_cast<const unsigned long long*>(P.sync) + ((long)(d * ntl + q) * 2 + (hv ^ 1)) * XS;
+  unsigned* diag = P.sync + (long)2 * ntl * 2 * XS * 2;
+  if (tid == 0) {
+    const unsigned mine = xcc_id();
+    st_tag(xmine + 2 * XT, __uint_as_float(mine), 0x7fffffffu, false);
+    const float theirs = wait_tag(xtheirs + 2 * XT, ld_tag(xtheirs + 2 * XT, false), 0x7fffffffu, false, diag, a.tmo_total);
+    hq[0] = (__float_as_uint(theirs) == mine && !(a.dbg & 64)) ? 1.f : 0.f;
+  }
+  __syncthreads();
+  const bool same_xcd = __builtin_amdgcn_readfirstlane(hq[0] != 0.f);
+  __syncthreads();
+  for (int i = tid; i < 2 * HP * 4; i += NT) hq[i] = 0.f;
+  const int pu0 = hv ? 0 : UB0 * 16, pw = (hv ? UB0 * 16 : H) - pu0;     // the partner's real units
+  const bool compute = w < nb;
+  const int ub = ub_lo + (compute ? w : 0);
+  const int u = lane >> 2, j = lane & 3;                  // MFMA: column (unit u, gate j); cell update: (row j, unit u)
+  const int unit = ub * 16 + u;
+  const int ldg = 2 * NP, ldc = 2 * HP, ldh = 2 * H;
+  float wr[RK];
+  {
+    // wf[d][ub][gate][kg][lane' = unit + 16 * ((k >> 2) & 3)][k & 3] (lstm_pack_kernel's fragment layout of the 16-row kernels)
+    const float* wf = P.wfrag + (((long)(d * UB + ub) * 4 + j) * KG) * 256 + u * 4;
+#pragma unroll
+    for (int k = 0; k < RK; ++k) wr[k] = wf[(k >> 4) * 256 + ((k >> 2) & 3) * 64 + (k & 3)];
+    if (compute) {
+#pragma unroll 4
+      for (int k = RK; k < HP; ++k) wlq[((long)w * QL + (k - RK)) * 64 + lane] = wf[(k >> 4) * 256 + ((k >> 2) & 3) * 64 + (k & 3)];
+    }
+  }
+  float c = 0.f;
+  __syncthreads();
+
+  for (int step = 0; step < tmax; ++step) {
+    const int t = d ? (tmax - 1 - step) : step;
+    const int nact = min(4, P.bs[t] - s0);
+    const long row0 = (long)P.off[t] + s0;
+    const float* hc = hq + (step & 1) * (HP * 4);
+    float* hcw = hq + (step & 1) * (HP * 4);
+    float* hn = hq + ((step & 1) ^ 1) * (HP * 4);
+    f32x4 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int tp = d ? t + 1 : t - 1;
+    const int nprev = step > 0 ? min(4, P.bs[tp] - s0) : 0;
+    const unsigned long long* src = xtheirs + ((step + 1) & 1) * XT;
+    f32x4 x = {0.f, 0.f, 0.f, 0.f};
+    if (compute && j < nact) x = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(P.gates + (row0 + j) * ldg + d * NP + ub * 64 + u * 4));
+    auto kgroup = [&](int kg) __attribute__((always_inline)) {
+      const float av = hc[kg * 64 + lane];              // lane (block b, row i): h[row i][k = 16 kg + b]
+#define QSTEP(jj) { const int k = kg * 16 + jj; \
+        const float bw = k < RK ? wr[k < RK ? k : 0] : wlq[((long)w * QL + (k >= RK ? k - RK : 0)) * 64 + lane]; \
+        acc[jj & 3] = MFMA4_BCAST(av, bw, acc[jj & 3], jj); }
+      QSTEP(0) QSTEP(1) QSTEP(2) QSTEP(3) QSTEP(4) QSTEP(5) QSTEP(6) QSTEP(7) QSTEP(8) QSTEP(9) QSTEP(10) QSTEP(11) QSTEP(12) QSTEP(13) QSTEP(14) QSTEP(15)
+#undef QSTEP
+    };
+    constexpr int KSPLIT = 4;                             // own k-groups before the partner's words are requested
+    if (compute) {
+#pragma unroll
+      for (int kg = 0; kg < KG; ++kg) {
+        const int own = kg - (hv ? UB0 : 0);
+        if ((kg < UB0) == (hv == 0) && own < KSPLIT) kgroup(kg);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned long long v = 0;
+    const int frow = tid / XW, fcc = tid - frow * XW;
+    const bool fetch = frow < nprev && fcc < pw;          // (4 rows x XW words <= 512 threads)
+    if (fetch) v = ld_tag_first(src + tid, same_xcd);
+    __builtin_amdgcn_sched_barrier(0);
+    if (compute) {
+#pragma unroll
+      for (int kg = 0; kg < KG; ++kg) {
+        const int own = kg - (hv ? UB0 : 0);
+        if ((kg < UB0) == (hv == 0) && own >= KSPLIT) kgroup(kg);
+      }
+    }
+    if (fetch) hcw[(pu0 + fcc) * 4 + frow] = wait_tag(src + tid, v, (unsigned)step, same_xcd, diag, a.tmo_total);
+    __syncthreads();                                      // the partner's half of h_{t-1} is in LDS
+    if (compute) {
+#pragma unroll
+      for (int kg = 0; kg < KG; ++kg)
+        if ((kg < UB0) != (hv == 0)) kgroup(kg);
+      const f32x4 sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);      // rows 0..3 of column (unit u, gate j)
+      // lane (u, j) needs gate g of row j: element j of lane (u, g)
+      float gate[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float b0 = quad_bcast(sum[0], g), b1 = quad_bcast(sum[1], g), b2 = quad_bcast(sum[2], g), b3 = quad_bcast(sum[3], g);
+        gate[g] = j == 0 ? b0 : (j == 1 ? b1 : (j == 2 ? b2 : b3));
+      }
+      const float gi = fast_sigmoid(gate[0] + x[0]);
+      const float gf = fast_sigmoid(gate[1] + x[1]);
+      const float gg = fast_tanh(gate[2] + x[2]);
+      const float go = fast_sigmoid(gate[3] + x[3]);
+      const float cn = gf * c + gi * gg;
+      const float hval = go * fast_tanh(cn);
+      if (j < nact) {
+        if (unit < H) st_tag(xmine + (step & 1) * XT + j * XW + (unit - ub_lo * 16), hval, (unsigned)(step + 1), same_xcd);
+        c = cn;
+        hn[unit * 4 + j] = hval;
+        if (unit < H) P.hout[(row0 + j) * ldh + d * H + unit] = hval;
+        *reinterpret_cast<f32x4*>(P.gates + (row0 + j) * ldg + d * NP + ub * 64 + u * 4) = f32x4{gi, gf, gg, go};
+        P.cell[(row0 + j) * ldc + d * HP + unit] = cn;
+      }
+    }
+    __syncthreads();
+  }
+  if (compute && unit < H && s0 + j < P.n) P.cn[(long)(s0 + j) * ldh + d * H + unit] = c;
+}
+
 template <int UB>
 __global__ __launch_bounds__(512) void lstm_fwd_pair_kernel(LstmArgs a) {
   // the two halves are separate instantiations: every K-range loop is static, so the LDS operand reads software-pipeline
   __shared__ __attribute__((aligned(16))) float hbuf[2][16 * UB * 16];
   __shared__ f32x4 wl[(UB + 1) / 2][UB][64];             // gate 3 ("o") fragments of every compute wave
-  if (pair_half(blockIdx.x)) lstm_fwd_pair_body<UB, 1>(a, hbuf, wl);
-  else lstm_fwd_pair_body<UB, 0>(a, hbuf, wl);
+  const PairId id = pair_id(a.nprob);
+  const LstmProblem& P = a.p[id.prob];
+  const int nq = quad_count(a, P);
+  if (id.tile < nq) {
+    if (pair_half(blockIdx.x)) lstm_fwd_quad_body<UB, 1>(a, P, id.d, id.tile, &hbuf[0][0], reinterpret_cast<float*>(&wl[0][0][0]));
+    else lstm_fwd_quad_body<UB, 0>(a, P, id.d, id.tile, &hbuf[0][0], reinterpret_cast<float*>(&wl[0][0][0]));
+    return;
+  }
+  const int s0 = 4 * nq + 16 * (id.tile - nq);
+  if (pair_half(blockIdx.x)) lstm_fwd_pair_body<UB, 1>(a, P, id.d, id.tile, s0, hbuf, wl);
+  else lstm_fwd_pair_body<UB, 0>(a, P, id.d, id.tile, s0, hbuf, wl);
 }
 
 // ------------------------------------------------------------------------------------------------ backward
@@ -619,7 +781,8 @@ __global__ __launch_bounds__((UB > 4 ? 16 : 4) * 64) void lstm_bwd_kernel(LstmAr
 // the start of the next step: no LDS staging, no extra barrier, and the round trip hides under the own-tile MFMAs.
 // W_hh fragments are resident: the own tile's K range in registers, the partner tile's half in registers, half in LDS.
 template <int UB, int hv>
-__device__ __forceinline__ void lstm_bwd_pair_body(const LstmArgs& a, float* dg, f32x4 (*wl)[64]) {
+__device__ __forceinline__ void lstm_bwd_pair_body(const LstmArgs& a, const LstmProblem& P, const int d, const int tile, const int s0,
+                                                   float* dg, f32x4 (*wl)[64]) {
   constexpr int HP = UB * 16, NP = UB * 64, KGB = NP / 16, UB0 = (UB + 1) / 2, NW = 8;
   constexpr int ub_lo = hv ? UB0 : 0, nb = hv ? UB - UB0 : UB0;          // own unit blocks
   constexpr int npb = UB - nb, pb_lo = hv ? 0 : UB0;                     // the partner's unit blocks
@@ -627,16 +790,11 @@ __device__ __forceinline__ void lstm_bwd_pair_body(const LstmArgs& a, float* dg,
   constexpr int KR = KO / 2, KL = KO - KR;                               // partner-tile fragments in registers / in LDS
   constexpr int DLD = nb * 64 + 16;                                      // row stride = 4 (mod 16) 16-byte chunks (swizzle)
   static_assert((DLD / 4) % 16 == 4, "dgates tile stride must keep the ds_read_b128 swizzle conflict-free");
-  const PairId id = pair_id(a.nprob);
-  const LstmProblem& P = a.p[id.prob];
   const int H = a.H;
-  const int tile = id.tile;
-  const int s0 = tile * 16;
   if (s0 >= P.n) return;
-  const int d = id.d;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, kk = lane >> 4;
   const int tmax = P.slen[s0];
-  const int ntiles = (P.n + 15) >> 4;
+  const int ntiles = sync_tiles(P.n);
   constexpr int XT = UB0 * 4 * 64, XS = 2 * XT + 8;                      // [step parity][tile][e][lane] tagged words (+ handshake line)
   unsigned long long* xmine = reinterpret_cast<unsigned long long*>(P.sync) + ((long)(d * ntiles + tile) * 2 + hv) * XS;
   const unsigned long long* xtheirs = reinterpret_cast<const unsigned long long*>(P.sync) + ((long)(d * ntiles + tile) * 2 + (hv ^ 1)) * XS;
@@ -788,13 +946,172 @@ __device__ __forceinline__ void lstm_bwd_pair_body(const LstmArgs& a, float* dg,
 #undef STAMP
 }
 
+// ---- backward, quad tile (4 sequences) on a CU pair: the 16-row body's split (own gate-gradient columns as the K range, the
+// partner's output tile first and sent from registers, the own tile second), on v_mfma_f32_4x4x1.  An output tile is 16 units;
+// the 16 blocks of an instruction are 4 unit-quads x 4 QUARTERS of the K range (every block multiplies its own A: rows of dgates
+// at the k of its quarter), so one instruction still does 64 columns of work; the four quarter sums meet through two
+// cross-lane adds.  Cell-gradient lanes: (row = lane >> 4, unit = lane & 15).
+template <int UB, int hv>
+__device__ __forceinline__ void lstm_bwd_quad_body(const LstmArgs& a, const LstmProblem& P, const int d, const int q, float* dgq, float* wlq) {
+  constexpr int HP = UB * 16, NP = UB * 64, KGB = NP / 16, UB0 = (UB + 1) / 2;
+  constexpr int ub_lo = hv ? UB0 : 0, nb = hv ? UB - UB0 : UB0;
+  constexpr int npb = UB - nb, pb_lo = hv ? 0 : UB0;
+  constexpr int KO = nb * 64, KQ = KO / 4, p_lo = ub_lo * 64;            // own gate-gradient columns, per quarter
+  constexpr int KR = KQ / 2, KL = KQ - KR;                               // partner-tile weights in registers / in LDS
+  constexpr int DLD = KO + 4;
+  const int H = a.H;
+  const int s0 = q * 4;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int row = lane >> 4, u = lane & 15;                              // cell-gradient role; as MFMA column: quarter `row`, unit u
+  const int tmax = P.slen[s0];
+  __builtin_amdgcn_s_setprio(3);
+  const int ntl = sync_tiles(P.n);
+  constexpr int XT = UB0 * 4 * 64, XS = 2 * XT + 8;
+  unsigned long long* xmine = reinterpret_cast<unsigned long long*>(P.sync) + ((long)(d * ntl + q) * 2 + hv) * XS;
+  const unsigned long long* xtheirs = reinterpret_cast<const unsigned long long*>(P.sync) + ((long)(d * ntl + q) * 2 + (hv ^ 1)) * XS;
+  unsigned* diag = P.sync + (long)2 * ntl * 2 * XS * 2;
+  if (tid == 0) {
+    const unsigned mine = xcc_id();
+    st_tag(xmine + 2 * XT, __uint_as_float(mine), 0x7fffffffu, false);
+    const float theirs = wait_tag(xtheirs + 2 * XT, ld_tag(xtheirs + 2 * XT, false), 0x7fffffffu, false, diag, a.tmo_total);
+    dgq[0] = (__float_as_uint(theirs) == mine && !(a.dbg & 64)) ? 1.f : 0.f;
+  }
+  __syncthreads();
+  const bool same_xcd = __builtin_amdgcn_readfirstlane(dgq[0] != 0.f);
+  __syncthreads();
+  const bool own = w < nb;
+  const bool par = w < npb;
+  if (!own && !par) {
+    for (int step = 0; step < tmax; ++step) { __syncthreads(); __syncthreads(); }
+    return;
+  }
+  const int ub = ub_lo + (own ? w : 0);
+  const int unit = ub * 16 + u;
+  const int ldg = 2 * NP, ldc = 2 * HP, ldh = 2 * H;
+  const int mylen = (s0 + row < P.n) ? P.slen[s0 + row] : 0;
+  // resident weights from wb[d][n-tile][kg][lane' = unit + 16 * ((p >> 2) & 3)][p & 3] (the 16-row kernels' fragment layout):
+  // lane (quarter, u) keeps W_hh_p[p = p_lo + quarter * KQ + k][unit] for k < KQ
+  float wo[KQ], wp[KR];
+  {
+    const float* wb = P.wfrag + (long)d * UB * KGB * 256 + u * 4;
+    const int pq = p_lo + row * KQ;
+    const int pb = pb_lo + (par ? w : 0);
+#pragma unroll
+    for (int k = 0; k < KQ; ++k) {
+      const int pp = pq + k;
+      wo[k] = own ? wb[((long)ub * KGB + (pp >> 4)) * 256 + ((pp >> 2) & 3) * 64 + (pp & 3)] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < KR; ++k) {
+      const int pp = pq + k;
+      wp[k] = par ? wb[((long)pb * KGB + (pp >> 4)) * 256 + ((pp >> 2) & 3) * 64 + (pp & 3)] : 0.f;
+    }
+    if (par) {
+#pragma unroll 4
+      for (int k = KR; k < KQ; ++k) {
+        const int pp = pq + k;
+        wlq[((long)w * KL + (k - KR)) * 64 + lane] = wb[((long)pb * KGB + (pp >> 4)) * 256 + ((pp >> 2) & 3) * 64 + (pp & 3)];
+      }
+    }
+  }
+  float dhr = 0.f, dcr = 0.f;
+  f32x4 in_g;
+  float in_ct, in_cp, in_dh;
+  auto load_inputs = [&](int step) __attribute__((always_inline)) {
+    const int t = d ? step : (tmax - 1 - step);
+    const int nact = min(4, P.bs[t] - s0);
+    const long row0 = (long)P.off[t] + s0;
+    const int tp = d ? t + 1 : t - 1;
+    const long prow0 = (tp >= 0 && tp < P.L) ? (long)P.off[tp] + s0 : 0;
+    in_g = f32x4{0.f, 0.f, 0.f, 0.f};
+    in_ct = 0.f; in_cp = 0.f; in_dh = 0.f;
+    if (own && row < nact) {
+      const long grow = row0 + row;
+      in_g = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(P.gates + grow * ldg + d * NP + ub * 64 + u * 4));
+      in_ct = __builtin_nontemporal_load(P.cell + grow * ldc + d * HP + unit);
+      const bool has_prev = d ? (t + 1 < mylen) : (t > 0);
+      if (has_prev) in_cp = __builtin_nontemporal_load(P.cell + (prow0 + row) * ldc + d * HP + unit);
+      if (unit < H) in_dh = __builtin_nontemporal_load(P.dh + grow * ldh + d * H + unit);
+    }
+  };
+  load_inputs(0);
+  // one output tile (16 units) over the own K range: 4 quarters side by side, then the quarter sums are added across lanes
+  auto tile_mfma = [&](auto weight) __attribute__((always_inline)) -> float {
+    f32x4 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kq = 0; kq < KQ / 4; ++kq) {
+      // A of block b = lane >> 2 (quarter b >> 2 = lane >> 4), row lane & 3: dgates[row][quarter * KQ + 4 kq ..]
+      const f32x4 af = *reinterpret_cast<const f32x4*>(&dgq[(lane & 3) * DLD + (lane >> 4) * KQ + kq * 4]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = MFMA4_OWN(af[i], weight(kq * 4 + i), acc[i]);
+    }
+    f32x4 sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      sum[e] += __shfl_xor(sum[e], 16, 64);
+      sum[e] += __shfl_xor(sum[e], 32, 64);
+    }
+    return row == 0 ? sum[0] : (row == 1 ? sum[1] : (row == 2 ? sum[2] : sum[3]));      // lane (row, u): dh_prev[row][tile unit u]
+  };
+
+  for (int step = 0; step < tmax; ++step) {
+    const int t = d ? step : (tmax - 1 - step);
+    const int nact = min(4, P.bs[t] - s0);
+    const long row0 = (long)P.off[t] + s0;
+    if (own) {
+      if (step > 0) {
+        const unsigned long long* src = xtheirs + ((step + 1) & 1) * XT + w * 64 + lane;
+        dhr += wait_tag(src, ld_tag_first(src, same_xcd), (unsigned)step, same_xcd, diag, a.tmo_total);
+      }
+      f32x4 dgv = {0.f, 0.f, 0.f, 0.f};
+      if (row < nact) {
+        const long grow = row0 + row;
+        const float gi = in_g[0], gf = in_g[1], gg = in_g[2], go = in_g[3];
+        const float ct = in_ct, cp = in_cp;
+        const float dh = dhr + in_dh;
+        float dc = dcr;
+        const bool last_fwd_step = d ? (t == 0) : (t == mylen - 1);
+        if (last_fwd_step && P.dcn && unit < H) dc += P.dcn[(long)(s0 + row) * ldh + d * H + unit];
+        const float tc = fast_tanh(ct);
+        dgv[3] = dh * tc * go * (1.f - go);
+        dc += dh * go * (1.f - tc * tc);
+        dgv[0] = dc * gg * gi * (1.f - gi);
+        dgv[1] = dc * cp * gf * (1.f - gf);
+        dgv[2] = dc * gi * (1.f - gg * gg);
+        dcr = dc * gf;
+        *reinterpret_cast<f32x4*>(P.gates + grow * ldg + d * NP + ub * 64 + u * 4) = dgv;
+      }
+      *reinterpret_cast<f32x4*>(&dgq[row * DLD + w * 64 + u * 4]) = dgv;
+    }
+    __syncthreads();
+    if (step + 1 < tmax) load_inputs(step + 1);
+    if (par) {
+      const float val = tile_mfma([&](int k) __attribute__((always_inline)) { return k < KR ? wp[k < KR ? k : 0] : wlq[((long)w * KL + (k >= KR ? k - KR : 0)) * 64 + lane]; });
+      st_tag(xmine + (step & 1) * XT + w * 64 + lane, val, (unsigned)(step + 1), same_xcd);
+    }
+    if (own) dhr = tile_mfma([&](int k) __attribute__((always_inline)) { return wo[k]; });
+    __syncthreads();
+  }
+}
+
 template <int UB>
 __global__ __launch_bounds__(512) void lstm_bwd_pair_kernel(LstmArgs a) {
   constexpr int UB0 = (UB + 1) / 2;
   __shared__ __attribute__((aligned(16))) float dg[16 * (UB0 * 64 + 16)];
   __shared__ f32x4 wl[UB0 * (UB0 * 4 - UB0 * 2)][64];    // partner-tile fragments kept in LDS: [wave][KL]
-  if (pair_half(blockIdx.x)) lstm_bwd_pair_body<UB, 1>(a, dg, wl);
-  else lstm_bwd_pair_body<UB, 0>(a, dg, wl);
+  const PairId id = pair_id(a.nprob);
+  const LstmProblem& P = a.p[id.prob];
+  const int nq = quad_count(a, P);
+  if (id.tile < nq) {
+    if (pair_half(blockIdx.x)) lstm_bwd_quad_body<UB, 1>(a, P, id.d, id.tile, dg, reinterpret_cast<float*>(&wl[0][0]));
+    else lstm_bwd_quad_body<UB, 0>(a, P, id.d, id.tile, dg, reinterpret_cast<float*>(&wl[0][0]));
+    return;
+  }
+  const int s0 = 4 * nq + 16 * (id.tile - nq);
+  if (pair_half(blockIdx.x)) lstm_bwd_pair_body<UB, 1>(a, P, id.d, id.tile, s0, dg, wl);
+  else lstm_bwd_pair_body<UB, 0>(a, P, id.d, id.tile, s0, dg, wl);
 }
 
 // ------------------------------------------------------------------------------------------------ weight (un)packing
@@ -902,7 +1219,8 @@ __global__ void lstm_unpack_kernel(float* __restrict__ dw_ihp, float* __restrict
 
 template <int UB>
 int launch_pair(const LstmArgs& a, bool backward, int max_tiles, hipStream_t s) {
-  dim3 grid(((max_tiles + 7) / 8) * 16 * 2 * a.nprob), block(512);     // groups of 8 tiles x 2 halves, see pair_id()
+  const int tiles = max_tiles + (a.quad_T > 0 ? MAXQ : 0);             // quad tiles take the first ids; whatever is not needed exits
+  dim3 grid(((tiles + 7) / 8) * 16 * 2 * a.nprob), block(512);         // groups of 8 tiles x 2 halves, see pair_id()
   if (backward) hipLaunchKernelGGL((lstm_bwd_pair_kernel<UB>), grid, block, 0, s, a);
   else hipLaunchKernelGGL((lstm_fwd_pair_kernel<UB>), grid, block, 0, s, a);
   NNR_CHECK_LAUNCH();
@@ -944,7 +1262,7 @@ extern "C" size_t nnr_lstm_sync_diag_offset(int n) {
 extern "C" size_t nnr_lstm_sync_bytes(int n) {
   const size_t ntiles = (size_t)(n + 15) / 16;
   // [2 directions][ntiles][2 halves][2 step parities][16 rows][7 * 16 units] tagged 8-byte words + 64 bytes of diagnostics
-  return 2 * ntiles * 2 * (2 * 16 * 112 + 8) * 8 + SYNC_PAD * sizeof(unsigned) + 128 * 16 * 8;
+  return 2 * (ntiles + MAXQ) * 2 * (2 * 16 * 112 + 8) * 8 + SYNC_PAD * sizeof(unsigned) + 128 * 16 * 8;      // (+ MAXQ quad-tile slots)
 }
 
 extern "C" int nnr_lstm_pack_weights(const float* w_ih_f, const float* w_hh_f, const float* b_ih_f, const float* b_hh_f,
@@ -992,6 +1310,16 @@ static int lstm_run(const nnr_lstm_problem* probs, int nprob, int H, bool backwa
     max_tiles = max(max_tiles, (p.n + 15) / 16);
   }
   for (int i = nprob; i < 4; ++i) a.p[i] = a.p[0];
+  {
+    // 4-row tiles for sequences longer than quad_T steps (0: off).  They buy latency with throughput (3.3 us per step of 4 rows vs
+    // 8.9 us per step of 16), so they pay while the launch is bound by its longest chain, not once the pair slots are oversubscribed
+    // several times: same-box A/B of the whole step (ms, T = 0 / 16 / 32 / 64): batch 8 (440 sequences per stream) 4.85 / 3.53 /
+    // 3.76 / 3.86; batch 16: 5.83 / 4.81 / 4.89 / 4.90; batch 32: 7.72 / 7.26 / 7.24 / 7.10; batch 64 (3 520): 11.66 / - / 11.77 / 11.75.
+    int maxn = 0;
+    for (int i = 0; i < nprob; ++i) maxn = max(maxn, a.p[i].n);
+    const char* e = getenv("NNR_LSTM_QUAD_T");
+    a.quad_T = e ? atoi(e) : (maxn <= 1024 ? 16 : (maxn <= 2048 ? 64 : 0));
+  }
   // 2-CU weights-stationary recurrence when the caller provides the exchange workspace
   bool pair = UB == 13 && (H % 2 == 0);
   for (int i = 0; i < nprob; ++i) pair = pair && a.p[i].sync != nullptr;

@@ -383,17 +383,25 @@ def test_pair_recurrence_timeout_is_counted_and_skips_the_optimizer(monkeypatch)
 
 @pytest.mark.parametrize('n,Lx,E,H,variant', [(37, 12, 16, 8, 'one'), (100, 32, 300, 200, 'one'), (45, 128, 300, 200, 'one'),
                                               (100, 32, 300, 200, 'pair'), (45, 128, 300, 200, 'pair'), (200, 128, 300, 200, 'pair'),
-                                              (45, 128, 300, 200, 'pair_fabric')])
+                                              (45, 128, 300, 200, 'pair_fabric'), (45, 128, 300, 200, 'pair_noquad'),
+                                              (203, 40, 300, 200, 'pair_quad6'), (45, 128, 300, 200, 'pair_quad20'),
+                                              (1100, 24, 300, 200, 'pair_quad3'), (45, 128, 300, 200, 'pair_fabric_quad20')])
 def test_bilstm_forward_backward_matches_oracle(n, Lx, E, H, variant, monkeypatch):
     """'one': one workgroup per 16-sequence tile (W_hh streamed from L2);  'pair': two workgroups on two CUs of one XCD with
-    W_hh resident, exchanging through that XCD's L2;  'pair_fabric': the same with the cross-XCD (write-through) exchange
-    flavour forced -- the fallback the kernel takes when the placement handshake finds the halves on different XCDs."""
+    W_hh resident, exchanging through that XCD's L2 (sequences longer than 64 steps in 4-row tiles);  'pair_fabric': the same with
+    the cross-XCD (write-through) exchange flavour forced -- the fallback the kernel takes when the placement handshake finds the
+    halves on different XCDs;  'pair_noquad' / 'pair_quadT': 4-row tiles off / for every sequence longer than T steps (T = 3 with
+    1 100 sequences: more long sequences than the 64 quad tiles hold, the rest stay in 16-row tiles)."""
     from nnr_amd import ops
     from nnr_amd.layers import LSTMParams
     from oracle.nnr_oracle import BiLSTM
     monkeypatch.setattr(ops, 'LSTM_PAIR', variant != 'one')
-    if variant == 'pair_fabric':
+    if 'fabric' in variant:
         monkeypatch.setenv('NNR_LSTM_DBG', '64')
+    if variant == 'pair_noquad':
+        monkeypatch.setenv('NNR_LSTM_QUAD_T', '0')
+    if 'quad' in variant and variant != 'pair_noquad':
+        monkeypatch.setenv('NNR_LSTM_QUAD_T', variant.split('quad')[1])
     d = dev()
     torch.manual_seed(n)
     lens = _lengths(n, Lx, n)

@@ -17,6 +17,27 @@ __global__ void layout(const float* A, const float* B, float* D, int K) {
   for (int i = 0; i < 4; ++i) D[i * 64 + lane] = acc[i];
 }
 
+// A[i][k0 + b] in lane (b, i); ABID = b broadcasts block b's A: 16 instructions consume one VGPR of A (16 k)
+__global__ void layout_abid(const float* A, const float* B, float* D, int K) {
+  const int lane = threadIdx.x;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    const float a = A[(lane & 3) * K + k0 + (lane >> 2)];
+#define STEP(j) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a, B[(k0 + j) * 64 + lane], acc, 4, j, 0);
+    STEP(0) STEP(1) STEP(2) STEP(3) STEP(4) STEP(5) STEP(6) STEP(7) STEP(8) STEP(9) STEP(10) STEP(11) STEP(12) STEP(13) STEP(14) STEP(15)
+#undef STEP
+  }
+  for (int i = 0; i < 4; ++i) D[i * 64 + lane] = acc[i];
+}
+// no broadcast: block b multiplies ITS OWN A (lane (b, i) = row i, k index kq(b)): columns 4b..4b+3 see k-quarter b >> 2
+__global__ void layout_own(const float* A, const float* B, float* D, int K) {      // D[i][lane] = sum_{k in quarter(lane>>4)} A[i][k] B[k][lane]
+  const int lane = threadIdx.x, q = lane >> 4, KQ = K / 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < KQ; ++k)
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(A[(lane & 3) * K + q * KQ + k], B[(q * KQ + k) * 64 + lane], acc, 0, 0, 0);
+  for (int i = 0; i < 4; ++i) D[i * 64 + lane] = acc[i];
+}
+
 template <int NACC>
 __global__ void rate(float* out, int iters) {
   f32x4 acc[NACC];
@@ -63,7 +84,7 @@ static float span(float* dD, int nw, int iters) {
 }
 
 int main() {
-  const int K = 24;
+  const int K = 32;
   std::vector<float> A(4 * K), B(K * 64), D(256), R(256, 0.f);
   for (int i = 0; i < 4 * K; ++i) A[i] = (float)((i * 7) % 11) - 5.f;
   for (int i = 0; i < K * 64; ++i) B[i] = (float)((i * 13) % 17) - 8.f;
@@ -77,6 +98,21 @@ int main() {
   int bad = 0;
   for (int i = 0; i < 256; ++i) bad += D[i] != R[i];
   printf("layout: D[i][lane] = sum_k A[i][k] B[k][lane]  mismatches %d / 256\n", bad);
+  hipLaunchKernelGGL(layout_abid, dim3(1), dim3(64), 0, 0, dA, dB, dD, K);
+  hipMemcpy(D.data(), dD, 256 * 4, hipMemcpyDeviceToHost);
+  int bad2 = 0;
+  for (int i = 0; i < 256; ++i) bad2 += D[i] != R[i];
+  printf("abid: one A register (lane (b,i) = A[i][k0+b]) + ABID = 0..15   mismatches %d / 256\n", bad2);
+  hipLaunchKernelGGL(layout_own, dim3(1), dim3(64), 0, 0, dA, dB, dD, K);
+  hipMemcpy(D.data(), dD, 256 * 4, hipMemcpyDeviceToHost);
+  int bad3 = 0;
+  for (int i = 0; i < 4; ++i) for (int c = 0; c < 64; ++c) {
+    float r = 0.f; const int q = c >> 4, KQ = K / 4;
+    for (int k = q * KQ; k < (q + 1) * KQ; ++k) r += A[i * K + k] * B[k * 64 + c];
+    bad3 += D[i * 64 + c] != r;
+  }
+  printf("own A per block (CBSZ = 0): column quarter q sums k-quarter q   mismatches %d / 256\n", bad3);
+  bad += bad2 + bad3;
   float t;
   hipLaunchKernelGGL(rate<1>, dim3(1), dim3(64), 0, 0, dD, 2000); hipMemcpy(&t, dD + 4096, 4, hipMemcpyDeviceToHost); printf("1 accumulator : %.1f clk / mfma (1 wave)\n", t);
   hipLaunchKernelGGL(rate<2>, dim3(1), dim3(64), 0, 0, dD, 2000); hipMemcpy(&t, dD + 4096, 4, hipMemcpyDeviceToHost); printf("2 accumulators: %.1f clk / mfma\n", t);
