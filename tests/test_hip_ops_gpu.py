@@ -481,6 +481,61 @@ def _softmax_pool_ref(x, score, mask):
     return torch.einsum('nl,nld->nd', a, x), a
 
 
+@pytest.mark.parametrize('quad_T', ['0', '16'])
+def test_pair_recurrence_makes_progress_beside_a_cu_saturating_kernel(quad_T, monkeypatch):
+    """The CU-pair recurrence spins on its partner workgroup.  Its forward-progress argument (a waiting workgroup's partner is the
+    next one of ITS launch to get a CU; every wait is bounded and counted) must hold when another HIP stream keeps every CU busy:
+    a stream of GPU-filling GEMM launches (the 128 x 80 LDS-DMA tile, 4 workgroups per CU) runs before, during and after the
+    forward and the backward recurrence of 1 600 sequences (200 pair tiles, 1.5 x the 128 pair slots of the chip) on a second
+    stream.  No exchange time-out, and bit-identical results to the same launches on an idle GPU."""
+    from nnr_amd import ops
+    from nnr_amd.layers import LSTMParams
+    monkeypatch.setenv('NNR_LSTM_QUAD_T', quad_T)
+    d = dev()
+    n, Lx, E, H = 1600, 48, 300, 200
+    lens = _lengths(n, Lx, 21)
+    mask = torch.arange(Lx)[None, :] < lens[:, None]
+    plan = ops.SeqPlan(mask.clone().to(d), None)
+    holder = LSTMParams(E, H).to(d)
+    torch.manual_seed(5)
+    with torch.no_grad():
+        for q in holder.parameters():
+            q.normal_(0, 0.08)
+    w = ops.LstmPacked(holder.param_list(), H, E)
+    cap = plan.cap
+    f32 = dict(device=d, dtype=torch.float32)
+    xw = torch.randn((cap, 2 * w.NP), **f32) * 0.5
+    dh = torch.randn((cap, 2 * H), **f32) * 0.1
+    dcn = torch.randn((n, 2 * H), **f32) * 0.1
+    A = torch.randn((65536, 512), **f32)
+    Bm = torch.randn((800, 512), **f32) * 0.05
+    Cm = torch.empty((65536, 800), **f32)
+
+    def run(busy):
+        st = dict(plan=plan, w=w, gates=xw.clone(), cell=torch.empty((cap, 2 * w.HP), **f32), hout=torch.zeros((cap, 2 * H), **f32),
+                  cn=torch.empty((n, 2 * H), **f32), dh=dh, dcn=dcn)
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream(device=d)
+        if busy:
+            with torch.cuda.stream(side):
+                for _ in range(24):           # ~0.5 ms each: the chip stays full for the whole recurrence (and beyond)
+                    ops.gemm(A, Bm, Cm, M=65536, N=800, K=512, lda=512, ldb=512, ldc=800, tile=15)
+        ops.lstm_fwd([st], H)
+        fwd = (st['hout'].clone(), st['cn'].clone())
+        ops.lstm_bwd([st], H)
+        torch.cuda.synchronize()
+        return fwd + (st['gates'].clone(),)
+
+    ops.lstm_sync_timeouts(reset=True)
+    quiet = run(False)
+    loaded = run(True)
+    assert ops.lstm_sync_timeouts() == 0
+    for a, b, what in zip(quiet, loaded, ('h', 'c_n', 'dgates')):
+        tot = int(plan.off[-1])
+        a, b = (a[:tot], b[:tot]) if a.shape[0] == cap else (a, b)
+        assert torch.isfinite(b).all() and torch.equal(a, b), what
+
+
 @pytest.mark.parametrize('dot', [False, True])
 def test_pool_packed_forward_backward(dot):
     from nnr_amd import ops
