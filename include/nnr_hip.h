@@ -204,6 +204,15 @@ int nnr_add_atomic(float* y, const float* x, long n, float alpha, hipStream_t st
 int nnr_add2d(float* y, int ldy, const float* x, int ldx, int rows, int cols, float alpha, int accumulate, hipStream_t stream);
 int nnr_dropout(const float* x, float* y, long n, float p, uint32_t seed, hipStream_t stream);
 int nnr_relu_bwd(const float* dy, const float* y, float* dx, long n, hipStream_t stream);
+/* SUE's per-user graph aggregate (layers.py:285-292: `graph @ feature` inside GCNLayer.forward, B users x [G, G] x [G, D]) with
+ * GCNLayer's epilogue:  y = dropout(relu?(graph_b . z_b + bias) + resid), r_out (optional) = the value after bias / ReLU (what the
+ * backward mask needs).  G <= 128.  p / seed: counter-based dropout over the flat [B, G, D] index (same mask as nnr_relu_drop_bwd). */
+int nnr_gcn_aggregate_fwd(const float* graph, const float* z, const float* bias, const float* resid, float* r_out, float* y, int B, int G,
+                          int D, int relu, float p, uint32_t seed, hipStream_t stream);
+/* Its backward:  ds = mask(dy) * (r > 0), dx0 (optional) = mask(dy) (the residual branch), dz_b = graph_b^T . ds_b.  r == NULL: plain
+ * dz_b = graph_b^T . dy_b (ds / dx0 untouched). */
+int nnr_gcn_aggregate_bwd(const float* graph, const float* dy, const float* r, float* ds, float* dx0, float* dz, int B, int G, int D, float p,
+                          uint32_t seed, hipStream_t stream);
 int nnr_relu_drop_bwd(const float* dy, const float* r, float* ds, float* dx, long n, float p, uint32_t seed, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------ multi-head self-attention core

@@ -653,6 +653,16 @@ def relu_drop_bwd(dy, r, ds, dx, p, seed):
 
 
 # ---------------------------------------------------------------------------------------------- SUE / loss / optimiser
+def gcn_aggregate_fwd(graph, z, bias, resid, r_out, y, B, G, D, relu, p, seed):
+    L.check(L.lib().nnr_gcn_aggregate_fwd(_p(graph), _p(z), _p(bias), _p(resid), _p(r_out), _p(y), B, G, D, int(relu), C.c_float(p),
+                                          C.c_uint32(int(seed) & 0xFFFFFFFF), _s()), 'nnr_gcn_aggregate_fwd')
+
+
+def gcn_aggregate_bwd(graph, dy, r, ds, dx0, dz, B, G, D, p, seed):
+    L.check(L.lib().nnr_gcn_aggregate_bwd(_p(graph), _p(dy), _p(r), _p(ds), _p(dx0), _p(dz), B, G, D, C.c_float(p),
+                                          C.c_uint32(int(seed) & 0xFFFFFFFF), _s()), 'nnr_gcn_aggregate_bwd')
+
+
 def sue_x0_fwd(hist, proxy, x0, B, Hn, Kc, D, p, seed):
     L.check(L.lib().nnr_sue_x0_fwd(_p(hist), _p(proxy), _p(x0), B, Hn, Kc, D, C.c_float(p), C.c_uint32(seed & 0xFFFFFFFF), _s()), 'nnr_sue_x0_fwd')
 

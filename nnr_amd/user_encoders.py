@@ -11,6 +11,8 @@ SUE (userEncoders.py:42-98):
 Backward is hand-written against the same kernels; parameter gradients accumulate into `param.grad`."""
 import math
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -54,6 +56,9 @@ class _SUEFunction(torch.autograd.Function):
         return dhist, dcand, None, None, None, None
 
 
+_GCN_FUSED = os.environ.get('NNR_GCN_FUSED', '1') != '0'      # A/B: dedicated per-user aggregate kernel vs the batched tile GEMM
+
+
 def gcn_forward(gcn, x0, graph, seed0, training):
     """GCN.forward (layers.py:318-323) over GCNLayer.forward (:285-292):  X <- dropout(relu(LN?((A X) W^T + b)) + X).  The dense
     product runs first (X W^T on all B*G rows), then the per-user G x G aggregate as a batched GEMM whose epilogue applies bias /
@@ -77,6 +82,9 @@ def gcn_forward(gcn, x0, graph, seed0, training):
             ln = layer.layer_normalization
             ops.layernorm_fwd(u, ln.weight, ln.bias, ln.eps, xhat, rstd, r, x if gcn.residual else None, y, pl, seed0 + l)
             lns.append((xhat, rstd))
+        elif _GCN_FUSED and G <= 128 and D % 4 == 0:
+            ops.gcn_aggregate_fwd(graph, z, layer.W.bias, x if gcn.residual else None, r, y, B, G, D, True, pl, seed0 + l)
+            lns.append(None)
         else:
             ops.gemm(graph, z, y, M=G, N=D, K=G, lda=G, ldb=D, ldc=D, trans_b=True, bias=layer.W.bias, act=ops.ACT_RELU, aux_out=r,
                      ldaux=D, resid=x if gcn.residual else None, ldres=D, drop=(3, pl, seed0 + l, D), batch=B, strideA=G * G,
@@ -98,6 +106,15 @@ def gcn_backward(gcn, gsv, dy, graph, leaf):
         pl = (gcn.dropout_rate if gsv['training'] else 0.0) if l + 1 < Lg else 0.0
         dS = torch.empty((B, G, D), **f32)
         dx = torch.empty((B, G, D), **f32)
+        if _GCN_FUSED and G <= 128 and D % 4 == 0 and gsv['lns'][l] is None:
+            # mask + ReLU gradient applied while dY is loaded, then dZ_b = A_b^T dS_b, one launch (csrc/gcn.hip)
+            dz = torch.empty((B, G, D), **f32)
+            ops.gcn_aggregate_bwd(graph, dy, gsv['rs'][l], dS, dx if gcn.residual else None, dz, B, G, D, pl, gsv['seed0'] + l)
+            ops.linear_bwd_data(dz.view(B * G, D), layer.W.weight, out=dx.view(B * G, D), accumulate=bool(gcn.residual))
+            leaf(lambda dS=dS, dz=dz, l=l, layer=layer: (ops.bias_grad(dS.view(B * G, D), grad_of(layer.W.bias)),
+                                                         ops.linear_bwd_weight(dz.view(B * G, D), gsv['xs'][l].view(B * G, D), grad_of(layer.W.weight))), dS, dz)
+            dy = dx
+            continue
         ops.relu_drop_bwd(dy, gsv['rs'][l], dS, dx, pl, gsv['seed0'] + l)        # dx = masked dy (residual branch)
         if not gcn.residual:
             dx.zero_()

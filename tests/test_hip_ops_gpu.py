@@ -536,6 +536,54 @@ def test_pair_recurrence_makes_progress_beside_a_cu_saturating_kernel(quad_T, mo
         assert torch.isfinite(b).all() and torch.equal(a, b), what
 
 
+@pytest.mark.parametrize('B,G,D', [(5, 68, 900), (3, 21, 52), (2, 128, 64), (4, 16, 20)])
+def test_gcn_aggregate_forward_backward(B, G, D):
+    """Per-user graph aggregate with GCNLayer's epilogue (csrc/gcn.hip) vs fp64, and the dropout mask of the forward, of the
+    backward and of the batched-GEMM path (same counter-based mask over the flat [B, G, D] index)."""
+    from nnr_amd import ops
+    d = dev()
+    f32 = dict(device=d, dtype=torch.float32)
+    A = (torch.rand(B, G, G, generator=torch.Generator().manual_seed(1)) < 0.3).float() * torch.rand(B, G, G, generator=torch.Generator().manual_seed(2))
+    z, x, bias = rnd(B, G, D, seed=3), rnd(B, G, D, seed=4), rnd(D, seed=5)
+    Ad, zd, xd, bd = A.to(d), z.to(d), x.to(d), bias.to(d)
+    pre = torch.relu(torch.bmm(A.double(), z.double()) + bias.double())
+    # p = 0: plain epilogue
+    r, y = torch.empty((B, G, D), **f32), torch.empty((B, G, D), **f32)
+    ops.gcn_aggregate_fwd(Ad, zd, bd, xd, r, y, B, G, D, True, 0.0, 7)
+    close(r, pre, what='gcn r')
+    close(y, pre + x.double(), what='gcn y')
+    y2 = torch.empty((B, G, D), **f32)
+    ops.gcn_aggregate_fwd(Ad, zd, None, None, None, y2, B, G, D, False, 0.0, 7)
+    close(y2, torch.bmm(A.double(), z.double()), what='gcn plain')
+    # p = 0.3: same mask as the batched GEMM epilogue and as the backward
+    p, seed = 0.3, 12345
+    ops.gcn_aggregate_fwd(Ad, zd, bd, xd, r, y, B, G, D, True, p, seed)
+    yg, rg = torch.empty((B, G, D), **f32), torch.empty((B, G, D), **f32)
+    ops.gemm(Ad, zd, yg, M=G, N=D, K=G, lda=G, ldb=D, ldc=D, trans_b=True, bias=bd, act=ops.ACT_RELU, aux_out=rg, ldaux=D, resid=xd, ldres=D,
+             drop=(3, p, seed, D), batch=B, strideA=G * G, strideB=G * D, strideC=G * D, stride_aux=G * D, stride_res=G * D, tile=2)
+    assert torch.equal(y == 0, yg == 0)
+    close(y, yg.double(), what='gcn y vs batched GEMM')
+    keep = (y != 0).cpu()
+    assert 0.6 < float(keep.float().mean()) < 0.8
+    close(y.cpu()[keep], ((pre + x.double()) / (1 - p))[keep], what='gcn y kept')
+    # backward
+    dy = rnd(B, G, D, seed=6)
+    dyd = dy.to(d)
+    ds, dx0, dz = torch.empty((B, G, D), **f32), torch.empty((B, G, D), **f32), torch.empty((B, G, D), **f32)
+    ops.gcn_aggregate_bwd(Ad, dyd, r, ds, dx0, dz, B, G, D, p, seed)
+    m = keep.double() / (1 - p)
+    close(dx0, dy.double() * m, what='gcn dx0')
+    ds_ref = dy.double() * m * (pre > 0)
+    close(ds, ds_ref, what='gcn ds')
+    close(dz, torch.bmm(A.double().transpose(1, 2), ds_ref), what='gcn dz')
+    ds1, dx1 = torch.empty((B, G, D), **f32), torch.empty((B, G, D), **f32)
+    ops.relu_drop_bwd(dyd, r, ds1, dx1, p, seed)
+    assert torch.equal(ds1, ds) and torch.equal(dx1, dx0)
+    dz2 = torch.empty((B, G, D), **f32)
+    ops.gcn_aggregate_bwd(Ad, dyd, None, None, None, dz2, B, G, D, 0.0, 0)
+    close(dz2, torch.bmm(A.double().transpose(1, 2), dy.double()), what='gcn plain A^T')
+
+
 @pytest.mark.parametrize('dot', [False, True])
 def test_pool_packed_forward_backward(dot):
     from nnr_amd import ops
