@@ -898,45 +898,43 @@ __global__ __launch_bounds__(256, OCC) void gemm_tn_pipe_kernel(nnr_gemm_args g)
   if (g.dyn_dim == 2) K = min(K, *g.dyn_dev);
   const int nbm = (M + BM - 1) / BM, nbn = (N + BN - 1) / BN;
   const int nblk = nbm * nbn;
-  // blockIdx -> (tile, reduction slice).  With split-K the grid is 1-D and XCD x (= blockIdx.x % 8 under round-robin placement;
-  // speed only) walks the slices z = x, x + 8, ...: ALL tiles of a slice run on ONE XCD, so every token row of A and of B is pulled
-  // into exactly one L2.  With the tiles of a slice spread over the eight XCDs (round 2's first layout) each XCD fetched its own
-  // copy of B's rows: 2.0x the operand bytes at the fabric counters for the 1664x300 shape.
-  int v, z;
-  // Long reductions only (>= 2048 k-tiles: the content dW_ih): there the time is unchanged and the fabric traffic drops
-  // to 1.36x; short ones keep the tiles of a slice spread over the XCDs - dealing them quantises to 8 slices at a time and the
-  // second wave that costs is worse than the duplicate fetches, which the Infinity Cache absorbs.
-  const bool deal = g.split_k > 1 && (K + BK - 1) / BK >= 2048 && nblk >= 32;
-  if (deal) {
-    const int L = blockIdx.x, x = L & 7, slot = L >> 3;
-    const int zi = slot / nblk;
-    v = slot - zi * nblk;
-    z = x + 8 * zi;
-  } else if (g.split_k > 1) {
-    z = blockIdx.x / nblk;
-    v = blockIdx.x - z * nblk;
+  // blockIdx -> (tile, reduction slice).  The host sizes split_k for the CAPACITY of the token buffers; the live reduction length
+  // (device side) is typically a fifth of it: use only as many slices (eff) as keep a slice long enough to amortise its prologue
+  // and its atomic epilogue (~96 stages) while still giving every CU a workgroup or two; the surplus workgroups exit.
+  // With split-K the grid is 1-D and the eff x nblk workgroups, in slice-major order, are dealt to the XCDs in eight CONTIGUOUS
+  // runs (XCD = blockIdx.x % 8 under round-robin placement; speed only): all tiles of a slice run on one XCD (a slice that
+  // straddles a run boundary on two), so a token row of A and of B is pulled into one L2 instead of into every L2 whose
+  // workgroups touch it -- 4-5x the operand bytes at the fabric counters for the 400 x 400 and 832 x 200 shapes when the tiles of
+  // a slice are spread round-robin (profiles/pmc_traffic.json, round 2 first collection).  deal_mode 0 = that spread layout (A/B).
+  int v, z = 0;
+  int kbeg = 0, kend = K;
+  if (g.split_k > 1) {
+    const int deal_mode = -g.k_chunk;                      // set by the launcher (k_chunk itself is not used by this kernel)
+    const int ktiles = (K + BK - 1) / BK;
+    const int want = (512 + nblk - 1) / nblk;
+    const int eff = max(1, min(min(g.split_k, max(want, ktiles / 96)), max(1, ktiles / 12)));
+    if (deal_mode) {
+      const int W = eff * nblk, per = (W + 7) >> 3;
+      const int L = blockIdx.x, x = L & 7, slot = L >> 3;
+      const int lin = x * per + slot;
+      if (slot >= per || lin >= W) return;
+      z = lin / nblk;
+      v = lin - z * nblk;
+    } else {
+      z = blockIdx.x / nblk;
+      v = blockIdx.x - z * nblk;
+      if (z >= eff) return;
+    }
+    const int per_k = (ktiles + eff - 1) / eff;
+    kbeg = z * per_k * BK;
+    kend = min(K, kbeg + per_k * BK);
+    if (kbeg >= kend) return;
   } else {
     const int b = blockIdx.x, q = nblk >> 3, rem = nblk & 7, x = b & 7, slot = b >> 3;
     v = x * q + min(x, rem) + slot;
-    z = 0;
   }
   const int bm = v / nbn, bn = v - bm * nbn;
   const int m0 = bm * BM, n0 = bn * BN;
-  int kbeg = 0, kend = K;
-  if (g.split_k > 1) {
-    // The host sizes split_k for the CAPACITY of the token buffers; the live reduction length (device side) is typically a
-    // fifth of it.  Use only as many slices as keep a slice long enough to amortise its prologue and its atomic epilogue
-    // (~96 stages) while still giving every CU a workgroup or two; the surplus slices exit.
-    const int ktiles = (K + BK - 1) / BK;
-    const int want = (512 + nblk - 1) / nblk;
-    int eff = max(1, min(min(g.split_k, max(want, ktiles / 96)), max(1, ktiles / 12)));
-    if (deal && eff >= 8) eff = min((eff + 7) & ~7, (g.split_k + 7) & ~7);      // whole multiples of the 8 XCDs (slices are dealt to XCDs)
-    if (z >= eff) return;
-    const int per = (ktiles + eff - 1) / eff;
-    kbeg = z * per * BK;
-    kend = min(K, kbeg + per * BK);
-    if (kbeg >= kend) return;
-  }
   const float* __restrict__ A = g.A;
   const float* __restrict__ B = g.B;
   const int* __restrict__ bidx = g.b_idx;
@@ -1079,7 +1077,10 @@ int launch_tn_pipe(const nnr_gemm_args& g, hipStream_t s) {
   constexpr int BM = 64 * TM, BN = 16 * TN;
   const int nbm = (g.M + BM - 1) / BM, nbn = (g.N + BN - 1) / BN;
   dim3 grid(g.split_k > 1 ? nbm * nbn * ((g.split_k + 7) / 8) * 8 : nbm * nbn), block(256);      // split-K: slices are dealt to XCDs (see the kernel)
-  hipLaunchKernelGGL((gemm_tn_pipe_kernel<TM, TN, NS, OCC, PRIO>), grid, block, 0, s, g);
+  static const int deal_mode = [] { const char* e = getenv("NNR_TN_DEAL"); return e ? atoi(e) : 1; }();      // A/B: 0 = tiles of a slice spread over the XCDs
+  nnr_gemm_args gg = g;
+  gg.k_chunk = -deal_mode;
+  hipLaunchKernelGGL((gemm_tn_pipe_kernel<TM, TN, NS, OCC, PRIO>), grid, block, 0, s, gg);
   NNR_CHECK_LAUNCH();
   return NNR_OK;
 }
@@ -1125,45 +1126,43 @@ __global__ __launch_bounds__(256, OCC) void gemm_tn_pipe2_kernel(nnr_gemm_args g
   if (g.dyn_dim == 2) K = min(K, *g.dyn_dev);
   const int nbm = (M + BM - 1) / BM, nbn = (N + BN - 1) / BN;
   const int nblk = nbm * nbn;
-  // blockIdx -> (tile, reduction slice).  With split-K the grid is 1-D and XCD x (= blockIdx.x % 8 under round-robin placement;
-  // speed only) walks the slices z = x, x + 8, ...: ALL tiles of a slice run on ONE XCD, so every token row of A and of B is pulled
-  // into exactly one L2.  With the tiles of a slice spread over the eight XCDs (round 2's first layout) each XCD fetched its own
-  // copy of B's rows: 2.0x the operand bytes at the fabric counters for the 1664x300 shape.
-  int v, z;
-  // Long reductions only (>= 2048 k-tiles: the content dW_ih): there the time is unchanged and the fabric traffic drops
-  // to 1.36x; short ones keep the tiles of a slice spread over the XCDs - dealing them quantises to 8 slices at a time and the
-  // second wave that costs is worse than the duplicate fetches, which the Infinity Cache absorbs.
-  const bool deal = g.split_k > 1 && (K + BK - 1) / BK >= 2048 && nblk >= 32;
-  if (deal) {
-    const int L = blockIdx.x, x = L & 7, slot = L >> 3;
-    const int zi = slot / nblk;
-    v = slot - zi * nblk;
-    z = x + 8 * zi;
-  } else if (g.split_k > 1) {
-    z = blockIdx.x / nblk;
-    v = blockIdx.x - z * nblk;
+  // blockIdx -> (tile, reduction slice).  The host sizes split_k for the CAPACITY of the token buffers; the live reduction length
+  // (device side) is typically a fifth of it: use only as many slices (eff) as keep a slice long enough to amortise its prologue
+  // and its atomic epilogue (~96 stages) while still giving every CU a workgroup or two; the surplus workgroups exit.
+  // With split-K the grid is 1-D and the eff x nblk workgroups, in slice-major order, are dealt to the XCDs in eight CONTIGUOUS
+  // runs (XCD = blockIdx.x % 8 under round-robin placement; speed only): all tiles of a slice run on one XCD (a slice that
+  // straddles a run boundary on two), so a token row of A and of B is pulled into one L2 instead of into every L2 whose
+  // workgroups touch it -- 4-5x the operand bytes at the fabric counters for the 400 x 400 and 832 x 200 shapes when the tiles of
+  // a slice are spread round-robin (profiles/pmc_traffic.json, round 2 first collection).  deal_mode 0 = that spread layout (A/B).
+  int v, z = 0;
+  int kbeg = 0, kend = K;
+  if (g.split_k > 1) {
+    const int deal_mode = -g.k_chunk;                      // set by the launcher (k_chunk itself is not used by this kernel)
+    const int ktiles = (K + BK - 1) / BK;
+    const int want = (512 + nblk - 1) / nblk;
+    const int eff = max(1, min(min(g.split_k, max(want, ktiles / 96)), max(1, ktiles / 12)));
+    if (deal_mode) {
+      const int W = eff * nblk, per = (W + 7) >> 3;
+      const int L = blockIdx.x, x = L & 7, slot = L >> 3;
+      const int lin = x * per + slot;
+      if (slot >= per || lin >= W) return;
+      z = lin / nblk;
+      v = lin - z * nblk;
+    } else {
+      z = blockIdx.x / nblk;
+      v = blockIdx.x - z * nblk;
+      if (z >= eff) return;
+    }
+    const int per_k = (ktiles + eff - 1) / eff;
+    kbeg = z * per_k * BK;
+    kend = min(K, kbeg + per_k * BK);
+    if (kbeg >= kend) return;
   } else {
     const int b = blockIdx.x, q = nblk >> 3, rem = nblk & 7, x = b & 7, slot = b >> 3;
     v = x * q + min(x, rem) + slot;
-    z = 0;
   }
   const int bm = v / nbn, bn = v - bm * nbn;
   const int m0 = bm * BM, n0 = bn * BN;
-  int kbeg = 0, kend = K;
-  if (g.split_k > 1) {
-    // The host sizes split_k for the CAPACITY of the token buffers; the live reduction length (device side) is typically a
-    // fifth of it.  Use only as many slices as keep a slice long enough to amortise its prologue and its atomic epilogue
-    // (~96 stages) while still giving every CU a workgroup or two; the surplus slices exit.
-    const int ktiles = (K + BK - 1) / BK;
-    const int want = (512 + nblk - 1) / nblk;
-    int eff = max(1, min(min(g.split_k, max(want, ktiles / 96)), max(1, ktiles / 12)));
-    if (deal && eff >= 8) eff = min((eff + 7) & ~7, (g.split_k + 7) & ~7);      // whole multiples of the 8 XCDs (slices are dealt to XCDs)
-    if (z >= eff) return;
-    const int per = (ktiles + eff - 1) / eff;
-    kbeg = z * per * BK;
-    kend = min(K, kbeg + per * BK);
-    if (kbeg >= kend) return;
-  }
   const float* __restrict__ A = g.A;
   const float* __restrict__ B = g.B;
   const int* __restrict__ bidx = g.b_idx;
@@ -1337,7 +1336,10 @@ int launch_tn_pipe2(const nnr_gemm_args& g, hipStream_t s) {
   constexpr int BM = 64 * TM, BN = 16 * TN;
   const int nbm = (g.M + BM - 1) / BM, nbn = (g.N + BN - 1) / BN;
   dim3 grid(g.split_k > 1 ? nbm * nbn * ((g.split_k + 7) / 8) * 8 : nbm * nbn), block(256);      // split-K: slices are dealt to XCDs (see the kernel)
-  hipLaunchKernelGGL((gemm_tn_pipe2_kernel<TM, TN, NS, OCC>), grid, block, 0, s, g);
+  static const int deal_mode = [] { const char* e = getenv("NNR_TN_DEAL"); return e ? atoi(e) : 1; }();      // A/B: 0 = tiles of a slice spread over the XCDs
+  nnr_gemm_args gg = g;
+  gg.k_chunk = -deal_mode;
+  hipLaunchKernelGGL((gemm_tn_pipe2_kernel<TM, TN, NS, OCC>), grid, block, 0, s, gg);
   NNR_CHECK_LAUNCH();
   return NNR_OK;
 }
