@@ -54,6 +54,7 @@ def parse(argv=None):
                     'launch cost ~5 %% of a step when all steps carry them)')
     ap.add_argument('--zipf_s', type=float, default=None, help='diagnostic: exponent of the synthetic word-id distribution (default: SynthSpec)')
     ap.add_argument('--no_cpu_baseline', action='store_true')
+    ap.add_argument('--no_isolated', action='store_true', help='skip the two serialised extra steps behind `roofline.isolated`')
     ap.add_argument('--cpu_baseline_batch', type=int, default=8)
     ap.add_argument('--cpu_baseline_steps', type=int, default=2)
     ap.add_argument('--plumbing_check', action='store_true', help='CPU only (gloo): run the launcher + the product\'s flat-buffer / '
@@ -245,8 +246,35 @@ def main():
     dt, calls = timed_run(a, trainer, batch_source(per_gpu), a.steps, a.warmup, prof, dp, torch, dev, world, True)
     sampled = len(range(0, a.steps, max(1, a.roofline_every)))
     roof = prof.roofline(PEAK_F32_TFLOPS, sampled_steps=sampled, ms_per_step=1000 * dt / a.steps)
-    if roof and (a.news_encoder, a.user_encoder, per_gpu, a.dense) != ('CNE', 'SUE', 64, False):
+    headline = (a.news_encoder, a.user_encoder, per_gpu, a.dense) == ('CNE', 'SUE', 64, False)
+    if roof and not headline:
         roof['traffic'] = None            # the committed PMC passes (profiles/pmc_traffic.json) are of the headline command only
+    if roof and headline:
+        # counter bytes (same PMC passes) over ALGORITHMIC operand bytes of the weight-gradient (token-reduction) GEMM launches
+        roof['weight_gradient_traffic'] = prof.weight_gradient_traffic()
+    if roof and world == 1 and not a.no_isolated:
+        # The dominant kernel's launches overlap with up to three other HIP streams inside the step, so `achieved` above divides its
+        # FLOPs by a wall duration it shares with them.  Two extra untimed steps with every launch serialised on ONE stream give the
+        # solo duration of the same launches at the same live sizes (the figure that measures the kernel, not the schedule).
+        fresh = batch_source(per_gpu)
+        ops.set_one_stream(True)
+        trainer.train_step(fresh(0))
+        torch.cuda.synchronize()
+        prof.enable(every=1)
+        t0 = time.perf_counter()
+        for i in range(2):
+            prof.begin_step(i)
+            trainer.train_step(fresh(1 + i))
+        torch.cuda.synchronize()
+        ser = (time.perf_counter() - t0) / 2
+        fam = prof.summary().get(roof['family'])
+        prof.disable()
+        ops.set_one_stream(False)
+        if fam and fam['ms'] > 0:
+            tf = fam['flops'] / (fam['ms'] * 1e-3) / 1e12
+            roof['isolated'] = {'achieved': round(tf, 2), 'frac': round(tf / PEAK_F32_TFLOPS, 4), 'avg_launch_us': round(1000 * fam['ms'] / fam['launches'], 2),
+                                'launches': fam['launches'], 'step_serialized_ms': round(1000 * ser, 3),
+                                'how': 'same launches of 2 extra untimed steps, every HIP stream of the step collapsed into one'}
 
     strong = None
     if world > 1 and weak and not a.no_strong and a.batch_size % world == 0:

@@ -123,6 +123,7 @@ def cne_forward(mod, title_text, title_mask, content_text, content_mask, categor
 
 
 _SIDE = {}
+ops.STREAM_CACHES.append(_SIDE)
 _BWD_SPLIT = os.environ.get('NNR_LSTM_BWD_SPLIT', '1') == '1'      # batch 8: 4.68 (split) vs 4.93 ms; batch 64: no difference
 _CNE_UNION = os.environ.get('NNR_CNE_UNION', '1') != '0'      # A/B switch: candidate + history call as one packed token stream
 

@@ -48,14 +48,31 @@ SIDE_CALL = os.environ.get('NNR_SIDE_CALL', '1') != '0'      # model.Model.forwa
 EXTRA_STREAMS = []          # every HIP stream this package created (side, title, leaf): see join_extra_streams()
 
 
+ONE_STREAM = [os.environ.get('NNR_ONE_STREAM') == '1']      # diagnostic: every launch on the caller's stream (solo kernel durations)
+STREAM_CACHES = []                                           # dicts of streams handed out by new_stream (dropped when the mode flips)
+
+
+def set_one_stream(flag):
+    """Serialise (True) / restore (False) the package's HIP streams: in serialised mode every launch goes to the caller's stream, so
+    the HIP-event spans of nnr_amd.profile are SOLO kernel durations (bench.py's `roofline.isolated`)."""
+    torch.cuda.synchronize()
+    ONE_STREAM[0] = bool(flag)
+    for c in STREAM_CACHES:
+        c.clear()
+    del EXTRA_STREAMS[:]
+
+
 def new_stream(dev, critical=False):
     """critical: a stream that carries a piece of the dependent chain (candidate call, title chain) rather than leaf work.
     (Measured and rejected: giving the critical streams a high HIP stream priority -- 13.43 vs 13.05 ms/step.)"""
-    if os.environ.get('NNR_ONE_STREAM') == '1':          # diagnostic: every launch on the caller's stream (solo kernel durations)
+    if ONE_STREAM[0]:
         return torch.cuda.current_stream(dev)
     st = torch.cuda.Stream(device=dev)
     EXTRA_STREAMS.append(st)
     return st
+
+
+STREAM_CACHES.append(_LEAF)
 
 
 def join_extra_streams(dev=None):
@@ -338,6 +355,8 @@ def gemm(A, B, C_=None, *, M, N, K, lda, ldb, ldc=0, trans_a=False, trans_b=Fals
             d = int(dyn.item())
             m, k = (min(M, d), K) if dyn_dim == 1 else (M, min(K, d))
         return 2.0 * m * N * k * max(1, batch) * flop_scale
+    if trans_a and trans_b and split_k > 1:
+        flops.tn_dims = (M, N, flop_scale)           # token-reduction GEMM: operand bytes of the launch = live reduction rows x (M + N) x 4
     flops.tag = 'M%d N%d K%d%s%s%s' % (M, N, K, ' b%d' % batch if batch > 1 else '', (' sk%d' % split_k if split_k > 1 else '') + (' kc%d' % k_chunk if k_chunk > 0 else ''), ' dyn' if dyn is not None else '')
     with _prof.span(fam, flops):
         L.check(L.lib().nnr_gemm_f32(C.byref(g), _s()), 'nnr_gemm_f32')

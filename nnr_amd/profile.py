@@ -108,6 +108,36 @@ def pmc_traffic(kernel):
     return None
 
 
+def tn_operand_bytes():
+    """Per weight-gradient (token-reduction GEMM) family: algorithmic operand bytes per launch = live reduction rows x (M + N) x 4,
+    over the recorded launches -- the figure the PMC traffic of profiles/pmc_traffic.json is compared with."""
+    torch.cuda.synchronize()
+    out = {}
+    for family, s, e, fn in _records:
+        dims = getattr(fn, 'tn_dims', None)
+        if dims:
+            M, N, fs = dims
+            d = out.setdefault(family, dict(bytes=0.0, launches=0))
+            d['bytes'] += float(fn()) / (2.0 * M * N * fs) * (M + N) * 4.0
+            d['launches'] += 1
+    return out
+
+
+def weight_gradient_traffic():
+    res = {}
+    tot_op = tot_hbm = 0.0
+    for family, d in tn_operand_bytes().items():
+        hbm = pmc_traffic(KERNEL_OF.get(family, family))
+        if hbm and d['launches']:
+            op = d['bytes'] / d['launches']
+            res[family] = {'operand_mb_per_launch': round(op / 1e6, 1), 'counter_mb_per_launch': round(hbm / 1e6, 1), 'ratio': round(hbm / op, 2)}
+            tot_op += d['bytes']
+            tot_hbm += hbm * d['launches']
+    if tot_op:
+        res['all'] = {'ratio': round(tot_hbm / tot_op, 2)}
+    return res or None
+
+
 def roofline(peak_tflops, sampled_steps=None, ms_per_step=None):
     fam = summary()
     if not fam:
@@ -119,7 +149,7 @@ def roofline(peak_tflops, sampled_steps=None, ms_per_step=None):
     return {
         'bound': 'mfma', 'achieved': round(ach, 3), 'peak': peak_tflops, 'unit': 'TFLOP/s', 'frac': round(ach / peak_tflops, 4),
         'traffic': pmc_traffic(KERNEL_OF.get(name, name)), 'traffic_source': 'profiles/pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes '
-        'of this command on the same build (PMC cannot be collected inside the timed run), FETCH_SIZE x2 per the gfx950 note', 'kernel': KERNEL_OF.get(name, name), 'launches': d['launches'],
+        'of this command on the same build (PMC cannot be collected inside the timed run), FETCH_SIZE x2 per the gfx950 note', 'kernel': KERNEL_OF.get(name, name), 'family': name, 'launches': d['launches'],
         'avg_launch_us': round(1000 * d['ms'] / max(1, d['launches']), 2),
         'share_of_instrumented_time': round(d['ms'] / total_ms, 3),
         'families': {k: {'ms': round(v['ms'], 3), 'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2) if v['ms'] > 0 else 0.0,
