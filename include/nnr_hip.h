@@ -114,10 +114,11 @@ int nnr_cne_pair_map(const int* order_t, const int* order_c, int n0, int n, int*
  * Replaces nn.LSTM(bidirectional) on a PackedSequence (newsEncoders.py:66-67, 119-127) and its backward.
  * Gate columns are kept in "p-order": p = (unit/16)*64 + (unit%16)*4 + gate, padded to NP = ceil(H/16)*64 per direction. */
 int nnr_lstm_dims(int H, int* UB, int* HP, int* NP);
-/* w_ihp [2*NP, E], b_p [2*NP] (= b_ih + b_hh), wf [2*UB*4*UB*256], wb [2*UB*(NP/16)*256] */
+/* w_ihp [2*NP, E], b_p [2*NP] (= b_ih + b_hh), wf [2*UB*4*UB*256], wb [2*UB*(NP/16)*256]; w_ihp_t (optional) [E, 2*NP] = w_ihp^T,
+ * the K-contiguous operand of the embedding-row gradient GEMM */
 int nnr_lstm_pack_weights(const float* w_ih_f, const float* w_hh_f, const float* b_ih_f, const float* b_hh_f, const float* w_ih_r,
                           const float* w_hh_r, const float* b_ih_r, const float* b_hh_r, int H, int E, float* w_ihp, float* b_p,
-                          float* wf, float* wb, hipStream_t stream);
+                          float* wf, float* wb, float* w_ihp_t, hipStream_t stream);
 /* dw_ihp [2*NP, E], db_p [2*NP], dw_hhp [2, NP, H] -> gradients in nn.LSTM's parameter layout.  zero_src != 0: the packed buffers are
  * returned all-zero (a persistent workspace the next step's split-K GEMMs accumulate into again: no per-step fill launches). */
 int nnr_lstm_unpack_grads(float* dw_ihp, float* db_p, float* dw_hhp, int H, int E, float* dw_ih_f, float* dw_hh_f,

@@ -1120,7 +1120,7 @@ __global__ void lstm_pack_kernel(const float* __restrict__ w_ih_f, const float* 
                                  const float* __restrict__ w_ih_r, const float* __restrict__ w_hh_r,
                                  const float* __restrict__ b_ih_r, const float* __restrict__ b_hh_r, int H, int E, int UB,
                                  float* __restrict__ w_ihp, float* __restrict__ b_p, float* __restrict__ wf,
-                                 float* __restrict__ wb) {
+                                 float* __restrict__ wb, float* __restrict__ w_ihp_t) {
   const int NP = UB * 64, KG = UB, KGB = NP / 16;
   const long n_ihp = (long)2 * NP * E, n_b = 2 * NP, n_wf = (long)2 * UB * 4 * KG * 256, n_wb = (long)2 * UB * KGB * 256;
   const long total = n_ihp + n_b + n_wf + n_wb;
@@ -1130,7 +1130,9 @@ __global__ void lstm_pack_kernel(const float* __restrict__ w_ih_f, const float* 
       const int e = i % E; const int dp = i / E; const int d = dp / NP, p = dp % NP;
       const int ub = p / 64, u = (p % 64) / 4, g = p % 4, unit = ub * 16 + u;
       const float* src = d ? w_ih_r : w_ih_f;
-      w_ihp[i] = (unit < H) ? src[(long)(g * H + unit) * E + e] : 0.f;
+      const float v = (unit < H) ? src[(long)(g * H + unit) * E + e] : 0.f;
+      w_ihp[i] = v;
+      if (w_ihp_t) w_ihp_t[(long)e * (2 * NP) + dp] = v;      // [E, 2 NP]: the K-contiguous B operand of the dX GEMM (NT form)
       continue;
     }
     i -= n_ihp;
@@ -1267,11 +1269,11 @@ extern "C" size_t nnr_lstm_sync_bytes(int n) {
 
 extern "C" int nnr_lstm_pack_weights(const float* w_ih_f, const float* w_hh_f, const float* b_ih_f, const float* b_hh_f,
                                      const float* w_ih_r, const float* w_hh_r, const float* b_ih_r, const float* b_hh_r,
-                                     int H, int E, float* w_ihp, float* b_p, float* wf, float* wb, hipStream_t stream) {
+                                     int H, int E, float* w_ihp, float* b_p, float* wf, float* wb, float* w_ihp_t, hipStream_t stream) {
   int UB;
   if (nnr_lstm_dims(H, &UB, nullptr, nullptr) != NNR_OK) return NNR_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(lstm_pack_kernel, dim3(1024), dim3(256), 0, stream, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r,
-                     b_ih_r, b_hh_r, H, E, UB, w_ihp, b_p, wf, wb);
+                     b_ih_r, b_hh_r, H, E, UB, w_ihp, b_p, wf, wb, w_ihp_t);
   NNR_CHECK_LAUNCH();
   return NNR_OK;
 }

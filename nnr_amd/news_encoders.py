@@ -136,6 +136,13 @@ def _side_stream(dev):
     return _SIDE[key]
 
 
+def _title_stream(dev):
+    key = (dev.type, dev.index, 2)
+    if key not in _SIDE:
+        _SIDE[key] = ops.new_stream(dev, critical=True)
+    return _SIDE[key]
+
+
 def _two_chains(dev, enable, title_fn, content_fn):
     """The title and the content chain of ONE encoder call are independent between their exchange points (c_n before the
     gate, the self-attention vectors before the cross attention and their gradients on the way back): on the big call the
@@ -146,10 +153,7 @@ def _two_chains(dev, enable, title_fn, content_fn):
         content_fn()
         return
     main = torch.cuda.current_stream(dev)
-    key = (dev.type, dev.index, 2)
-    if key not in _SIDE:
-        _SIDE[key] = ops.new_stream(dev, critical=True)
-    s2 = _SIDE[key]
+    s2 = _title_stream(dev)
     s2.wait_stream(main)
     with torch.cuda.stream(s2):
         title_fn()
@@ -246,9 +250,13 @@ def _cne_fwd_pre(mod, title_text, title_mask, content_text, content_mask, catego
         mask2 = [m.view(-1, Lx) for _, m in parts]      # views: the in-place mask[:,0]=1 must reach the caller's tensors
         perm = _torch_tie_perm(mask2).to(dev) if mod.tie_order == 'torch' else None
         plan = ops.SeqPlan(mask2[0], ids2[0], perm, *((mask2[1], ids2[1]) if union else ()))
+        plan_ev = None
+        if union and name == 'content':
+            plan_ev = torch.cuda.Event()
+            plan_ev.record()
         w = mod._packed_weights(name, lstm)
         cap = plan.cap
-        st = dict(name=name, L=Lx, plan=plan, w=w, lstm=lstm, Hlin=Hlin, Mlin=Mlin, satt=satt, catt=catt, seed=seed + _SITE[name])
+        st = dict(name=name, L=Lx, plan=plan, plan_ev=plan_ev, w=w, lstm=lstm, Hlin=Hlin, Mlin=Mlin, satt=satt, catt=catt, seed=seed + _SITE[name])
         st['gates'] = torch.empty((cap, 2 * w.NP), **f32)
         # dropout(embedding rows) materialised ONCE per token (6 TB/s gather): fused into the GEMM's A loader the counter hash
         # is recomputed by each of the 21 column blocks (-16 % on this GEMM and on the dW_ih GEMM of the backward)
@@ -267,7 +275,17 @@ def _cne_fwd_pre(mod, title_text, title_mask, content_text, content_mask, catego
                                 mod.title_self_attention, mod.title_cross_attention),
                 lambda: prepare(1, 'content', content_text, content_mask, mod.max_content_length, mod.content_lstm, mod.content_H,
                                 mod.content_M, mod.content_self_attention, mod.content_cross_attention))
-    return dict(streams=streams, n=n, n0=n0, union=union, B=B, N=N, p=p, seed=seed, category=category, subCategory=subCategory)
+    sv = dict(streams=streams, n=n, n0=n0, union=union, B=B, N=N, p=p, seed=seed, category=category, subCategory=subCategory)
+    if union:
+        # rank pairing (newsEncoders.py:128-129): inside ONE call the partner of sorted position r is the other stream's position r;
+        # in a union of two calls it is the other stream's position with the same (call, position inside the call).  Needs both
+        # plans and nothing else: issued on the title stream behind the title projection, it is done long before the recurrence ends
+        s2 = _title_stream(dev)
+        with torch.cuda.stream(s2):
+            s2.wait_event(streams[1]['plan_ev'])
+            sv['pm'] = ops.cne_pair_map(streams[0]['plan'], streams[1]['plan'])
+        sv['pm_stream'] = s2
+    return sv
 
 
 def _cne_fwd_post(mod, sv, par=False):
@@ -279,9 +297,9 @@ def _cne_fwd_post(mod, sv, par=False):
     D = mod.news_embedding_dim
     f32 = dict(device=dev, dtype=torch.float32)
 
-    # rank pairing (newsEncoders.py:128-129): inside ONE call the partner of sorted position r is the other stream's position r;
-    # in a union of two calls it is the other stream's position with the same (call, position inside the call)
-    t_['pm'], c_['pm'] = ops.cne_pair_map(t_['plan'], c_['plan']) if sv['union'] else (None, None)
+    if sv['union']:
+        torch.cuda.current_stream(dev).wait_stream(sv['pm_stream'])
+    t_['pm'], c_['pm'] = sv['pm'] if sv['union'] else (None, None)
 
     def gate_and_self(st, other):
         plan, cap = st['plan'], st['plan'].cap

@@ -488,10 +488,9 @@ class LstmPacked:
         self.b_p = torch.empty(2 * np_, **f)
         self.wf = torch.empty(2 * ub * 4 * ub * 256, **f)
         self.wb = torch.empty(2 * ub * (np_ // 16) * 256, **f)
-        L.check(L.lib().nnr_lstm_pack_weights(*[_p(t) for t in p], H, E, _p(self.w_ihp), _p(self.b_p), _p(self.wf), _p(self.wb), _s()),
-                'nnr_lstm_pack_weights')
         self.w_ihp_t = torch.empty((E, 2 * np_), **f)             # [E, 2*NP]: K-contiguous B operand of the dX GEMM (NT form)
-        transpose2d(self.w_ihp, self.w_ihp_t, 2 * np_, E)
+        L.check(L.lib().nnr_lstm_pack_weights(*[_p(t) for t in p], H, E, _p(self.w_ihp), _p(self.b_p), _p(self.wf), _p(self.wb),
+                                              _p(self.w_ihp_t), _s()), 'nnr_lstm_pack_weights')
 
 
 def lstm_unpack_grads(dw_ihp, db_p, dw_hhp, H, E, grads, zero_src=False):
