@@ -9,7 +9,7 @@ OUT=$ROOT/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd $ROOT
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
-CMD="python3 $ROOT/bench.py --steps 12 --warmup 4 --no_cpu_baseline"
+CMD="python3 $ROOT/bench.py --steps 12 --warmup 4 --no_cpu_baseline --no_isolated"
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_$TAG
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG/kt -- $CMD > $OUT/bench_under_kernel_trace.json 2> $OUT/kt.err
