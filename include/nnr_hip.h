@@ -135,7 +135,9 @@ typedef struct nnr_lstm_problem {
   const float* wb;    /* backward fragment-layout W_hh */
   const float* dh;    /* bwd: dL/dH [rows, 2*H] */
   const float* dcn;   /* bwd: dL/dc_n [n, 2*H] or NULL */
-  unsigned* sync;     /* optional workspace of nnr_lstm_sync_bytes(n) bytes (zeroed by the library): when every problem of a
+  unsigned* sync;     /* optional workspace of nnr_lstm_sync_bytes(n) bytes, ZERO-FILLED ONCE BY THE CALLER before its first launch
+                       * and reusable by later launches without clearing (exchange words carry a per-launch epoch; one workspace
+                       * must not be shared by two launches that can be in flight together): when every problem of a
                        * launch has one and H = 200, each 16-sequence tile runs on a PAIR of CUs with W_hh resident in
                        * registers/LDS, exchanging half of h_t per step; after the launch the 64 bytes at
                        * nnr_lstm_sync_diag_offset(n) hold diagnostics (word 0 = spin-wait time-outs of that launch, must be 0) */

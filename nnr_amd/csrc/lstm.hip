@@ -110,7 +110,7 @@ __device__ __forceinline__ float wait_tag(const unsigned long long* p, unsigned 
   return __uint_as_float((unsigned)v);
 }
 
-struct LstmArgs { LstmProblem p[4]; int nprob; int H; int dbg; unsigned* tmo_total; int quad_T; };   // dbg: timing-attribution mask (NNR_LSTM_DBG), 0 in production
+struct LstmArgs { LstmProblem p[4]; int nprob; int H; int dbg; unsigned* tmo_total; int quad_T; unsigned epoch; };   // epoch: launch counter << 10, the high bits of every exchange tag   // dbg: timing-attribution mask (NNR_LSTM_DBG), 0 in production
 
 // ------------------------------------------------------------------------------------------------ forward
 template <int UB>
@@ -311,8 +311,8 @@ __device__ __forceinline__ void lstm_fwd_pair_body(const LstmArgs& a, const Lstm
   // placement handshake through the fabric path (valid wherever the partner runs): do both halves sit on one XCD?
   if (tid == 0) {
     const unsigned mine = xcc_id();
-    st_tag(xmine + 2 * XT, __uint_as_float(mine), 0x7fffffffu, false);
-    const float theirs = wait_tag(xtheirs + 2 * XT, ld_tag(xtheirs + 2 * XT, false), 0x7fffffffu, false, diag, a.tmo_total);
+    st_tag(xmine + 2 * XT, __uint_as_float(mine), a.epoch + 0x3ffu, false);
+    const float theirs = wait_tag(xtheirs + 2 * XT, ld_tag(xtheirs + 2 * XT, false), a.epoch + 0x3ffu, false, diag, a.tmo_total);
     hbuf[0][0] = (__float_as_uint(theirs) == mine && !(a.dbg & 64)) ? 1.f : 0.f;
   }
   __syncthreads();
@@ -395,7 +395,7 @@ __device__ __forceinline__ void lstm_fwd_pair_body(const LstmArgs& a, const Lstm
     if (compute && !(a.dbg & 16)) phase_a(KSPLIT, KG);
     STAMP(5);
     if (!(a.dbg & 1)) {
-      const unsigned tag = (unsigned)step;
+      const unsigned tag = a.epoch + (unsigned)step;
 #pragma unroll
       for (int j = 0; j < MAXW; ++j) {
         const int i = tid + NT * j, row = i / XW, cc = i - row * XW;
@@ -447,7 +447,7 @@ __device__ __forceinline__ void lstm_fwd_pair_body(const LstmArgs& a, const Lstm
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int row = kk * 4 + e;
-        if (row < nact && unit < H && !(a.dbg & 2)) st_tag(xmine + (step & 1) * XT + row * XW + (unit - ub_lo * 16), hv_[e], (unsigned)(step + 1), same_xcd);
+        if (row < nact && unit < H && !(a.dbg & 2)) st_tag(xmine + (step & 1) * XT + row * XW + (unit - ub_lo * 16), hv_[e], a.epoch + (unsigned)(step + 1), same_xcd);
       }
       STAMP(10);
 #pragma unroll
@@ -503,8 +503,8 @@ __device__ __forceinline__ void lstm_fwd_quad_body(const LstmArgs& a, const Lstm
   unsigned* diag = P.sync + (long)2 * ntl * 2 * XS * 2;
   if (tid == 0) {
     const unsigned mine = xcc_id();
-    st_tag(xmine + 2 * XT, __uint_as_float(mine), 0x7fffffffu, false);
-    const float theirs = wait_tag(xtheirs + 2 * XT, ld_tag(xtheirs + 2 * XT, false), 0x7fffffffu, false, diag, a.tmo_total);
+    st_tag(xmine + 2 * XT, __uint_as_float(mine), a.epoch + 0x3ffu, false);
+    const float theirs = wait_tag(xtheirs + 2 * XT, ld_tag(xtheirs + 2 * XT, false), a.epoch + 0x3ffu, false, diag, a.tmo_total);
     hq[0] = (__float_as_uint(theirs) == mine && !(a.dbg & 64)) ? 1.f : 0.f;
   }
   __syncthreads();
@@ -575,7 +575,7 @@ __device__ __forceinline__ void lstm_fwd_quad_body(const LstmArgs& a, const Lstm
         if ((kg < UB0) == (hv == 0) && own >= KSPLIT) kgroup(kg);
       }
     }
-    if (fetch) hcw[(pu0 + fcc) * 4 + frow] = wait_tag(src + tid, v, (unsigned)step, same_xcd, diag, a.tmo_total);
+    if (fetch) hcw[(pu0 + fcc) * 4 + frow] = wait_tag(src + tid, v, a.epoch + (unsigned)step, same_xcd, diag, a.tmo_total);
     __syncthreads();                                      // the partner's half of h_{t-1} is in LDS
     if (compute) {
 #pragma unroll
@@ -596,7 +596,7 @@ __device__ __forceinline__ void lstm_fwd_quad_body(const LstmArgs& a, const Lstm
       const float cn = gf * c + gi * gg;
       const float hval = go * fast_tanh(cn);
       if (j < nact) {
-        if (unit < H) st_tag(xmine + (step & 1) * XT + j * XW + (unit - ub_lo * 16), hval, (unsigned)(step + 1), same_xcd);
+        if (unit < H) st_tag(xmine + (step & 1) * XT + j * XW + (unit - ub_lo * 16), hval, a.epoch + (unsigned)(step + 1), same_xcd);
         c = cn;
         hn[unit * 4 + j] = hval;
         if (unit < H) P.hout[(row0 + j) * ldh + d * H + unit] = hval;
@@ -801,8 +801,8 @@ __device__ __forceinline__ void lstm_bwd_pair_body(const LstmArgs& a, const Lstm
   unsigned* diag = P.sync + (long)2 * ntiles * 2 * XS * 2;
   if (tid == 0) {
     const unsigned mine = xcc_id();
-    st_tag(xmine + 2 * XT, __uint_as_float(mine), 0x7fffffffu, false);
-    const float theirs = wait_tag(xtheirs + 2 * XT, ld_tag(xtheirs + 2 * XT, false), 0x7fffffffu, false, diag, a.tmo_total);
+    st_tag(xmine + 2 * XT, __uint_as_float(mine), a.epoch + 0x3ffu, false);
+    const float theirs = wait_tag(xtheirs + 2 * XT, ld_tag(xtheirs + 2 * XT, false), a.epoch + 0x3ffu, false, diag, a.tmo_total);
     dg[0] = (__float_as_uint(theirs) == mine && !(a.dbg & 64)) ? 1.f : 0.f;
   }
   __syncthreads();
@@ -882,7 +882,7 @@ __device__ __forceinline__ void lstm_bwd_pair_body(const LstmArgs& a, const Lstm
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = ld_tag_first(src + e * 64, same_xcd);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) dhr[e] += wait_tag(src + e * 64, v[e], (unsigned)step, same_xcd, diag, a.tmo_total);
+        for (int e = 0; e < 4; ++e) dhr[e] += wait_tag(src + e * 64, v[e], a.epoch + (unsigned)step, same_xcd, diag, a.tmo_total);
       }
       if (stamp && step < 128) tbuf[step * 16 + 5] = wall_clock64() + (unsigned long long)(dhr[0] == 123.456f);
 #pragma unroll
@@ -925,7 +925,7 @@ __device__ __forceinline__ void lstm_bwd_pair_body(const LstmArgs& a, const Lstm
       }
       unsigned long long* dst = xmine + (step & 1) * XT + (w * 4) * 64 + lane;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) st_tag(dst + e * 64, acc[e], (unsigned)(step + 1), same_xcd);
+      for (int e = 0; e < 4; ++e) st_tag(dst + e * 64, acc[e], a.epoch + (unsigned)(step + 1), same_xcd);
       STAMP(8);
     }
     // ---- (3) the own output tile over the own K range (stays in registers: same lane needs it next step)
@@ -972,8 +972,8 @@ __device__ __forceinline__ void lstm_bwd_quad_body(const LstmArgs& a, const Lstm
   unsigned* diag = P.sync + (long)2 * ntl * 2 * XS * 2;
   if (tid == 0) {
     const unsigned mine = xcc_id();
-    st_tag(xmine + 2 * XT, __uint_as_float(mine), 0x7fffffffu, false);
-    const float theirs = wait_tag(xtheirs + 2 * XT, ld_tag(xtheirs + 2 * XT, false), 0x7fffffffu, false, diag, a.tmo_total);
+    st_tag(xmine + 2 * XT, __uint_as_float(mine), a.epoch + 0x3ffu, false);
+    const float theirs = wait_tag(xtheirs + 2 * XT, ld_tag(xtheirs + 2 * XT, false), a.epoch + 0x3ffu, false, diag, a.tmo_total);
     dgq[0] = (__float_as_uint(theirs) == mine && !(a.dbg & 64)) ? 1.f : 0.f;
   }
   __syncthreads();
@@ -1063,7 +1063,7 @@ __device__ __forceinline__ void lstm_bwd_quad_body(const LstmArgs& a, const Lstm
     if (own) {
       if (step > 0) {
         const unsigned long long* src = xtheirs + ((step + 1) & 1) * XT + w * 64 + lane;
-        dhr += wait_tag(src, ld_tag_first(src, same_xcd), (unsigned)step, same_xcd, diag, a.tmo_total);
+        dhr += wait_tag(src, ld_tag_first(src, same_xcd), a.epoch + (unsigned)step, same_xcd, diag, a.tmo_total);
       }
       f32x4 dgv = {0.f, 0.f, 0.f, 0.f};
       if (row < nact) {
@@ -1089,7 +1089,7 @@ __device__ __forceinline__ void lstm_bwd_quad_body(const LstmArgs& a, const Lstm
     if (step + 1 < tmax) load_inputs(step + 1);
     if (par) {
       const float val = tile_mfma([&](int k) __attribute__((always_inline)) { return k < KR ? wp[k < KR ? k : 0] : wlq[((long)w * KL + (k >= KR ? k - KR : 0)) * 64 + lane]; });
-      st_tag(xmine + (step & 1) * XT + w * 64 + lane, val, (unsigned)(step + 1), same_xcd);
+      st_tag(xmine + (step & 1) * XT + w * 64 + lane, val, a.epoch + (unsigned)(step + 1), same_xcd);
     }
     if (own) dhr = tile_mfma([&](int k) __attribute__((always_inline)) { return wo[k]; });
     __syncthreads();
@@ -1327,8 +1327,14 @@ static int lstm_run(const nnr_lstm_problem* probs, int nprob, int H, bool backwa
   for (int i = 0; i < nprob; ++i) pair = pair && a.p[i].sync != nullptr;
   { const char* e = getenv("NNR_LSTM_PAIR"); if (e && atoi(e) == 0) pair = false; }
   if (pair) {
+    // Exchange words carry (launch epoch, step) tags, so words of earlier launches never match and the 25-32 MB workspace is NOT
+    // cleared per launch (4 x 31 us of fill kernels per step, each in front of a recurrence launch): only its diagnostics block is.
+    // Contract: the caller zero-fills a workspace ONCE, before its first launch.
+    static unsigned launch_counter = 0;
+    a.epoch = ((++launch_counter) & 0x3fffffu) << 10;
     for (int i = 0; i < nprob; ++i)
-      if (hipMemsetAsync(a.p[i].sync, 0, nnr_lstm_sync_bytes(a.p[i].n), stream) != hipSuccess) return NNR_ERR_LAUNCH;
+      if (hipMemsetAsync(reinterpret_cast<char*>(a.p[i].sync) + nnr_lstm_sync_diag_offset(a.p[i].n), 0, SYNC_PAD * sizeof(unsigned), stream) != hipSuccess)
+        return NNR_ERR_LAUNCH;
     return launch_pair<13>(a, backward, max_tiles, stream);
   }
   switch (UB) {

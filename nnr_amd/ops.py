@@ -533,14 +533,27 @@ def lstm_last_launch_timeouts():
     return sum(int(t[off // 4].item()) for t, off in LAST_LSTM_SYNC)
 
 
-def _lstm_probs(items, H=0):
+_SYNC_WS = {}
+
+
+def _sync_workspace(dev, n, slot):
+    """Exchange workspace of the CU-pair recurrence: zero-filled once, then reused launch after launch (the words carry a launch
+    epoch, csrc/lstm.hip).  One per (stream kind, direction of the pass): launches that can be in flight together never share one."""
+    key = (dev.index, n, slot)
+    ws = _SYNC_WS.get(key)
+    if ws is None:
+        ws = _SYNC_WS[key] = torch.zeros(L.lib().nnr_lstm_sync_bytes(n) // 4, dtype=torch.int32, device=dev)
+    return ws
+
+
+def _lstm_probs(items, H=0, backward=False):
     arr = (L.LstmProblem * len(items))()
     del LAST_LSTM_SYNC[:]
     for a, it in zip(arr, items):
         pl = it['plan']
         if LSTM_PAIR and H == 200:
             _timeout_counter(it['gates'].device)
-            it['sync'] = torch.empty(L.lib().nnr_lstm_sync_bytes(pl.n) // 4, dtype=torch.int32, device=it['gates'].device)
+            it['sync'] = _sync_workspace(it['gates'].device, pl.n, (it.get('name'), len(LAST_LSTM_SYNC), backward))
             LAST_LSTM_SYNC.append((it['sync'], L.lib().nnr_lstm_sync_diag_offset(pl.n)))
         a.sync = _p(it.get('sync'))
         a.bs, a.off, a.slen, a.prev_f, a.prev_r = _p(pl.bs), _p(pl.off), _p(pl.slen), _p(pl.prev_f), _p(pl.prev_r)
@@ -563,7 +576,7 @@ def lstm_fwd(items, H):
 
 
 def lstm_bwd(items, H):
-    arr = _lstm_probs(items, H)
+    arr = _lstm_probs(items, H, backward=True)
     with _prof.span('lstm_bwd', _lstm_flops(items, H)):
         L.check(L.lib().nnr_lstm_bwd(arr, len(items), H, _s()), 'nnr_lstm_bwd')
 
