@@ -909,10 +909,20 @@ __global__ __launch_bounds__(256, OCC) void gemm_tn_pipe_kernel(nnr_gemm_args g)
   int v, z = 0;
   int kbeg = 0, kend = K;
   if (g.split_k > 1) {
-    const int deal_mode = -g.k_chunk;                      // set by the launcher (k_chunk itself is not used by this kernel)
+    const int deal_mode = (-g.k_chunk) & 3;                // set by the launcher (k_chunk itself is not used by this kernel)
+    const int want_wg = (((-g.k_chunk) >> 2) & 63) ? (((-g.k_chunk) >> 2) & 63) * 64 : 512;      // workgroups wanted at least (tuning knob, default 512)
+    const int slice_stages = ((-g.k_chunk) >> 8) ? ((-g.k_chunk) >> 8) : 96;                     // stages per slice aimed at (tuning knob)
     const int ktiles = (K + BK - 1) / BK;
-    const int want = (512 + nblk - 1) / nblk;
-    const int eff = max(1, min(min(g.split_k, max(want, ktiles / 96)), max(1, ktiles / 12)));
+    const int want = (want_wg + nblk - 1) / nblk;
+    int eff = max(1, min(min(g.split_k, max(want, ktiles / slice_stages)), max(1, ktiles / 12)));
+    if (deal_mode != 2) {
+      // whole waves of workgroups: eff x nblk just above a multiple of the chip's resident slots leaves a last wave that is mostly
+      // empty (400 x 400 x 77 k tokens: 1 000 workgroups on 768 slots = 379 us, 740 or 1 520 workgroups = 279 / 293 us)
+      constexpr int slots = OCC * 256;
+      const int W = eff * nblk, wv = W / slots;
+      const int target = W < slots ? slots : (((W - wv * slots) * 2 < slots) ? wv * slots : (wv + 1) * slots);
+      eff = max(1, min(target / nblk, min(g.split_k, max(1, ktiles / 12))));
+    }
     if (deal_mode) {
       const int W = eff * nblk, per = (W + 7) >> 3;
       const int L = blockIdx.x, x = L & 7, slot = L >> 3;
@@ -1078,8 +1088,10 @@ int launch_tn_pipe(const nnr_gemm_args& g, hipStream_t s) {
   const int nbm = (g.M + BM - 1) / BM, nbn = (g.N + BN - 1) / BN;
   dim3 grid(g.split_k > 1 ? nbm * nbn * ((g.split_k + 7) / 8) * 8 : nbm * nbn), block(256);      // split-K: slices are dealt to XCDs (see the kernel)
   static const int deal_mode = [] { const char* e = getenv("NNR_TN_DEAL"); return e ? atoi(e) : 1; }();      // A/B: 0 = tiles of a slice spread over the XCDs
+  static const int want_code = [] { const char* e = getenv("NNR_TN_WANT"); return e ? atoi(e) / 64 : 0; }();    // tuning: minimum workgroup count (default 512)
   nnr_gemm_args gg = g;
-  gg.k_chunk = -deal_mode;
+  static const int stage_code = [] { const char* e = getenv("NNR_TN_STAGES"); return e ? atoi(e) : 0; }();       // tuning: stages per split-K slice (default 96)
+  gg.k_chunk = -((deal_mode & 3) | ((want_code & 63) << 2) | (stage_code << 8));
   hipLaunchKernelGGL((gemm_tn_pipe_kernel<TM, TN, NS, OCC, PRIO>), grid, block, 0, s, gg);
   NNR_CHECK_LAUNCH();
   return NNR_OK;
@@ -1137,10 +1149,20 @@ __global__ __launch_bounds__(256, OCC) void gemm_tn_pipe2_kernel(nnr_gemm_args g
   int v, z = 0;
   int kbeg = 0, kend = K;
   if (g.split_k > 1) {
-    const int deal_mode = -g.k_chunk;                      // set by the launcher (k_chunk itself is not used by this kernel)
+    const int deal_mode = (-g.k_chunk) & 3;                // set by the launcher (k_chunk itself is not used by this kernel)
+    const int want_wg = (((-g.k_chunk) >> 2) & 63) ? (((-g.k_chunk) >> 2) & 63) * 64 : 512;      // workgroups wanted at least (tuning knob, default 512)
+    const int slice_stages = ((-g.k_chunk) >> 8) ? ((-g.k_chunk) >> 8) : 96;                     // stages per slice aimed at (tuning knob)
     const int ktiles = (K + BK - 1) / BK;
-    const int want = (512 + nblk - 1) / nblk;
-    const int eff = max(1, min(min(g.split_k, max(want, ktiles / 96)), max(1, ktiles / 12)));
+    const int want = (want_wg + nblk - 1) / nblk;
+    int eff = max(1, min(min(g.split_k, max(want, ktiles / slice_stages)), max(1, ktiles / 12)));
+    if (deal_mode != 2) {
+      // whole waves of workgroups: eff x nblk just above a multiple of the chip's resident slots leaves a last wave that is mostly
+      // empty (400 x 400 x 77 k tokens: 1 000 workgroups on 768 slots = 379 us, 740 or 1 520 workgroups = 279 / 293 us)
+      constexpr int slots = OCC * 256;
+      const int W = eff * nblk, wv = W / slots;
+      const int target = W < slots ? slots : (((W - wv * slots) * 2 < slots) ? wv * slots : (wv + 1) * slots);
+      eff = max(1, min(target / nblk, min(g.split_k, max(1, ktiles / 12))));
+    }
     if (deal_mode) {
       const int W = eff * nblk, per = (W + 7) >> 3;
       const int L = blockIdx.x, x = L & 7, slot = L >> 3;
@@ -1337,8 +1359,10 @@ int launch_tn_pipe2(const nnr_gemm_args& g, hipStream_t s) {
   const int nbm = (g.M + BM - 1) / BM, nbn = (g.N + BN - 1) / BN;
   dim3 grid(g.split_k > 1 ? nbm * nbn * ((g.split_k + 7) / 8) * 8 : nbm * nbn), block(256);      // split-K: slices are dealt to XCDs (see the kernel)
   static const int deal_mode = [] { const char* e = getenv("NNR_TN_DEAL"); return e ? atoi(e) : 1; }();      // A/B: 0 = tiles of a slice spread over the XCDs
+  static const int want_code = [] { const char* e = getenv("NNR_TN_WANT"); return e ? atoi(e) / 64 : 0; }();    // tuning: minimum workgroup count (default 512)
   nnr_gemm_args gg = g;
-  gg.k_chunk = -deal_mode;
+  static const int stage_code = [] { const char* e = getenv("NNR_TN_STAGES"); return e ? atoi(e) : 0; }();       // tuning: stages per split-K slice (default 96)
+  gg.k_chunk = -((deal_mode & 3) | ((want_code & 63) << 2) | (stage_code << 8));
   hipLaunchKernelGGL((gemm_tn_pipe2_kernel<TM, TN, NS, OCC>), grid, block, 0, s, gg);
   NNR_CHECK_LAUNCH();
   return NNR_OK;
