@@ -206,8 +206,8 @@ def wt_prefetch(dev):
     start of a training forward pass: the copies are needed by the BACKWARD pass only, so they leave the critical chain --
     made lazily, the first user's stream does the copy and users on the other streams wait for it (measured: a 383 us stall
     of the history call's backward behind the candidate call's)."""
-    if not USE_WT or not _WT:
-        return
+    if not USE_WT or not _WT or torch.cuda.is_current_stream_capturing():      # (under hipGraph capture the copies are refreshed lazily by wt():
+        return                                                               # ending a capture that holds this fork segfaults in the HIP runtime)
     from .layers import PARAM_EPOCH
     live = [(k, e, e.ref()) for k, e in _WT.items()]
     live = [(k, e, w) for k, e, w in live if w is not None and isinstance(w, torch.nn.Parameter) and e.ptr == w.data_ptr()]
