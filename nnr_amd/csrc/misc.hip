@@ -24,28 +24,33 @@ __global__ void gate_bwd_kernel(const float* __restrict__ dHt, const float* __re
   }
 }
 
-// ---- out[s, :] = sum_{t < slen[s]} x[off[t] + s, :]   (one wave per sequence)
+// ---- out[s, :] = sum_{t < slen[s]} x[off[t] + s, :]
+// One workgroup per sequence: thread (h, c) = (tid / 128, tid % 128) sums the float4 column c of the rows t = h, h + 2, ... with 8 rows in
+// flight (the row address depends on off[t], so a plain loop pays one memory round trip per token), the two halves meet in LDS.  The launch
+// is bound by its longest sequence: 128 rows are 8 round trips here (one wave per sequence and a second pass for columns 64..99: 32).
 __global__ __launch_bounds__(256) void packed_seq_sum_kernel(const float* __restrict__ x, int D, const int* __restrict__ off,
                                                              const int* __restrict__ slen, int n, float* __restrict__ out) {
-  const int lane = threadIdx.x & 63, s = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (s >= n) return;
+  __shared__ f32x4 part[128];
+  const int s = blockIdx.x, h = threadIdx.x >> 7, c0 = threadIdx.x & 127;
   const int len = slen[s], nv = D >> 2;
-  for (int c0 = 0; c0 < nv; c0 += 64) {
-    const int c = c0 + lane;
+  for (int cb = 0; cb < nv; cb += 128) {
+    const int c = cb + c0;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (c < nv) {
-      // 8 rows in flight: the row address depends on off[t], so a plain loop pays one memory round trip per token
-      int t = 0;
-      for (; t + 8 <= len; t += 8) {
+      int t = h;
+      for (; t + 14 < len; t += 16) {
         f32x4 v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(x + ((long)off[t + u] + s) * D + 4 * c);
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(x + ((long)off[t + 2 * u] + s) * D + 4 * c);
 #pragma unroll
         for (int u = 0; u < 8; ++u) acc += v[u];
       }
-      for (; t < len; ++t) acc += *reinterpret_cast<const f32x4*>(x + ((long)off[t] + s) * D + 4 * c);
-      *reinterpret_cast<f32x4*>(out + (long)s * D + 4 * c) = acc;
+      for (; t < len; t += 2) acc += *reinterpret_cast<const f32x4*>(x + ((long)off[t] + s) * D + 4 * c);
     }
+    if (cb) __syncthreads();
+    if (h == 1) part[c0] = acc;
+    __syncthreads();
+    if (h == 0 && c < nv) *reinterpret_cast<f32x4*>(out + (long)s * D + 4 * c) = acc + part[c0];
   }
 }
 
@@ -752,7 +757,7 @@ extern "C" int nnr_gate_bwd(const float* dHt, const float* H, const float* G, fl
 
 extern "C" int nnr_packed_seq_sum(const float* x, int D, const int* off, const int* slen, int n, float* out, hipStream_t stream) {
   if (D & 3) return NNR_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(packed_seq_sum_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, x, D, off, slen, n, out);
+  hipLaunchKernelGGL(packed_seq_sum_kernel, dim3(n), dim3(256), 0, stream, x, D, off, slen, n, out);
   NNR_CHECK_LAUNCH();
   return NNR_OK;
 }

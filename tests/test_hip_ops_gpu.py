@@ -584,6 +584,22 @@ def test_gcn_aggregate_forward_backward(B, G, D):
     close(dz2, torch.bmm(A.double().transpose(1, 2), dy.double()), what='gcn plain A^T')
 
 
+@pytest.mark.parametrize('n,Lx,D', [(333, 32, 400), (45, 128, 400), (7, 5, 8), (50, 40, 1000)])
+def test_packed_seq_sum_matches_index_add(n, Lx, D):
+    """out[s] = sum over the packed rows of sequence s (the per-sequence reduction of the gate gradient, newsEncoders.py:128-129 backward)."""
+    from nnr_amd import ops
+    lens = _lengths(n, Lx, 31)
+    mask = torch.arange(Lx)[None, :] < lens[:, None]
+    plan = ops.SeqPlan(mask.clone().to(dev()), None)
+    tot = int(plan.off[-1])
+    x = rnd(plan.cap, D, seed=8).to(dev())
+    out = torch.empty((n, D), device=dev(), dtype=torch.float32)
+    ops.packed_seq_sum(x, D, plan, out)
+    ref = torch.zeros((n, D), dtype=torch.float64)
+    ref.index_add_(0, plan.row_seq[:tot].cpu().long(), x[:tot].cpu().double())
+    close(out, ref, tol=1e-5, what='packed_seq_sum')
+
+
 @pytest.mark.parametrize('dot', [False, True])
 def test_pool_packed_forward_backward(dot):
     from nnr_amd import ops
