@@ -113,7 +113,7 @@ class GradientExchange:
     every rank by construction.  With world_size 1 nothing is exchanged unless NNR_DP_FORCE=1 (single-GPU ordering tests on a
     one-rank communicator).  Returns the 1/world scale the fused clip+Adam kernel applies."""
 
-    def __init__(self, flat, early_modules=()):
+    def __init__(self, flat, early_modules=(), table_param=None):
         self.flat = flat
         self.grad = flat.grad
         self.force = os.environ.get('NNR_DP_FORCE') == '1'
@@ -127,9 +127,26 @@ class GradientExchange:
             if any(not e for a, b, e in spans if a >= lo and b <= hi):      # not contiguous in this layout: one bucket
                 lo = hi = None
         self.early_span = (lo, hi) if lo is not None else None
-        self.late_spans = [(0, total)] if lo is None else [(a, b) for a, b in ((0, lo), (hi, total)) if b > a]
+        # TABLE bucket = the word-embedding table's gradient (70 % of the floats of CNE+SUE): final when the last embedding-row
+        # scatter GEMM of the backward pass is done, while the LSTM weight-gradient GEMMs of the step's tail are still running
+        self.table_span = None
+        if table_param is not None and os.environ.get('NNR_DP_TABLE_BUCKET', '1') != '0':
+            for p, o in zip(flat.params, flat.offsets):
+                if p is table_param:
+                    self.table_span = (o, o + (p.numel() + 3) // 4 * 4)
+        cuts = sorted(x for x in (self.early_span, self.table_span) if x is not None)
+        self.late_spans, pos = [], 0
+        for a, b in cuts:
+            if a > pos:
+                self.late_spans.append((pos, a))
+            pos = max(pos, b)
+        if pos < total:
+            self.late_spans.append((pos, total))
         self._pending = None
+        self._pending_table = None
+        self._table_events = []
         self._comm = None
+        self._helper = None
         self.events = None            # tests: {'early_issued': Event, ...} recorded on the issuing stream when set to a dict
 
     def active(self):
@@ -137,10 +154,13 @@ class GradientExchange:
 
     def describe(self):
         es = self.early_span
+        ts = self.table_span
         return {'buckets': ([{'name': 'early (user encoder)', 'floats': es[1] - es[0]}] if es else []) +
+                           ([{'name': 'table (word embedding)', 'floats': ts[1] - ts[0]}] if ts else []) +
                            [{'name': 'late', 'floats': sum(b - a for a, b in self.late_spans)}],
                 'binding': 'C-ABI nnr_dp_allreduce' if (os.environ.get('NNR_DP_NATIVE') == '1' and self.grad.is_cuda) else 'torch.distributed all_reduce',
-                'overlap': 'early bucket is reduced while the news-encoder backward runs' if es else 'none (single bucket)'}
+                'overlap': ('early bucket is reduced while the news-encoder backward runs' if es else 'none (single bucket)') +
+                           ('; table bucket while the LSTM weight-gradient GEMMs of the tail run' if ts else '')}
 
     def _reduce(self, view, async_op):
         nx = _native_exchange() if view.is_cuda else None
@@ -167,6 +187,29 @@ class GradientExchange:
             self.events['early_issued'].record()
         self._pending = self._reduce(self.grad[a:b], True)
 
+    def table_scatter_done(self, expected):
+        """One of the `expected` embedding-row scatter GEMMs of this backward pass is ordered on the CURRENT stream (they run on
+        different HIP streams).  When the last one has reported, the table bucket is handed to the exchange on a helper stream that
+        waits for all of them -- no stream of the backward pass waits for another one here."""
+        if self.table_span is None or not self.active() or not self.grad.is_cuda or self._pending_table is not None:
+            return
+        ev = torch.cuda.Event()
+        ev.record()
+        self._table_events.append(ev)
+        if len(self._table_events) < expected:
+            return
+        if self._helper is None:
+            self._helper = torch.cuda.Stream(device=self.grad.device)
+        a, b = self.table_span
+        with torch.cuda.stream(self._helper):
+            for e in self._table_events:
+                self._helper.wait_event(e)
+            if self.events is not None:
+                self.events['table_issued'] = torch.cuda.Event(enable_timing=True)
+                self.events['table_issued'].record()
+            self._pending_table = (self._reduce(self.grad[a:b], True), self._helper)
+        self._table_events = []
+
     def finish(self):
         """All gradients are final on the current stream: reduce what is left, order the early bucket before the caller's next
         launch, return 1/world."""
@@ -174,16 +217,32 @@ class GradientExchange:
         if not self.active():
             return 1.0 / w
         pend, self._pending = self._pending, None
+        pend_t, self._pending_table = self._pending_table, None
+        self._table_events = []
         spans = list(self.late_spans)
         if pend is None and self.early_span is not None:       # early_ready was never called this step
-            spans = [(0, self.grad.numel())]
-        for a, b in spans:
-            self._reduce(self.grad[a:b], False)
-        if pend is not None:
-            if isinstance(pend, torch.cuda.Stream):
-                torch.cuda.current_stream(self.grad.device).wait_stream(pend)
+            spans.append(self.early_span)
+        if pend_t is None and self.table_span is not None:     # no scatter GEMM reported (another encoder, CPU tensors)
+            spans.append(self.table_span)
+        spans.sort()
+        merged = []
+        for a, b in spans:                                     # adjacent slices as one collective
+            if merged and merged[-1][1] == a:
+                merged[-1] = (merged[-1][0], b)
             else:
-                pend.wait()                                    # NCCL: the current stream waits; gloo: the host waits
+                merged.append((a, b))
+        for a, b in merged:
+            self._reduce(self.grad[a:b], False)
+        cur = torch.cuda.current_stream(self.grad.device) if self.grad.is_cuda else None
+        for p in (pend, pend_t[0] if pend_t is not None else None):
+            if p is None:
+                continue
+            if isinstance(p, torch.cuda.Stream):
+                cur.wait_stream(p)
+            else:
+                p.wait()                                       # NCCL: the current stream waits; gloo: the host waits
+        if pend_t is not None:
+            cur.wait_stream(pend_t[1])
         if self.events is not None and self.grad.is_cuda:
             self.events['finished'] = torch.cuda.Event(enable_timing=True)
             self.events['finished'].record()

@@ -363,6 +363,7 @@ def cne_backward_many(mod, pairs):
     dev = pairs[0][1].device
     for q in mod.parameters():          # materialise (zero-fill) missing .grad buffers on the main stream BEFORE forking
         grad_of(q)
+    mod.__dict__['_table_scatters'] = 2 * len(pairs)      # embedding-row scatter GEMMs of this pass (title + content per call)
     with ops.leaf_scope(dev) as leaf:        # weight-gradient GEMMs of the pre phase: leaves, joined after the recurrence + post phase
         _cne_bwd_rest(mod, pairs, H, dev, leaf)
 
@@ -494,6 +495,11 @@ def _cne_bwd_post(mod, sv, st, leaf=None):
                  trans_b=True, b_idx=(plan.prev_f, plan.prev_r)[d], split_k=ops.split_for(NP, H, cap, bm, bn, target), atomic=True,
                  dyn=plan.total, dyn_dim=2, tile=t, flop_scale=4.0 * H / NP)
 
+    def table_hook():
+        hook = mod.__dict__.get('_table_scatter_hook')       # data parallel: the table's gradient bucket goes out after the last scatter
+        if hook is not None:
+            hook(mod.__dict__.get('_table_scatters', 2))
+
     def dx_scatter():
         # d(embedding rows): dX = dgates . W_ihp (NT on the transposed packed weight), scattered (atomic) into the table
         # gradient through the dropout mask.  The title streams' launch runs BESIDE the content recurrence, whose workgroups
@@ -507,16 +513,19 @@ def _cne_bwd_post(mod, sv, st, leaf=None):
         # one the tail of the step would otherwise still be waiting for
         if _TITLE_DX_FIRST:
             dx_scatter()
+            table_hook()
         dw_ih(); dw_hh(0); dw_hh(1)
     else:
         # two balanced halves: leaf stream dW_ih + dW_hh(reverse), this stream the scatter GEMM + dW_hh(forward)
         leaf(lambda: (dw_ih(), dw_hh(1)), dw_ihp, db_p, dw_hhp)
         dx_scatter()
+        table_hook()
         dw_hh(0)
         leaf.sync()
     ops.lstm_unpack_grads(dw_ihp, db_p, dw_hhp, H, E, [grad_of(q) for q in st['lstm'].param_list()], zero_src=True)
     if leaf is None and not _TITLE_DX_FIRST:
         dx_scatter()
+        table_hook()
 
 
 class CNE(NewsEncoder):

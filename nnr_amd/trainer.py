@@ -74,9 +74,13 @@ class Trainer:
         # bucketed exchange: the user encoder's own gradients are final first (its backward runs before the news encoder's)
         ue = getattr(model, 'user_encoder', None)
         own = [m for name, m in ue.named_children() if name != 'news_encoder'] if ue is not None else []
-        self.exchange = dp.GradientExchange(self.flat, early_modules=[_Own(ue, own)] if ue is not None else [])
+        ne = getattr(model, 'news_encoder', None)
+        table = ne.word_embedding.weight if (ne is not None and hasattr(ne, 'word_embedding')) else None
+        self.exchange = dp.GradientExchange(self.flat, early_modules=[_Own(ue, own)] if ue is not None else [], table_param=table)
         if ue is not None:
             ue.__dict__['_grads_ready_hook'] = self.exchange.early_ready
+        if ne is not None:
+            ne.__dict__['_table_scatter_hook'] = self.exchange.table_scatter_done      # (CNE calls it after each embedding-row scatter GEMM)
 
     def train_step(self, batch):
         """One optimizer step on `batch` (21 device tensors, Model.forward order).  Returns (logits, loss) as device

@@ -269,4 +269,8 @@ def test_gradient_exchange_overlaps_the_news_encoder_backward(binding):
     print(out)
     assert out['backward_left_when_early_bucket_went_out_ms'] >= 1.0, out           # the CNE backward of a batch-32 step is several ms
     assert out['max_grad_diff_vs_no_exchange_rel'] <= 1e-5, out                      # (f32 atomics reorder sums between runs)
-    assert [b['name'] for b in out['buckets']['buckets']] == ['early (user encoder)', 'late']
+    assert [b['name'] for b in out['buckets']['buckets']] == ['early (user encoder)', 'table (word embedding)', 'late']
+    # the word-embedding table's bucket goes out behind the last embedding-row scatter GEMM, before the tail of the step (the LSTM
+    # weight-gradient GEMMs, the stream joins) is done
+    assert out['table_bucket_issued_ms'] is not None and out['early_bucket_issued_ms'] < out['table_bucket_issued_ms'] < out['exchange_finished_ms'], out
+    assert out['step_left_when_table_bucket_went_out_ms'] >= 0.05, out

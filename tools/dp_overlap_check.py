@@ -41,6 +41,7 @@ tr.train_step(batch)
 torch.cuda.synchronize()
 ev = tr.exchange.events
 t_early, t_done = start.elapsed_time(ev['early_issued']), start.elapsed_time(ev['finished'])
+t_table = start.elapsed_time(ev['table_issued']) if 'table_issued' in ev else None
 os.environ['NNR_DP_FORCE'] = '0'
 ref = Trainer(build(), cfg)
 ref.exchange.force = False
@@ -50,6 +51,8 @@ torch.cuda.synchronize()
 # same initial parameters, same batch: the first step's gradients must agree (f32 atomics reorder sums: relative 1e-5 of the norm)
 diff = float((g_first - ref.flat.grad).abs().max()) / max(1e-12, float(ref.flat.grad.norm()))
 print(json.dumps({'binding': binding, 'early_bucket_issued_ms': round(t_early, 3), 'exchange_finished_ms': round(t_done, 3),
-                  'backward_left_when_early_bucket_went_out_ms': round(t_done - t_early, 3), 'buckets': tr.exchange.describe(),
+                  'backward_left_when_early_bucket_went_out_ms': round(t_done - t_early, 3),
+                  'table_bucket_issued_ms': None if t_table is None else round(t_table, 3),
+                  'step_left_when_table_bucket_went_out_ms': None if t_table is None else round(t_done - t_table, 3), 'buckets': tr.exchange.describe(),
                   'max_grad_diff_vs_no_exchange_rel': diff}))
 dist.destroy_process_group()
