@@ -82,6 +82,8 @@ typedef struct nnr_gemm_args {
   uint32_t drop_thresh;
   float drop_scale;
   int vec_epi;
+  int sched;                /* token-reduction (split-K) launches: bits 0-1 how workgroups are dealt to the XCDs, bits 2-7 / 8+ tuning
+                             * overrides of the device-side slice count (NNR_TN_DEAL / NNR_TN_WANT / NNR_TN_STAGES) */
 } nnr_gemm_args;
 
 int nnr_gemm_f32(const nnr_gemm_args* args, hipStream_t stream);

@@ -909,9 +909,9 @@ __global__ __launch_bounds__(256, OCC) void gemm_tn_pipe_kernel(nnr_gemm_args g)
   int v, z = 0;
   int kbeg = 0, kend = K;
   if (g.split_k > 1) {
-    const int deal_mode = (-g.k_chunk) & 3;                // set by the launcher (k_chunk itself is not used by this kernel)
-    const int want_wg = (((-g.k_chunk) >> 2) & 63) ? (((-g.k_chunk) >> 2) & 63) * 64 : 512;      // workgroups wanted at least (tuning knob, default 512)
-    const int slice_stages = ((-g.k_chunk) >> 8) ? ((-g.k_chunk) >> 8) : 96;                     // stages per slice aimed at (tuning knob)
+    const int deal_mode = g.sched & 3;                // set by the launcher
+    const int want_wg = ((g.sched >> 2) & 63) ? ((g.sched >> 2) & 63) * 64 : 512;      // workgroups wanted at least (tuning knob, default 512)
+    const int slice_stages = (g.sched >> 8) ? (g.sched >> 8) : 96;                     // stages per slice aimed at (tuning knob)
     const int ktiles = (K + BK - 1) / BK;
     const int want = (want_wg + nblk - 1) / nblk;
     int eff = max(1, min(min(g.split_k, max(want, ktiles / slice_stages)), max(1, ktiles / 12)));
@@ -1091,7 +1091,7 @@ int launch_tn_pipe(const nnr_gemm_args& g, hipStream_t s) {
   static const int want_code = [] { const char* e = getenv("NNR_TN_WANT"); return e ? atoi(e) / 64 : 0; }();    // tuning: minimum workgroup count (default 512)
   nnr_gemm_args gg = g;
   static const int stage_code = [] { const char* e = getenv("NNR_TN_STAGES"); return e ? atoi(e) : 0; }();       // tuning: stages per split-K slice (default 96)
-  gg.k_chunk = -((deal_mode & 3) | ((want_code & 63) << 2) | (stage_code << 8));
+  gg.sched = (deal_mode & 3) | ((want_code & 63) << 2) | (stage_code << 8);
   hipLaunchKernelGGL((gemm_tn_pipe_kernel<TM, TN, NS, OCC, PRIO>), grid, block, 0, s, gg);
   NNR_CHECK_LAUNCH();
   return NNR_OK;
@@ -1149,9 +1149,9 @@ __global__ __launch_bounds__(256, OCC) void gemm_tn_pipe2_kernel(nnr_gemm_args g
   int v, z = 0;
   int kbeg = 0, kend = K;
   if (g.split_k > 1) {
-    const int deal_mode = (-g.k_chunk) & 3;                // set by the launcher (k_chunk itself is not used by this kernel)
-    const int want_wg = (((-g.k_chunk) >> 2) & 63) ? (((-g.k_chunk) >> 2) & 63) * 64 : 512;      // workgroups wanted at least (tuning knob, default 512)
-    const int slice_stages = ((-g.k_chunk) >> 8) ? ((-g.k_chunk) >> 8) : 96;                     // stages per slice aimed at (tuning knob)
+    const int deal_mode = g.sched & 3;                // set by the launcher
+    const int want_wg = ((g.sched >> 2) & 63) ? ((g.sched >> 2) & 63) * 64 : 512;      // workgroups wanted at least (tuning knob, default 512)
+    const int slice_stages = (g.sched >> 8) ? (g.sched >> 8) : 96;                     // stages per slice aimed at (tuning knob)
     const int ktiles = (K + BK - 1) / BK;
     const int want = (want_wg + nblk - 1) / nblk;
     int eff = max(1, min(min(g.split_k, max(want, ktiles / slice_stages)), max(1, ktiles / 12)));
@@ -1362,7 +1362,7 @@ int launch_tn_pipe2(const nnr_gemm_args& g, hipStream_t s) {
   static const int want_code = [] { const char* e = getenv("NNR_TN_WANT"); return e ? atoi(e) / 64 : 0; }();    // tuning: minimum workgroup count (default 512)
   nnr_gemm_args gg = g;
   static const int stage_code = [] { const char* e = getenv("NNR_TN_STAGES"); return e ? atoi(e) : 0; }();       // tuning: stages per split-K slice (default 96)
-  gg.k_chunk = -((deal_mode & 3) | ((want_code & 63) << 2) | (stage_code << 8));
+  gg.sched = (deal_mode & 3) | ((want_code & 63) << 2) | (stage_code << 8);
   hipLaunchKernelGGL((gemm_tn_pipe2_kernel<TM, TN, NS, OCC>), grid, block, 0, s, gg);
   NNR_CHECK_LAUNCH();
   return NNR_OK;
