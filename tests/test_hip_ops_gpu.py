@@ -385,7 +385,8 @@ def test_pair_recurrence_timeout_is_counted_and_skips_the_optimizer(monkeypatch)
                                               (100, 32, 300, 200, 'pair'), (45, 128, 300, 200, 'pair'), (200, 128, 300, 200, 'pair'),
                                               (45, 128, 300, 200, 'pair_fabric'), (45, 128, 300, 200, 'pair_noquad'),
                                               (203, 40, 300, 200, 'pair_quad6'), (45, 128, 300, 200, 'pair_quad20'),
-                                              (1100, 24, 300, 200, 'pair_quad3'), (45, 128, 300, 200, 'pair_fabric_quad20')])
+                                              (1100, 24, 300, 200, 'pair_quad3'), (45, 128, 300, 200, 'pair_fabric_quad20'),
+                                              (200, 32, 300, 200, 'pair_ones'), (90, 40, 300, 200, 'pair_quad6_ones')])
 def test_bilstm_forward_backward_matches_oracle(n, Lx, E, H, variant, monkeypatch):
     """'one': one workgroup per 16-sequence tile (W_hh streamed from L2);  'pair': two workgroups on two CUs of one XCD with
     W_hh resident, exchanging through that XCD's L2 (sequences longer than 64 steps in 4-row tiles);  'pair_fabric': the same with
@@ -401,10 +402,12 @@ def test_bilstm_forward_backward_matches_oracle(n, Lx, E, H, variant, monkeypatc
     if variant == 'pair_noquad':
         monkeypatch.setenv('NNR_LSTM_QUAD_T', '0')
     if 'quad' in variant and variant != 'pair_noquad':
-        monkeypatch.setenv('NNR_LSTM_QUAD_T', variant.split('quad')[1])
+        monkeypatch.setenv('NNR_LSTM_QUAD_T', variant.split('quad')[1].split('_')[0])
     d = dev()
     torch.manual_seed(n)
     lens = _lengths(n, Lx, n)
+    if variant.endswith('ones'):
+        lens[n // 3:] = 1          # padded history slots: whole tiles of one-token sequences take the element-wise path of the pair kernels
     mask = torch.arange(Lx)[None, :] < lens[:, None]
     x = rnd(n, Lx, E, seed=1, scale=0.5)
     ref = BiLSTM(E, H).double()
