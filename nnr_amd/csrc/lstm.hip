@@ -1377,10 +1377,12 @@ static int lstm_run(const nnr_lstm_problem* probs, int nprob, int H, bool backwa
     // 8.9 us per step of 16), so they pay while the launch is bound by its longest chain, not once the pair slots are oversubscribed
     // several times: same-box A/B of the whole step (ms, T = 0 / 16 / 32 / 64): batch 8 (440 sequences per stream) 4.85 / 3.53 /
     // 3.76 / 3.86; batch 16: 5.83 / 4.81 / 4.89 / 4.90; batch 32: 7.72 / 7.26 / 7.24 / 7.10; batch 64 (3 520): 11.66 / - / 11.77 / 11.75.
+    // Only the few sequences of more than 96 steps at batch 64 and beyond (a dozen quad tiles shorten the 128-step chain the forward launch
+    // is bound by: 1.11 -> 0.91 ms; T = 0 / 64 / 96 / 112: 11.58 / 11.63 / 11.46 / 11.47 ms per step once one-token tiles are element-wise).
     int maxn = 0;
     for (int i = 0; i < nprob; ++i) maxn = max(maxn, a.p[i].n);
     const char* e = getenv("NNR_LSTM_QUAD_T");
-    a.quad_T = e ? atoi(e) : (maxn <= 1024 ? 16 : (maxn <= 2048 ? 64 : 0));
+    a.quad_T = e ? atoi(e) : (maxn <= 1024 ? 16 : (maxn <= 2048 ? 64 : 96));
   }
   // 2-CU weights-stationary recurrence when the caller provides the exchange workspace
   bool pair = UB == 13 && (H % 2 == 0);
