@@ -538,8 +538,8 @@ _SYNC_WS = {}
 
 def _sync_workspace(dev, n, slot):
     """Exchange workspace of the CU-pair recurrence: zero-filled once, then reused launch after launch (the words carry a launch
-    epoch, csrc/lstm.hip).  One per (stream kind, direction of the pass): launches that can be in flight together never share one."""
-    key = (dev.index, n, slot)
+    epoch, csrc/lstm.hip).  One per (stream kind, direction of the pass, HIP stream): launches that can be in flight together never share one."""
+    key = (dev.index, n, slot, torch._C._cuda_getCurrentRawStream(_DEV_INDEX[0] if _DEV_INDEX else torch.cuda.current_device()))      # (per launch stream)
     ws = _SYNC_WS.get(key)
     if ws is None:
         ws = _SYNC_WS[key] = torch.zeros(L.lib().nnr_lstm_sync_bytes(n) // 4, dtype=torch.int32, device=dev)
