@@ -199,6 +199,9 @@ int nnr_embed_gather(const float* table, const int* idx, long n, const int* n_de
                      float p, uint32_t seed, hipStream_t stream);
 int nnr_embed_scatter(const float* dout, const int* idx, long n, int dim, float* dtable_accum, float p, uint32_t seed,
                       hipStream_t stream);
+/* the same over the first min(n, *n_dev) rows (packed token streams: the live row count stays on the device) */
+int nnr_embed_scatter_dyn(const float* dout, const int* idx, long n, const int* n_dev, int dim, float* dtable, float p, uint32_t seed,
+                          hipStream_t stream);
 int nnr_transpose2d(const float* in, float* out, long rows, int cols, int accumulate, hipStream_t stream);
 /* `count` independent transposes out[c][r] = in[r][c] in ONE launch; the descriptors live in device memory (the host side keeps
  * them for the W^T copies of the weights that the data-gradient GEMMs multiply by: refreshed once per optimizer step). */

@@ -220,11 +220,13 @@ __global__ __launch_bounds__(256) void embed_gather_kernel(const float* __restri
 // LDS table per workgroup (ds_add_f32) and leave the block as one atomic row per hot id; the workgroups are persistent
 // (grid-stride) so there are few such flushes.
 constexpr int SC_HOT = 32, SC_MAXD = 320;
-__global__ __launch_bounds__(256) void embed_scatter_kernel(const float* __restrict__ dout, const int* __restrict__ idx, long n, int dim,
+__global__ __launch_bounds__(256) void embed_scatter_kernel(const float* __restrict__ dout, const int* __restrict__ idx, long n,
+                                                            const int* __restrict__ n_dev, int dim,
                                                             float* __restrict__ dtable, uint32_t seed, uint32_t thr, float scale) {
   __shared__ float hot[SC_HOT * SC_MAXD];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const bool use_hot = dim <= SC_MAXD;
+  if (n_dev) n = min(n, (long)*n_dev);                 // live row count kept on the device (packed token streams)
   if (use_hot) for (int i = threadIdx.x; i < SC_HOT * dim; i += 256) hot[i] = 0.f;
   __syncthreads();
   for (long row = blockIdx.x * 4L + wv; row < n; row += gridDim.x * 4L) {
@@ -831,13 +833,21 @@ extern "C" int nnr_embed_gather(const float* table, const int* idx, long n, cons
   NNR_CHECK_LAUNCH();
   return NNR_OK;
 }
-extern "C" int nnr_embed_scatter(const float* dout, const int* idx, long n, int dim, float* dtable, float p, uint32_t seed, hipStream_t stream) {
+static int embed_scatter_launch(const float* dout, const int* idx, long n, const int* n_dev, int dim, float* dtable, float p, uint32_t seed,
+                                hipStream_t stream) {
   const float sc = p > 0.f ? 1.f / (1.f - p) : 1.f;
   const long want = (n + 3) / 4;
-  hipLaunchKernelGGL(embed_scatter_kernel, dim3((int)(want < 1 ? 1 : (want > 1024 ? 1024 : want))), dim3(256), 0, stream, dout, idx, n, dim, dtable, seed,
-                     nnr_drop_thresh(p), sc);
+  hipLaunchKernelGGL(embed_scatter_kernel, dim3((int)(want < 1 ? 1 : (want > 1024 ? 1024 : want))), dim3(256), 0, stream, dout, idx, n, n_dev, dim, dtable,
+                     seed, nnr_drop_thresh(p), sc);
   NNR_CHECK_LAUNCH();
   return NNR_OK;
+}
+extern "C" int nnr_embed_scatter(const float* dout, const int* idx, long n, int dim, float* dtable, float p, uint32_t seed, hipStream_t stream) {
+  return embed_scatter_launch(dout, idx, n, nullptr, dim, dtable, p, seed, stream);
+}
+extern "C" int nnr_embed_scatter_dyn(const float* dout, const int* idx, long n, const int* n_dev, int dim, float* dtable, float p, uint32_t seed,
+                                     hipStream_t stream) {
+  return embed_scatter_launch(dout, idx, n, n_dev, dim, dtable, p, seed, stream);
 }
 extern "C" int nnr_transpose2d(const float* in, float* out, long rows, int cols, int accumulate, hipStream_t stream) {
   EW_LAUNCH(transpose2d_kernel, rows * cols, in, out, rows, cols, accumulate);

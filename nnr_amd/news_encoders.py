@@ -124,6 +124,7 @@ def cne_forward(mod, title_text, title_mask, content_text, content_mask, categor
 
 _SIDE = {}
 ops.STREAM_CACHES.append(_SIDE)
+_DX_SPLIT = os.environ.get('NNR_DX_SPLIT', '1') == '1'      # embedding-row gradient as plain GEMM + scatter kernel (11.46 vs 11.51 ms fused)
 _BWD_SPLIT = os.environ.get('NNR_LSTM_BWD_SPLIT', '1') == '1'      # batch 8: 4.68 (split) vs 4.93 ms; batch 64: no difference
 _CNE_UNION = os.environ.get('NNR_CNE_UNION', '1') != '0'      # A/B switch: candidate + history call as one packed token stream
 
@@ -505,6 +506,15 @@ def _cne_bwd_post(mod, sv, st, leaf=None):
         # gradient through the dropout mask.  The title streams' launch runs BESIDE the content recurrence, whose workgroups
         # hold 98 KB of LDS per CU: there the 40 KB tile (tile 15) can move in next to them, the 80 KB one (the automatic
         # choice for this long reduction) cannot and crawls (384 us for 4 GFLOP, measured).
+        if _DX_SPLIT:
+            # plain-store GEMM into the cell-state buffer (dead after the recurrence backward; xd / hout are still being read by the
+            # weight-gradient GEMMs on the leaf stream) + the row-scatter kernel: the atomic epilogue of the fused form costs the GEMM
+            # 18 % (764 vs 624 us alone, tools/dx_epilogue_bench.py)
+            dx = st['cell'].view(-1)[:cap * E].view(cap, E)
+            ops.gemm(dg, w.w_ihp_t, dx, M=cap, N=E, K=2 * NP, lda=2 * NP, ldb=2 * NP, ldc=E, dyn=plan.total, dyn_dim=1,
+                     tile=0 if leaf is not None else _TITLE_DX_TILE, flop_scale=4.0 * H / NP)
+            ops.embed_scatter(dx, plan.tok, grad_of(emb), p, st['seed'], dyn=plan.total)
+            return
         ops.gemm(dg, w.w_ihp_t, grad_of(emb), M=cap, N=E, K=2 * NP, lda=2 * NP, ldb=2 * NP, ldc=E, c_idx=plan.tok, atomic=True,
                  drop=(4, p, st['seed'], E), dyn=plan.total, dyn_dim=1, tile=0 if leaf is not None else _TITLE_DX_TILE, flop_scale=4.0 * H / NP)
 

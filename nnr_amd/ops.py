@@ -776,8 +776,12 @@ def embed_gather(table, idx, p, seed, out=None, dyn=None):
     return out
 
 
-def embed_scatter(dout, idx, dtable, p, seed):
+def embed_scatter(dout, idx, dtable, p, seed, dyn=None):
     n, dim = idx.numel(), dtable.shape[1]
+    if dyn is not None:
+        L.check(L.lib().nnr_embed_scatter_dyn(_p(dout), _p(idx), C.c_long(n), _p(dyn), dim, _p(dtable), C.c_float(p), C.c_uint32(seed & 0xFFFFFFFF),
+                                              _s()), 'nnr_embed_scatter_dyn')
+        return
     L.check(L.lib().nnr_embed_scatter(_p(dout), _p(idx), C.c_long(n), dim, _p(dtable), C.c_float(p), C.c_uint32(seed & 0xFFFFFFFF), _s()),
             'nnr_embed_scatter')
 
