@@ -124,6 +124,7 @@ def cne_forward(mod, title_text, title_mask, content_text, content_mask, categor
 
 _SIDE = {}
 ops.STREAM_CACHES.append(_SIDE)
+_POST_INLINE = os.environ.get('NNR_POST_INLINE', '0') == '1'      # A/B: the content stream's tail GEMMs on one HIP stream
 _DX_SPLIT = os.environ.get('NNR_DX_SPLIT', '1') == '1'      # embedding-row gradient as plain GEMM + scatter kernel (11.46 vs 11.51 ms fused)
 _BWD_SPLIT = os.environ.get('NNR_LSTM_BWD_SPLIT', '1') == '1'      # batch 8: 4.68 (split) vs 4.93 ms; batch 64: no difference
 _CNE_UNION = os.environ.get('NNR_CNE_UNION', '1') != '0'      # A/B switch: candidate + history call as one packed token stream
@@ -527,11 +528,16 @@ def _cne_bwd_post(mod, sv, st, leaf=None):
         dw_ih(); dw_hh(0); dw_hh(1)
     else:
         # two balanced halves: leaf stream dW_ih + dW_hh(reverse), this stream the scatter GEMM + dW_hh(forward)
-        leaf(lambda: (dw_ih(), dw_hh(1)), dw_ihp, db_p, dw_hhp)
-        dx_scatter()
-        table_hook()
-        dw_hh(0)
-        leaf.sync()
+        if _POST_INLINE:
+            dx_scatter()
+            table_hook()
+            dw_ih(); dw_hh(0); dw_hh(1)
+        else:
+            leaf(lambda: (dw_ih(), dw_hh(1)), dw_ihp, db_p, dw_hhp)
+            dx_scatter()
+            table_hook()
+            dw_hh(0)
+            leaf.sync()
     ops.lstm_unpack_grads(dw_ihp, db_p, dw_hhp, H, E, [grad_of(q) for q in st['lstm'].param_list()], zero_src=True)
     if leaf is None and not _TITLE_DX_FIRST:
         dx_scatter()
