@@ -124,6 +124,7 @@ def cne_forward(mod, title_text, title_mask, content_text, content_mask, categor
 
 _SIDE = {}
 ops.STREAM_CACHES.append(_SIDE)
+_LSTM_FWD_SPLIT = os.environ.get('NNR_LSTM_FWD_SPLIT', '0') == '1'      # A/B: title recurrence launched on the title stream
 _POST_INLINE = os.environ.get('NNR_POST_INLINE', '0') == '1'      # A/B: the content stream's tail GEMMs on one HIP stream
 _DX_SPLIT = os.environ.get('NNR_DX_SPLIT', '1') == '1'      # embedding-row gradient as plain GEMM + scatter kernel (11.46 vs 11.51 ms fused)
 _BWD_SPLIT = os.environ.get('NNR_LSTM_BWD_SPLIT', '1') == '1'      # batch 8: 4.68 (split) vs 4.93 ms; batch 64: no difference
@@ -203,7 +204,7 @@ def cne_forward_many(mod, calls):
     mod._packed_weights('title', mod.title_lstm)        # (re)pack on the main stream BEFORE forking: both calls read them
     mod._packed_weights('content', mod.content_lstm)
     pre = _fork_join(len(calls), dev, lambda i, on_main: _cne_fwd_pre(mod, *calls[i], par=on_main))
-    items = [st for sv in pre for st in (sv['streams'][1],)] + [st for sv in pre for st in (sv['streams'][0],)]   # content streams first
+    items = [st for sv in pre for st in (sv['streams'][1],)] + [st for sv in pre for st in (sv['streams'][0],) if not st.get('lstm_done')]   # content streams first
     for i in range(0, len(items), 4):
         ops.lstm_fwd(items[i:i + 4], H)
     return _fork_join(len(calls), dev, lambda i, on_main: _cne_fwd_post(mod, pre[i], on_main))
@@ -268,6 +269,11 @@ def _cne_fwd_pre(mod, title_text, title_mask, content_text, content_mask, catego
         st['cell'] = torch.empty((cap, 2 * w.HP), **f32)
         st['hout'] = torch.empty((cap, H2), **f32)
         st['cn'] = torch.empty((n, H2), **f32)
+        if _LSTM_FWD_SPLIT and par and name == 'title':
+            # the title recurrence (32 steps, a fifth of the tokens) right behind its own projection on the title stream: it runs under
+            # the content stream's projection GEMM instead of adding to the recurrence launch the whole forward pass waits for
+            ops.lstm_fwd([st], H)
+            st['lstm_done'] = True
         streams[slot] = st
 
     # the title and the content stream are independent up to the recurrence: plan + gather + input projection of the
