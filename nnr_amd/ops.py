@@ -236,6 +236,7 @@ def wt_prefetch(dev):
 
 # LDS-DMA staged weight-gradient tiles (csrc/gemm.hip: gemm_tn_pipe_kernel): (tile id, rows, cols, workgroups to aim for)
 TN_PIPE = os.environ.get('NNR_TN_PIPE', '1') != '0'
+_TN_WIDE = os.environ.get('NNR_TN_WIDE', '0') == '1'      # A/B: 128 x 160 tile for the 1664 x 300 weight gradient
 _TN_SMALL_LDS = os.environ.get('NNR_TN_SMALL_LDS', '1') == '1'      # 53 KB tiles everywhere: they fit beside a recurrence workgroup (98 KB)
                                                                     # and beside each other; the 78 KB 128 x 208 tile is faster alone (83 vs 70 TF
                                                                     # on 400 x 400) but the step is 12.35 vs 12.52 ms with the small ones
@@ -248,6 +249,8 @@ def tn_tile(M, N, K, gather=False):
     layers stay on the register-staged 64x80 tile."""
     if not TN_PIPE or K < 8192 or (M & 3) or (N & 3) or (M >= 512 and N >= 512):
         return 0, 64, 80, 2048
+    if _TN_WIDE and not gather and M >= 1024 and 160 < N <= 320:
+        return 30, 128, 160, 2048         # dW_ih (1664 x 300): two 160-column blocks instead of four 80-column ones: A (d gates) is fetched twice, not 4x
     if _TN_SMALL_LDS:
         return (20 if gather else 26), 128, 80, 2048
     if N <= 208 or (N > 320 and N <= 416):
@@ -347,7 +350,7 @@ def gemm(A, B, C_=None, *, M, N, K, lda, ldb, ldc=0, trans_a=False, trans_b=Fals
         t = 5 if not trans_b else 4
     fam = 'gemm_%s_%s' % ('tn' if trans_a else ('nn' if trans_b else 'nt'),
                           {1: '256x80', 2: '64x80', 3: '128x208', 4: '128x80', 5: '128x80k32', 6: '64x80k64', 7: '16x80skinny', 8: 'pipe128x80k32', 9: 'pipe2_128x80', 13: 'pipe128x80s4',
-                           15: 'pipe128x80', 16: 'pipe128x80s2', 20: 'pipe128x80', 26: 'pipe2_128x80', 27: 'pipe2_128x208', 22: 'pipe64x80', 23: 'pipe256x80', 24: 'pipe128x208', 25: 'pipe128x128'}.get(t, 'tile%d' % t))
+                           15: 'pipe128x80', 16: 'pipe128x80s2', 20: 'pipe128x80', 26: 'pipe2_128x80', 27: 'pipe2_128x208', 30: 'pipe2_128x160', 22: 'pipe64x80', 23: 'pipe256x80', 24: 'pipe128x208', 25: 'pipe128x128'}.get(t, 'tile%d' % t))
 
     def flops(M=M, N=N, K=K, dyn=dyn, dyn_dim=dyn_dim, batch=batch):
         m, k = M, K

@@ -60,10 +60,10 @@ def tn():
         bidx = (torch.arange(cap, device=d, dtype=torch.int32) - 3200).clamp_min(-1) if gather else None
         fns = {}
         for t in tiles:
-            if gather and t == 26:
+            if gather and t in (26,):
                 continue
-            bm = {2: 64, 26: 128, 27: 128}[t]
-            bn = {27: 208}.get(t, 80)
+            bm = {2: 64, 26: 128, 27: 128, 30: 128}[t]
+            bn = {27: 208, 30: 160}.get(t, 80)
             for target in (256, 512, 1024, 2048):
                 sk = ops.split_for(M, N, cap, tile_m=bm, tile_n=bn, target_blocks=target)
                 fns['t%d/%d' % (t, target)] = (lambda t=t, sk=sk: ops.gemm(a, b, c, M=M, N=N, K=cap, lda=M, ldb=N, ldc=N, trans_a=True, trans_b=True,
