@@ -236,7 +236,7 @@ def wt_prefetch(dev):
 
 # LDS-DMA staged weight-gradient tiles (csrc/gemm.hip: gemm_tn_pipe_kernel): (tile id, rows, cols, workgroups to aim for)
 TN_PIPE = os.environ.get('NNR_TN_PIPE', '1') != '0'
-_TN_WIDE = os.environ.get('NNR_TN_WIDE', '0') == '1'      # A/B: 128 x 160 tile for the 1664 x 300 weight gradient
+_TN_WIDE = os.environ.get('NNR_TN_WIDE', '1') == '1'      # 128 x 160 tile for the 1664 x 300 weight gradient: counter traffic 2.0x -> 1.5x of its operands, step +0.05 ms
 _TN_SMALL_LDS = os.environ.get('NNR_TN_SMALL_LDS', '1') == '1'      # 53 KB tiles everywhere: they fit beside a recurrence workgroup (98 KB)
                                                                     # and beside each other; the 78 KB 128 x 208 tile is faster alone (83 vs 70 TF
                                                                     # on 400 x 400) but the step is 12.35 vs 12.52 ms with the small ones
