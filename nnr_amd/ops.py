@@ -236,6 +236,7 @@ def wt_prefetch(dev):
 
 # LDS-DMA staged weight-gradient tiles (csrc/gemm.hip: gemm_tn_pipe_kernel): (tile id, rows, cols, workgroups to aim for)
 TN_PIPE = os.environ.get('NNR_TN_PIPE', '1') != '0'
+_TN_SQUARE = os.environ.get('NNR_TN_SQUARE', '1') == '1'      # LDS-DMA tile for the 900 x 900 weight gradients of the user encoder (same step time, 8 instead of 12 atomic slices)
 _TN_WIDE = os.environ.get('NNR_TN_WIDE', '1') == '1'      # 128 x 160 tile for the 1664 x 300 weight gradient: counter traffic 2.0x -> 1.5x of its operands, step +0.05 ms
 _TN_SMALL_LDS = os.environ.get('NNR_TN_SMALL_LDS', '1') == '1'      # 53 KB tiles everywhere: they fit beside a recurrence workgroup (98 KB)
                                                                     # and beside each other; the 78 KB 128 x 208 tile is faster alone (83 vs 70 TF
@@ -247,6 +248,8 @@ def tn_tile(M, N, K, gather=False):
     for.  Measured on the step's shapes (tools/gemm_pipe_bench.py tn, TFLOP/s old -> new): 1664x300 82 -> 96 (128x80),
     832x200 with gathered rows 68 -> 86, 400x400 75 -> 82, 200x400 62 -> 73 (128x208); short reductions and the 900x900 SUE
     layers stay on the register-staged 64x80 tile."""
+    if _TN_SQUARE and TN_PIPE and K >= 2048 and M >= 512 and N >= 512 and not gather and not ((M & 3) or (N & 3)):
+        return 26, 128, 80, 2048          # SUE's 900 x 900 x 4 352 weight gradients: 8 slices of 544 rows instead of 12 of 363 on the 64 x 80 tile
     if not TN_PIPE or K < 8192 or (M & 3) or (N & 3) or (M >= 512 and N >= 512):
         return 0, 64, 80, 2048
     if _TN_WIDE and not gather and M >= 1024 and 160 < N <= 320:
