@@ -209,7 +209,11 @@ def main():
     from nnr_amd.trainer import Trainer
     from nnr_amd import profile as prof
 
-    rank, local, world = dp.init_from_env('nccl' if a.gpus > 1 else None)
+    # NNR_DP_BACKEND=gloo + NNR_SHARE_GPU=1: test mode -- N ranks on ONE GPU, exchanging through gloo (RCCL refuses two ranks on a device):
+    # the launcher, the rank code, the sharding and the bucketed GradientExchange run end to end on device tensors of a 1-GPU box
+    rank, local, world = dp.init_from_env(os.environ.get('NNR_DP_BACKEND', 'nccl') if a.gpus > 1 else None)
+    if os.environ.get('NNR_SHARE_GPU') == '1':
+        local = 0
     assert world == a.gpus, 'world size %d != --gpus %d (launch with torch.distributed.run --nproc-per-node %d, or let bench.py do it)' % (world, a.gpus, a.gpus)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)

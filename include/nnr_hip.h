@@ -299,6 +299,8 @@ int nnr_layernorm_fwd(const float* u, const float* gamma, const float* beta, flo
                       float* r_out, const float* resid, float* y, float p, uint32_t seed, hipStream_t stream);
 int nnr_layernorm_bwd(const float* dv, const float* xhat, const float* rstd, const float* gamma, long rows, int D, float* du,
                       float* dgamma, float* dbeta, hipStream_t stream);
+/* *out_zeroed += sum g^2, a DETERMINISTIC function of g (fixed-order two-level sum: data-parallel ranks must clip by the same bits);
+ * launches of one process must be stream-ordered (one device-global scratch) */
 int nnr_sumsq(const float* g, long n, float* out_zeroed, hipStream_t stream);
 /* clip_grad_norm_(max_norm = clip) + torch.optim.Adam step on one flat buffer (trainer.py:118-120); grads are scaled by
  * grad_scale first (1/world_size after the RCCL sum all-reduce).  A step whose squared gradient norm is not finite is

@@ -605,8 +605,15 @@ __global__ void logits_bwd_kernel(const float* __restrict__ dlogits, const float
 }
 
 // ---- optimiser (trainer.py:118-120): global L2 norm -> clip coefficient -> Adam (torch.optim.Adam defaults), one flat buffer
+// The norm must be a DETERMINISTIC function of the gradient: under data parallelism every rank computes it from the same all-reduced buffer,
+// and a clip coefficient that differs in the last bit (f32 atomics add the block sums in arrival order) lets the ranks' parameters drift apart
+// (tools/dp_two_rank_check.py).  Block sums go to fixed slots; the last block to arrive adds the slots in a fixed order.
+constexpr int SUMSQ_BLOCKS = 1024;
+__device__ float g_sumsq_part[SUMSQ_BLOCKS];
+__device__ unsigned g_sumsq_arrived;
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ out) {
   __shared__ float part[4];
+  __shared__ bool last;
   float acc = 0.f;
   const long n4 = n >> 2;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
@@ -617,7 +624,23 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+  if (threadIdx.x == 0) {
+    g_sumsq_part[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+    __threadfence();
+    last = atomicAdd(&g_sumsq_arrived, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  float t = 0.f;
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) t += __builtin_nontemporal_load(&g_sumsq_part[i]);
+  t = wave_sum(t);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    *out += (part[0] + part[1]) + (part[2] + part[3]);      // (out: zeroed by the caller; += keeps the old contract of accumulating into it)
+    g_sumsq_arrived = 0;                                    // ready for the next launch (launches of one process are stream-ordered)
+  }
 }
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             long n, const float* __restrict__ sumsq, float grad_scale, float clip, float lr, float b1, float b2,
@@ -964,7 +987,12 @@ extern "C" int nnr_logits_bwd(const float* dlogits, const float* user, const flo
   EW_LAUNCH(logits_bwd_kernel, (long)B * N * D, dlogits, user, cand, (long)B * N, D, duser, dcand, dcand_accumulate);
 }
 
-extern "C" int nnr_sumsq(const float* g, long n, float* out_zeroed, hipStream_t stream) { EW_LAUNCH(sumsq_kernel, n / 4 + 1, g, n, out_zeroed); }
+extern "C" int nnr_sumsq(const float* g, long n, float* out_zeroed, hipStream_t stream) {
+  const long want = (n / 4 + 255) / 256;
+  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)(want < 1 ? 1 : (want > SUMSQ_BLOCKS ? SUMSQ_BLOCKS : want))), dim3(256), 0, stream, g, n, out_zeroed);
+  NNR_CHECK_LAUNCH();
+  return NNR_OK;
+}
 
 extern "C" int nnr_clip_adam(float* p, const float* g, float* m, float* v, long n, const float* sumsq, float grad_scale, float clip,
                              float lr, float beta1, float beta2, float eps, float weight_decay, int step, hipStream_t stream) {

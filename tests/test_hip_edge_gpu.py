@@ -274,3 +274,34 @@ def test_gradient_exchange_overlaps_the_news_encoder_backward(binding):
     # weight-gradient GEMMs, the stream joins) is done
     assert out['table_bucket_issued_ms'] is not None and out['early_bucket_issued_ms'] < out['table_bucket_issued_ms'] < out['exchange_finished_ms'], out
     assert out['step_left_when_table_bucket_went_out_ms'] >= 0.05, out
+
+
+def test_two_ranks_of_the_product_path_on_one_gpu():
+    """>= 2 RCCL ranks need >= 2 GPUs; the rest of the multi-rank path does not.  Two ranks of the product's trainer share this GPU and exchange
+    through gloo (tools/dp_two_rank_check.py): the bucketed exchange (early / table / late) reproduces the mean of the per-shard gradients, and
+    the ranks' parameters stay bit-identical over optimizer steps although they were initialised differently."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', '29571',
+           os.path.join(root, 'tools', 'dp_two_rank_check.py')]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    print(out)
+    assert out['ok'] and out['world'] == 2 and out['parameters_identical_across_ranks']
+    assert out['buckets'] == ['early (user encoder)', 'table (word embedding)', 'late']
+
+
+def test_bench_launcher_runs_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` as the driver types it (launcher -> torch.distributed.run -> two ranks), in the shared-GPU gloo test mode."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    env.update(NNR_DP_BACKEND='gloo', NNR_SHARE_GPU='1')
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--no_cpu_baseline', '--batch_size', '8'],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert out['n_gpus'] == 2 and out['scaling'] == 'weak' and out['config']['global_batch'] == 16 and out['value'] > 0
+    assert out['strong_scaling']['per_gpu_batch'] == 4 and out['config']['recurrence_exchange_timeouts'] == 0
