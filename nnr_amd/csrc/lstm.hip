@@ -1383,6 +1383,7 @@ static int lstm_run(const nnr_lstm_problem* probs, int nprob, int H, bool backwa
     for (int i = 0; i < nprob; ++i) maxn = max(maxn, a.p[i].n);
     const char* e = getenv("NNR_LSTM_QUAD_T");
     a.quad_T = e ? atoi(e) : (maxn <= 1024 ? 16 : (maxn <= 2048 ? 64 : 96));
+    if (backward) { const char* eb = getenv("NNR_LSTM_QUAD_T_BWD"); if (eb) a.quad_T = atoi(eb); }      // (A/B: own threshold for the backward launches)
   }
   // 2-CU weights-stationary recurrence when the caller provides the exchange workspace
   bool pair = UB == 13 && (H % 2 == 0);
