@@ -238,9 +238,10 @@ def wt_prefetch(dev):
 TN_PIPE = os.environ.get('NNR_TN_PIPE', '1') != '0'
 _TN_SQUARE = os.environ.get('NNR_TN_SQUARE', '1') == '1'      # LDS-DMA tile for the 900 x 900 weight gradients of the user encoder (same step time, 8 instead of 12 atomic slices)
 _TN_WIDE = os.environ.get('NNR_TN_WIDE', '1') == '1'      # 128 x 160 tile for the 1664 x 300 weight gradient: counter traffic 2.0x -> 1.5x of its operands, step +0.05 ms
-_TN_SMALL_LDS = os.environ.get('NNR_TN_SMALL_LDS', '1') == '1'      # 53 KB tiles everywhere: they fit beside a recurrence workgroup (98 KB)
-                                                                    # and beside each other; the 78 KB 128 x 208 tile is faster alone (83 vs 70 TF
-                                                                    # on 400 x 400) but the step is 12.35 vs 12.52 ms with the small ones
+_TN_SMALL_LDS = os.environ.get('NNR_TN_SMALL_LDS', '0') == '1'      # 1: 53 KB 128 x 80 tiles everywhere.  Mid-round they won (12.35 vs 12.52 ms:
+                                                                    # they fitted beside a 98 KB recurrence workgroup); since the recurrence holds
+                                                                    # 120-130 KB and the split-K slices come in whole waves, the 78 KB 128 x 208
+                                                                    # tile for N = 200 / 400 is ahead again (11.38 vs 11.43 ms, 4 rounds each)
 
 
 def tn_tile(M, N, K, gather=False):
