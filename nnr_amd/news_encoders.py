@@ -517,7 +517,8 @@ def _cne_bwd_post(mod, sv, st, leaf=None):
             # plain-store GEMM into the cell-state buffer (dead after the recurrence backward; xd / hout are still being read by the
             # weight-gradient GEMMs on the leaf stream) + the row-scatter kernel: the atomic epilogue of the fused form costs the GEMM
             # 18 % (764 vs 624 us alone, tools/dx_epilogue_bench.py)
-            dx = st['cell'].view(-1)[:cap * E].view(cap, E)
+            # (the cell buffer is [cap, 2*HP]: large enough only when 2*HP >= E -- not at --hidden_dim <= 144 with E = 300)
+            dx = st['cell'].view(-1)[:cap * E].view(cap, E) if st['cell'].numel() >= cap * E else torch.empty((cap, E), **f32)
             ops.gemm(dg, w.w_ihp_t, dx, M=cap, N=E, K=2 * NP, lda=2 * NP, ldb=2 * NP, ldc=E, dyn=plan.total, dyn_dim=1,
                      tile=0 if leaf is not None else _TITLE_DX_TILE, flop_scale=4.0 * H / NP)
             ops.embed_scatter(dx, plan.tok, grad_of(emb), p, st['seed'], dyn=plan.total)

@@ -259,6 +259,8 @@ def tn_tile(M, N, K, gather=False):
         return (20 if gather else 26), 128, 80, 2048
     if N <= 208 or (N > 320 and N <= 416):
         return 27, 128, 208, 640          # gen-2 loop, 128 x 208 (one token row per DMA instruction: takes gathered rows)
+    if gather:
+        return 20, 128, 80, 2048          # gathered rows wider than 208 columns (dW_hh at --hidden_dim 212..256): tile 26 has no gather path
     return 26, 128, 80, 2048             # gen-2 loop, 128 x 80
 
 

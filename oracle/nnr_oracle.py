@@ -54,6 +54,17 @@ def default_config(**over):
 
 
 # --------------------------------------------------------------------------- small pieces
+def forced_dropout(x, p, training, keep=None):
+    """F.dropout(x, p, training) -- or, when a parity test injects the keep-mask the HIP path's counter-based generator
+    produced for this very site and call, the same arithmetic with THAT mask:  x * keep / (1 - p).  (Dropout masks are
+    generator-specific, so a train-mode step of the two implementations can only be compared element for element with the
+    mask shared; every dropout site of the path has such a hook: newsEncoders.py:53,117-118, userEncoders.py:80,91,171,
+    layers.py:319-322.)"""
+    if keep is None or not training or p <= 0.0:
+        return F.dropout(x, p, training)
+    return x * (keep.to(x.dtype).reshape(x.shape) * (1.0 / (1.0 - p)))
+
+
 def masked_softmax(scores, mask, dim):
     """softmax after masked_fill(mask==0, -1e9)  (layers.py:143,171,199)."""
     if mask is not None:
@@ -246,8 +257,14 @@ class NewsEncoder(nn.Module):
         self.dropout_rate = config.dropout_rate
         self.auxiliary_loss = None
 
-    def drop(self, x):
-        return F.dropout(x, self.dropout_rate, self.training)
+    # parity tests: {(site, call index): keep-mask}; sites 'title' / 'content' (newsEncoders.py:117-118, the title-only encoders
+    # use 'title' for :163,193), 'cat' / 'sub' (:53), 'mid' (:165,197); call index 0 = the candidate call, 1 = the history call
+    forced_keep = None
+    _call_index = 0
+
+    def drop(self, x, site=None):
+        keep = None if self.forced_keep is None else self.forced_keep.get((site, self._call_index))
+        return forced_dropout(x, self.dropout_rate, self.training, keep)
 
     def initialize(self):  # newsEncoders.py:24-27
         nn.init.uniform_(self.category_embedding.weight, -0.1, 0.1)
@@ -256,8 +273,10 @@ class NewsEncoder(nn.Module):
             self.subCategory_embedding.weight[0].zero_()
 
     def feature_fusion(self, rep, category, subCategory):  # newsEncoders.py:50-54
-        return torch.cat([rep, self.drop(self.category_embedding(category)),
-                          self.drop(self.subCategory_embedding(subCategory))], dim=2)
+        out = torch.cat([rep, self.drop(self.category_embedding(category), 'cat'),
+                         self.drop(self.subCategory_embedding(subCategory), 'sub')], dim=2)
+        self._call_index += 1          # (Model.forward resets it: candidate call, then history call)
+        return out
 
 
 class CNE(NewsEncoder):
@@ -307,8 +326,8 @@ class CNE(NewsEncoder):
         cmask[:, 0] = 1
         tlen = tmask.sum(dim=1).long()
         clen = cmask.sum(dim=1).long()
-        xt = self.drop(self.word_embedding(title_text)).view(n, self.T, -1)
-        xc = self.drop(self.word_embedding(content_text)).view(n, self.C, -1)
+        xt = self.drop(self.word_embedding(title_text), 'title').view(n, self.T, -1)
+        xc = self.drop(self.word_embedding(content_text), 'content').view(n, self.C, -1)
         Ht, mt = self.title_lstm(xt, tlen)
         Hc, mc = self.content_lstm(xc, clen)
         # cross-selective gate, newsEncoders.py:128-131 (padded rows stay zero because H is zero there).
@@ -349,8 +368,8 @@ class CNN(NewsEncoder):
                 category, subCategory, user_embedding):
         B, N = title_text.shape[:2]
         mask = title_mask.view(B * N, self.T)
-        w = self.drop(self.word_embedding(title_text)).view(B * N, self.T, -1)
-        c = self.drop(self.conv(w.transpose(1, 2)).transpose(1, 2))
+        w = self.drop(self.word_embedding(title_text), 'title').view(B * N, self.T, -1)
+        c = self.drop(self.conv(w.transpose(1, 2)).transpose(1, 2), 'mid')
         rep = self.attention(c, mask).view(B, N, -1)
         return self.feature_fusion(rep, category, subCategory)
 
@@ -376,8 +395,8 @@ class MHSA(NewsEncoder):
                 category, subCategory, user_embedding):
         B, N = title_text.shape[:2]
         mask = title_mask.view(B * N, self.T)
-        w = self.drop(self.word_embedding(title_text)).view(B * N, self.T, -1)
-        c = self.drop(self.multiheadAttention(w, w, w, mask))
+        w = self.drop(self.word_embedding(title_text), 'title').view(B * N, self.T, -1)
+        c = self.drop(self.multiheadAttention(w, w, w, mask), 'mid')
         rep = self.attention(c, mask).view(B, N, self.feature_dim)
         return self.feature_fusion(rep, category, subCategory)
 
@@ -438,11 +457,13 @@ class GCN(nn.Module):
         for l in self.gcn_layers:
             l.initialize()
 
+    forced_keep = None          # parity tests: {layer index: keep-mask [B, G, D]} (layers.py:319-322)
+
     def forward(self, x, graph):
         for i, layer in enumerate(self.gcn_layers):
             x = layer(x, graph)
             if i + 1 < len(self.gcn_layers):
-                x = F.dropout(x, self.p, self.training)
+                x = forced_dropout(x, self.p, self.training, None if self.forced_keep is None else self.forced_keep.get(i))
         return x
 
 
@@ -460,6 +481,7 @@ class SUE(UserEncoder):
         self.clusterFeatureAffine = nn.Linear(D, D, bias=True)
         self.interClusterAttention = CandidatePool(D, D, self.attention_dim)
         self.p = config.dropout_rate
+        self.forced_keep = None
         self.cluster_num = config.category_num + 1      # +1: the padding cluster
         self.H = config.max_history_num
 
@@ -481,7 +503,8 @@ class SUE(UserEncoder):
         idx = a['user_history_category_indices']                      # [B, H] int64 in [0, K]
         hist = self.encode_history(a)                                 # [B, H, D]
         # the reference applies dropout_ to the batch-expanded proxy tensor (one mask per sample), :80
-        proxy = F.dropout(self.proxy_node_embedding.unsqueeze(0).expand(B, -1, -1), self.p, self.training)
+        fk = self.forced_keep or {}         # parity tests: 'proxy' [B, K, D] (userEncoders.py:80), 'affine' [B, N, C, D] (:91)
+        proxy = forced_dropout(self.proxy_node_embedding.unsqueeze(0).expand(B, -1, -1), self.p, self.training, fk.get('proxy'))
         x0 = torch.cat([hist, proxy], dim=1)                          # [B, G, D]
         g = (self.gcn(x0, a['user_history_graph']) + x0)[:, :self.H]  # [B, H, D]
         # intra-cluster attention == scatter_softmax / scatter_sum over the cluster index (userEncoders.py:85-89)
@@ -496,7 +519,7 @@ class SUE(UserEncoder):
         denom = torch.einsum('bnj,bjc->bnc', e, member)               # per-cluster sums
         alpha = e / torch.gather(denom, 2, pick)
         feat = torch.einsum('bnj,bjc,bjd->bncd', alpha, member, g)    # empty clusters -> 0
-        feat = F.dropout(torch.relu(self.clusterFeatureAffine(feat)) + feat, self.p, self.training)
+        feat = forced_dropout(torch.relu(self.clusterFeatureAffine(feat)) + feat, self.p, self.training, fk.get('affine'))
         C = self.cluster_num
         out = self.interClusterAttention(feat.reshape(B * N, C, D), cand.reshape(B * N, D),
                                          cmask.unsqueeze(1).expand(-1, N, -1).reshape(B * N, C))
@@ -580,6 +603,7 @@ class Model(nn.Module):
                 user_history_category_mask, user_history_category_indices,
                 news_category, news_subCategory, news_title_text, news_title_mask, news_title_entity,
                 news_content_text, news_content_mask, news_content_entity):
+        self.news_encoder._call_index = 0
         cand = self.news_encoder(news_title_text, news_title_mask, news_title_entity, news_content_text,
                                  news_content_mask, news_content_entity, news_category, news_subCategory, None)
         user = self.user_encoder(user_title_text, user_title_mask, user_title_entity, user_content_text,

@@ -1,0 +1,71 @@
+"""Data parallelism of the product path on real devices (reference: trainer.py:212-220,252-258,297 -- DistributedDataParallel over
+NCCL, per-rank DistributedSampler / negative sampling).  tests/dp_rank_main.py is the per-rank program; it compares the exchanged
+gradients with the MEAN OF THE ORACLE'S per-shard gradients, the ranks' parameters with each other, and a two-epoch loader loop
+(per-rank sampler + negative sampling -> DeviceCorpus -> train_step) with the oracle stepping on averaged gradients.
+
+* `..._share_one_gpu_through_gloo`: runs on the 1-GPU lease (the ranks share GPU 0, gloo carries the exchange).
+* `test_rccl_ranks_one_per_gpu[...]`: REAL RCCL, one rank per GPU, both bindings (torch.distributed "nccl" and the C-ABI's nnr_dp_*);
+  runs whenever the box has >= 2 GPUs and skips cleanly otherwise -- so any multi-GPU run of `pytest -m gpu` exercises
+  dist.all_reduce(async_op=True) on slices of the flat buffer from three streams, the helper-stream hand-off of the table bucket,
+  HSA_ENABLE_IPC_MODE_LEGACY=0 and the pair recurrence's bounded spin with RCCL kernels resident on the CUs."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _launch(world, backend, port, native=False, extra=()):
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'NNR_DP_NATIVE')}
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')           # dmabuf IPC: RCCL's intra-node transport needs it on this image
+    if native:
+        env['NNR_DP_NATIVE'] = '1'
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'tests', 'dp_rank_main.py'), '--backend', backend, *extra]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=1500)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-4000:])
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    print(out)
+    return out
+
+
+def _check(out, world):
+    assert out['ok'] and out['world'] == world
+    assert out['buckets'] == ['early (user encoder)', 'table (word embedding)', 'late']
+    assert out['grad_err_vs_oracle_mean_of_shard_gradients'] <= 1e-4          # the oracle leg (per-shard mean, as under the reference's DDP)
+    assert out['grad_rel_err_vs_mean_of_shard_gradients'] <= 2e-5
+    assert out['parameters_identical_across_ranks']
+    ep = out['epoch']
+    assert ep['negative_samples_identical_across_ranks'] and ep['sampler_covers_every_behaviour'] and ep['parameters_identical_across_ranks']
+    assert ep['worst_loss_diff_vs_oracle'] <= 5e-5 and ep['steps_per_rank'] == 10
+
+
+def test_two_ranks_of_the_product_path_share_one_gpu_through_gloo():
+    out = _launch(2, 'gloo', 29571)
+    _check(out, 2)
+
+
+@pytest.mark.parametrize('binding', ['torch', 'native'])
+def test_rccl_ranks_one_per_gpu(binding):
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip('needs >= 2 GPUs (this lease has %d): RCCL refuses two ranks on one device' % n)
+    out = _launch(2, 'nccl', 29581 + (binding == 'native'), native=(binding == 'native'))
+    _check(out, 2)
+    assert out['rccl_ranks'] == 2 and out['backend'] == 'nccl'
+    assert out['binding'] == ('C-ABI nnr_dp_allreduce' if binding == 'native' else 'torch.distributed all_reduce')
+
+
+def test_rccl_all_visible_gpus():
+    """Every GPU of the box as one rank each (4 or 8 on a full node); per-rank batch 4."""
+    n = torch.cuda.device_count()
+    if n < 4:
+        pytest.skip('needs >= 4 GPUs (this lease has %d)' % n)
+    w = 8 if n >= 8 else 4
+    out = _launch(w, 'nccl', 29591, extra=('--skip_epoch',))
+    assert out['ok'] and out['rccl_ranks'] == w and out['grad_err_vs_oracle_mean_of_shard_gradients'] <= 1e-4

@@ -109,6 +109,19 @@ def test_bench_shaped_batch_matches_oracle():
     _compare(model, ref, corpus.batch(8, np.random.default_rng(4)))
 
 
+@pytest.mark.parametrize('hidden', [48, 100, 128, 224, 256])
+def test_hidden_dims_with_full_width_word_rows(hidden):
+    """--hidden_dim values whose buffers / tiles differ from the default 200 at the reference's word_embedding_dim 300 and a token
+    capacity >= 8 192 rows (B = 2: 110 news x 128): hidden <= 144 makes the cell-state buffer [cap, 2*HP] SMALLER than the
+    embedding-row gradient [cap, 300] staged in it (round-2 advisor finding: news_encoders.py dx_scatter), hidden 212..256 puts
+    the gathered dW_hh GEMM (N = hidden) past the 208-column tile (ops.tn_tile fell through to a tile without a gather path)."""
+    cfg = _cfg(batch_size=2, hidden_dim=hidden)
+    assert cfg.word_embedding_dim == 300
+    model, ref = _models(cfg, seed=hidden)
+    corpus = SynthCorpus(SynthSpec(vocabulary_size=cfg.vocabulary_size, news_pool=400, seed=12))
+    _compare(model, ref, corpus.batch(2, np.random.default_rng(hidden)))
+
+
 def test_forward_bitwise_deterministic_and_backward_accumulates():
     from nnr_amd.model import negative_log_softmax
     cfg = _cfg(batch_size=4)
@@ -274,23 +287,6 @@ def test_gradient_exchange_overlaps_the_news_encoder_backward(binding):
     # weight-gradient GEMMs, the stream joins) is done
     assert out['table_bucket_issued_ms'] is not None and out['early_bucket_issued_ms'] < out['table_bucket_issued_ms'] < out['exchange_finished_ms'], out
     assert out['step_left_when_table_bucket_went_out_ms'] >= 0.05, out
-
-
-def test_two_ranks_of_the_product_path_on_one_gpu():
-    """>= 2 RCCL ranks need >= 2 GPUs; the rest of the multi-rank path does not.  Two ranks of the product's trainer share this GPU and exchange
-    through gloo (tools/dp_two_rank_check.py): the bucketed exchange (early / table / late) reproduces the mean of the per-shard gradients, and
-    the ranks' parameters stay bit-identical over optimizer steps although they were initialised differently."""
-    import json, os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', '29571',
-           os.path.join(root, 'tools', 'dp_two_rank_check.py')]
-    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
-    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
-    out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
-    print(out)
-    assert out['ok'] and out['world'] == 2 and out['parameters_identical_across_ranks']
-    assert out['buckets'] == ['early (user encoder)', 'table (word embedding)', 'late']
 
 
 def test_bench_launcher_runs_two_ranks_on_one_gpu():

@@ -2,8 +2,8 @@
 dimensions): the HIP path driven by the product Trainer -- every HIP stream, the leaf-stream weight gradients, the CU-pair
 recurrence on a full chip, the flat-buffer clip+Adam -- against the CPU oracle on the SAME batch.  This is the only size at
 which all four streams, leaf deferral and ~880 pair-recurrence workgroups are active at once; a cross-stream race that needs
-hundreds of tiles in flight would not show at the batch 2-8 fixtures.  Dropout 0 (masks are generator-specific), train mode,
-tie_order 'stable'.  Bars: logits 1e-4 (BASELINE.json north_star), loss 2e-5, every parameter gradient within 1e-4 of the
+hundreds of tiles in flight would not show at the batch 2-8 fixtures.  Train mode, tie_order 'stable'; dropout 0 AND dropout
+ON (the benchmarked configuration) with the HIP generator's keep-masks injected into the oracle at every site (tests/hip_masks.py).  Bars: logits 1e-4 (BASELINE.json north_star), loss 2e-5, every parameter gradient within 1e-4 of the
 gradient scale, gradient norms 1e-4 relative, parameters after the Adam step as in tests/test_oracle_golden.py.
 Reference sites: trainer.py:105-120, model.py:120-133, newsEncoders.py:102-141, userEncoders.py:68-98 / 164-173."""
 import numpy as np
@@ -11,7 +11,7 @@ import pytest
 import torch
 
 from nnr_amd.config import make_config
-from nnr_amd.synth import SynthSpec, SynthCorpus, to_torch
+from nnr_amd.synth import SynthSpec, SynthCorpus, BATCH_FIELDS, to_torch
 
 pytestmark = pytest.mark.gpu
 
@@ -36,13 +36,24 @@ def _pair(cfg, seed, train=True):
     return model, ref
 
 
-def _check_step(model, ref, cfg, batch, lr_steps=1):
+def _check_step(model, ref, cfg, batch, lr_steps=1, inject_masks=False):
     from nnr_amd import ops
     from nnr_amd.trainer import Trainer
     from oracle import nnr_oracle as O
     trainer = Trainer(model, cfg)
     ops.lstm_sync_timeouts(reset=True)
-    logits, loss = trainer.train_step(to_torch(batch, 'cuda'))
+    dev_batch = to_torch(batch, 'cuda')
+    if inject_masks:
+        # dropout ON: the keep-mask of every dropout site of THIS call, from the HIP generator, goes into the oracle
+        import hip_masks
+        rates = hip_masks.inject(model, ref, dict(zip(BATCH_FIELDS, dev_batch)))
+        p = float(cfg.dropout_rate)
+        for k, r in rates.items():
+            if k.startswith(('cat', 'sub', 'sue')):
+                assert abs(r - (1 - p)) < 0.01, (k, r)
+            elif k.startswith('gcn'):
+                assert abs(r - (1 - p / 2)) < 0.01, (k, r)
+    logits, loss = trainer.train_step(dev_batch)
     torch.cuda.synchronize()
     assert ops.lstm_sync_timeouts() == 0
     got_grads = {k: p.grad.detach().cpu().double() for k, p in model.named_parameters()}
@@ -89,6 +100,45 @@ def test_cne_sue_batch64_vocab60000_matches_oracle():
     batch = SynthCorpus(SynthSpec(vocabulary_size=cfg.vocabulary_size)).batch(64, np.random.default_rng(100))
     err, worst = _check_step(model, ref, cfg, batch)
     print('CNE+SUE batch 64: logits max|diff| %.2e, worst gradient deviation %.2e of its scale' % (err, worst))
+
+
+def test_cne_sue_batch64_vocab60000_DROPOUT_ON_matches_oracle():
+    """The configuration bench.py measures (BASELINE.json configs[2]: CNE+SUE, MIND-200k, batch 64, V = 60 000, gcn 4, dropout
+    0.2 ON, train mode) pinned to the oracle end to end: all six dropout sites of the reference (newsEncoders.py:53,117-118,
+    userEncoders.py:80,91, layers.py:319-322 -- p/2 between GCN layers, none after the last, one proxy mask per sample, the
+    in-place dropout after relu(Wx+b)+x) run with the masks of the HIP generator; logits, loss, every parameter gradient, the
+    clipped norm and the Adam step are compared.  A wrong seed / offset / index / scale at any site -- forward gather,
+    weight-gradient loader or scatter epilogue -- fails here."""
+    cfg = make_config(['--news_encoder=CNE', '--user_encoder=SUE', '--dataset=200k', '--batch_size=64'],
+                      corpus_sizes=dict(vocabulary_size=60000), tie_order='stable')
+    assert abs(cfg.dropout_rate - 0.2) < 1e-12 and cfg.gcn_layer_num == 4          # config.py:87-90
+    model, ref = _pair(cfg, seed=2)
+    batch = SynthCorpus(SynthSpec(vocabulary_size=cfg.vocabulary_size)).batch(64, np.random.default_rng(102))
+    err, worst = _check_step(model, ref, cfg, batch, inject_masks=True)
+    print('CNE+SUE batch 64, dropout 0.2 ON: logits max|diff| %.2e, worst gradient deviation %.2e of its scale' % (err, worst))
+
+
+def test_cne_sue_large_batch16_vocab130000_DROPOUT_ON_matches_oracle():
+    """BASELINE.json configs[4]'s per-GPU shard (MIND-large: dropout 0.1, config.py:91-94; batch 128 over 8 GPUs = 16 per GPU,
+    trainer.py:218; V = 130 000), dropout ON with injected masks."""
+    cfg = make_config(['--news_encoder=CNE', '--user_encoder=SUE', '--dataset=large', '--batch_size=128', '--world_size=8'],
+                      corpus_sizes=dict(vocabulary_size=130000), tie_order='stable')
+    assert abs(cfg.dropout_rate - 0.1) < 1e-12
+    model, ref = _pair(cfg, seed=3)
+    batch = SynthCorpus(SynthSpec(vocabulary_size=cfg.vocabulary_size)).batch(16, np.random.default_rng(103))
+    err, worst = _check_step(model, ref, cfg, batch, inject_masks=True)
+    print('CNE+SUE batch 16 (large), dropout 0.1 ON: logits max|diff| %.2e, worst gradient deviation %.2e' % (err, worst))
+
+
+def test_mhsa_mhsa_batch64_DROPOUT_ON_matches_oracle():
+    """BASELINE.json configs[1] (MHSA+MHSA, batch 64) with every dropout site on: word rows and attention output at 0.2
+    (newsEncoders.py:193,196), category rows (:53), and the user encoder's hard-wired p = 0.5 (userEncoders.py:171)."""
+    cfg = make_config(['--news_encoder=MHSA', '--user_encoder=MHSA', '--dataset=200k', '--batch_size=64'],
+                      corpus_sizes=dict(vocabulary_size=60000))
+    model, ref = _pair(cfg, seed=4)
+    batch = SynthCorpus(SynthSpec(vocabulary_size=cfg.vocabulary_size)).batch(64, np.random.default_rng(104))
+    err, worst = _check_step(model, ref, cfg, batch, inject_masks=True)
+    print('MHSA+MHSA batch 64, dropout ON: logits max|diff| %.2e, worst gradient deviation %.2e' % (err, worst))
 
 
 def test_mhsa_mhsa_batch64_train_mode_with_injected_user_dropout_mask():

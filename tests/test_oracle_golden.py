@@ -5,16 +5,18 @@ import numpy as np
 import pytest
 import torch
 
-from golden_io import GoldenCase, ALL_CASES
+from golden_io import GoldenCase, ALL_CASES, DROPOUT_CASES
 from oracle import nnr_oracle as O
 
 
-def _run(case, steps):
+def _run(case, steps, dropout=False):
     cfg = case.config
     torch.manual_seed(0)
     model = O.Model(cfg, case.word_table())
     case.load_into(model)
     model.train() if case.meta['mode'] == 'train' else model.eval()
+    if dropout:
+        case.inject_dropout(model)
     opt = O.make_optimizer(model, cfg)
     res = []
     for _ in range(steps):
@@ -78,6 +80,35 @@ def test_oracle_matches_reference_golden(tag, lstm_backend):
     for s in range(steps):
         assert abs(res[s][1] - float(case.expect('loss_step%d' % s))) < 5e-6
     check_params_after_adam(case, model, steps)
+
+
+@pytest.mark.parametrize('tag', DROPOUT_CASES)
+def test_oracle_dropout_on_matches_reference(tag):
+    """Train mode, dropout ON: the reference ran with recorded keep-masks (tools/make_goldens.py dropout); replayed at the
+    oracle's sites the whole step must agree -- pins the position, rate, mask shape and 1/(1-p) scale of every dropout site
+    (newsEncoders.py:53,117-118,163,165,193,196; userEncoders.py:80,91,171; layers.py:319-322) to the reference itself."""
+    case = GoldenCase(tag)
+    model, res = _run(case, 1, dropout=True)
+    logits, loss, grads, norm, batch = res[0]
+    np.testing.assert_allclose(logits.numpy(), case.expect('logits'), rtol=0, atol=5e-6)
+    assert abs(loss - float(case.expect('loss'))) < 5e-6
+    assert abs(norm - float(case.expect('grad_total_norm'))) < 1e-5 * max(1.0, norm)
+    for k, g in grads.items():
+        e, a = case.expect_grad(k, g)
+        scale = max(1e-3, float(case.expect('gradnorm/' + k)), 0.05 * float(case.expect('grad_total_norm')))
+        assert np.abs(a - e).max() <= 2e-5 * scale, k
+    check_params_after_adam(case, model, 1)
+
+
+def test_forced_dropout_is_F_dropout_with_the_mask_shared():
+    """The hook's arithmetic is F.dropout's: with the mask torch itself drew, the outputs are bit-identical."""
+    x = torch.randn(7, 5, 11)
+    for p in (0.1, 0.2, 0.25, 0.5):
+        torch.manual_seed(3)
+        y = torch.nn.functional.dropout(x, p, True)
+        keep = y != 0
+        assert torch.equal(O.forced_dropout(x, p, True, keep), y)
+    assert torch.equal(O.forced_dropout(x, 0.2, False, keep), x)
 
 
 def test_oracle_state_dict_keys_match_reference():

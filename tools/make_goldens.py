@@ -68,8 +68,42 @@ class stable_sort_patch:
         torch.sort = self.orig
 
 
-def run_case(tag, cfg, spec, batch_size, seed, mode, gain=None, full_arrays=True, adam_steps=3):
-    """mode: 'train' (dropout_rate must be 0) or 'eval' (for MHSA-user's hard-wired F.dropout)."""
+class record_dropout:
+    """Dropout-ON fixtures (`python tools/make_goldens.py dropout`): the reference runs in train mode with its dropout modules
+    active; every call of torch.nn.functional.dropout (nn.Dropout.forward and the F.dropout of userEncoders.py:171 both end
+    there) draws its keep-mask from a seeded numpy generator instead of torch's Philox stream, applies the SAME arithmetic
+    (x * keep / (1 - p), in place when the reference asks for in place) and records (p, mask) in call order.  The fixture
+    stores the masks; the oracle replays them at its own dropout sites (oracle.forced_dropout), which pins WHERE each site sits,
+    its p (rate, rate / 2 between GCN layers, 0.5 at userEncoders.py:171), its shape and its scale to the reference itself."""
+
+    def __init__(self, seed):
+        self.rng = np.random.default_rng(seed)
+        self.calls = []
+
+    def __enter__(self):
+        import torch.nn.functional as F
+        self.F, self.orig = F, F.dropout
+
+        def dropout(input, p=0.5, training=True, inplace=False):
+            if not training or p == 0.0:
+                return input
+            keep = self.rng.random(tuple(input.shape)) >= p
+            self.calls.append((float(p), keep))
+            m = torch.from_numpy(keep.astype(np.float32)) * (1.0 / (1.0 - p))
+            return input.mul_(m) if inplace else input * m
+        F.dropout = dropout
+        return self
+
+    def __exit__(self, *a):
+        self.F.dropout = self.orig
+
+
+def run_case(tag, cfg, spec, batch_size, seed, mode, gain=None, full_arrays=True, adam_steps=3, dropout_seed=None, _rec_drop=None):
+    """mode: 'train' (dropout_rate must be 0 unless dropout_seed is given) or 'eval' (for MHSA-user's hard-wired F.dropout)."""
+    if dropout_seed is not None:
+        assert adam_steps == 1 and mode == 'train'
+        with record_dropout(dropout_seed) as rec_drop:
+            return run_case(tag, cfg, spec, batch_size, seed, mode, gain, full_arrays, adam_steps, None, _rec_drop=rec_drop)
     torch.manual_seed(seed)
     corpus = SynthCorpus(spec)
     batch = corpus.batch(batch_size, np.random.default_rng(seed + 100))
@@ -121,6 +155,11 @@ def run_case(tag, cfg, spec, batch_size, seed, mode, gain=None, full_arrays=True
         out['grad/' + k] = g if full_arrays else g.reshape(-1)[:64].copy()
     for k in BATCH_FIELDS:
         out['in/' + k] = batch[k]
+    if _rec_drop is not None:
+        out['drop_p'] = np.array([p for p, _ in _rec_drop.calls], np.float64)
+        for i, (_, keep) in enumerate(_rec_drop.calls):
+            out['drop_shape/%d' % i] = np.array(keep.shape, np.int64)
+            out['drop_bits/%d' % i] = np.packbits(keep.reshape(-1))
     out['word_table'] = table if gain is None else np.zeros(0, np.float32)
     if gain is None:
         for k, v in params0.items():
@@ -177,10 +216,27 @@ def extra_cases():
                      full_arrays=False)
 
 
+def dropout_cases():
+    """Round 3: the reference in TRAIN mode with dropout ON (masks recorded, see record_dropout)."""
+    with stable_sort_patch():
+        cfg = tiny_cfg('CNE', 'SUE')
+        cfg.dropout_rate, cfg.gcn_layer_num = 0.2, 3          # two inter-layer GCN dropouts (p/2), none after the last layer
+        run_case('drop_tiny_CNE_SUE_stable', cfg, tiny_spec(cfg, 6), batch_size=4, seed=41, mode='train', gain=2.0, adam_steps=1, dropout_seed=1)
+    cfg = tiny_cfg('MHSA', 'MHSA')
+    cfg.dropout_rate = 0.2
+    run_case('drop_tiny_MHSA_MHSA', cfg, tiny_spec(cfg, 7), batch_size=3, seed=43, mode='train', gain=2.0, adam_steps=1, dropout_seed=2)
+    cfg = tiny_cfg('CNN', 'ATT')
+    cfg.dropout_rate = 0.25
+    run_case('drop_tiny_CNN_ATT', cfg, tiny_spec(cfg, 8), batch_size=3, seed=47, mode='train', gain=2.0, adam_steps=1, dropout_seed=3)
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'extra':
         torch.set_num_threads(8)
         return extra_cases()
+    if len(sys.argv) > 1 and sys.argv[1] == 'dropout':
+        torch.set_num_threads(8)
+        return dropout_cases()
     torch.set_num_threads(8)
     # tiny dims, reference's own initialisation, every array stored
     for news, user, mode in (('CNE', 'SUE', 'train'), ('MHSA', 'MHSA', 'eval'), ('CNN', 'ATT', 'train')):
