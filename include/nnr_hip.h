@@ -308,6 +308,11 @@ int nnr_sumsq(const float* g, long n, float* out_zeroed, hipStream_t stream);
 int nnr_clip_adam(float* p, const float* g, float* m, float* v, long n, const float* sumsq, float grad_scale, float clip, float lr,
                   float beta1, float beta2, float eps, float weight_decay, int step, hipStream_t stream);
 
+/* Steps nnr_clip_adam skipped so far in this process (non-finite gradient norm: overflow, or the NaN poison of a timed-out recurrence
+ * exchange).  The reference would go visibly NaN there (trainer.py:118-120); here the step is dropped and COUNTED -- poll this every few
+ * hundred steps (synchronous device read); reset != 0 clears the counter. */
+int nnr_adam_skipped_steps(unsigned* host_out, int reset);
+
 /* ------------------------------------------------------------------------------------------------ data parallelism (RCCL over xGMI)
  * Replaces DistributedDataParallel's gradient all-reduce / parameter broadcast (trainer.py:212-219,297): one communicator per
  * process = per GPU, ONE in-place fp32 sum all-reduce of the flat gradient buffer per step; the 1/world average is folded into
@@ -319,6 +324,40 @@ int nnr_dp_init(const void* uid128, int rank, int world, nnr_dp_ctx** ctx);     
 int nnr_dp_allreduce(nnr_dp_ctx* ctx, float* flat, size_t n, hipStream_t stream);
 int nnr_dp_broadcast(nnr_dp_ctx* ctx, float* flat, size_t n, int root, hipStream_t stream);
 int nnr_dp_destroy(nnr_dp_ctx* ctx);
+
+/* ------------------------------------------------------------------------------------------------ fills / copies
+ * What the host framework's fill / copy / index-put kernels did inside the step (optimizer.zero_grad() at trainer.py:116,
+ * torch.cat of the two encoder calls' id tensors, `user_history_category_mask[:, -1] = 1` at userEncoders.py:73), as entry points,
+ * so that a whole training step is a sequence of calls into this library (see the tape below). */
+int nnr_fill_zero(void* p, size_t bytes, hipStream_t stream);
+int nnr_copy_bytes(void* dst, const void* src, size_t bytes, hipStream_t stream);          /* device to device */
+int nnr_fill_column_u8(uint8_t* m, int rows, int cols, int col, int value, hipStream_t stream);   /* m[:, col] = value */
+
+/* ------------------------------------------------------------------------------------------------ launch-sequence tape
+ * Replaces the per-call Python dispatch of the reference's training step (trainer.py:105-120: ~140 framework calls per step)
+ * by a native replay: the host side records the entry-point calls of ONE step -- function, arguments (by-pointer structs are
+ * copied), HIP stream -- plus the step's cross-stream dependencies, and replays the sequence with one call per segment
+ * (csrc/tape.hip).  Every replayed call runs the real entry point above.  Per-step changes are patched in before a replay:
+ * value patches (dropout seeds, Adam's step number: value[kind] + addend) and input patches (pointers into the batch tensors:
+ * input[kind - 1000] + addend).  A tape owns nothing but its argument copies and events: buffers stay caller-owned and must
+ * outlive it.  Not thread-safe; one tape is replayed by one host thread. */
+typedef struct nnr_tape nnr_tape;
+int nnr_tape_create(nnr_tape** out);
+int nnr_tape_destroy(nnr_tape* t);
+int nnr_tape_fn_id(const char* entry_point_name);      /* >= 0, or -1: not recordable (no stream argument / host-only query) */
+int nnr_tape_fn_nargs(int fn);                         /* arguments before the trailing hipStream_t */
+int nnr_tape_call(nnr_tape* t, int fn, hipStream_t stream, const uint64_t* slots, int nslots, const int* blob_slot,
+                  const void* const* blob_ptr, const size_t* blob_bytes, int nblobs, int tag, size_t* slot_off_out, size_t* blob_off_out);
+int nnr_tape_wait_stream(nnr_tape* t, hipStream_t waiter, hipStream_t signaller);
+int nnr_tape_event_record(nnr_tape* t, uint64_t key, hipStream_t s);
+int nnr_tape_event_wait(nnr_tape* t, hipStream_t s, uint64_t key);
+int nnr_tape_segment(nnr_tape* t);
+int nnr_tape_patch(nnr_tape* t, size_t arena_byte_off, int kind, int width, int64_t addend);
+int nnr_tape_finalize(nnr_tape* t);
+int nnr_tape_info(const nnr_tape* t, int* calls, int* ops, int* segments, int* streams, size_t* arena_bytes);
+int nnr_tape_replay(nnr_tape* t, int segment, const uint64_t* values, int nvalues, const uint64_t* inputs, int ninputs, int timing_set);
+int nnr_tape_timings(nnr_tape* t, int set, float* ms, int n);
+int nnr_tape_last_error(const nnr_tape* t, int* rc, int* call, char* name, int name_cap);
 
 #ifdef __cplusplus
 }

@@ -60,6 +60,10 @@ SYMBOLS = [
     'nnr_sue_intra_fwd', 'nnr_sue_intra_bwd', 'nnr_logits_loss_fwd', 'nnr_logits_fwd', 'nnr_nls_loss', 'nnr_logits_bwd', 'nnr_sumsq', 'nnr_clip_adam',
     'nnr_mhsa_fwd', 'nnr_mhsa_bwd', 'nnr_embed_gather', 'nnr_embed_scatter', 'nnr_embed_scatter_dyn', 'nnr_transpose2d', 'nnr_transpose_batch', 'nnr_corpus_batch', 'nnr_history_graph', 'nnr_rank_metrics',
     'nnr_dp_unique_id', 'nnr_dp_init', 'nnr_dp_allreduce', 'nnr_dp_broadcast', 'nnr_dp_destroy',
+    'nnr_fill_zero', 'nnr_copy_bytes', 'nnr_fill_column_u8', 'nnr_adam_skipped_steps',
+    'nnr_tape_create', 'nnr_tape_destroy', 'nnr_tape_fn_id', 'nnr_tape_fn_nargs', 'nnr_tape_call', 'nnr_tape_wait_stream', 'nnr_tape_event_record',
+    'nnr_tape_event_wait', 'nnr_tape_segment', 'nnr_tape_patch', 'nnr_tape_finalize', 'nnr_tape_info', 'nnr_tape_replay', 'nnr_tape_timings',
+    'nnr_tape_last_error',
 ]
 
 
@@ -90,6 +94,22 @@ def lib():
         _lib.nnr_lstm_sync_bytes.restype = C.c_size_t
         _lib.nnr_lstm_sync_diag_offset.restype = C.c_size_t
     return _lib
+
+
+def build_id():
+    """Identity of the kernels that are running: sha256 over the sources libnnr_hip.so is built from (csrc/*.hip, common.h, the
+    header) and, separately, over the loaded binary.  profiles/pmc_traffic.json carries both: counter traffic collected on another
+    build is not quoted (nnr_amd.profile.pmc_traffic)."""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(_HERE, 'csrc')
+    for f in sorted(os.listdir(src)):
+        if f.endswith(('.hip', '.h')):
+            h.update(f.encode())
+            h.update(open(os.path.join(src, f), 'rb').read())
+    h.update(open(os.path.join(os.path.dirname(_HERE), 'include', 'nnr_hip.h'), 'rb').read())
+    lib_hash = hashlib.sha256(open(LIB_PATH, 'rb').read()).hexdigest()[:16] if os.path.exists(LIB_PATH) else None
+    return {'src_sha256': h.hexdigest()[:16], 'lib_sha256': lib_hash}
 
 
 CALLS = [0]          # C-ABI calls checked so far (bench.py reports calls per step; each is one or a few kernel launches)

@@ -1390,11 +1390,27 @@ static int lstm_run(const nnr_lstm_problem* probs, int nprob, int H, bool backwa
   for (int i = 0; i < nprob; ++i) pair = pair && a.p[i].sync != nullptr;
   { const char* e = getenv("NNR_LSTM_PAIR"); if (e && atoi(e) == 0) pair = false; }
   if (pair) {
+    // The launch epoch below is HOST state copied into the kernel arguments: a hipGraph that captured this launch would replay it
+    // with the captured epoch, and a reader could then accept the previous replay's exchange words before the partner rewrites them.
+    // While the stream is capturing, take the one-CU kernel (no exchange).  (The launch tape of tape.hip is not a capture: it calls
+    // this entry point again on every replay.)
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) pair = false;
+  }
+  if (pair) {
     // Exchange words carry (launch epoch, step) tags, so words of earlier launches never match and the 25-32 MB workspace is NOT
     // cleared per launch (4 x 31 us of fill kernels per step, each in front of a recurrence launch): only its diagnostics block is.
     // Contract: the caller zero-fills a workspace ONCE, before its first launch.
     static unsigned launch_counter = 0;
-    a.epoch = ((++launch_counter) & 0x3fffffu) << 10;
+    unsigned ep = (++launch_counter) & 0x3fffffu;
+    if (ep == 0) {
+      // the 22-bit epoch wrapped (4 M launches): words that were never rewritten since epoch e could match launch e again.  Start
+      // the next lap from clean workspaces (zero = "no word of any epoch": epoch 0 is never issued).
+      for (int i = 0; i < nprob; ++i)
+        if (hipMemsetAsync(a.p[i].sync, 0, nnr_lstm_sync_bytes(a.p[i].n), stream) != hipSuccess) return NNR_ERR_LAUNCH;
+      ep = (++launch_counter) & 0x3fffffu;
+    }
+    a.epoch = ep << 10;
     for (int i = 0; i < nprob; ++i)
       if (hipMemsetAsync(reinterpret_cast<char*>(a.p[i].sync) + nnr_lstm_sync_diag_offset(a.p[i].n), 0, SYNC_PAD * sizeof(unsigned), stream) != hipSuccess)
         return NNR_ERR_LAUNCH;

@@ -642,6 +642,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
     g_sumsq_arrived = 0;                                    // ready for the next launch (launches of one process are stream-ordered)
   }
 }
+__device__ unsigned g_adam_skipped;          // optimizer steps skipped because the gradient norm was not finite (nnr_adam_skipped_steps)
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             long n, const float* __restrict__ sumsq, float grad_scale, float clip, float lr, float b1, float b2,
                             float eps, float wd, float bc1, float bc2_sqrt) {
@@ -649,7 +650,10 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   // a gradient whose norm is not finite (overflow, or the NaN poison of a timed-out recurrence exchange, lstm.hip) must not
   // reach the parameters or the moments: the step is skipped as a whole (torch's clip_grad_norm_ + Adam would write NaN into
   // all three, permanently)
-  if (!isfinite(*sumsq)) return;
+  if (!isfinite(*sumsq)) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_adam_skipped, 1u);
+    return;
+  }
   float coef = grad_scale;
   if (clip > 0.f) {
     const float norm = sqrtf(*sumsq) * grad_scale;
@@ -670,10 +674,10 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 
 // ---- LayerNorm over the last dimension for --gcn_layer_norm (layers.py:273-274,287-288: nn.LayerNorm([out_dim]) between the
 // graph convolution and the ReLU), fused with what follows it in GCNLayer.forward / GCN.forward:
-//   y = dropout(relu(LN(u) * gamma + beta) + resid).   One wave per row (D <= 1024), the row lives in registers; biased variance,
+//   y = dropout(relu(LN(u) * gamma + beta) + resid).   One wave per row (D <= 1280), the row lives in registers; biased variance,
 //   1 / sqrt(var + eps) exactly as ATen.  Saved for backward: xhat = (u - mean) * rstd, rstd, and r = relu(.) (as the GEMM
 //   epilogue of the LayerNorm-free path saves it).
-constexpr int LN_MAXPL = 16;      // elements per lane
+constexpr int LN_MAXPL = 20;      // elements per lane (D <= 1280: --hidden_dim 256 gives D = 1124)
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ u, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float eps, long rows, int D, float* __restrict__ xhat, float* __restrict__ rstd_out,
                                                      float* __restrict__ r_out, const float* __restrict__ resid, float* __restrict__ y,
@@ -999,4 +1003,12 @@ extern "C" int nnr_clip_adam(float* p, const float* g, float* m, float* v, long 
   const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
   const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
   EW_LAUNCH(adam_kernel, n, p, g, m, v, n, sumsq, grad_scale, clip, lr, beta1, beta2, eps, weight_decay, bc1, bc2s);
+}
+extern "C" int nnr_adam_skipped_steps(unsigned* host_out, int reset) {
+  // synchronous read of the device counter (diagnostics: the training loop polls it every few hundred steps, never per step)
+  unsigned v = 0;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_adam_skipped), sizeof(v)) != hipSuccess) return NNR_ERR_LAUNCH;
+  if (host_out) *host_out = v;
+  if (reset) { const unsigned z = 0; if (hipMemcpyToSymbol(HIP_SYMBOL(g_adam_skipped), &z, sizeof(z)) != hipSuccess) return NNR_ERR_LAUNCH; }
+  return NNR_OK;
 }

@@ -14,7 +14,7 @@
 namespace {
 
 constexpr int MAXT = 2;   // positions per lane: supports L <= 128 (the selects below assume exactly 2)
-constexpr int MAXV_ALL = 4;   // float4 per lane:   supports D <= 1024
+constexpr int MAXV_ALL = 5;   // float4 per lane:   supports D <= 1280 (SUE at --hidden_dim 256: D = 1124)
 
 struct PoolArgs {
   const float* x; int ldx; int D; int n; int L;
@@ -297,7 +297,8 @@ static int pool_launch(const nnr_pool_args* p, hipStream_t stream) {
   const int nv = (p->D + 3) / 4;
   if (nv <= 64) hipLaunchKernelGGL((pool_kernel<BWD, 1, 4>), grid, block, 0, stream, a);
   else if (nv <= 128) hipLaunchKernelGGL((pool_kernel<BWD, 2, 4>), grid, block, 0, stream, a);
-  else hipLaunchKernelGGL((pool_kernel<BWD, 4, 2>), grid, block, 0, stream, a);
+  else if (nv <= 256) hipLaunchKernelGGL((pool_kernel<BWD, 4, 2>), grid, block, 0, stream, a);
+  else hipLaunchKernelGGL((pool_kernel<BWD, 5, 2>), grid, block, 0, stream, a);
   NNR_CHECK_LAUNCH();
   return NNR_OK;
 }

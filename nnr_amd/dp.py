@@ -147,6 +147,7 @@ class GradientExchange:
         self._table_events = []
         self._comm = None
         self._helper = None
+        self._finish_events = []      # (start, end) HIP events around finish() on the caller's stream (bench.py: exposed exchange time)
         self.events = None            # tests: {'early_issued': Event, ...} recorded on the issuing stream when set to a dict
 
     def active(self):
@@ -177,9 +178,20 @@ class GradientExchange:
             nx.allreduce(view)
         return self._comm
 
+    def _native(self):
+        return os.environ.get('NNR_DP_NATIVE') == '1' and self.grad.is_cuda
+
     def early_ready(self):
         """The early bucket's gradients are final on the CURRENT stream: start reducing them."""
-        if self.early_span is None or self._pending is not None or not self.active():
+        if self.early_span is None or not self.active():
+            return
+        if self._native():
+            return self._early_ready()           # RCCL through the C-ABI: the call itself is part of a recorded launch sequence
+        from .tape import host_call              # torch.distributed: the host's own work, re-run between the segments of a replay
+        host_call(self._early_ready)
+
+    def _early_ready(self):
+        if self._pending is not None:
             return
         a, b = self.early_span
         if self.events is not None and self.grad.is_cuda:
@@ -191,7 +203,15 @@ class GradientExchange:
         """One of the `expected` embedding-row scatter GEMMs of this backward pass is ordered on the CURRENT stream (they run on
         different HIP streams).  When the last one has reported, the table bucket is handed to the exchange on a helper stream that
         waits for all of them -- no stream of the backward pass waits for another one here."""
-        if self.table_span is None or not self.active() or not self.grad.is_cuda or self._pending_table is not None:
+        if self.table_span is None or not self.active() or not self.grad.is_cuda:
+            return
+        if self._native():
+            return self._table_scatter_done(expected)
+        from .tape import host_call
+        host_call(lambda: self._table_scatter_done(expected))
+
+    def _table_scatter_done(self, expected):
+        if self._pending_table is not None:
             return
         ev = torch.cuda.Event()
         ev.record()
@@ -216,6 +236,26 @@ class GradientExchange:
         w = world_size()
         if not self.active():
             return 1.0 / w
+        if self._native():
+            return self._finish()
+        from .tape import host_call
+        return host_call(self._finish)
+
+    def exposed_ms(self):
+        """Mean time the caller's stream spent inside finish() over the steps since the last call (HIP events around it on that
+        stream: waiting for the overlapped buckets + reducing the late one = the exchange time the backward pass did not hide)."""
+        pairs, self._finish_events = self._finish_events, []
+        if not pairs:
+            return None
+        torch.cuda.synchronize()
+        return round(sum(a.elapsed_time(b) for a, b in pairs) / len(pairs), 4)
+
+    def _finish(self):
+        w = world_size()
+        t0 = None
+        if self.grad.is_cuda and len(self._finish_events) < 256:
+            t0 = torch.cuda.Event(enable_timing=True)
+            t0.record()
         pend, self._pending = self._pending, None
         pend_t, self._pending_table = self._pending_table, None
         self._table_events = []
@@ -246,6 +286,10 @@ class GradientExchange:
         if self.events is not None and self.grad.is_cuda:
             self.events['finished'] = torch.cuda.Event(enable_timing=True)
             self.events['finished'].record()
+        if t0 is not None:
+            t1 = torch.cuda.Event(enable_timing=True)
+            t1.record()
+            self._finish_events.append((t0, t1))
         return 1.0 / w
 
 

@@ -344,8 +344,13 @@ def _cne_fwd_post(mod, sv, par=False):
 
     _two_chains(dev, par, lambda: cross(t_, c_, 0), lambda: cross(c_, t_, H2))
     if sv['union']:
-        cat = torch.cat([_i32(x).reshape(-1) for x in sv.pop('category')])
-        sub = torch.cat([_i32(x).reshape(-1) for x in sv.pop('subCategory')])
+        # (two device-to-device copies through the library instead of torch.cat: the step stays a sequence of C-ABI calls)
+        n0_ = sv['n0']
+        cat, sub = torch.empty(n, device=dev, dtype=torch.int32), torch.empty(n, device=dev, dtype=torch.int32)
+        for dst, key in ((cat, 'category'), (sub, 'subCategory')):
+            a_, b_ = (_i32(x).reshape(-1).contiguous() for x in sv.pop(key))
+            ops.copy_bytes(dst[:n0_], a_)
+            ops.copy_bytes(dst[n0_:], b_)
     else:
         cat = _i32(sv.pop('category')).reshape(n).contiguous()
         sub = _i32(sv.pop('subCategory')).reshape(n).contiguous()

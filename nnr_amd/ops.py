@@ -358,12 +358,26 @@ def gemm(A, B, C_=None, *, M, N, K, lda, ldb, ldc=0, trans_a=False, trans_b=Fals
                           {1: '256x80', 2: '64x80', 3: '128x208', 4: '128x80', 5: '128x80k32', 6: '64x80k64', 7: '16x80skinny', 8: 'pipe128x80k32', 9: 'pipe2_128x80', 13: 'pipe128x80s4',
                            15: 'pipe128x80', 16: 'pipe128x80s2', 20: 'pipe128x80', 26: 'pipe2_128x80', 27: 'pipe2_128x208', 30: 'pipe2_128x160', 22: 'pipe64x80', 23: 'pipe256x80', 24: 'pipe128x208', 25: 'pipe128x128'}.get(t, 'tile%d' % t))
 
-    def flops(M=M, N=N, K=K, dyn=dyn, dyn_dim=dyn_dim, batch=batch):
+    def flops(vals=None, M=M, N=N, K=K, dyn=dyn, dyn_dim=dyn_dim, batch=batch):
+        # vals: {data_ptr of a device-side size: its value at the time of the launch} (replayed launches: the size buffers are
+        # overwritten by the next step, so the trainer snapshots them per timed replay); None: read the buffer now
         m, k = M, K
         if dyn is not None:
-            d = int(dyn.item())
+            d = int(vals[dyn.data_ptr()]) if vals is not None else int(dyn.item())
             m, k = (min(M, d), K) if dyn_dim == 1 else (M, min(K, d))
         return 2.0 * m * N * k * max(1, batch) * flop_scale
+    flops.dyn = [dyn] if dyn is not None else []
+
+    def op_bytes(vals=None, M=M, N=N, K=K, dyn=dyn, dyn_dim=dyn_dim, batch=batch):
+        # algorithmic HBM bytes of the launch: A and B read once, C written once (+ read when accumulated into), every extra
+        # epilogue stream (aux_out, mul, resid) once; true extents
+        m, k = M, K
+        if dyn is not None:
+            d = int(vals[dyn.data_ptr()]) if vals is not None else int(dyn.item())
+            m, k = (min(M, d), K) if dyn_dim == 1 else (M, min(K, d))
+        outs = (1 if C_ is not None else 0) + (1 if accumulate else 0) + (1 if aux_out is not None else 0) + (1 if mul is not None else 0) + (1 if resid is not None else 0)
+        return 4.0 * max(1, batch) * (m * k + N * k + m * N * outs)
+    flops.bytes_fn = op_bytes
     if trans_a and trans_b and split_k > 1:
         flops.tn_dims = (M, N, flop_scale)           # token-reduction GEMM: operand bytes of the launch = live reduction rows x (M + N) x 4
     flops.tag = 'M%d N%d K%d%s%s%s' % (M, N, K, ' b%d' % batch if batch > 1 else '', (' sk%d' % split_k if split_k > 1 else '') + (' kc%d' % k_chunk if k_chunk > 0 else ''), ' dyn' if dyn is not None else '')
@@ -575,7 +589,12 @@ def _lstm_probs(items, H=0, backward=False):
 
 def _lstm_flops(items, H):
     totals = [it['plan'].total for it in items]
-    return lambda: sum(float(t.item()) for t in totals) * 2 * (2.0 * H * 4 * H)     # tokens x 2 directions x [1,H]x[H,4H]
+
+    def flops(vals=None):
+        tok = sum(float(vals[t.data_ptr()]) if vals is not None else float(t.item()) for t in totals)
+        return tok * 2 * (2.0 * H * 4 * H)                                          # tokens x 2 directions x [1,H]x[H,4H]
+    flops.dyn = totals
+    return flops
 
 
 def lstm_fwd(items, H):
@@ -793,6 +812,28 @@ def embed_scatter(dout, idx, dtable, p, seed, dyn=None):
         return
     L.check(L.lib().nnr_embed_scatter(_p(dout), _p(idx), C.c_long(n), dim, _p(dtable), C.c_float(p), C.c_uint32(seed & 0xFFFFFFFF), _s()),
             'nnr_embed_scatter')
+
+
+def fill_zero(t):
+    """t.zero_() as an entry point of the library (hipMemsetAsync on the current stream): part of the launch tape."""
+    assert t.is_contiguous()
+    L.check(L.lib().nnr_fill_zero(_p(t), C.c_size_t(t.numel() * t.element_size()), _s()), 'nnr_fill_zero')
+    return t
+
+
+def copy_bytes(dst, src):
+    """dst <- src (device to device, same byte size, both contiguous)."""
+    nb = src.numel() * src.element_size()
+    assert dst.is_contiguous() and src.is_contiguous() and dst.numel() * dst.element_size() == nb
+    L.check(L.lib().nnr_copy_bytes(_p(dst), _p(src), C.c_size_t(nb), _s()), 'nnr_copy_bytes')
+    return dst
+
+
+def fill_column_u8(mask, col, value):
+    """mask[:, col] = value for a contiguous 2-D bool / uint8 tensor (userEncoders.py:73)."""
+    assert mask.dim() == 2 and mask.is_contiguous() and mask.element_size() == 1
+    rows, cols = mask.shape
+    L.check(L.lib().nnr_fill_column_u8(_p(mask), rows, cols, col % cols, int(value), _s()), 'nnr_fill_column_u8')
 
 
 def transpose2d(x, out, rows, cols, accumulate=False):

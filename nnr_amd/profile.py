@@ -24,20 +24,31 @@ KERNEL_OF = {
 
 
 _enabled, _every = False, 1
+TAPE_HOOK = [None]     # set by nnr_amd.tape while a step is being recorded: the next recorded call gets (family, flops_fn) as its tag
+TAPE_RECORDS = []      # (family, flops_fn, ms) of timing replays, appended by the trainer (same role as _records for eager launches)
 
 
-def enable(every=1):
+_eager = True
+
+
+def enable(every=1, eager=True):
     """Start recording spans; with every > 1 only the steps announced by begin_step(i) with i % every == 0 are instrumented
-    (two HIP events per launch cost ~5 % of a step when every launch of every step carries them)."""
-    global _on, _enabled, _every
-    _enabled, _every = True, max(1, int(every))
-    _on = True
+    (two HIP events per launch cost ~5 % of a step when every launch of every step carries them).  eager=False: the steps are
+    REPLAYED from a tape (nnr_amd.tape): no torch events around the Python-side launches -- begin_step() only says which steps to
+    instrument and the trainer asks the tape for a timing replay (HIP events recorded natively around the same calls)."""
+    global _on, _enabled, _every, _eager
+    _enabled, _every, _eager = True, max(1, int(every)), bool(eager)
+    _on = _eager
     _records.clear()
+    TAPE_RECORDS.clear()
 
 
 def begin_step(i):
+    """Returns whether step i is an instrumented one."""
     global _on
-    _on = _enabled and (i % _every == 0)
+    inst = _enabled and (i % _every == 0)
+    _on = inst and _eager
+    return inst
 
 
 def disable():
@@ -46,7 +57,7 @@ def disable():
 
 
 def active():
-    return _on
+    return _on or TAPE_HOOK[0] is not None
 
 
 class span:
@@ -56,6 +67,8 @@ class span:
         self.family, self.flops_fn = family, flops_fn
 
     def __enter__(self):
+        if TAPE_HOOK[0] is not None:
+            TAPE_HOOK[0](self.family, self.flops_fn)
         if _on:
             self.s = torch.cuda.Event(enable_timing=True)
             self.e = torch.cuda.Event(enable_timing=True)
@@ -71,49 +84,76 @@ class span:
 
 def by_shape():
     """Diagnostic: time and achieved TFLOP/s per (family, shape tag)."""
-    torch.cuda.synchronize()
     out = {}
-    for family, s, e, fn in _records:
+    for family, fn, ms in _all_records():
         tag = getattr(fn, 'tag', '')
         d = out.setdefault((family, tag), dict(ms=0.0, flops=0.0, launches=0))
-        d['ms'] += s.elapsed_time(e)
+        d['ms'] += ms
         d['flops'] += float(fn())
         d['launches'] += 1
     return out
 
 
-def summary():
+def _all_records():
+    """(family, flops_fn, ms) of every instrumented launch: eager launches (torch events) and replayed ones (the tape's events)."""
     torch.cuda.synchronize()
-    fam = {}
     for family, s, e, fn in _records:
+        yield family, fn, s.elapsed_time(e)
+    for family, fn, ms in TAPE_RECORDS:
+        yield family, fn, ms
+
+
+def summary():
+    fam = {}
+    for family, fn, ms in _all_records():
         d = fam.setdefault(family, dict(ms=0.0, flops=0.0, launches=0))
-        d['ms'] += s.elapsed_time(e)
+        d['ms'] += ms
         d['flops'] += float(fn())
         d['launches'] += 1
     return fam
 
 
+_PMC = {}
+
+
+def _pmc_file():
+    """profiles/pmc_traffic.json if it belongs to THIS build (its build_id equals the sources' or the loaded binary's hash), else
+    None; the reason is kept for the bench line."""
+    if 'data' not in _PMC:
+        import json
+        import os
+        from . import _lib
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'pmc_traffic.json')
+        _PMC['data'], _PMC['why'] = None, 'profiles/pmc_traffic.json missing or unreadable'
+        try:
+            d = json.load(open(path))
+            have, now = d.get('build_id') or {}, _lib.build_id()
+            if have.get('src_sha256') == now['src_sha256'] or (have.get('lib_sha256') and have.get('lib_sha256') == now['lib_sha256']):
+                _PMC['data'], _PMC['why'] = d, 'build_id matches (%s)' % now['src_sha256']
+            else:
+                _PMC['why'] = 'profiles/pmc_traffic.json was collected on another build (%s, running %s): not quoted' % (have.get('src_sha256'), now['src_sha256'])
+        except (OSError, ValueError, KeyError):
+            pass
+    return _PMC['data']
+
+
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC passes of this same command (profiles/pmc_traffic.json:
+    """HBM bytes per launch of `kernel` from the committed PMC passes of this same command ON THIS BUILD (profiles/pmc_traffic.json:
     rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, corrected for gfx950 by tools/pmc_traffic.py), or None."""
-    import json
-    import os
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'pmc_traffic.json')
-    try:
-        for k in json.load(open(path))['kernels']:
-            if k['kernel'] == kernel:
-                return k['hbm_bytes_per_launch']
-    except (OSError, ValueError, KeyError):
-        pass
+    d = _pmc_file()
+    if d is None:
+        return None
+    for k in d.get('kernels', []):
+        if k['kernel'] == kernel:
+            return k['hbm_bytes_per_launch']
     return None
 
 
 def tn_operand_bytes():
     """Per weight-gradient (token-reduction GEMM) family: algorithmic operand bytes per launch = live reduction rows x (M + N) x 4,
     over the recorded launches -- the figure the PMC traffic of profiles/pmc_traffic.json is compared with."""
-    torch.cuda.synchronize()
     out = {}
-    for family, s, e, fn in _records:
+    for family, fn, _ms in _all_records():
         dims = getattr(fn, 'tn_dims', None)
         if dims:
             M, N, fs = dims
@@ -121,6 +161,20 @@ def tn_operand_bytes():
             d['bytes'] += float(fn()) / (2.0 * M * N * fs) * (M + N) * 4.0
             d['launches'] += 1
     return out
+
+
+def operand_bytes(family):
+    """Algorithmic HBM bytes per launch of a GEMM family over the recorded launches: every operand read once, every output written
+    once (fn.op_bytes, set by ops.gemm from the true -- device-side -- extents)."""
+    tot, n = 0.0, 0
+    for fam, fn, _ms in _all_records():
+        if fam != family:
+            continue
+        b = fn.op_bytes if hasattr(fn, 'op_bytes') else (fn.bytes_fn() if hasattr(fn, 'bytes_fn') else None)
+        if b is not None:
+            tot += float(b)
+            n += 1
+    return (tot / n) if n else None
 
 
 def weight_gradient_traffic():
@@ -149,7 +203,10 @@ def roofline(peak_tflops, sampled_steps=None, ms_per_step=None):
     return {
         'bound': 'mfma', 'achieved': round(ach, 3), 'peak': peak_tflops, 'unit': 'TFLOP/s', 'frac': round(ach / peak_tflops, 4),
         'traffic': pmc_traffic(KERNEL_OF.get(name, name)), 'traffic_source': 'profiles/pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes '
-        'of this command on the same build (PMC cannot be collected inside the timed run), FETCH_SIZE x2 per the gfx950 note', 'kernel': KERNEL_OF.get(name, name), 'family': name, 'launches': d['launches'],
+        'of this command (PMC cannot be collected inside the timed run), FETCH_SIZE x2 per the gfx950 note; quoted only when the file\'s build_id equals the running build: ' + _PMC.get('why', ''),
+        'algorithmic_bytes_per_launch': (lambda b: None if b is None else round(b))(operand_bytes(name)),
+        'traffic_over_algorithmic': (lambda t, b: None if not (t and b) else round(t / b, 2))(pmc_traffic(KERNEL_OF.get(name, name)), operand_bytes(name)),
+        'kernel': KERNEL_OF.get(name, name), 'family': name, 'launches': d['launches'],
         'avg_launch_us': round(1000 * d['ms'] / max(1, d['launches']), 2),
         'share_of_instrumented_time': round(d['ms'] / total_ms, 3),
         'families': {k: {'ms': round(v['ms'], 3), 'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2) if v['ms'] > 0 else 0.0,

@@ -2,12 +2,21 @@
 forward, loss, zero_grad, backward, [gradient all-reduce], clip_grad_norm_(gradient_clip_norm), Adam.step -- with the
 optimizer state in flat fp32 buffers and clip+Adam fused into one HBM-bound kernel.  The epoch loop, dev evaluation and
 checkpoint bookkeeping of the reference are control plane and out of scope."""
+import os
+
 import torch
 import torch.nn as nn
 
 from . import dp, ops
+from . import profile as _prof
 from .layers import PARAM_EPOCH
 from .model import negative_log_softmax
+
+# NNR_NATIVE_STEP=0: always the autograd path (loss.backward() through the encoders' autograd Functions).
+# NNR_REPLAY=0: the native step is issued call by call from Python every step (no tape).
+_NATIVE_STEP = os.environ.get('NNR_NATIVE_STEP', '1') != '0'
+_REPLAY = os.environ.get('NNR_REPLAY', '1') != '0'
+_WARM_STEPS = 2          # eager steps before a tape is recorded (first-use allocations: workspaces, W^T copies, packed weights)
 
 
 class FlatParams:
@@ -43,7 +52,10 @@ class FlatParams:
         self.offsets = offs
 
     def zero_grad(self):
-        self.grad.zero_()
+        if self.grad.is_cuda:
+            ops.fill_zero(self.grad)
+        else:
+            self.grad.zero_()
 
 
 class _Own:
@@ -59,9 +71,32 @@ class _Own:
             yield from m.parameters()
 
 
+class _Const:
+    """A launch's algorithmic FLOPs with the device-side sizes of ITS step bound (see Trainer._snapshot_sizes)."""
+
+    def __init__(self, fn, value):
+        self.value = value
+        for k in ('tag', 'tn_dims', 'op_bytes'):
+            if hasattr(fn, k):
+                setattr(self, k, getattr(fn, k))
+
+    def __call__(self):
+        return self.value
+
+
 class Trainer:
-    def __init__(self, model, config):
+    def __init__(self, model, config, native=None, replay=None):
+        """native: run the CNE+SUE step as a plain sequence of C-ABI calls (nnr_amd.step) instead of through autograd (default: on,
+        NNR_NATIVE_STEP); replay: record that sequence once per batch shape and replay it natively (nnr_amd.tape; default: on,
+        NNR_REPLAY).  Models the native step does not cover (MHSA / CNN / ATT encoders, tie_order 'torch') take the autograd path."""
         self.model = model
+        self.native = _NATIVE_STEP if native is None else bool(native)
+        self.replay = _REPLAY if replay is None else bool(replay)
+        self.tapes = {}              # batch-shape key -> nnr_amd.tape.Tape
+        self.native_steps = {}       # batch-shape key -> eager native steps run so far
+        self.timing = False          # set by the caller (bench.py): the next step carries HIP events around its GEMM / recurrence calls
+        self._snaps = {}             # tape -> [snapshot of the device-side sizes per timing replay]
+        self.last_path = None        # 'autograd' | 'native' | 'record' | 'replay'  (diagnostics / tests)
         self.config = config
         self.flat = FlatParams(model)
         self.m = torch.zeros_like(self.flat.flat)
@@ -86,6 +121,11 @@ class Trainer:
         """One optimizer step on `batch` (21 device tensors, Model.forward order).  Returns (logits, loss) as device
         tensors -- no host synchronisation (the reference's float(loss) sync at trainer.py:115 is the caller's choice)."""
         model = self.model
+        if self.native and batch[15].is_cuda and model.training:
+            from . import step as native_step
+            if native_step.supported(model):
+                return self._native_train_step(batch, native_step)
+        self.last_path = 'autograd'
         self.flat.zero_grad()
         logits = model(*batch)
         loss = negative_log_softmax(logits)
@@ -95,13 +135,97 @@ class Trainer:
         self.optimizer_step(scale)
         return logits.detach(), loss.detach()
 
+    # ------------------------------------------------------------------------------------------------ native step / tape
+    def _body(self, batch, native_step):
+        self.flat.zero_grad()
+        logits, loss = native_step.forward_backward(self, batch)
+        scale = self.exchange.finish()
+        self.optimizer_step(scale)
+        return logits, loss
+
+    def _next_seeds(self):
+        """The dropout seeds the next encoder calls will draw (NewsEncoder._next_seed / UserEncoder._next_seed)."""
+        ne, ue = self.model.news_encoder, self.model.user_encoder
+        return {'news_seed': (ne._seed_base + 104729 * (ne._calls + 1)) & 0x7FFFFFFF,
+                'user_seed': (ue._seed_base + 15485863 * (ue._calls + 1)) & 0x7FFFFFFF}
+
+    def _native_train_step(self, batch, native_step):
+        key = tuple((tuple(t.shape), t.dtype) for t in batch)
+        tape = self.tapes.get(key)
+        eager_profile = _prof._on                       # eager HIP-event spans requested (bench's isolated leg, tools): no tape
+        if tape is not None and self.replay and not eager_profile and not ops.ONE_STREAM[0] and tape.matches(batch):
+            values = self._next_seeds()
+            self.model.news_encoder._calls += 1         # the replayed calls consume the same per-call seeds the eager ones would
+            self.model.user_encoder._calls += 1
+            self.step_count += 1
+            values['adam_step'] = self.step_count
+            timing = self.timing and tape._nsets < 64
+            tape.replay(values, batch, timing=timing)
+            if timing:
+                self._snapshot_sizes(tape)
+            PARAM_EPOCH[0] += 1
+            self.last_path = 'replay'
+            return tape.out
+        n = self.native_steps.get(key, 0)
+        self.native_steps[key] = n + 1
+        can_record = (self.replay and tape is None and n >= _WARM_STEPS and not eager_profile and not ops.ONE_STREAM[0] and len(self.tapes) < 4
+                      and not torch.cuda.is_current_stream_capturing())
+        if not can_record:
+            self.last_path = 'native'
+            logits, loss = self._body(batch, native_step)
+            return logits, loss
+        from .tape import Tape
+        tape = Tape(batch, self._next_seeds())
+        try:
+            tape.out = tape.record(lambda: self._body(batch, native_step))
+        except Exception:
+            tape.close()
+            raise
+        self.tapes[key] = tape
+        self.last_path = 'record'
+        return tape.out
+
+    def _snapshot_sizes(self, tape):
+        """After a timing replay: copy the device-side sizes (live token counts) the timed launches depended on; the buffers are
+        overwritten by the next step.  (A few 4-byte device copies on the step's stream, only on instrumented steps.)"""
+        dyn = {}
+        for _, fn in tape.tags:
+            for t in getattr(fn, 'dyn', ()):
+                dyn[t.data_ptr()] = t
+        ptrs = list(dyn)
+        snap = torch.stack([dyn[p].reshape(-1)[0] for p in ptrs]) if ptrs else None
+        self._snaps.setdefault(tape, []).append((ptrs, snap))
+
+    def collect_timings(self):
+        """Move the HIP-event timings of every timing replay so far into nnr_amd.profile (synchronises)."""
+        for tape, snaps in self._snaps.items():
+            for (ptrs, snap), rec in zip(snaps, tape.timings()[-len(snaps):]):
+                vals = dict(zip(ptrs, snap.tolist())) if snap is not None else {}
+                for family, fn, ms in rec:
+                    c = _Const(fn, float(fn(vals)))
+                    if hasattr(fn, 'bytes_fn'):
+                        c.op_bytes = fn.bytes_fn(vals)
+                    _prof.TAPE_RECORDS.append((family, c, ms))
+        self._snaps = {}
+
     def optimizer_step(self, grad_scale=1.0):
         self.step_count += 1
-        self.sumsq.zero_()
+        ops.fill_zero(self.sumsq)
         ops.sumsq(self.flat.grad, self.sumsq)
         ops.clip_adam(self.flat.flat, self.flat.grad, self.m, self.v, self.sumsq, grad_scale, self.gradient_clip_norm, self.lr, 0.9, 0.999,
                       1e-8, self.weight_decay, self.step_count)
         PARAM_EPOCH[0] += 1           # parameters changed behind torch's back: invalidate cached weight layouts
+
+    def skipped_steps(self, reset=False):
+        """Optimizer steps dropped so far because the gradient norm was not finite (nnr_clip_adam leaves parameters and moments
+        untouched for such a step; the reference's clip_grad_norm_ + Adam would go NaN, trainer.py:118-120).  A training loop polls
+        this every few hundred steps and stops when it moves.  Synchronises.  (step_count, i.e. Adam's bias correction, still
+        advances for a skipped step: the host cannot know without a sync; one step's drift of 1 - beta^t is below 1e-3 after step 7.)"""
+        import ctypes as C
+        from . import _lib as L
+        v = C.c_uint()
+        L.check(L.lib().nnr_adam_skipped_steps(C.byref(v), int(reset)), 'nnr_adam_skipped_steps')
+        return int(v.value)
 
     def grad_total_norm(self, grad_scale=1.0):
         s = torch.zeros(1, device=self.flat.grad.device, dtype=torch.float32)

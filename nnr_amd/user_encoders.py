@@ -196,7 +196,9 @@ def sue_forward(mod, hist, cand, graph, cmask, cidx):
     return out.view(B, N, D), sv
 
 
-def sue_backward(mod, sv, dout):
+def sue_backward(mod, sv, dout, dhist_out=None, dcand_accum=None):
+    """dhist_out [B, Hn, D] (optional): where the history gradient is written; dcand_accum [B*N, D] (optional): the candidate
+    gradient is ADDED into it (the step without autograd sums the click predictor's and this encoder's share there)."""
     B, Hn, D, N, Kc, G, Cn, A, p, seed = (sv[k] for k in ('B', 'Hn', 'D', 'N', 'Kc', 'G', 'Cn', 'A', 'p', 'seed'))
     dev = dout.device
     f32 = dict(device=dev, dtype=torch.float32)
@@ -204,7 +206,7 @@ def sue_backward(mod, sv, dout):
     dout = dout.view(B * N, D)
     ia = mod.interClusterAttention
     with ops.leaf_scope(dev) as leaf:
-        res = _sue_backward_body(mod, sv, dout, leaf, B, Hn, D, N, Kc, G, Cn, A, p, seed, dev, f32, cand2, ia)
+        res = _sue_backward_body(mod, sv, dout, leaf, B, Hn, D, N, Kc, G, Cn, A, p, seed, dev, f32, cand2, ia, dhist_out, dcand_accum)
     # every parameter gradient of this encoder is now ordered on the current stream (the leaf stream was joined on exit):
     # a data-parallel trainer starts reducing them while the news encoder's backward is still to come (dp.GradientExchange).
     # (Measured and rejected: issuing this encoder's weight-gradient GEMMs only after its data-gradient chain, so that they
@@ -215,7 +217,7 @@ def sue_backward(mod, sv, dout):
     return res
 
 
-def _sue_backward_body(mod, sv, dout, leaf, B, Hn, D, N, Kc, G, Cn, A, p, seed, dev, f32, cand2, ia):
+def _sue_backward_body(mod, sv, dout, leaf, B, Hn, D, N, Kc, G, Cn, A, p, seed, dev, f32, cand2, ia, dhist_out=None, dcand_accum=None):
     # ---- inter-cluster pool
     df2 = torch.empty((B * N * Cn, D), **f32)
     dv = torch.empty((B * N, D), **f32)
@@ -247,8 +249,10 @@ def _sue_backward_body(mod, sv, dout, leaf, B, Hn, D, N, Kc, G, Cn, A, p, seed, 
     ops.sue_slice_bwd(dg, dpad, B, Hn, G, D)
     dy = gcn_backward(mod.gcn, sv['gcn'], dpad, sv['graph'], leaf)
     ops.add_(dy, dpad)                                                       # gcn(X0) + X0
-    dhist = torch.empty((B, Hn, D), **f32)
+    dhist = torch.empty((B, Hn, D), **f32) if dhist_out is None else dhist_out
     ops.sue_x0_bwd(dy, dhist, grad_of(mod.proxy_node_embedding), B, Hn, Kc, D, p, seed + 1)
+    if dcand_accum is not None:
+        ops.add_(dcand_accum, dcand)
     return dhist, dcand.view(B, N, D)
 
 
@@ -292,7 +296,10 @@ class SUE(UserEncoder):
     def encode_user(self, history_embedding, user_history_mask, user_history_graph, user_history_category_mask,
                     user_history_category_indices, candidate_news_representation):
         """Everything of forward() after the history news have been encoded (userEncoders.py:73-75, 79-98)."""
-        user_history_category_mask[:, -1] = 1            # in place on the caller's tensor (userEncoders.py:73)
+        if user_history_category_mask.is_cuda and user_history_category_mask.dim() == 2 and user_history_category_mask.is_contiguous():
+            ops.fill_column_u8(user_history_category_mask, -1, 1)      # in place on the caller's tensor (userEncoders.py:73)
+        else:
+            user_history_category_mask[:, -1] = 1
         graph = user_history_graph.contiguous()
         cidx = user_history_category_indices.contiguous()
         assert cidx.dtype == torch.int64 and graph.dtype == torch.float32

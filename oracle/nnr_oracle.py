@@ -627,7 +627,7 @@ def train_step(model, optimizer, batch, gradient_clip_norm=4.0):
     if gradient_clip_norm > 0:
         nn.utils.clip_grad_norm_(model.parameters(), gradient_clip_norm)
     optimizer.step()
-    return logits.detach(), float(loss)
+    return logits.detach(), float(loss.detach())
 
 
 def make_optimizer(model, config):

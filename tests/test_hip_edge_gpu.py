@@ -109,13 +109,14 @@ def test_bench_shaped_batch_matches_oracle():
     _compare(model, ref, corpus.batch(8, np.random.default_rng(4)))
 
 
-@pytest.mark.parametrize('hidden', [48, 100, 128, 224, 256])
-def test_hidden_dims_with_full_width_word_rows(hidden):
+@pytest.mark.parametrize('hidden,ln', [(48, False), (100, False), (128, False), (224, False), (256, False), (256, True)])
+def test_hidden_dims_with_full_width_word_rows(hidden, ln):
     """--hidden_dim values whose buffers / tiles differ from the default 200 at the reference's word_embedding_dim 300 and a token
     capacity >= 8 192 rows (B = 2: 110 news x 128): hidden <= 144 makes the cell-state buffer [cap, 2*HP] SMALLER than the
     embedding-row gradient [cap, 300] staged in it (round-2 advisor finding: news_encoders.py dx_scatter), hidden 212..256 puts
-    the gathered dW_hh GEMM (N = hidden) past the 208-column tile (ops.tn_tile fell through to a tile without a gather path)."""
-    cfg = _cfg(batch_size=2, hidden_dim=hidden)
+    the gathered dW_hh GEMM (N = hidden) past the 208-column tile (ops.tn_tile fell through to a tile without a gather path);
+    hidden 256 makes the news vector 1 124 wide (pool / LayerNorm kernels were limited to 1 024 columns)."""
+    cfg = _cfg(batch_size=2, hidden_dim=hidden, gcn_layer_norm=ln)
     assert cfg.word_embedding_dim == 300
     model, ref = _models(cfg, seed=hidden)
     corpus = SynthCorpus(SynthSpec(vocabulary_size=cfg.vocabulary_size, news_pool=400, seed=12))

@@ -118,6 +118,53 @@ def test_cne_sue_batch64_vocab60000_DROPOUT_ON_matches_oracle():
     print('CNE+SUE batch 64, dropout 0.2 ON: logits max|diff| %.2e, worst gradient deviation %.2e of its scale' % (err, worst))
 
 
+def test_cne_sue_batch64_REPLAYED_step_dropout_on_matches_oracle():
+    """The step bench.py times is a native REPLAY of the recorded launch sequence (nnr_amd/tape.py).  Three steps bring the trainer
+    to that state (call by call, call by call, record); the oracle is then synchronised to the product's parameters and the FOURTH
+    step -- replayed from the tape on a new batch, with that step's seeds -- is compared: logits, loss, every gradient, total norm."""
+    import hip_masks
+    from nnr_amd import ops
+    from nnr_amd.trainer import Trainer
+    from oracle import nnr_oracle as O
+    cfg = make_config(['--news_encoder=CNE', '--user_encoder=SUE', '--dataset=200k', '--batch_size=64'],
+                      corpus_sizes=dict(vocabulary_size=60000), tie_order='stable')
+    model, ref = _pair(cfg, seed=5)
+    trainer = Trainer(model, cfg)
+    corpus = SynthCorpus(SynthSpec(vocabulary_size=cfg.vocabulary_size))
+    rng = np.random.default_rng(105)
+    ops.lstm_sync_timeouts(reset=True)
+    for want in ('native', 'native', 'record'):
+        trainer.train_step(to_torch(corpus.batch(64, rng), 'cuda'))
+        assert trainer.last_path == want
+    torch.cuda.synchronize()
+    ref.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()})
+    batch = corpus.batch(64, rng)
+    dev_batch = to_torch(batch, 'cuda')
+    hip_masks.inject(model, ref, dict(zip(BATCH_FIELDS, dev_batch)))
+    logits, loss = trainer.train_step(dev_batch)
+    torch.cuda.synchronize()
+    assert trainer.last_path == 'replay' and ops.lstm_sync_timeouts() == 0
+    got_norm = trainer.grad_total_norm()
+    rl = ref(*to_torch(batch))
+    rloss = O.negative_log_softmax(rl)
+    ref.zero_grad()
+    rloss.backward()
+    rnorm = float(torch.sqrt(sum((q.grad.double() ** 2).sum() for q in ref.parameters())))
+    err = float((logits.cpu() - rl.detach()).abs().max())
+    assert err <= 1e-4 and abs(float(loss) - float(rloss)) <= 2e-5, (err, float(loss), float(rloss))
+    assert abs(got_norm - rnorm) <= 1e-4 * max(1.0, rnorm), (got_norm, rnorm)
+    rp = dict(ref.named_parameters())
+    worst = 0.0
+    for k, p in model.named_parameters():
+        g, rg = p.grad.detach().cpu().double(), rp[k].grad.double()
+        scale = max(1e-3, 0.05 * rnorm, float(rg.norm()))
+        d = float((g - rg).abs().max())
+        worst = max(worst, d / scale)
+        assert d <= 1e-4 * scale, 'grad %s: %.3e vs scale %.3e' % (k, d, scale)
+    print('CNE+SUE batch 64, dropout ON, REPLAYED step: logits max|diff| %.2e, worst gradient deviation %.2e, tape %s' %
+          (err, worst, trainer.tapes[next(iter(trainer.tapes))].info()))
+
+
 def test_cne_sue_large_batch16_vocab130000_DROPOUT_ON_matches_oracle():
     """BASELINE.json configs[4]'s per-GPU shard (MIND-large: dropout 0.1, config.py:91-94; batch 128 over 8 GPUs = 16 per GPU,
     trainer.py:218; V = 130 000), dropout ON with injected masks."""

@@ -1,0 +1,210 @@
+"""The launch-sequence tape (nnr_amd/tape.py over csrc/tape.hip: `nnr_tape_*`) and the native CNE+SUE step (nnr_amd/step.py).
+
+The reference issues its training step from Python call by call (trainer.py:105-120); so did rounds 1-2 of this build (~140 C-ABI
+calls, 4.4 ms of interpreter time per step).  Now the step is (a) written as a plain sequence of C-ABI calls without an autograd
+graph, (b) recorded once per batch shape and (c) replayed natively with one call per segment.  Checked here:
+  * tape mechanics on a hand-made two-stream sequence: argument copies, input-pointer patches, value (seed) patches, event order;
+  * the native step == the autograd step (same seeds: bit-equal logits, gradients within the atomics' reordering noise);
+  * warm-up -> record -> replay: every step of a dropout-ON run, INCLUDING the replayed ones, against the CPU oracle with the HIP
+    generator's masks injected (tests/hip_masks.py), <= 10 C-ABI calls per replayed step;
+  * a batch of another shape falls back to the call-by-call path and gets its own tape; eval mode / other encoders never record."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from nnr_amd.config import make_config
+from nnr_amd.synth import SynthSpec, SynthCorpus, BATCH_FIELDS, to_torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _models(cfg, seed=0):
+    from nnr_amd.model import Model
+    from oracle import nnr_oracle as O
+    O.BiLSTM.backend = 'aten'
+    torch.manual_seed(seed)
+    ref = O.Model(cfg)
+    ref.initialize()
+    with torch.no_grad():
+        for p in ref.parameters():
+            if float(p.abs().max()) == 0.0:
+                p.normal_(0, 0.05)
+    ref.train()
+    model = Model(cfg)
+    model.load_state_dict(ref.state_dict())
+    return model.cuda().train(), ref
+
+
+def test_tape_mechanics_two_streams_inputs_and_seeds():
+    """y = dropout(x_in, seed) on stream A; z = y + 2 * x_in on stream B after an event; replayed on OTHER inputs with OTHER seeds."""
+    from nnr_amd import ops
+    from nnr_amd.tape import Tape
+    n = 1 << 16
+    x0 = torch.randn(n, device='cuda')
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    seeds = {'news_seed': 1000, 'user_seed': 900000}
+    tape = Tape([x0], seeds)
+    out = {}
+
+    def body():
+        main = torch.cuda.current_stream()
+        sa.wait_stream(main)
+        with torch.cuda.stream(sa):
+            y = ops.dropout(x0, 0.5, seeds['news_seed'] + 3)
+            ev = torch.cuda.Event()
+            ev.record()
+        with torch.cuda.stream(sb):
+            sb.wait_event(ev)
+            z = torch.empty_like(y)
+            ops.copy_bytes(z, y)
+            ops.add_(z, x0, 2.0)
+        main.wait_stream(sb)
+        out['y'], out['z'] = y, z
+        return z
+    z = tape.record(body)
+    torch.cuda.synchronize()
+    want = ops.dropout(x0, 0.5, 1003) + 2 * x0
+    assert torch.equal(z, want)
+    info = tape.info()
+    assert info['calls'] == 3 and info['segments'] == 1 and info['streams'] >= 2, info
+    x1 = torch.randn(n, device='cuda')
+    tape.replay({'news_seed': 5000, 'user_seed': 1, 'adam_step': 7}, [x1])
+    torch.cuda.synchronize()
+    assert torch.equal(out['z'], ops.dropout(x1, 0.5, 5003) + 2 * x1)             # other input, other seed, same buffers
+    assert not torch.equal(out['y'] != 0, ops.dropout(x1, 0.5, 1003) != 0)
+    with pytest.raises(Exception):
+        tape.replay({'news_seed': 1, 'user_seed': 1, 'adam_step': 1}, [])          # missing input
+    tape.close()
+
+
+def test_recording_refuses_what_it_cannot_replay():
+    from nnr_amd import ops
+    from nnr_amd.tape import Tape, TapeError
+    x = torch.randn(64, device='cuda')
+    t = Tape([x], {'news_seed': 10, 'user_seed': 20})
+    with pytest.raises(TapeError):
+        t.record(lambda: torch.zeros(8, device='cuda'))                # a framework fill kernel would be missing from the tape
+    t.close()
+    t = Tape([x], {'news_seed': 10, 'user_seed': 1 << 20})
+    with pytest.raises(TapeError):
+        t.record(lambda: ops.dropout(x, 0.5, 777777))                  # a seed that is not derived from the step's seeds
+    t.close()
+
+
+def _grads(model):
+    return {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+
+
+def test_native_step_equals_autograd_step():
+    from nnr_amd.trainer import Trainer
+    cfg = make_config(['--news_encoder=CNE', '--user_encoder=SUE'], corpus_sizes=dict(vocabulary_size=900), tie_order='stable', batch_size=6)
+    model, _ = _models(cfg)
+    batch = SynthCorpus(SynthSpec(vocabulary_size=900, news_pool=500, seed=3)).batch(6, np.random.default_rng(1))
+    res = {}
+    for mode in ('autograd', 'native'):
+        model.news_encoder._calls = model.user_encoder._calls = 0
+        tr = Trainer(model, cfg, native=(mode == 'native'), replay=False)
+        tr.lr = 0.0                                                     # Adam with lr 0: both runs start from the same parameters
+        logits, loss = tr.train_step(to_torch(batch, 'cuda'))
+        torch.cuda.synchronize()
+        assert tr.last_path == mode
+        res[mode] = (logits.clone(), loss.clone(), tr.flat.grad.clone())
+    assert torch.equal(res['autograd'][0], res['native'][0]) and torch.equal(res['autograd'][1], res['native'][1])
+    ga, gn = res['autograd'][2], res['native'][2]
+    assert float((ga - gn).abs().max()) <= 2e-5 * float(ga.abs().max())
+
+
+@pytest.mark.parametrize('batch_size', [4, 9])
+def test_warmup_record_replay_against_oracle_dropout_on(batch_size):
+    """Seven consecutive optimizer steps, dropout 0.2 ON, each compared with the oracle (masks of that step injected): steps 0-1 are
+    issued call by call, step 2 records the tape, steps 3-6 are native replays -- on different batches (input patches), with advancing
+    seeds and Adam step numbers (value patches)."""
+    import hip_masks
+    from nnr_amd import _lib
+    from nnr_amd.trainer import Trainer
+    from oracle import nnr_oracle as O
+    cfg = make_config(['--news_encoder=CNE', '--user_encoder=SUE'], corpus_sizes=dict(vocabulary_size=900), tie_order='stable', batch_size=batch_size)
+    assert cfg.dropout_rate == 0.2
+    model, ref = _models(cfg, seed=batch_size)
+    tr = Trainer(model, cfg, native=True, replay=True)
+    opt = O.make_optimizer(ref, cfg)
+    corpus = SynthCorpus(SynthSpec(vocabulary_size=900, news_pool=500, seed=4))
+    rng = np.random.default_rng(2)
+    paths, calls = [], []
+    for step in range(7):
+        batch = corpus.batch(batch_size, rng)
+        dev = to_torch(batch, 'cuda')
+        hip_masks.inject(model, ref, dict(zip(BATCH_FIELDS, dev)))
+        c0 = _lib.CALLS[0]
+        logits, loss = tr.train_step(dev)
+        calls.append(_lib.CALLS[0] - c0)
+        torch.cuda.synchronize()
+        paths.append(tr.last_path)
+        rl, rloss = O.train_step(ref, opt, to_torch(batch), cfg.gradient_clip_norm)
+        # (after k optimizer steps the two parameter sets differ by Adam's sign noise on unresolved gradients, <= k * lr per element:
+        # the bar scales with the size of the logits, which are O(10) for this noise-initialised model)
+        err = float((logits.cpu() - rl).abs().max())
+        bar = 1e-4 * max(1.0, float(rl.abs().max()))
+        assert err <= bar and abs(float(loss) - rloss) <= bar, (step, paths, err, bar, float(loss), rloss)
+        assert bool((dev[16][:, :, 0]).all()) and bool(dev[11][:, -1].all())          # the in-place mask mutations reached THIS batch's tensors
+    assert paths == ['native', 'native', 'record', 'replay', 'replay', 'replay', 'replay'], paths
+    assert max(calls[3:]) <= 10 and min(calls[:2]) > 100, calls
+    rp = dict(ref.named_parameters())
+    for k, p in model.named_parameters():
+        assert float((p.detach().cpu() - rp[k].detach()).abs().max()) <= 7 * 1e-4 * 1.01 + 1e-4, k       # Adam: <= lr per step per element
+    info = tr.tapes[next(iter(tr.tapes))].info()
+    print(info, calls)
+    assert info['segments'] == 1 and info['calls'] > 100
+
+
+def test_other_shapes_and_modes_fall_back():
+    from nnr_amd.trainer import Trainer
+    cfg = make_config(['--news_encoder=CNE', '--user_encoder=SUE'], corpus_sizes=dict(vocabulary_size=900), tie_order='stable', batch_size=4)
+    model, _ = _models(cfg, seed=5)
+    tr = Trainer(model, cfg)
+    corpus = SynthCorpus(SynthSpec(vocabulary_size=900, news_pool=500, seed=6))
+    rng = np.random.default_rng(3)
+    seq = []
+    for bs in (4, 4, 4, 4, 3, 4, 3, 3, 3):
+        logits, _ = tr.train_step(to_torch(corpus.batch(bs, rng), 'cuda'))
+        assert logits.shape[0] == bs and bool(torch.isfinite(logits).all())
+        seq.append(tr.last_path)
+    assert seq == ['native', 'native', 'record', 'replay', 'native', 'replay', 'native', 'record', 'replay'], seq
+    assert len(tr.tapes) == 2
+    # another encoder pair never takes the native step
+    cfg2 = make_config(['--news_encoder=MHSA', '--user_encoder=MHSA'], corpus_sizes=dict(vocabulary_size=900), batch_size=4)
+    from nnr_amd.model import Model
+    m2 = Model(cfg2)
+    m2.initialize()
+    tr2 = Trainer(m2.cuda().train(), cfg2)
+    for _ in range(4):
+        tr2.train_step(to_torch(corpus.batch(4, rng), 'cuda'))
+    assert tr2.last_path == 'autograd' and not tr2.tapes
+
+
+def test_timing_replay_feeds_the_live_roofline():
+    """bench.py's per-family HIP-event figures come from timing replays: events recorded natively around the tagged calls."""
+    from nnr_amd import profile as prof
+    from nnr_amd.trainer import Trainer
+    cfg = make_config(['--news_encoder=CNE', '--user_encoder=SUE'], corpus_sizes=dict(vocabulary_size=900), tie_order='stable', batch_size=8)
+    model, _ = _models(cfg, seed=6)
+    tr = Trainer(model, cfg)
+    corpus = SynthCorpus(SynthSpec(vocabulary_size=900, news_pool=500, seed=7))
+    rng = np.random.default_rng(4)
+    for _ in range(3):
+        tr.train_step(to_torch(corpus.batch(8, rng), 'cuda'))
+    prof.enable(every=2, eager=False)
+    for i in range(4):
+        tr.timing = prof.begin_step(i)
+        tr.train_step(to_torch(corpus.batch(8, rng), 'cuda'))
+        assert tr.last_path == 'replay'
+    tr.timing = False
+    tr.collect_timings()
+    prof.disable()
+    fam = prof.summary()
+    assert 'lstm_fwd' in fam and 'lstm_bwd' in fam and any(k.startswith('gemm_nt') for k in fam) and any(k.startswith('gemm_tn') for k in fam)
+    assert fam['lstm_fwd']['launches'] == 2 and fam['lstm_fwd']['flops'] > 0 and fam['lstm_fwd']['ms'] > 0
+    r = prof.roofline(157.3, sampled_steps=2, ms_per_step=5.0)
+    assert r['achieved'] > 0 and r['step']['gflop'] > 0

@@ -6,8 +6,12 @@ Usage: python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter
 import collections
 import csv
 import json
+import os
 import re
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from nnr_amd import _lib      # noqa: E402  (build_id only: hashes of the kernel sources / the built library, no GPU call)
 
 
 def short(n):
@@ -52,7 +56,7 @@ for (k, grid), (fk, n) in sorted(BY_GRID['FETCH_SIZE'].items(), key=lambda kv: -
         wk, wn = BY_GRID['WRITE_SIZE'].get((k, grid), [0.0, 1])
         shapes.append(dict(kernel=k, slot_in_step=grid, launches=n, fetch_bytes_per_launch=round(2 * fk * 1024 / n),
                            write_bytes_per_launch=round(wk * 1024 / max(1, wn))))
-json.dump(dict(weight_gradient_launch_shapes=shapes, note='FETCH_SIZE x2 (gfx950 caveat) + WRITE_SIZE, bytes per launch averaged over the launches of one bench run', kernels=out),
+json.dump(dict(build_id=_lib.build_id(), weight_gradient_launch_shapes=shapes, note='FETCH_SIZE x2 (gfx950 caveat) + WRITE_SIZE, bytes per launch averaged over the launches of one bench run', kernels=out),
           open(sys.argv[3], 'w'), indent=1)
 for o in shapes:
     print('  %-40s slot %2s  %3d launches  fetch %8.1f MB  write %7.1f MB' % (o['kernel'][:40], o['slot_in_step'], o['launches'], o['fetch_bytes_per_launch'] / 1e6, o['write_bytes_per_launch'] / 1e6))
