@@ -172,6 +172,9 @@ typedef struct nnr_pool_args {
   float* dx; int lddx; int dx_accumulate;
   float* dscore;
   float* dv; int lddv;
+  /* forward only, instead of `score`: score[row] = <th[row, :A], w2>  (the w2 . tanh(.) of layers.py:168 computed in the pool's
+   * own pass over the tokens; A <= 256, A % 4 == 0, th rows laid out like x) */
+  const float* th; int ldth; int A; const float* w2;
 } nnr_pool_args;
 int nnr_attn_pool_fwd(const nnr_pool_args* a, hipStream_t stream);
 int nnr_attn_pool_bwd(const nnr_pool_args* a, hipStream_t stream);
@@ -236,10 +239,12 @@ int nnr_mhsa_bwd(const float* qkv, const uint8_t* mask, const float* prob, const
                  float scale, float* dqkv, float drop_p, uint32_t seed, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------ SUE (userEncoders.py:68-98) */
+/* cmask_fix (optional): the [B, Kc + 1] cluster mask; its last column is set to 1 in place by the same launch (:73).
+ * dx0_add (optional): second addend of the upstream gradient (the outer residual of :81), dX0 = dx0 + dx0_add. */
 int nnr_sue_x0_fwd(const float* hist, const float* proxy, float* x0, int B, int Hn, int Kc, int D, float p, uint32_t seed,
-                   hipStream_t stream);                                          /* :80 */
-int nnr_sue_x0_bwd(const float* dx0, float* dhist, float* dproxy_accum, int B, int Hn, int Kc, int D, float p, uint32_t seed,
-                   hipStream_t stream);
+                   uint8_t* cmask_fix, hipStream_t stream);                      /* :80 */
+int nnr_sue_x0_bwd(const float* dx0, const float* dx0_add, float* dhist, float* dproxy_accum, int B, int Hn, int Kc, int D, float p,
+                   uint32_t seed, hipStream_t stream);
 int nnr_sue_slice_fwd(const float* gcn, const float* x0, float* gfeat, int B, int Hn, int G, int D, hipStream_t stream);   /* :81-82 */
 int nnr_sue_slice_bwd(const float* dgfeat, float* dpad, int B, int Hn, int G, int D, hipStream_t stream);
 /* torch_scatter.scatter_softmax + scatter_sum (userEncoders.py:85-89): kf [B,Hn,A], qc [B,N,A], g [B,Hn,D], cidx int64 [B,Hn]
@@ -299,9 +304,9 @@ int nnr_layernorm_fwd(const float* u, const float* gamma, const float* beta, flo
                       float* r_out, const float* resid, float* y, float p, uint32_t seed, hipStream_t stream);
 int nnr_layernorm_bwd(const float* dv, const float* xhat, const float* rstd, const float* gamma, long rows, int D, float* du,
                       float* dgamma, float* dbeta, hipStream_t stream);
-/* *out_zeroed += sum g^2, a DETERMINISTIC function of g (fixed-order two-level sum: data-parallel ranks must clip by the same bits);
+/* *out = sum g^2 (stored), a DETERMINISTIC function of g (fixed-order two-level sum: data-parallel ranks must clip by the same bits);
  * launches of one process must be stream-ordered (one device-global scratch) */
-int nnr_sumsq(const float* g, long n, float* out_zeroed, hipStream_t stream);
+int nnr_sumsq(const float* g, long n, float* out, hipStream_t stream);
 /* clip_grad_norm_(max_norm = clip) + torch.optim.Adam step on one flat buffer (trainer.py:118-120); grads are scaled by
  * grad_scale first (1/world_size after the RCCL sum all-reduce).  A step whose squared gradient norm is not finite is
  * skipped as a whole (parameters and moments untouched). */
@@ -324,6 +329,21 @@ int nnr_dp_init(const void* uid128, int rank, int world, nnr_dp_ctx** ctx);     
 int nnr_dp_allreduce(nnr_dp_ctx* ctx, float* flat, size_t n, hipStream_t stream);
 int nnr_dp_broadcast(nnr_dp_ctx* ctx, float* flat, size_t n, int root, hipStream_t stream);
 int nnr_dp_destroy(nnr_dp_ctx* ctx);
+
+/* ------------------------------------------------------------------------------------------------ fused small launches (csrc/fuse.hip)
+ * feature_fusion (newsEncoders.py:50-54) for the union of the candidate call (rows [0, n0), ids cat0 / sub0) and the history call
+ * (rows [n0, n0 + n1), ids cat1 / sub1; n1 may be 0): out[row, 0:cd] = dropout(category row), out[row, cd:cd+sd] = dropout(subCategory
+ * row); masks = nnr_small_embed_fwd's (flat index row * dim + column, one seed per table).  Backward accumulates both table gradients. */
+int nnr_fusion_rows_fwd(const float* cat_table, const float* sub_table, const int* cat0, const int* sub0, int n0, const int* cat1,
+                        const int* sub1, int n1, int cd, int sd, float* out, int ldo, float p, uint32_t seed_cat, uint32_t seed_sub,
+                        hipStream_t stream);
+int nnr_fusion_rows_bwd(const int* cat0, const int* sub0, int n0, const int* cat1, const int* sub1, int n1, int cd, int sd, const float* dout,
+                        int lddo, float* dcat_table_accum, float* dsub_table_accum, float p, uint32_t seed_cat, uint32_t seed_sub,
+                        hipStream_t stream);
+/* Click predictor + loss + their backward in one launch (model.py:126-127, trainer.py:64-66): logits [B, N], loss (scalar, a fixed-order
+ * mean), dlogits [B, N] (optional), duser / dcand [B, N, D] (both or neither); terms_ws: B floats of scratch.  N <= 64. */
+int nnr_click_loss(const float* user, const float* cand, int B, int N, int D, float* logits, float* loss, float* dlogits, float* duser,
+                   float* dcand, float* terms_ws, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------ fills / copies
  * What the host framework's fill / copy / index-put kernels did inside the step (optimizer.zero_grad() at trainer.py:116,
@@ -357,6 +377,7 @@ int nnr_tape_finalize(nnr_tape* t);
 int nnr_tape_info(const nnr_tape* t, int* calls, int* ops, int* segments, int* streams, size_t* arena_bytes);
 int nnr_tape_replay(nnr_tape* t, int segment, const uint64_t* values, int nvalues, const uint64_t* inputs, int ninputs, int timing_set);
 int nnr_tape_timings(nnr_tape* t, int set, float* ms, int n);
+int nnr_tape_timeline(nnr_tape* t, int set, float* start_ms, float* dur_ms, int* stream_idx, int n);
 int nnr_tape_last_error(const nnr_tape* t, int* rc, int* call, char* name, int name_cap);
 
 #ifdef __cplusplus

@@ -1525,8 +1525,19 @@ extern "C" int nnr_gemm_f32(const nnr_gemm_args* a, hipStream_t stream) {
     static const bool use_pipe = [] { const char* e = getenv("NNR_GEMM_PIPE"); return !(e && atoi(e) == 0); }();   // A/B switch
     if (g.rowdot_w) tile = 3;
     else if (plain && wg64 <= 512 && g.K >= 64) tile = 7;   // small row-parallel launch: 16 x 80 tiles, K split over the 4 waves
-    else if (use_pipe && use_t9 && pipe_ok(g) && !g.a_idx && g.K >= 800 && wg64 > 512) tile = 9;   // long reductions (dX: K = 1664, SUE: K = 900): the
+    else if (use_pipe && use_t9 && pipe_ok(g) && !g.a_idx && g.K >= 800 && wg64 > 512) {
+      tile = 9;              // long reductions (dX: K = 1664, SUE: K = 900): the
                              // software-pipelined loop with the lean DMA issue, 2 workgroups / CU (130 vs 112 TF, 93 vs 79 TF)
+      // Launches of one or two waves of workgroups (SUE: 4 352 / 6 080 rows x 900 columns) are bound by the CU that carries the most
+      // tiles: 4 352 x 900 is 408 tiles of 128 x 80 (the busiest CU works through 2 x 80 columns of a 128-row stripe) but 510 tiles of
+      // 128 x 64 (2 x 64 columns, and no column padding: 900 = 14.06 x 64 vs 11.25 x 80) -- take the narrower tile when that wins by > 8 %.
+      static const bool use_n64 = [] { const char* e = getenv("NNR_NT64"); return !(e && atoi(e) == 0); }();   // A/B
+      if (use_n64 && !g.dyn_dev && g.batch <= 1) {
+        const long nbm = (g.M + 127) / 128, t80 = nbm * ((g.N + 79) / 80), t64 = nbm * ((g.N + 63) / 64);
+        const long load80 = ((t80 + 255) / 256) * 80, load64 = ((t64 + 255) / 256) * 64;
+        if (t80 < 1024 && load64 * 100 < load80 * 92) tile = 31;
+      }
+    }
     else if (use_pipe && pipe_ok(g) && (g.dyn_dev || wg128 >= 640)) tile = 15;   // GPU-filling NT: LDS-DMA staged 128 x 80, BK 16, 4 workgroups / CU
                              // (112 vs 98 TF on the 131 072-row CNE shapes, tools/gemm_pipe_bench.py)
     else if (use_pipe && pipe_ok(g) && wg64 > 512 && g.K >= 128) tile = 16;      // mid-size NT (SUE: 4 352 x 900 x 900): same tile, two 13 KB stages,
@@ -1571,6 +1582,7 @@ extern "C" int nnr_gemm_f32(const nnr_gemm_args* a, hipStream_t stream) {
     case 28: if (!tn_pipe_ok(g) || g.b_idx) return NNR_ERR_ARG; return launch_tn_pipe2<2, 5, 4, 2>(g, stream);    // gen-2 TN 128 x 80, 4 stages
     case 29: if (!tn_pipe_ok(g) || g.b_idx) return NNR_ERR_ARG; return launch_tn_pipe2<4, 5, 3, 2>(g, stream);    // gen-2 TN 256 x 80
     case 30: if (!tn_pipe_ok(g)) return NNR_ERR_ARG; return launch_tn_pipe2<2, 10, 3, 2>(g, stream);              // gen-2 TN 128 x 160 (N = 300 in two column blocks)
+    case 31: if (!pipe_ok(g) || g.a_idx) return NNR_ERR_ARG; return launch_pipe2<2, 4, 3, 2>(g, stream);          // gen-2 NT 128 x 64, 3 x 24 KB stages, 2 workgroups / CU
     case 7:
       if (g.trans_a || g.a_idx || g.b_idx || g.c_idx || g.dyn_dev || g.split_k > 1 || g.k_chunk > 0 || g.rowdot_w || g.colsum_out || g.atomic ||
           (g.drop_target != 0 && g.drop_target != 3)) return NNR_ERR_ARG;

@@ -301,21 +301,27 @@ __global__ void add2d_kernel(float* __restrict__ y, int ldy, const float* __rest
 
 // ---- SUE graph input (userEncoders.py:80): X0[b, :Hn] = hist[b] ; X0[b, Hn + k] = dropout_(proxy[k])  (mask per sample)
 //      backward: dhist = dX0[:, :Hn] ; dproxy[k] += sum_b mask * dX0[b, Hn + k]
+//      cmask_fix (forward, optional): the [B, Kc + 1] cluster mask whose last column the reference sets in place (userEncoders.py:73);
+//      dx0_add (backward, optional): a second addend of the upstream gradient (the outer residual gcn(X0) + X0, :81)
 __global__ void sue_x0_kernel(const float* __restrict__ hist, const float* __restrict__ proxy, float* __restrict__ x0, int B,
-                              int Hn, int Kc, int D, const float* __restrict__ dx0, float* __restrict__ dhist,
-                              float* __restrict__ dproxy, uint32_t seed, uint32_t thr, float scale) {
+                              int Hn, int Kc, int D, const float* __restrict__ dx0, const float* __restrict__ dx0_add,
+                              float* __restrict__ dhist, float* __restrict__ dproxy, uint8_t* __restrict__ cmask_fix, uint32_t seed,
+                              uint32_t thr, float scale) {
   const int G = Hn + Kc;
   const long total = (long)B * G * D;
+  if (cmask_fix)
+    for (long b = blockIdx.x * (long)blockDim.x + threadIdx.x; b < B; b += (long)gridDim.x * blockDim.x) cmask_fix[b * (Kc + 1) + Kc] = 1;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int c = i % D; const long q = i / D; const int j = q % G; const int b = q / G;
+    const float up = dx0 ? (dx0_add ? dx0[i] + dx0_add[i] : dx0[i]) : 0.f;
     if (j < Hn) {
       if (x0) x0[i] = hist[((long)b * Hn + j) * D + c];
-      if (dhist) dhist[((long)b * Hn + j) * D + c] = dx0[i];
+      if (dhist) dhist[((long)b * Hn + j) * D + c] = up;
     } else {
       const int k = j - Hn;
       const float m = nnr_keep(seed, (uint64_t)((long)b * Kc + k) * D + c, thr) ? scale : 0.f;
       if (x0) x0[i] = proxy[(long)k * D + c] * m;
-      if (dproxy) atomicAdd(&dproxy[(long)k * D + c], dx0[i] * m);
+      if (dproxy) atomicAdd(&dproxy[(long)k * D + c], up * m);
     }
   }
 }
@@ -638,7 +644,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = t;
   __syncthreads();
   if (threadIdx.x == 0) {
-    *out += (part[0] + part[1]) + (part[2] + part[3]);      // (out: zeroed by the caller; += keeps the old contract of accumulating into it)
+    *out = (part[0] + part[1]) + (part[2] + part[3]);       // (round 3: STORED, not accumulated -- the caller's fill launch in front of every call is gone)
     g_sumsq_arrived = 0;                                    // ready for the next launch (launches of one process are stream-ordered)
   }
 }
@@ -898,16 +904,16 @@ extern "C" int nnr_add2d(float* y, int ldy, const float* x, int ldx, int rows, i
 }
 
 extern "C" int nnr_sue_x0_fwd(const float* hist, const float* proxy, float* x0, int B, int Hn, int Kc, int D, float p, uint32_t seed,
-                              hipStream_t stream) {
+                              uint8_t* cmask_fix, hipStream_t stream) {
   const float sc = p > 0.f ? 1.f / (1.f - p) : 1.f;
-  EW_LAUNCH(sue_x0_kernel, (long)B * (Hn + Kc) * D, hist, proxy, x0, B, Hn, Kc, D, (const float*)nullptr, (float*)nullptr,
-            (float*)nullptr, seed, nnr_drop_thresh(p), sc);
+  EW_LAUNCH(sue_x0_kernel, (long)B * (Hn + Kc) * D, hist, proxy, x0, B, Hn, Kc, D, (const float*)nullptr, (const float*)nullptr, (float*)nullptr,
+            (float*)nullptr, cmask_fix, seed, nnr_drop_thresh(p), sc);
 }
-extern "C" int nnr_sue_x0_bwd(const float* dx0, float* dhist, float* dproxy, int B, int Hn, int Kc, int D, float p, uint32_t seed,
-                              hipStream_t stream) {
+extern "C" int nnr_sue_x0_bwd(const float* dx0, const float* dx0_add, float* dhist, float* dproxy, int B, int Hn, int Kc, int D, float p,
+                              uint32_t seed, hipStream_t stream) {
   const float sc = p > 0.f ? 1.f / (1.f - p) : 1.f;
-  EW_LAUNCH(sue_x0_kernel, (long)B * (Hn + Kc) * D, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, B, Hn, Kc, D, dx0,
-            dhist, dproxy, seed, nnr_drop_thresh(p), sc);
+  EW_LAUNCH(sue_x0_kernel, (long)B * (Hn + Kc) * D, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, B, Hn, Kc, D, dx0, dx0_add,
+            dhist, dproxy, (uint8_t*)nullptr, seed, nnr_drop_thresh(p), sc);
 }
 extern "C" int nnr_sue_slice_fwd(const float* gcn, const float* x0, float* gfeat, int B, int Hn, int G, int D, hipStream_t stream) {
   EW_LAUNCH(sue_slice_kernel, (long)B * G * D, gcn, x0, gfeat, (const float*)nullptr, (float*)nullptr, B, Hn, G, D);

@@ -30,6 +30,7 @@ struct PoolArgs {
   float* dx; int lddx; int dx_accumulate;
   float* dscore;
   float* dv; int lddv;
+  const float* th; int ldth; int A; const float* w2;      // score = <th[row, :A], w2> computed here (forward)
 };
 
 __device__ __forceinline__ long item_row(const PoolArgs& a, int s, int t) {
@@ -98,6 +99,31 @@ __global__ __launch_bounds__(256) void pool_kernel(PoolArgs a) {
 #pragma unroll
           for (int j = 0; j < MAXV; ++j) p += xv[u][j][0] * q[j][0] + xv[u][j][1] * q[j][1] + xv[u][j][2] * q[j][2] + xv[u][j][3] * q[j][3];
           p = wave_sum(p) * a.scale;
+          if (t < len && lane == 0) tok[t] = p;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < MAXT; ++k) {
+        const int t = lane + 64 * k;
+        sc[k] = (t < len) ? tok[t] : -INFINITY;
+      }
+    } else if (a.th) {
+      // additive-attention score w2 . tanh(W1 x + b1) from the tanh rows: wave w takes tokens w, w + 4, ... (4 rows in flight)
+      const int na = a.A >> 2;
+      const f32x4 wv = (lane < na) ? *reinterpret_cast<const f32x4*>(a.w2 + 4 * lane) : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int t0 = w; t0 < len; t0 += 4 * NWV) {
+        f32x4 tv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int t = min(t0 + u * NWV, len - 1);
+          tv[u] = (lane < na) ? *reinterpret_cast<const f32x4*>(a.th + item_row(a, s, t) * a.ldth + 4 * lane) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int t = t0 + u * NWV;
+          float p = tv[u][0] * wv[0] + tv[u][1] * wv[1] + tv[u][2] * wv[2] + tv[u][3] * wv[3];
+          p = wave_sum(p);
           if (t < len && lane == 0) tok[t] = p;
         }
       }
@@ -275,7 +301,8 @@ static int pool_check(const nnr_pool_args* p) {
   if ((p->D & 3) || p->D > 4 * 64 * MAXV_ALL || (p->ldx & 3)) return NNR_ERR_UNSUPPORTED;
   if (p->L > 64 * MAXT) return NNR_ERR_UNSUPPORTED;
   if (p->packed && (!p->off || !p->slen || !p->order)) return NNR_ERR_ARG;
-  if (!p->v && !p->score && !p->alpha) return NNR_ERR_ARG;
+  if (!p->v && !p->score && !p->alpha && !p->th) return NNR_ERR_ARG;
+  if (p->th && (!p->w2 || p->A <= 0 || p->A > 256 || (p->A & 3) || (p->ldth & 3))) return NNR_ERR_UNSUPPORTED;
   return NNR_OK;
 }
 
@@ -287,6 +314,7 @@ static PoolArgs to_args(const nnr_pool_args* p) {
   a.alpha = p->alpha; a.out = p->out; a.ldo = p->ldo; a.add_in = p->add_in; a.ldadd = p->ldadd;
   a.dout = p->dout; a.lddo = p->lddo; a.dout2 = p->dout2; a.lddo2 = p->lddo2;
   a.dx = p->dx; a.lddx = p->lddx; a.dx_accumulate = p->dx_accumulate; a.dscore = p->dscore; a.dv = p->dv; a.lddv = p->lddv;
+  a.th = p->th; a.ldth = p->ldth; a.A = p->A; a.w2 = p->w2;
   return a;
 }
 
@@ -306,7 +334,7 @@ static int pool_launch(const nnr_pool_args* p, hipStream_t stream) {
 extern "C" int nnr_attn_pool_fwd(const nnr_pool_args* p, hipStream_t stream) {
   int rc = pool_check(p);
   if (rc != NNR_OK) return rc;
-  if (!p->out || (!p->v && !p->score)) return NNR_ERR_ARG;
+  if (!p->out || (!p->v && !p->score && !p->th)) return NNR_ERR_ARG;
   return pool_launch<false>(p, stream);
 }
 

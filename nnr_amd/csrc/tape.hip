@@ -47,7 +47,7 @@ const Entry REGISTRY[] = {
   R(nnr_sue_x0_fwd), R(nnr_sue_x0_bwd), R(nnr_sue_slice_fwd), R(nnr_sue_slice_bwd), R(nnr_sue_intra_fwd), R(nnr_sue_intra_bwd),
   R(nnr_corpus_batch), R(nnr_history_graph), R(nnr_logits_loss_fwd), R(nnr_logits_fwd), R(nnr_nls_loss), R(nnr_logits_bwd),
   R(nnr_layernorm_fwd), R(nnr_layernorm_bwd), R(nnr_sumsq), R(nnr_clip_adam), R(nnr_dp_allreduce), R(nnr_dp_broadcast),
-  R(nnr_fill_zero), R(nnr_copy_bytes), R(nnr_fill_column_u8),
+  R(nnr_fill_zero), R(nnr_copy_bytes), R(nnr_fill_column_u8), R(nnr_fusion_rows_fwd), R(nnr_fusion_rows_bwd), R(nnr_click_loss),
 };
 #undef R
 constexpr int NREG = (int)(sizeof(REGISTRY) / sizeof(REGISTRY[0]));
@@ -250,6 +250,23 @@ extern "C" int nnr_tape_timings(nnr_tape* t, int set, float* ms, int n) {
     if (hipEventSynchronize(t->tset[set][2 * i + 1]) != hipSuccess || hipEventElapsedTime(&v, t->tset[set][2 * i], t->tset[set][2 * i + 1]) != hipSuccess)
       v = -1.f;
     ms[i] = v;
+  }
+  return m;
+}
+// start_ms[tag] = start of the tagged call relative to the start of tagged call 0, stream_idx[tag] = index of its HIP stream in the
+// tape (a per-call timeline of one replayed step, tools/tape_timeline.py).
+extern "C" int nnr_tape_timeline(nnr_tape* t, int set, float* start_ms, float* dur_ms, int* stream_idx, int n) {
+  if (!t || set < 0 || set >= (int)t->tset.size() || t->tset[set].empty()) return NNR_ERR_ARG;
+  const int m = n < t->ntagged ? n : t->ntagged;
+  std::vector<int> st(t->ntagged, -1);
+  for (const Call& c : t->calls) if (c.tag >= 0) st[c.tag] = c.stream;
+  for (int i = 0; i < m; ++i) {
+    float a = -1.f, d = -1.f;
+    if (hipEventSynchronize(t->tset[set][2 * i + 1]) == hipSuccess) {
+      if (hipEventElapsedTime(&a, t->tset[set][0], t->tset[set][2 * i]) != hipSuccess) a = -1.f;
+      if (hipEventElapsedTime(&d, t->tset[set][2 * i], t->tset[set][2 * i + 1]) != hipSuccess) d = -1.f;
+    }
+    start_ms[i] = a; dur_ms[i] = d; stream_idx[i] = st[i];
   }
   return m;
 }

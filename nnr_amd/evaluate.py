@@ -86,13 +86,17 @@ def compute_scores(model, corpus, batch_size, cache='auto'):
         return compute_scores_cached(model, corpus, batch_size)
     was_training = model.training
     model.eval()
+    model.news_encoder.__dict__['_dedup_stats'] = [0, 0]
     scores = torch.zeros(corpus.num, device=corpus.device, dtype=torch.float32)
     for start in range(0, corpus.num, batch_size):
         idx = torch.arange(start, min(start + batch_size, corpus.num), device=corpus.device, dtype=torch.int32)
         batch = corpus.train_batch(idx)                       # candidate fields are [B, 1, ...] = the unsqueeze of util.py:43-48
         scores[start:start + idx.numel()] = model(*batch).squeeze(dim=1)
     model.train(was_training)
-    LAST_STATS.update(mode='per-sample', encoder_rows=int(corpus.num * (corpus.H + 1)), per_sample_rows=int(corpus.num * (corpus.H + 1)))
+    rows = int(corpus.num * (corpus.H + 1))
+    enc, of = model.news_encoder.__dict__.get('_dedup_stats', [0, 0])
+    # CNE: history slots whose representation is the constant PAD representation are not encoded (news_encoders.cne_history_dedup)
+    LAST_STATS.update(mode='per-sample', encoder_rows=rows - (of - enc), per_sample_rows=rows, pad_slots_skipped=of - enc)
     return scores
 
 

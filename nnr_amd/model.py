@@ -110,7 +110,21 @@ class Model(nn.Module):
         user_embedding = None
         if self.training and torch.is_grad_enabled() and news_title_text.is_cuda:
             ops.wt_prefetch(news_title_text.device)      # W^T copies the backward pass will want, off the critical chain
-        if hasattr(self.news_encoder, 'forward_pair'):
+        ne = self.news_encoder
+        if (hasattr(ne, 'forward_pair') and not self.training and not torch.is_grad_enabled() and news_title_text.is_cuda
+                and getattr(ne, 'pad_dedup', True) and ne.tie_order == 'stable' and hasattr(self.user_encoder, 'encode_user')):
+            # inference: the history call without its redundant PAD slots (exact; news_encoders.cne_history_dedup)
+            news_representation = ne(news_title_text, news_title_mask, news_title_entity, news_content_text, news_content_mask,
+                                     news_content_entity, news_category, news_subCategory, user_embedding)
+            history_embedding, rows = newsEncoders.cne_history_dedup(ne, user_title_text, user_title_mask, user_content_text, user_content_mask,
+                                                                     user_category, user_subCategory)
+            st = ne.__dict__.setdefault('_dedup_stats', [0, 0])
+            st[0] += rows
+            st[1] += user_title_text.shape[0] * user_title_text.shape[1]
+            user_representation = self.user_encoder.encode_user(history_embedding, user_history_mask, user_history_graph,
+                                                                user_history_category_mask, user_history_category_indices,
+                                                                news_representation)
+        elif hasattr(self.news_encoder, 'forward_pair'):
             # same arithmetic as the two encoder calls of model.py:123-125, issued in lock-step so that launch-latency-bound
             # stages (the Bi-LSTM recurrences) of the candidate call and of the history call share one launch
             news_representation, history_embedding = self.news_encoder.forward_pair(

@@ -201,8 +201,10 @@ def cne_forward_many(mod, calls):
     phases of the first (small) call run on a second HIP stream, filling the gaps of the big call's kernels."""
     H = mod.hidden_dim
     dev = (calls[0][0][0] if isinstance(calls[0][0], tuple) else calls[0][0]).device
-    mod._packed_weights('title', mod.title_lstm)        # (re)pack on the main stream BEFORE forking: both calls read them
-    mod._packed_weights('content', mod.content_lstm)
+    if len(calls) > 1:
+        mod._packed_weights('title', mod.title_lstm)    # (re)pack on the main stream BEFORE forking: both calls read them
+        mod._packed_weights('content', mod.content_lstm)
+    # (one call -- the union of candidate and history call: each token stream's chain packs its own weights on its own HIP stream)
     pre = _fork_join(len(calls), dev, lambda i, on_main: _cne_fwd_pre(mod, *calls[i], par=on_main))
     items = [st for sv in pre for st in (sv['streams'][1],)] + [st for sv in pre for st in (sv['streams'][0],) if not st.get('lstm_done')]   # content streams first
     for i in range(0, len(items), 4):
@@ -227,7 +229,9 @@ def _torch_tie_perm(masks):
     return q[torch.sort(l, descending=True, stable=True)[1]].to(torch.int32)
 
 
-def _cne_fwd_pre(mod, title_text, title_mask, content_text, content_mask, category, subCategory, par=False):
+def _cne_fwd_pre(mod, title_text, title_mask, content_text, content_mask, category, subCategory, par=False, partner=None):
+    """partner (optional, single call only): (pc_of_title, pt_of_content) int64 [n] -- for sequence i, the sequence whose CONTENT
+    memory gates title i / whose TITLE memory gates content i -- instead of the call's own rank pairing (see cne_history_dedup)."""
     union = isinstance(title_text, tuple)            # (candidate call's tensor, history call's tensor) per argument
     if union:
         B, N = title_text[0].shape[:2]
@@ -293,6 +297,13 @@ def _cne_fwd_pre(mod, title_text, title_mask, content_text, content_mask, catego
             s2.wait_event(streams[1]['plan_ev'])
             sv['pm'] = ops.cne_pair_map(streams[0]['plan'], streams[1]['plan'])
         sv['pm_stream'] = s2
+    if partner is not None:
+        assert not union
+        pc_t, pt_c = partner
+        pt, pc = streams[0]['plan'], streams[1]['plan']
+        # title at sorted position s is sequence order_t[s]; its partner content is sequence pc_t[.], at content position rank_c[.]
+        sv['pm_override'] = (pc.rank.long()[pc_t[pt.order.long()]].to(torch.int32).contiguous(),
+                             pt.rank.long()[pt_c[pc.order.long()]].to(torch.int32).contiguous())
     return sv
 
 
@@ -307,7 +318,7 @@ def _cne_fwd_post(mod, sv, par=False):
 
     if sv['union']:
         torch.cuda.current_stream(dev).wait_stream(sv['pm_stream'])
-    t_['pm'], c_['pm'] = sv['pm'] if sv['union'] else (None, None)
+    t_['pm'], c_['pm'] = sv['pm'] if sv['union'] else sv.get('pm_override', (None, None))
 
     def gate_and_self(st, other):
         plan, cap = st['plan'], st['plan'].cap
@@ -319,15 +330,19 @@ def _cne_fwd_post(mod, sv, par=False):
                  rowvec=st['mproj'], ldrv=H2, rowvec_map=plan.row_seq, act=ops.ACT_SIGMOID, aux_out=st['G'], ldaux=H2,
                  mul=st['hout'], ldmul=H2)
         st['th'] = torch.empty((cap, A), **f32)
-        st['score'] = torch.empty(cap, **f32)
         sa = st['satt']
         ops.gemm(st['Ht'], sa.affine1.weight, st['th'], M=cap, N=A, K=H2, lda=H2, ldb=H2, ldc=A, dyn=plan.total, dyn_dim=1,
                  bias=sa.affine1.bias, act=ops.ACT_TANH)
-        ops.rowdot(st['th'], sa.affine2.weight, st['score'], dyn=plan.total)
         st['alpha_s'] = torch.empty(cap, **f32)
         st['selfv'] = torch.empty((n, H2), **f32)
-        ops.pool_fwd(x=st['Ht'], ldx=H2, D=H2, n=n, Lx=st['L'], plan=plan, score=st['score'], alpha=st['alpha_s'],
-                     out=st['selfv'], ldo=H2)
+        if A <= 256 and A % 4 == 0:
+            # the w2 . tanh(.) score is computed inside the pool's own pass over the tokens (one launch less on the chain)
+            ops.pool_fwd(x=st['Ht'], ldx=H2, D=H2, n=n, Lx=st['L'], plan=plan, th=st['th'], w2=sa.affine2.weight, alpha=st['alpha_s'],
+                         out=st['selfv'], ldo=H2)
+        else:
+            score = torch.empty(cap, **f32)
+            ops.rowdot(st['th'], sa.affine2.weight, score, dyn=plan.total)
+            ops.pool_fwd(x=st['Ht'], ldx=H2, D=H2, n=n, Lx=st['L'], plan=plan, score=score, alpha=st['alpha_s'], out=st['selfv'], ldo=H2)
 
     _two_chains(dev, par, lambda: gate_and_self(t_, c_), lambda: gate_and_self(c_, t_))
 
@@ -343,23 +358,20 @@ def _cne_fwd_post(mod, sv, par=False):
                      alpha=st['alpha_c'], out=rep[:, col0:], ldo=D, add_in=st['selfv'], ldadd=H2)
 
     _two_chains(dev, par, lambda: cross(t_, c_, 0), lambda: cross(c_, t_, H2))
+    # feature fusion (newsEncoders.py:50-54): category + subCategory rows of both calls in ONE launch, the two calls' id tensors read
+    # where they lie (round 2: torch.cat x 2 + two launches)
     if sv['union']:
-        # (two device-to-device copies through the library instead of torch.cat: the step stays a sequence of C-ABI calls)
-        n0_ = sv['n0']
-        cat, sub = torch.empty(n, device=dev, dtype=torch.int32), torch.empty(n, device=dev, dtype=torch.int32)
-        for dst, key in ((cat, 'category'), (sub, 'subCategory')):
-            a_, b_ = (_i32(x).reshape(-1).contiguous() for x in sv.pop(key))
-            ops.copy_bytes(dst[:n0_], a_)
-            ops.copy_bytes(dst[n0_:], b_)
+        cat0, cat1 = (_i32(x).reshape(-1).contiguous() for x in sv.pop('category'))
+        sub0, sub1 = (_i32(x).reshape(-1).contiguous() for x in sv.pop('subCategory'))
     else:
-        cat = _i32(sv.pop('category')).reshape(n).contiguous()
-        sub = _i32(sv.pop('subCategory')).reshape(n).contiguous()
+        cat0, cat1 = _i32(sv.pop('category')).reshape(n).contiguous(), None
+        sub0, sub1 = _i32(sv.pop('subCategory')).reshape(n).contiguous(), None
     cd, sd = mod.category_embedding.weight.shape[1], mod.subCategory_embedding.weight.shape[1]
-    ops.small_embed_fwd(mod.category_embedding.weight, cat, rep[:, 2 * H2:], D, p, seed + _SITE['cat'])
-    ops.small_embed_fwd(mod.subCategory_embedding.weight, sub, rep[:, 2 * H2 + cd:], D, p, seed + _SITE['sub'])
-    sv.update(cat=cat, sub=sub, cd=cd, sd=sd)
+    ops.fusion_rows_fwd(mod.category_embedding.weight, mod.subCategory_embedding.weight, cat0, sub0, cat1, sub1, rep[:, 2 * H2:], D, p,
+                        seed + _SITE['cat'], seed + _SITE['sub'])
+    sv.update(cats=(cat0, sub0, cat1, sub1), cd=cd, sd=sd)
     for st in sv['streams']:                             # not needed by backward
-        st.pop('score'); st.pop('mproj')
+        st.pop('mproj')
     if sv['union']:
         n0 = sv['n0']
         return (rep[:n0].view(B, N, D), rep[n0:].view(B, (n - n0) // B, D)), sv
@@ -425,8 +437,8 @@ def _cne_bwd_pre(mod, sv, drep, par=False, leaf=None):
     drep = drep.reshape(n, D)
     emb = mod.word_embedding.weight
 
-    ops.small_embed_bwd(sv['cat'], sv['cd'], drep[:, 2 * H2:], D, grad_of(mod.category_embedding.weight), p, seed + _SITE['cat'])
-    ops.small_embed_bwd(sv['sub'], sv['sd'], drep[:, 2 * H2 + sv['cd']:], D, grad_of(mod.subCategory_embedding.weight), p, seed + _SITE['sub'])
+    ops.fusion_rows_bwd(*sv['cats'], sv['cd'], sv['sd'], drep[:, 2 * H2:], D, grad_of(mod.category_embedding.weight),
+                        grad_of(mod.subCategory_embedding.weight), p, seed + _SITE['cat'], seed + _SITE['sub'])
 
     # ---- cross attention pools: dHt (overwrite), dv -> K / Q params and the gradient of the OTHER stream's self vector
     def cross_bwd(st, other, col0):
@@ -554,6 +566,61 @@ def _cne_bwd_post(mod, sv, st, leaf=None):
     if leaf is None and not _TITLE_DX_FIRST:
         dx_scatter()
         table_hook()
+
+
+@torch.no_grad()
+def cne_history_dedup(mod, title_text, title_mask, content_text, content_mask, category, subCategory):
+    """SURVEY.md section 8 f-3, the EXACT part for CNE (inference, dropout off): every short history is right-padded with news 0
+    (MIND_corpus.py:352-353,369) -- on MIND-shaped batches half of the 50 slots per user -- and userEncoders.py:76-78 runs the news
+    encoder over all of them.  A PAD slot's representation depends only on its own (constant) inputs and on the two cell states that
+    gate it (newsEncoders.py:128-129: the content at its title's sorted rank, the title at its content's sorted rank).  When both of
+    those belong to PAD-like sequences too (one token, id 0 -- their cell states are one constant each), the slot's representation is
+    THE constant r_pad.  Those slots are dropped from the encoder call, one representative computes r_pad, and every kept sequence
+    keeps its original partner (a dropped partner is replaced by the representative: same cell state).  Decided on the device from
+    the ranks; one host read of the kept count.  Returns (representations [B, H, D], number of sequences actually encoded)."""
+    assert not mod.training or mod.dropout_rate == 0.0, 'de-duplication is exact only without dropout (one mask per slot otherwise)'
+    B, Hn = title_text.shape[:2]
+    n, T, Cx = B * Hn, mod.max_title_length, mod.max_content_length
+    dev = title_text.device
+    tm, cm = title_mask.view(n, T), content_mask.view(n, Cx)
+    tm[:, 0] = 1                                        # in place on the caller's tensors, as every CNE call does (newsEncoders.py:108-109)
+    cm[:, 0] = 1
+    tt, ct = _i32(title_text).reshape(n, T), _i32(content_text).reshape(n, Cx)
+    tlen, clen = tm.sum(dim=1), cm.sum(dim=1)
+    order_t = torch.sort(tlen, descending=True, stable=True)[1]
+    order_c = torch.sort(clen, descending=True, stable=True)[1]
+    rank_t, rank_c = torch.empty_like(order_t), torch.empty_like(order_c)
+    ar = torch.arange(n, device=dev)
+    rank_t[order_t], rank_c[order_c] = ar, ar
+    pc_t, pt_c = order_c[rank_t], order_t[rank_c]       # partner sequences under the call's own rank pairing
+    cat, sub = _i32(category).reshape(n), _i32(subCategory).reshape(n)
+    padlike = (tlen == 1) & (tt[:, 0] == 0) & (clen == 1) & (ct[:, 0] == 0) & (cat == 0) & (sub == 0)
+    drop = padlike & padlike[pc_t] & padlike[pt_c]
+    nd = int(drop.sum())
+    if nd <= 1 or mod.tie_order != 'stable':
+        rep, _ = cne_forward(mod, title_text, title_mask, content_text, content_mask, category, subCategory)
+        return rep, n
+    rep_idx = torch.nonzero(drop)[0, 0]                                  # the representative PAD slot
+    keep = ~drop
+    keep[rep_idx] = True
+    kept = torch.nonzero(keep).flatten()                                 # original index of compact sequence k
+    compact = torch.full((n,), -1, device=dev, dtype=torch.long)
+    compact[kept] = torch.arange(kept.numel(), device=dev)
+    rep_c = compact[rep_idx]
+    remap = lambda partner: torch.where(compact[partner[kept]] >= 0, compact[partner[kept]], rep_c)
+    sel = lambda x, w: x.reshape(n, w)[kept].unsqueeze(0).contiguous() if w else x.reshape(n)[kept].unsqueeze(0).contiguous()
+    (out, _), = [(_cne_fwd_post(mod, sv, False)) for sv in [_cne_fwd_pre_and_lstm(mod, sel(tt, T), sel(tm, T), sel(ct, Cx), sel(cm, Cx),
+                                                                                 sel(cat, 0), sel(sub, 0), (remap(pc_t), remap(pt_c)))]]
+    D = out.shape[-1]
+    full = out.view(-1, D)[rep_c].expand(n, D).clone()
+    full[kept] = out.view(-1, D)
+    return full.view(B, Hn, D), int(kept.numel())
+
+
+def _cne_fwd_pre_and_lstm(mod, tt, tm, ct, cm, cat, sub, partner):
+    sv = _cne_fwd_pre(mod, tt, tm, ct, cm, cat, sub, par=False, partner=partner)
+    ops.lstm_fwd([sv['streams'][1], sv['streams'][0]], mod.hidden_dim)
+    return sv
 
 
 class CNE(NewsEncoder):

@@ -344,6 +344,11 @@ def gemm(A, B, C_=None, *, M, N, K, lda, ldb, ldc=0, trans_a=False, trans_b=Fals
         t = 7
     elif pipe_nt and a_idx is None and K >= 800 and wg64 > 512:
         t = 9
+        if dyn is None and batch <= 1 and os.environ.get('NNR_NT64', '1') != '0':
+            nbm = (M + 127) // 128
+            t80, t64 = nbm * ((N + 79) // 80), nbm * ((N + 63) // 64)
+            if t80 < 1024 and ((t64 + 255) // 256) * 64 * 100 < ((t80 + 255) // 256) * 80 * 92:
+                t = 31
     elif pipe_nt and (dyn is not None or wg128 >= 640):
         t = 15
     elif pipe_nt and wg64 > 512 and K >= 128:
@@ -356,7 +361,7 @@ def gemm(A, B, C_=None, *, M, N, K, lda, ldb, ldc=0, trans_a=False, trans_b=Fals
         t = 5 if not trans_b else 4
     fam = 'gemm_%s_%s' % ('tn' if trans_a else ('nn' if trans_b else 'nt'),
                           {1: '256x80', 2: '64x80', 3: '128x208', 4: '128x80', 5: '128x80k32', 6: '64x80k64', 7: '16x80skinny', 8: 'pipe128x80k32', 9: 'pipe2_128x80', 13: 'pipe128x80s4',
-                           15: 'pipe128x80', 16: 'pipe128x80s2', 20: 'pipe128x80', 26: 'pipe2_128x80', 27: 'pipe2_128x208', 30: 'pipe2_128x160', 22: 'pipe64x80', 23: 'pipe256x80', 24: 'pipe128x208', 25: 'pipe128x128'}.get(t, 'tile%d' % t))
+                           15: 'pipe128x80', 16: 'pipe128x80s2', 20: 'pipe128x80', 26: 'pipe2_128x80', 27: 'pipe2_128x208', 30: 'pipe2_128x160', 31: 'pipe2_128x64', 22: 'pipe64x80', 23: 'pipe256x80', 24: 'pipe128x208', 25: 'pipe128x128'}.get(t, 'tile%d' % t))
 
     def flops(vals=None, M=M, N=N, K=K, dyn=dyn, dyn_dim=dyn_dim, batch=batch):
         # vals: {data_ptr of a device-side size: its value at the time of the launch} (replayed launches: the size buffers are
@@ -612,7 +617,7 @@ def lstm_bwd(items, H):
 # ---------------------------------------------------------------------------------------------- pooling
 def _pool_args(x, ldx, D, n, Lx, plan=None, mask=None, mask_div=1, score=None, v=None, ldv=0, scale=1.0, alpha=None, out=None,
                ldo=0, add_in=None, ldadd=0, dout=None, lddo=0, dout2=None, lddo2=0, dx=None, lddx=0, dx_accumulate=False,
-               dscore=None, dv=None, lddv=0):
+               dscore=None, dv=None, lddv=0, th=None, w2=None):
     a = L.PoolArgs()
     a.x, a.ldx, a.D, a.n, a.L = _p(x), ldx, D, n, Lx
     a.packed = int(plan is not None)
@@ -625,6 +630,8 @@ def _pool_args(x, ldx, D, n, Lx, plan=None, mask=None, mask_div=1, score=None, v
     a.out, a.ldo, a.add_in, a.ldadd = _p(out), ldo, _p(add_in), ldadd
     a.dout, a.lddo, a.dout2, a.lddo2 = _p(dout), lddo, _p(dout2), lddo2
     a.dx, a.lddx, a.dx_accumulate, a.dscore, a.dv, a.lddv = _p(dx), lddx, int(dx_accumulate), _p(dscore), _p(dv), lddv
+    if th is not None:            # forward: score = <th[row], w2> inside the pool's pass (instead of a separate nnr_rowdot launch)
+        a.th, a.ldth, a.A, a.w2 = _p(th), th.stride(0), th.shape[1], _p(w2)
     return a
 
 
@@ -722,12 +729,17 @@ def gcn_aggregate_bwd(graph, dy, r, ds, dx0, dz, B, G, D, p, seed):
                                           C.c_uint32(int(seed) & 0xFFFFFFFF), _s()), 'nnr_gcn_aggregate_bwd')
 
 
-def sue_x0_fwd(hist, proxy, x0, B, Hn, Kc, D, p, seed):
-    L.check(L.lib().nnr_sue_x0_fwd(_p(hist), _p(proxy), _p(x0), B, Hn, Kc, D, C.c_float(p), C.c_uint32(seed & 0xFFFFFFFF), _s()), 'nnr_sue_x0_fwd')
+def sue_x0_fwd(hist, proxy, x0, B, Hn, Kc, D, p, seed, cmask_fix=None):
+    """cmask_fix: the [B, Kc + 1] cluster mask; its last column is set in place by the same launch (userEncoders.py:73)."""
+    if cmask_fix is not None:
+        assert cmask_fix.is_contiguous() and cmask_fix.element_size() == 1 and tuple(cmask_fix.shape) == (B, Kc + 1)
+    L.check(L.lib().nnr_sue_x0_fwd(_p(hist), _p(proxy), _p(x0), B, Hn, Kc, D, C.c_float(p), C.c_uint32(seed & 0xFFFFFFFF), _p(cmask_fix), _s()),
+            'nnr_sue_x0_fwd')
 
 
-def sue_x0_bwd(dx0, dhist, dproxy, B, Hn, Kc, D, p, seed):
-    L.check(L.lib().nnr_sue_x0_bwd(_p(dx0), _p(dhist), _p(dproxy), B, Hn, Kc, D, C.c_float(p), C.c_uint32(seed & 0xFFFFFFFF), _s()), 'nnr_sue_x0_bwd')
+def sue_x0_bwd(dx0, dhist, dproxy, B, Hn, Kc, D, p, seed, dx0_add=None):
+    L.check(L.lib().nnr_sue_x0_bwd(_p(dx0), _p(dx0_add), _p(dhist), _p(dproxy), B, Hn, Kc, D, C.c_float(p), C.c_uint32(seed & 0xFFFFFFFF), _s()),
+            'nnr_sue_x0_bwd')
 
 
 def sue_slice_fwd(gcn, x0, gfeat, B, Hn, G, D):
@@ -764,8 +776,29 @@ def logits_bwd(dlogits, user, cand, B, N, D, duser, dcand, accumulate=False):
     L.check(L.lib().nnr_logits_bwd(_p(dlogits), _p(user), _p(cand), B, N, D, _p(duser), _p(dcand), int(accumulate), _s()), 'nnr_logits_bwd')
 
 
-def sumsq(g, out_zeroed):
-    L.check(L.lib().nnr_sumsq(_p(g), C.c_long(g.numel()), _p(out_zeroed), _s()), 'nnr_sumsq')
+def sumsq(g, out):
+    """out[0] = sum g^2 (stored; fixed-order sum)."""
+    L.check(L.lib().nnr_sumsq(_p(g), C.c_long(g.numel()), _p(out), _s()), 'nnr_sumsq')
+
+
+def fusion_rows_fwd(cat_table, sub_table, cat0, sub0, cat1, sub1, out_view, ldo, p, seed_cat, seed_sub):
+    """feature_fusion's category / subCategory rows of one encoder call (cat1 = sub1 = None) or of the union of two calls."""
+    n0, n1 = cat0.numel(), (cat1.numel() if cat1 is not None else 0)
+    L.check(L.lib().nnr_fusion_rows_fwd(_p(cat_table), _p(sub_table), _p(cat0), _p(sub0), n0, _p(cat1), _p(sub1), n1, cat_table.shape[1],
+                                        sub_table.shape[1], _p(out_view), ldo, C.c_float(p), C.c_uint32(seed_cat & 0xFFFFFFFF),
+                                        C.c_uint32(seed_sub & 0xFFFFFFFF), _s()), 'nnr_fusion_rows_fwd')
+
+
+def fusion_rows_bwd(cat0, sub0, cat1, sub1, cd, sd, dout_view, lddo, dcat_table, dsub_table, p, seed_cat, seed_sub):
+    n0, n1 = cat0.numel(), (cat1.numel() if cat1 is not None else 0)
+    L.check(L.lib().nnr_fusion_rows_bwd(_p(cat0), _p(sub0), n0, _p(cat1), _p(sub1), n1, cd, sd, _p(dout_view), lddo, _p(dcat_table), _p(dsub_table),
+                                        C.c_float(p), C.c_uint32(seed_cat & 0xFFFFFFFF), C.c_uint32(seed_sub & 0xFFFFFFFF), _s()), 'nnr_fusion_rows_bwd')
+
+
+def click_loss(user, cand, B, N, D, logits, loss, dlogits, duser, dcand, terms_ws):
+    """logits, loss, d loss / d logits, d user, d cand in one launch (model.py:126-127, trainer.py:64-66)."""
+    L.check(L.lib().nnr_click_loss(_p(user), _p(cand), B, N, D, _p(logits), _p(loss), _p(dlogits), _p(duser), _p(dcand), _p(terms_ws), _s()),
+            'nnr_click_loss')
 
 
 def clip_adam(p, g, m, v, sumsq_buf, grad_scale, clip, lr, beta1, beta2, eps, wd, step):

@@ -38,20 +38,18 @@ def forward_backward(trainer, batch):
         n0 = B * N
         n = n0 + rep_h.shape[0] * rep_h.shape[1]
         # user encoder (userEncoders.py:73-98)
-        ops.fill_column_u8(user_history_category_mask, -1, 1)
         from .user_encoders import sue_forward, sue_backward
         assert user_history_graph.is_contiguous() and user_history_category_indices.is_contiguous()
         user, ssv = sue_forward(ue, rep_h, rep_c, user_history_graph, user_history_category_mask, user_history_category_indices)
-        # click predictor + loss (model.py:126-127, trainer.py:64-66) and d loss / d logits in the same launch
+        # click predictor + loss (model.py:126-127, trainer.py:64-66) and their backward in ONE launch.  The gradient of the union
+        # stream's representations lives in one [n, D] buffer: rows [0, n0) the candidates (click predictor + user encoder), rows
+        # [n0, n) the history news (user encoder)
         logits = torch.empty((B, N), **f32)
         loss = torch.empty((), **f32)
-        dlogits = torch.empty((B, N), **f32)
-        ops.logits_loss_fwd(user, rep_c, B, N, D, logits, loss, dlogits)
-        # backward: one [n, D] gradient buffer for the union stream -- rows [0, n0) the candidates (click predictor + user encoder),
-        # rows [n0, n) the history news (user encoder)
         drep = torch.empty((n, D), **f32)
         duser = torch.empty((B, N, D), **f32)
-        ops.logits_bwd(dlogits, user, rep_c, B, N, D, duser, drep[:n0])
+        trainer.wait_grad_zeroed()                     # the flat gradient buffer was cleared on the leaf stream while the forward pass ran
+        ops.click_loss(user, rep_c, B, N, D, logits, loss, None, duser, drep[:n0], torch.empty(B, **f32))
         sue_backward(ue, ssv, duser, dhist_out=drep[n0:].view(B, -1, D), dcand_accum=drep[:n0])
         cne_backward_many(ne, [(sv, drep)])
         ops.join_extra_streams()

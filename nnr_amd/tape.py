@@ -30,6 +30,13 @@ VALUE_KINDS = {'news_seed': 0, 'user_seed': 1, 'adam_step': 2}
 _VALUE_ARGS = {('nnr_clip_adam', 13): 'adam_step'}            # (entry point, argument index) -> value kind, for plain integers
 
 
+TAG_ALL = [False]
+
+
+def _no_flops(vals=None):
+    return 0.0
+
+
 class TapeError(L.NnrHipError):
     pass
 
@@ -214,6 +221,8 @@ class Tape:
                 raise TapeError('%s: argument %d of type %s cannot be recorded' % (name, i, type(a).__name__))
             slots[i] = v
         tag = -1
+        if self._pending_tag is None and TAG_ALL[0]:
+            self._pending_tag = (name[4:], _no_flops)          # diagnostics (tools/tape_timeline.py): every call carries timing events
         if self._pending_tag is not None:
             tag = len(self.tags)
             self.tags.append(self._pending_tag)
@@ -299,6 +308,13 @@ class Tape:
             m = self.lib.nnr_tape_timings(self.h, s, buf, n)
             out.append([(self.tags[i][0], self.tags[i][1], float(buf[i])) for i in range(max(0, m)) if buf[i] >= 0])
         return out
+
+    def timeline(self, set_index=0):
+        """[(start_ms, dur_ms, stream index, family, shape tag)] of one timing replay, starts relative to the first tagged call."""
+        n = len(self.tags)
+        a, d, st = (C.c_float * max(1, n))(), (C.c_float * max(1, n))(), (C.c_int * max(1, n))()
+        m = self.lib.nnr_tape_timeline(self.h, set_index, a, d, st, n)
+        return [(float(a[i]), float(d[i]), int(st[i]), self.tags[i][0], getattr(self.tags[i][1], 'tag', '')) for i in range(max(0, m))]
 
     def info(self):
         calls, ops_, segs, streams = C.c_int(), C.c_int(), C.c_int(), C.c_int()

@@ -136,8 +136,29 @@ class Trainer:
         return logits.detach(), loss.detach()
 
     # ------------------------------------------------------------------------------------------------ native step / tape
+    def _zero_grad_aside(self):
+        """Clear the flat gradient buffer on the leaf stream: nothing writes a gradient before the backward pass, so the 100 MB fill
+        leaves the head of the step's dependent chain (forward_backward waits for it via wait_grad_zeroed)."""
+        dev = self.flat.grad.device
+        main = torch.cuda.current_stream(dev)
+        key = (dev.type, dev.index)
+        if key not in ops._LEAF:
+            ops._LEAF[key] = ops.new_stream(dev)
+        leaf = ops._LEAF[key]
+        leaf.wait_stream(main)                          # behind the previous step's optimizer (it reads the gradients)
+        with torch.cuda.stream(leaf):
+            self.flat.zero_grad()
+            self._zeroed = torch.cuda.Event()
+            self._zeroed.record()
+
+    def wait_grad_zeroed(self):
+        ev, self._zeroed = getattr(self, '_zeroed', None), None
+        if ev is not None:
+            # (the other streams of the backward pass fork from this one, the leaf stream is ordered behind its own fill)
+            torch.cuda.current_stream(self.flat.grad.device).wait_event(ev)
+
     def _body(self, batch, native_step):
-        self.flat.zero_grad()
+        self._zero_grad_aside()
         logits, loss = native_step.forward_backward(self, batch)
         scale = self.exchange.finish()
         self.optimizer_step(scale)
@@ -210,7 +231,6 @@ class Trainer:
 
     def optimizer_step(self, grad_scale=1.0):
         self.step_count += 1
-        ops.fill_zero(self.sumsq)
         ops.sumsq(self.flat.grad, self.sumsq)
         ops.clip_adam(self.flat.flat, self.flat.grad, self.m, self.v, self.sumsq, grad_scale, self.gradient_clip_norm, self.lr, 0.9, 0.999,
                       1e-8, self.weight_decay, self.step_count)
@@ -228,6 +248,6 @@ class Trainer:
         return int(v.value)
 
     def grad_total_norm(self, grad_scale=1.0):
-        s = torch.zeros(1, device=self.flat.grad.device, dtype=torch.float32)
+        s = torch.empty(1, device=self.flat.grad.device, dtype=torch.float32)
         ops.sumsq(self.flat.grad, s)
         return float(s.sqrt()) * grad_scale

@@ -165,7 +165,11 @@ def sue_forward(mod, hist, cand, graph, cmask, cidx):
     sv = dict(B=B, Hn=Hn, D=D, N=N, Kc=Kc, G=G, Cn=Cn, A=A, p=p, seed=seed, hist=hist, cand=cand, cidx=cidx, cmask=cmask,
               graph=graph)
     x0 = torch.empty((B, G, D), **f32)
-    ops.sue_x0_fwd(hist, mod.proxy_node_embedding, x0, B, Hn, Kc, D, p, seed + 1)
+    # (+ the in-place `user_history_category_mask[:, -1] = 1` of userEncoders.py:73 in the same launch)
+    fix = cmask if (cmask.is_cuda and cmask.dim() == 2 and cmask.is_contiguous() and tuple(cmask.shape) == (B, Kc + 1)) else None
+    if fix is None:
+        cmask[:, -1] = 1
+    ops.sue_x0_fwd(hist, mod.proxy_node_embedding, x0, B, Hn, Kc, D, p, seed + 1, cmask_fix=fix)
     # ---- GCN
     x, gsv = gcn_forward(mod.gcn, x0, graph, seed + 10, mod.training)
     sv['gcn'] = gsv
@@ -227,7 +231,10 @@ def _sue_backward_body(mod, sv, dout, leaf, B, Hn, D, N, Kc, G, Cn, A, p, seed, 
     ops.gemm(dv, ia.K.weight, dqv, M=B * N, N=A, K=D, lda=D, ldb=D, ldc=A)
     leaf(lambda: (ops.linear_bwd_weight(sv['qv'], dv, grad_of(ia.K.weight)), ops.linear_bwd_weight(dqv, cand2, grad_of(ia.Q.weight)),
                   ops.bias_grad(dqv, grad_of(ia.Q.bias))), dv, dqv)
-    dcand = ops.linear_bwd_data(dqv, ia.Q.weight)                                                        # [B*N, D]
+    if dcand_accum is not None:                      # the step without autograd: straight into the union gradient buffer's candidate rows
+        dcand = ops.linear_bwd_data(dqv, ia.Q.weight, out=dcand_accum, accumulate=True)
+    else:
+        dcand = ops.linear_bwd_data(dqv, ia.Q.weight)                                                    # [B*N, D]
     # ---- cluster affine
     dS = torch.empty((B * N * Cn, D), **f32)
     dfeat = torch.empty((B * N * Cn, D), **f32)
@@ -248,11 +255,8 @@ def _sue_backward_body(mod, sv, dout, leaf, B, Hn, D, N, Kc, G, Cn, A, p, seed, 
     dpad = torch.empty((B, G, D), **f32)
     ops.sue_slice_bwd(dg, dpad, B, Hn, G, D)
     dy = gcn_backward(mod.gcn, sv['gcn'], dpad, sv['graph'], leaf)
-    ops.add_(dy, dpad)                                                       # gcn(X0) + X0
     dhist = torch.empty((B, Hn, D), **f32) if dhist_out is None else dhist_out
-    ops.sue_x0_bwd(dy, dhist, grad_of(mod.proxy_node_embedding), B, Hn, Kc, D, p, seed + 1)
-    if dcand_accum is not None:
-        ops.add_(dcand_accum, dcand)
+    ops.sue_x0_bwd(dy, dhist, grad_of(mod.proxy_node_embedding), B, Hn, Kc, D, p, seed + 1, dx0_add=dpad)      # d(gcn(X0) + X0)
     return dhist, dcand.view(B, N, D)
 
 
@@ -296,10 +300,7 @@ class SUE(UserEncoder):
     def encode_user(self, history_embedding, user_history_mask, user_history_graph, user_history_category_mask,
                     user_history_category_indices, candidate_news_representation):
         """Everything of forward() after the history news have been encoded (userEncoders.py:73-75, 79-98)."""
-        if user_history_category_mask.is_cuda and user_history_category_mask.dim() == 2 and user_history_category_mask.is_contiguous():
-            ops.fill_column_u8(user_history_category_mask, -1, 1)      # in place on the caller's tensor (userEncoders.py:73)
-        else:
-            user_history_category_mask[:, -1] = 1
+        # (user_history_category_mask[:, -1] = 1, in place on the caller's tensor, userEncoders.py:73: done by sue_forward's first launch)
         graph = user_history_graph.contiguous()
         cidx = user_history_category_indices.contiguous()
         assert cidx.dtype == torch.int64 and graph.dtype == torch.float32

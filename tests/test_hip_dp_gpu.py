@@ -28,7 +28,11 @@ def _launch(world, backend, port, native=False, extra=()):
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.join(ROOT, 'tests', 'dp_rank_main.py'), '--backend', backend, *extra]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=1500)
-    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-4000:])
+    if r.returncode != 0:                                       # keep the ranks' full output where a gpurun call brings it back
+        os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+        with open(os.path.join(ROOT, 'gpurun_out', 'dp_rank_main_%s_%d.log' % (backend, world)), 'w') as f:
+            f.write(r.stdout + '\n---- stderr ----\n' + r.stderr)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-6000:])
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
     print(out)
     return out

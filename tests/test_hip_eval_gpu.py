@@ -95,6 +95,29 @@ def test_cached_news_representations_give_the_reference_scores(tag):
     print('%s: cached %d encoder rows vs %d per-sample rows' % (tag, st['encoder_rows'], st['per_sample_rows']))
 
 
+def test_cne_pad_slot_dedup_gives_the_reference_scores():
+    """f-3, exact part for CNE: PAD history slots gated only by PAD-like partners are not encoded (one representative is); the scores
+    are the reference's util.compute_scores goldens and equal the full per-sample form."""
+    from nnr_amd import evaluate as E
+    from nnr_amd.model import Model
+    z = np.load(os.path.join(GOLD, 'eval_tiny_CNE_SUE_stable.npz'))
+    cast = {'int': int, 'float': float, 'str': str, 'bool': lambda v: v == 'True'}
+    cfg = SimpleNamespace(**{k: cast[t](v) for k, v, t in zip(z['cfg_keys'], z['cfg_vals'], z['cfg_types'])})
+    cfg.tie_order = str(z['tie_order'])
+    model = Model(cfg, torch.zeros(cfg.vocabulary_size, cfg.word_embedding_dim))
+    model.load_state_dict({k[len('state/'):]: torch.from_numpy(z[k].copy()) for k in z.files if k.startswith('state/')})
+    model = model.cuda().train()
+    dc = E.dev_corpus({k: z[k] for k in z.files}, 'cuda', int(z['category_num']))
+    dedup = E.compute_scores(model, dc, batch_size=8)
+    st = dict(E.LAST_STATS)
+    model.news_encoder.pad_dedup = False
+    plain = E.compute_scores(model, dc, batch_size=8)
+    assert E.LAST_STATS['pad_slots_skipped'] == 0 and st['pad_slots_skipped'] > 0, (st, E.LAST_STATS)
+    assert float((dedup - plain).abs().max()) <= 2e-6
+    assert float(np.abs(dedup.cpu().numpy() - z['scores']).max()) <= 2e-5
+    print('CNE eval: %d of %d encoder rows skipped (PAD slots with PAD partners)' % (st['pad_slots_skipped'], st['per_sample_rows']))
+
+
 def test_cne_representations_are_not_cacheable():
     from nnr_amd import evaluate as E
     from nnr_amd.config import make_config

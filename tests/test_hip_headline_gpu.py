@@ -93,15 +93,6 @@ def _check_step(model, ref, cfg, batch, lr_steps=1, inject_masks=False):
     return err, worst
 
 
-def test_cne_sue_batch64_vocab60000_matches_oracle():
-    cfg = make_config(['--news_encoder=CNE', '--user_encoder=SUE', '--dataset=200k', '--batch_size=64'],
-                      corpus_sizes=dict(vocabulary_size=60000), dropout_rate=0.0, tie_order='stable')
-    model, ref = _pair(cfg, seed=0)
-    batch = SynthCorpus(SynthSpec(vocabulary_size=cfg.vocabulary_size)).batch(64, np.random.default_rng(100))
-    err, worst = _check_step(model, ref, cfg, batch)
-    print('CNE+SUE batch 64: logits max|diff| %.2e, worst gradient deviation %.2e of its scale' % (err, worst))
-
-
 def test_cne_sue_batch64_vocab60000_DROPOUT_ON_matches_oracle():
     """The configuration bench.py measures (BASELINE.json configs[2]: CNE+SUE, MIND-200k, batch 64, V = 60 000, gcn 4, dropout
     0.2 ON, train mode) pinned to the oracle end to end: all six dropout sites of the reference (newsEncoders.py:53,117-118,
@@ -165,6 +156,27 @@ def test_cne_sue_batch64_REPLAYED_step_dropout_on_matches_oracle():
           (err, worst, trainer.tapes[next(iter(trainer.tapes))].info()))
 
 
+def test_cne_sue_batch64_inference_with_pad_dedup_matches_oracle():
+    """f-3 (exact part for the headline encoder) at the headline size: eval-mode logits of a MIND-shaped batch (half of the 3 200
+    history slots are PAD news) with the redundant PAD slots not encoded, against the oracle's full forward and against the full
+    HIP forward."""
+    cfg = make_config(['--news_encoder=CNE', '--user_encoder=SUE', '--dataset=200k', '--batch_size=64'],
+                      corpus_sizes=dict(vocabulary_size=60000), tie_order='stable')
+    model, ref = _pair(cfg, seed=6, train=False)
+    batch = SynthCorpus(SynthSpec(vocabulary_size=cfg.vocabulary_size)).batch(64, np.random.default_rng(106))
+    with torch.no_grad():
+        got = model(*to_torch(batch, 'cuda'))
+        enc, of = model.news_encoder._dedup_stats
+        model.news_encoder.pad_dedup = False
+        full = model(*to_torch(batch, 'cuda'))
+        want = ref(*to_torch(batch))
+    torch.cuda.synchronize()
+    assert of == 3200 and enc <= 0.62 * of, (enc, of)
+    e1, e2 = float((got.cpu() - want).abs().max()), float((got - full).abs().max())
+    assert e1 <= 1e-4 and e2 <= 1e-5, (e1, e2)
+    print('inference, batch 64: %d of %d history sequences encoded; logits max|diff| vs oracle %.2e, vs the full HIP forward %.2e' % (enc, of, e1, e2))
+
+
 def test_cne_sue_large_batch16_vocab130000_DROPOUT_ON_matches_oracle():
     """BASELINE.json configs[4]'s per-GPU shard (MIND-large: dropout 0.1, config.py:91-94; batch 128 over 8 GPUs = 16 per GPU,
     trainer.py:218; V = 130 000), dropout ON with injected masks."""
@@ -186,23 +198,3 @@ def test_mhsa_mhsa_batch64_DROPOUT_ON_matches_oracle():
     batch = SynthCorpus(SynthSpec(vocabulary_size=cfg.vocabulary_size)).batch(64, np.random.default_rng(104))
     err, worst = _check_step(model, ref, cfg, batch, inject_masks=True)
     print('MHSA+MHSA batch 64, dropout ON: logits max|diff| %.2e, worst gradient deviation %.2e' % (err, worst))
-
-
-def test_mhsa_mhsa_batch64_train_mode_with_injected_user_dropout_mask():
-    """MHSA-user's hard-wired F.dropout(p = 0.5) (userEncoders.py:171) in TRAIN mode: the keep-mask of the HIP path's
-    counter-based generator for this call is computed on the GPU and injected into the oracle, so the whole train-mode step is
-    compared (news-encoder dropout_rate 0)."""
-    from nnr_amd import ops
-    cfg = make_config(['--news_encoder=MHSA', '--user_encoder=MHSA', '--dataset=200k', '--batch_size=64'],
-                      corpus_sizes=dict(vocabulary_size=60000), dropout_rate=0.0)
-    model, ref = _pair(cfg, seed=1)
-    B, Hn, D = 64, cfg.max_history_num, model.news_embedding_dim
-    ue = model.user_encoder
-    ue._calls = 0
-    seed = (ue._seed_base + 15485863 * 1) & 0x7FFFFFFF                     # UserEncoder._next_seed() of the first call
-    keep = ops.dropout(torch.ones(B * Hn * D, device='cuda'), 0.5, seed) > 0
-    assert 0.45 < float(keep.float().mean()) < 0.55
-    ref.user_encoder.forced_dropout_keep = keep.cpu().view(B, Hn, D)
-    batch = SynthCorpus(SynthSpec(vocabulary_size=cfg.vocabulary_size)).batch(64, np.random.default_rng(101))
-    err, worst = _check_step(model, ref, cfg, batch)
-    print('MHSA+MHSA batch 64 (train, p=0.5 mask injected): logits max|diff| %.2e, worst gradient deviation %.2e' % (err, worst))

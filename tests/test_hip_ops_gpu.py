@@ -83,8 +83,8 @@ def test_gemm_skinny_tile_all_epilogues(M, N, K):
     close(ob, ab.double() @ bb.double(), what='skinny batched NN')
 
 
-PIPE_TILES = [8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19]
-PIPE2_TILES = [9, 10, 11, 12, 14]
+PIPE_TILES = [8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 31]
+PIPE2_TILES = [9, 10, 11, 12, 14, 31]
 
 
 @pytest.mark.parametrize('tile', PIPE_TILES)
