@@ -50,7 +50,7 @@ def parse(argv=None):
     ap.add_argument('--dense', action='store_true', help='all titles/abstracts at full length (worst-case roofline variant)')
     ap.add_argument('--device_corpus', action='store_true', help='build every batch inside the timed step from the device-resident '
                     'corpus (id-only batches: nnr_corpus_batch + nnr_history_graph) instead of re-using pre-built batches')
-    ap.add_argument('--roofline_every', type=int, default=4, help='instrument every n-th timed step with HIP events (the two events per '
+    ap.add_argument('--roofline_every', type=int, default=10, help='instrument every n-th timed step with HIP events (the two events per '
                     'launch cost ~5 %% of a step when all steps carry them)')
     ap.add_argument('--zipf_s', type=float, default=None, help='diagnostic: exponent of the synthetic word-id distribution (default: SynthSpec)')
     ap.add_argument('--no_cpu_baseline', action='store_true')

@@ -88,6 +88,11 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise NnrHipError('libnnr_hip.so not found at %s -- run `python -c "import __graft_entry__ as g; g.build()"` '
                               '(there is no CPU / PyTorch fallback on the product path)' % LIB_PATH)
+        # PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so); it must be in the process BEFORE this library is
+        # loaded, so that the library's DT_NEEDED entry binds to that copy.  Loaded first, libnnr_hip.so would pull in /opt/rocm's
+        # runtime next to torch's: two HIP runtimes in one process, and every torch stream / allocation handed to an entry point is
+        # foreign to the second one (each call fails with NNR_ERR_LAUNCH) -- found by running build() and smoke() in ONE process.
+        import torch  # noqa: F401
         _lib = C.CDLL(LIB_PATH)
         for s in SYMBOLS:
             getattr(_lib, s).restype = ci

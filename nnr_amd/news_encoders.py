@@ -204,7 +204,19 @@ def cne_forward_many(mod, calls):
     if len(calls) > 1:
         mod._packed_weights('title', mod.title_lstm)    # (re)pack on the main stream BEFORE forking: both calls read them
         mod._packed_weights('content', mod.content_lstm)
-    # (one call -- the union of candidate and history call: each token stream's chain packs its own weights on its own HIP stream)
+    else:
+        # one call (the union of candidate and history call): the two re-packs need nothing of this step but the parameters, so they
+        # run on the leaf stream next to the planner / row gather of the chains; each chain waits for them in front of its projection
+        key = (dev.type, dev.index)
+        if key not in ops._LEAF:
+            ops._LEAF[key] = ops.new_stream(dev)
+        leaf = ops._LEAF[key]
+        leaf.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(leaf):
+            mod._packed_weights('title', mod.title_lstm)
+            mod._packed_weights('content', mod.content_lstm)
+            mod.__dict__['_packed_ev'] = torch.cuda.Event()
+            mod.__dict__['_packed_ev'].record()
     pre = _fork_join(len(calls), dev, lambda i, on_main: _cne_fwd_pre(mod, *calls[i], par=on_main))
     items = [st for sv in pre for st in (sv['streams'][1],)] + [st for sv in pre for st in (sv['streams'][0],) if not st.get('lstm_done')]   # content streams first
     for i in range(0, len(items), 4):
@@ -263,6 +275,9 @@ def _cne_fwd_pre(mod, title_text, title_mask, content_text, content_mask, catego
             plan_ev.record()
         w = mod._packed_weights(name, lstm)
         cap = plan.cap
+        pev = mod.__dict__.get('_packed_ev')
+        if pev is not None:
+            torch.cuda.current_stream(dev).wait_event(pev)
         st = dict(name=name, L=Lx, plan=plan, plan_ev=plan_ev, w=w, lstm=lstm, Hlin=Hlin, Mlin=Mlin, satt=satt, catt=catt, seed=seed + _SITE[name])
         st['gates'] = torch.empty((cap, 2 * w.NP), **f32)
         # dropout(embedding rows) materialised ONCE per token (6 TB/s gather): fused into the GEMM's A loader the counter hash
@@ -450,7 +465,7 @@ def _cne_bwd_pre(mod, sv, drep, par=False, leaf=None):
         dqv = torch.empty((n, A), **f32)
         ops.gemm(dv, ca.K.weight, dqv, M=n, N=A, K=H2, lda=H2, ldb=H2, ldc=A)                 # dqv = dv . K^T
         leaf(lambda: (ops.linear_bwd_weight(st['qv'], dv, grad_of(ca.K.weight)),             # dK[A,H2] += qv^T dv
-                      ops.linear_bwd_weight(dqv, other['selfv'], grad_of(ca.Q.weight)), ops.bias_grad(dqv, grad_of(ca.Q.bias))), dv, dqv)
+                      ops.linear_bwd_weight(dqv, other['selfv'], grad_of(ca.Q.weight), db=grad_of(ca.Q.bias))), dv, dqv)      # (bias gradient fused: column sums of dqv)
         other['dself_x'] = ops.linear_bwd_data(dqv, ca.Q.weight)                              # grad of other.selfv via the query
 
     _two_chains(dev, par, lambda: cross_bwd(t_, c_, 0), lambda: cross_bwd(c_, t_, H2))
@@ -476,8 +491,8 @@ def _cne_bwd_pre(mod, sv, drep, par=False, leaf=None):
         dP = torch.empty((n, H2), **f32)                  # d mproj[rank]
         ops.packed_seq_sum(dpre, H2, plan, dP)
         pm, opm = st['pm'], other['pm']                   # union of two calls: mproj[s] = M(cn_other[pm[s]])  (pm^-1 = other's pm)
-        leaf(lambda: (ops.linear_bwd_weight(dP, other['cn'], grad_of(st['Mlin'].weight), **({} if pm is None else {'b_idx': pm})),
-                      ops.bias_grad(dP, grad_of(st['Mlin'].bias))), dP)
+        leaf(lambda: ops.linear_bwd_weight(dP, other['cn'], grad_of(st['Mlin'].weight), db=grad_of(st['Mlin'].bias),
+                                           **({} if pm is None else {'b_idx': pm})), dP)
         other['dcn'] = ops.linear_bwd_data(dP, st['Mlin'].weight, **({} if opm is None else {'a_idx': opm}))   # [n, H2], rank-indexed
         st['dHt'] = None
 

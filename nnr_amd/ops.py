@@ -67,9 +67,16 @@ def new_stream(dev, critical=False):
     (Measured and rejected: giving the critical streams a high HIP stream priority -- 13.43 vs 13.05 ms/step.)"""
     if ONE_STREAM[0]:
         return torch.cuda.current_stream(dev)
-    st = torch.cuda.Stream(device=dev)
+    # NNR_PRIO=1 (A/B, round 3 -- the whole step is now enqueued at once by the native replay, so the hardware queues arbitrate): the
+    # chain-carrying side streams get HIP's high priority.  Measured: no difference (11.20 / 10.80 vs 11.33 / 10.75 ms, 20 steps /
+    # sustained).  Running the MAIN chain on a high-priority stream as well did not finish (the pair recurrence's partner workgroups
+    # of lower-priority launches wait behind it): not offered.
+    st = torch.cuda.Stream(device=dev, priority=-1) if (critical and STREAM_PRIO >= 1) else torch.cuda.Stream(device=dev)
     EXTRA_STREAMS.append(st)
     return st
+
+
+STREAM_PRIO = int(os.environ.get('NNR_PRIO', '0'))
 
 
 STREAM_CACHES.append(_LEAF)
@@ -344,7 +351,7 @@ def gemm(A, B, C_=None, *, M, N, K, lda, ldb, ldc=0, trans_a=False, trans_b=Fals
         t = 7
     elif pipe_nt and a_idx is None and K >= 800 and wg64 > 512:
         t = 9
-        if dyn is None and batch <= 1 and os.environ.get('NNR_NT64', '1') != '0':
+        if dyn is None and batch <= 1 and os.environ.get('NNR_NT64', '0') == '1':
             nbm = (M + 127) // 128
             t80, t64 = nbm * ((N + 79) // 80), nbm * ((N + 63) // 64)
             if t80 < 1024 and ((t64 + 255) // 256) * 64 * 100 < ((t80 + 255) // 256) * 80 * 92:

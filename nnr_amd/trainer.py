@@ -171,8 +171,19 @@ class Trainer:
                 'user_seed': (ue._seed_base + 15485863 * (ue._calls + 1)) & 0x7FFFFFFF}
 
     def _native_train_step(self, batch, native_step):
+        return self._native_train_step_on_current(batch, native_step)
+
+    def _native_train_step_on_current(self, batch, native_step):
         key = tuple((tuple(t.shape), t.dtype) for t in batch)
         tape = self.tapes.get(key)
+        hyper = (self.lr, self.weight_decay, self.gradient_clip_norm, dp.world_size(), float(self.model.news_encoder.dropout_rate),
+                 float(self.model.user_encoder.dropout_rate))
+        if tape is not None and tape.hyper != hyper:
+            # scalars that are baked into the recorded arguments changed (learning rate, clip, weight decay, dropout rate, world size):
+            # drop the tape and record a fresh one on the next step
+            tape.close()
+            del self.tapes[key]
+            tape = None
         eager_profile = _prof._on                       # eager HIP-event spans requested (bench's isolated leg, tools): no tape
         if tape is not None and self.replay and not eager_profile and not ops.ONE_STREAM[0] and tape.matches(batch):
             values = self._next_seeds()
@@ -197,6 +208,7 @@ class Trainer:
             return logits, loss
         from .tape import Tape
         tape = Tape(batch, self._next_seeds())
+        tape.hyper = hyper
         try:
             tape.out = tape.record(lambda: self._body(batch, native_step))
         except Exception:

@@ -229,8 +229,8 @@ def _sue_backward_body(mod, sv, dout, leaf, B, Hn, D, N, Kc, G, Cn, A, p, seed, 
                  alpha=sv['alpha_o'], dout=dout, lddo=D, dx=df2, lddx=D, dv=dv, lddv=D)
     dqv = torch.empty((B * N, A), **f32)
     ops.gemm(dv, ia.K.weight, dqv, M=B * N, N=A, K=D, lda=D, ldb=D, ldc=A)
-    leaf(lambda: (ops.linear_bwd_weight(sv['qv'], dv, grad_of(ia.K.weight)), ops.linear_bwd_weight(dqv, cand2, grad_of(ia.Q.weight)),
-                  ops.bias_grad(dqv, grad_of(ia.Q.bias))), dv, dqv)
+    leaf(lambda: (ops.linear_bwd_weight(sv['qv'], dv, grad_of(ia.K.weight)),
+                  ops.linear_bwd_weight(dqv, cand2, grad_of(ia.Q.weight), db=grad_of(ia.Q.bias))), dv, dqv)
     if dcand_accum is not None:                      # the step without autograd: straight into the union gradient buffer's candidate rows
         dcand = ops.linear_bwd_data(dqv, ia.Q.weight, out=dcand_accum, accumulate=True)
     else:
@@ -250,7 +250,7 @@ def _sue_backward_body(mod, sv, dout, leaf, B, Hn, D, N, Kc, G, Cn, A, p, seed, 
     ops.linear_bwd_data(dkf, mod.intraCluster_K.weight, out=dg.view(B * Hn, D), accumulate=True)
     ops.linear_bwd_data(dqc, mod.intraCluster_Q.weight, out=dcand, accumulate=True)
     leaf(lambda: (ops.linear_bwd_weight(dkf, sv['gfeat'].view(B * Hn, D), grad_of(mod.intraCluster_K.weight)),
-                  ops.linear_bwd_weight(dqc, cand2, grad_of(mod.intraCluster_Q.weight)), ops.bias_grad(dqc, grad_of(mod.intraCluster_Q.bias))), dkf, dqc)
+                  ops.linear_bwd_weight(dqc, cand2, grad_of(mod.intraCluster_Q.weight), db=grad_of(mod.intraCluster_Q.bias))), dkf, dqc)
     # ---- GCN (+ outer residual)
     dpad = torch.empty((B, G, D), **f32)
     ops.sue_slice_bwd(dg, dpad, B, Hn, G, D)

@@ -184,6 +184,28 @@ def test_other_shapes_and_modes_fall_back():
     assert tr2.last_path == 'autograd' and not tr2.tapes
 
 
+def test_changed_hyperparameters_invalidate_the_tape():
+    """The learning rate is an argument of nnr_clip_adam and therefore part of the recording: changing it drops the tape (the next step
+    records again) instead of replaying the stale value."""
+    from nnr_amd.trainer import Trainer
+    cfg = make_config(['--news_encoder=CNE', '--user_encoder=SUE'], corpus_sizes=dict(vocabulary_size=900), tie_order='stable', batch_size=4)
+    model, _ = _models(cfg, seed=7)
+    tr = Trainer(model, cfg)
+    corpus = SynthCorpus(SynthSpec(vocabulary_size=900, news_pool=500, seed=8))
+    rng = np.random.default_rng(5)
+    step = lambda: tr.train_step(to_torch(corpus.batch(4, rng), 'cuda'))
+    for _ in range(4):
+        step()
+    assert tr.last_path == 'replay'
+    before = tr.flat.flat.clone()
+    tr.lr = 0.0
+    step()
+    torch.cuda.synchronize()
+    assert tr.last_path == 'record' and torch.equal(before, tr.flat.flat)          # lr 0: parameters must not move
+    step()
+    assert tr.last_path == 'replay' and torch.equal(before, tr.flat.flat)
+
+
 def test_timing_replay_feeds_the_live_roofline():
     """bench.py's per-family HIP-event figures come from timing replays: events recorded natively around the tagged calls."""
     from nnr_amd import profile as prof

@@ -9,14 +9,19 @@ OUT=$ROOT/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd $ROOT
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
-CMD="python3 $ROOT/bench.py --steps 12 --warmup 4 --no_cpu_baseline --no_isolated"
+CMD="python3 $ROOT/bench.py --steps 12 --warmup 4 --no_cpu_baseline --no_isolated --sustained_seconds 0"
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_$TAG
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG/kt -- $CMD > $OUT/bench_under_kernel_trace.json 2> $OUT/kt.err
 F=$(find /tmp/prof_$TAG/kt -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && cp $F $OUT/kernel_stats.csv
+# PMC passes: rocprofv3 serialises every dispatch; the call-by-call native step (NNR_REPLAY=0: same kernels, same order, issued from
+# Python) is used here -- the natively replayed step, enqueued as a whole across four streams, did not finish under dispatch
+# serialisation within 24 minutes (round 3)
+export NNR_REPLAY=0
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/prof_$TAG/$C -- $CMD > $OUT/bench_under_pmc_$C.json 2> $OUT/pmc_$C.err
+  timeout 900 rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/prof_$TAG/$C -- $CMD > $OUT/bench_under_pmc_$C.json 2> $OUT/pmc_$C.err
 done
+unset NNR_REPLAY
 FF=$(find /tmp/prof_$TAG/FETCH_SIZE -name "*counter_collection.csv" | head -1)
 FW=$(find /tmp/prof_$TAG/WRITE_SIZE -name "*counter_collection.csv" | head -1)
 cd $ROOT
