@@ -29,6 +29,7 @@ from .layers import Attention, ScaledDotProduct_CandidateAttention, MultiHeadAtt
 _SITE = dict(title=1, content=2, cat=3, sub=4)
 _TITLE_DX_FIRST = os.environ.get('NNR_TITLE_DX_FIRST', '0') == '1'       # measured: no gain either way (12.39 vs 12.42-12.58 ms/step)
 _TITLE_DX_TILE = int(os.environ.get('NNR_TITLE_DX_TILE', '0'))
+_DX_TILE = int(os.environ.get('NNR_DX_TILE', '0'))          # A/B: tile of the content streams' embedding-row gradient GEMM (0 = automatic: 9)
 
 
 class NewsEncoder(nn.Module):
@@ -552,7 +553,7 @@ def _cne_bwd_post(mod, sv, st, leaf=None):
             # (the cell buffer is [cap, 2*HP]: large enough only when 2*HP >= E -- not at --hidden_dim <= 144 with E = 300)
             dx = st['cell'].view(-1)[:cap * E].view(cap, E) if st['cell'].numel() >= cap * E else torch.empty((cap, E), **f32)
             ops.gemm(dg, w.w_ihp_t, dx, M=cap, N=E, K=2 * NP, lda=2 * NP, ldb=2 * NP, ldc=E, dyn=plan.total, dyn_dim=1,
-                     tile=0 if leaf is not None else _TITLE_DX_TILE, flop_scale=4.0 * H / NP)
+                     tile=_DX_TILE if leaf is not None else _TITLE_DX_TILE, flop_scale=4.0 * H / NP)
             ops.embed_scatter(dx, plan.tok, grad_of(emb), p, st['seed'], dyn=plan.total)
             return
         ops.gemm(dg, w.w_ihp_t, grad_of(emb), M=cap, N=E, K=2 * NP, lda=2 * NP, ldb=2 * NP, ldc=E, c_idx=plan.tok, atomic=True,

@@ -420,12 +420,15 @@ def linear_bwd_data(dy, w, out=None, accumulate=False, **kw):
     return out
 
 
-def linear_bwd_weight(dy, x, dw, dyn=None, rows=None, db=None, **kw):
+def linear_bwd_weight(dy, x, dw, dyn=None, rows=None, db=None, small_lds=False, **kw):
     """dw[N,K] += dy[rows,N]^T . x[rows,K]   (split-K atomics; dw must already hold the running gradient);
-    db[N] += column sums of dy, fused into the same launch."""
+    db[N] += column sums of dy, fused into the same launch.  small_lds: the 19 KB register-staged tile (for launches meant to run
+    beside the recurrence, whose workgroups hold 120-130 KB of LDS per CU)."""
     R = dy.shape[0] if rows is None else rows
     N, K = dw.shape
     t, bm, bn, target = tn_tile(N, K, R)
+    if small_lds:
+        t, bm, bn, target = 2, 64, 80, 2048
     if t and ((dy.stride(0) | x.stride(0)) & 3 or (dy.data_ptr() | x.data_ptr()) & 15):
         t, bm, bn, target = 0, 64, 80, 2048
     gemm(dy, x, dw, M=N, N=K, K=R, lda=dy.stride(0), ldb=x.stride(0), ldc=dw.stride(0), trans_a=True, trans_b=True,

@@ -241,6 +241,9 @@ def _sue_backward_body(mod, sv, dout, leaf, B, Hn, D, N, Kc, G, Cn, A, p, seed, 
     ops.relu_drop_bwd(df2, sv['rc'], dS, dfeat, p, seed + 2)
     ops.linear_bwd_data(dS, mod.clusterFeatureAffine.weight, out=dfeat, accumulate=True)
     dS_aff = dS
+    # (Measured and rejected in round 3: handing the five 900 x 900 weight-gradient GEMMs of this encoder to the news encoder's backward,
+    # to run beside the backward recurrence on the 19 KB tile instead of beside this chain's data-gradient GEMMs: 11.41-11.43 vs
+    # 11.19-11.25 ms/step.)
     leaf(lambda: ops.linear_bwd_weight(dS_aff, sv['feat'], grad_of(mod.clusterFeatureAffine.weight), db=grad_of(mod.clusterFeatureAffine.bias)), dS_aff)
     # ---- intra-cluster attention
     dg = torch.empty((B, Hn, D), **f32)

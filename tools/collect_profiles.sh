@@ -14,6 +14,7 @@ cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_$TAG
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG/kt -- $CMD > $OUT/bench_under_kernel_trace.json 2> $OUT/kt.err
 F=$(find /tmp/prof_$TAG/kt -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && cp $F $OUT/kernel_stats.csv
+[ -n "$SKIP_PMC" ] && { ls -la $OUT; exit 0; }     # (tools/collect_pmc.sh collects the counter passes on their own)
 # PMC passes: rocprofv3 serialises every dispatch; the call-by-call native step (NNR_REPLAY=0: same kernels, same order, issued from
 # Python) is used here -- the natively replayed step, enqueued as a whole across four streams, did not finish under dispatch
 # serialisation within 24 minutes (round 3)
