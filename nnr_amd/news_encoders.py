@@ -29,6 +29,14 @@ from .layers import Attention, ScaledDotProduct_CandidateAttention, MultiHeadAtt
 _SITE = dict(title=1, content=2, cat=3, sub=4)
 _TITLE_DX_FIRST = os.environ.get('NNR_TITLE_DX_FIRST', '0') == '1'       # measured: no gain either way (12.39 vs 12.42-12.58 ms/step)
 _TITLE_DX_TILE = int(os.environ.get('NNR_TITLE_DX_TILE', '0'))
+_DP_TABLE_FIRST = int(os.environ.get('NNR_DP_TABLE_FIRST', '0'))       # 1: always, -1: when world_size > 1, 0 (default): never -- no multi-GPU box to measure it on
+
+
+def _dp_world():
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
 _DX_TILE = int(os.environ.get('NNR_DX_TILE', '0'))          # A/B: tile of the content streams' embedding-row gradient GEMM (0 = automatic: 9)
 
 
@@ -523,6 +531,7 @@ def _cne_bwd_post(mod, sv, st, leaf=None):
     if key not in ws or ws[key][0].shape != (2 * NP, E) or ws[key][0].device != dg.device:
         ws[key] = (torch.zeros((2 * NP, E), **f32), torch.zeros(2 * NP, **f32), torch.zeros((2, NP, H), **f32))
     dw_ihp, db_p, dw_hhp = ws[key]
+    ops.tape_keep(dw_ihp, db_p, dw_hhp)
 
     def dw_ih():
         t, bm, bn, target = ops.tn_tile(2 * NP, E, cap)
@@ -559,6 +568,23 @@ def _cne_bwd_post(mod, sv, st, leaf=None):
         ops.gemm(dg, w.w_ihp_t, grad_of(emb), M=cap, N=E, K=2 * NP, lda=2 * NP, ldb=2 * NP, ldc=E, c_idx=plan.tok, atomic=True,
                  drop=(4, p, st['seed'], E), dyn=plan.total, dyn_dim=1, tile=0 if leaf is not None else _TITLE_DX_TILE, flop_scale=4.0 * H / NP)
 
+    # Data parallelism (world > 1), NNR_DP_TABLE_FIRST (opt-in: its benefit needs >= 2 GPUs to measure): the word-embedding table is 70 % of the
+    # gradient bytes and its bucket can only leave after the LAST embedding-row scatter.  Both token streams then compute their
+    # embedding-row gradient FIRST -- the weight-gradient GEMMs of the stream are issued behind the scatter instead of beside the dX
+    # GEMM --, so the table bucket's all-reduce (72 MB: ~0.8 ms on one xGMI ring) starts ~2 ms before the end of the backward pass
+    # and is hidden behind those GEMMs, instead of ~0.5 ms before it.  Single-GPU cost of this order: +0.05-0.1 ms.
+    table_first = _DP_TABLE_FIRST == 1 or (_DP_TABLE_FIRST < 0 and mod.__dict__.get('_table_scatter_hook') is not None and _dp_world() > 1)
+    if table_first:
+        dx_scatter()
+        table_hook()
+        if leaf is None:
+            dw_ih(); dw_hh(0); dw_hh(1)
+        else:
+            leaf(lambda: (dw_ih(), dw_hh(1)), dw_ihp, db_p, dw_hhp)         # (the leaf stream waits for this stream: behind the scatter)
+            dw_hh(0)
+            leaf.sync()
+        ops.lstm_unpack_grads(dw_ihp, db_p, dw_hhp, H, E, [grad_of(q) for q in st['lstm'].param_list()], zero_src=True)
+        return
     if leaf is None:
         # title streams (side stream, beside the content recurrence): the scatter GEMM first -- it is the largest launch and the
         # one the tail of the step would otherwise still be waiting for

@@ -163,6 +163,17 @@ def leaf_deferred(dev, rows, fn, *tensors):
             join_extra_streams(dev)
 
 
+def tape_keep(*tensors):
+    """A launch tape that is recording right now (nnr_amd.tape) takes a reference to `tensors`: cached device buffers that live in
+    module-level tables (W^T copies and their descriptor table, slot / exchange workspaces, packed-gradient accumulators) are replaced
+    when a table is rebuilt -- e.g. after other models of the process were garbage-collected -- and a tape must not be left pointing
+    at freed memory.  No-op when nothing records."""
+    from . import tape as _tape
+    t = _tape.ACTIVE[0]
+    if t is not None:
+        t.keep.extend(x for x in tensors if x is not None)
+
+
 _WT = {}
 USE_WT = os.environ.get('NNR_WT', '1') != '0'      # A/B switch: data-gradient GEMMs as NT products on cached W^T
 
@@ -189,6 +200,7 @@ def wt(w):
     if e is not None and e.epoch == PARAM_EPOCH[0] and e.version == w._version and e.ptr == w.data_ptr() and e.ref() is w:
         if e.stream != cur:
             torch.cuda.current_stream(w.device).wait_event(e.event)
+        tape_keep(e.t)
         return e.t
     rows, cols = w.shape
     if e is None or e.ref() is not w or e.ptr != w.data_ptr() or e.t.shape != (cols, rows):
@@ -200,6 +212,7 @@ def wt(w):
         e.t = torch.empty((cols, rows), device=w.device, dtype=torch.float32)      # kept across refreshes: stable address
         _WT[id(w)] = e
         _WT_TABLE['ids'] = None
+    tape_keep(e.t)
     transpose2d(w, e.t, rows, cols)
     e.event = torch.cuda.Event()
     e.event.record()
@@ -232,6 +245,7 @@ def wt_prefetch(dev):
         _LEAF[key] = new_stream(dev)
     leaf = _LEAF[key]
     leaf.wait_stream(torch.cuda.current_stream(dev))       # behind the optimizer step that changed the parameters
+    tape_keep(_WT_TABLE['dev'], *[e.t for _, e, _ in live])
     with torch.cuda.stream(leaf):
         L.check(L.lib().nnr_transpose_batch(_p(_WT_TABLE['dev']), _WT_TABLE['count'], _s()), 'nnr_transpose_batch')
         ev = torch.cuda.Event()
@@ -453,6 +467,7 @@ def _slot_ws(dev, n):
     if ws is None or ws.numel() < need:
         ws = torch.zeros(max(need, 32 * 1024), device=dev, dtype=torch.float32)
         _SLOT_WS[key] = ws
+    tape_keep(ws)
     return ws
 
 
@@ -581,6 +596,7 @@ def _sync_workspace(dev, n, slot):
     ws = _SYNC_WS.get(key)
     if ws is None:
         ws = _SYNC_WS[key] = torch.zeros(L.lib().nnr_lstm_sync_bytes(n) // 4, dtype=torch.int32, device=dev)
+    tape_keep(ws)
     return ws
 
 

@@ -40,6 +40,9 @@ from oracle import corpus_oracle as CO, nnr_oracle as O           # checker only
 ap = argparse.ArgumentParser()
 ap.add_argument('--backend', default='gloo', choices=['gloo', 'nccl'])
 ap.add_argument('--skip_epoch', action='store_true')
+ap.add_argument('--only_epoch', action='store_true', help='diagnostics: part C only')
+ap.add_argument('--trace2', action='store_true', help='diagnostics: device-side per-step checksums of the parameter buckets, compared at the end (no extra host sync)')
+ap.add_argument('--trace', action='store_true', help='diagnostics: per step, which bucket of the parameters differs between the ranks')
 args = ap.parse_args()
 
 rank, local, world = dp.init_from_env(args.backend)
@@ -92,49 +95,52 @@ def backward_only(tr, batch):
     ops.join_extra_streams()
 
 
-cpu_model = build(0)
-ref = O.Model(cfg)
-ref.load_state_dict(cpu_model.state_dict())
-ref.train()
-rl = O.negative_log_softmax(ref(*[t.clone() for t in shard_cpu]))
-rl.backward()
-names = [k for k, _ in ref.named_parameters()]
-want_oracle = dict(zip(names, gather_mean([p.grad.numpy() for _, p in ref.named_parameters()])))
+err_prod = err_oracle = 0.0
+worst_name, params_same, rccl_ranks = '', True, None
+if not args.only_epoch:
+    cpu_model = build(0)
+    ref = O.Model(cfg)
+    ref.load_state_dict(cpu_model.state_dict())
+    ref.train()
+    rl = O.negative_log_softmax(ref(*[t.clone() for t in shard_cpu]))
+    rl.backward()
+    names = [k for k, _ in ref.named_parameters()]
+    want_oracle = dict(zip(names, gather_mean([p.grad.numpy() for _, p in ref.named_parameters()])))
 
-noex = Trainer(build(0).to(dev).train(), cfg)                  # exchange-free gradient of this rank's shard, averaged by hand
-noex.exchange.active = lambda: False
-backward_only(noex, shard)
-want_prod = noex.flat.grad.clone()
-dist.all_reduce(want_prod)
-want_prod /= world
+    noex = Trainer(build(0).to(dev).train(), cfg)                  # exchange-free gradient of this rank's shard, averaged by hand
+    noex.exchange.active = lambda: False
+    backward_only(noex, shard)
+    want_prod = noex.flat.grad.clone()
+    dist.all_reduce(want_prod)
+    want_prod /= world
 
-tr0 = Trainer(build(0).to(dev).train(), cfg)
-assert tr0.exchange.active() and tr0.exchange.early_span is not None and tr0.exchange.table_span is not None
-backward_only(tr0, shard)
-scale = tr0.exchange.finish()
-got = tr0.flat.grad * scale
-torch.cuda.synchronize()
-err_prod = float((got - want_prod).abs().max()) / max(1e-12, float(want_prod.abs().max()))
-total = float(np.sqrt(sum(float((g ** 2).sum()) for g in want_oracle.values())))
-err_oracle, worst_name = 0.0, ''
-for k, p in tr0.model.named_parameters():
-    if k.startswith('user_encoder.news_encoder.'):
-        continue
-    g = (p.grad.detach() * scale).cpu().double().numpy()
-    w = want_oracle[k]
-    e = float(np.abs(g - w).max()) / max(1e-3, 0.05 * total, float(np.linalg.norm(w)))
-    if e > err_oracle:
-        err_oracle, worst_name = e, k
+    tr0 = Trainer(build(0).to(dev).train(), cfg)
+    assert tr0.exchange.active() and tr0.exchange.early_span is not None and tr0.exchange.table_span is not None
+    backward_only(tr0, shard)
+    scale = tr0.exchange.finish()
+    got = tr0.flat.grad * scale
+    torch.cuda.synchronize()
+    err_prod = float((got - want_prod).abs().max()) / max(1e-12, float(want_prod.abs().max()))
+    total = float(np.sqrt(sum(float((g ** 2).sum()) for g in want_oracle.values())))
+    err_oracle, worst_name = 0.0, ''
+    for k, p in tr0.model.named_parameters():
+        if k.startswith('user_encoder.news_encoder.'):
+            continue
+        g = (p.grad.detach() * scale).cpu().double().numpy()
+        w = want_oracle[k]
+        e = float(np.abs(g - w).max()) / max(1e-3, 0.05 * total, float(np.linalg.norm(w)))
+        if e > err_oracle:
+            err_oracle, worst_name = e, k
 
-tr = Trainer(build(100 + rank).to(dev).train(), cfg)         # different initial parameters per rank: the constructor's broadcast fixes that
-for _ in range(2):
-    tr.train_step([t.clone() for t in shard])
-torch.cuda.synchronize()
-params_same = all_equal(tr.flat.flat.cpu().numpy()) and bool(torch.isfinite(tr.flat.flat).all())
-rccl_ranks = None
-if args.backend == 'nccl':
-    rccl_ranks = dist.get_world_size()
-    assert dist.get_backend() == 'nccl'
+    tr = Trainer(build(100 + rank).to(dev).train(), cfg)         # different initial parameters per rank: the constructor's broadcast fixes that
+    for _ in range(2):
+        tr.train_step([t.clone() for t in shard])
+    torch.cuda.synchronize()
+    params_same = all_equal(tr.flat.flat.cpu().numpy()) and bool(torch.isfinite(tr.flat.flat).all())
+    rccl_ranks = None
+    if args.backend == 'nccl':
+        rccl_ranks = dist.get_world_size()
+        assert dist.get_backend() == 'nccl'
 
 # --------------------------------------------------------------------------------------------- C: two epochs over a tiny corpus
 epoch = None
@@ -192,6 +198,36 @@ if not args.skip_epoch:
             opt.step()
             worst_loss = max(worst_loss, abs(float(loss) - float(rloss)))
             steps += 1
+            if args.trace2:
+                ex = trainer.exchange
+                regions = [('early', ex.early_span), ('table', ex.table_span)] + [('late%d' % i, sp) for i, sp in enumerate(ex.late_spans)]
+                if steps == 1:
+                    chk = torch.zeros((64, len(regions), 2), device=dev, dtype=torch.float64)
+                    chk_paths = []
+                for ri, (_, (a_, b_)) in enumerate(regions):
+                    chk[steps - 1, ri, 0] = trainer.flat.flat[a_:b_].double().abs().sum()          # enqueued behind the step, not read here
+                    chk[steps - 1, ri, 1] = trainer.flat.grad[a_:b_].double().abs().sum()
+                chk_paths.append(trainer.last_path)
+            if args.trace:
+                ex = trainer.exchange
+                regions = [('early', ex.early_span), ('table', ex.table_span)] + [('late%d' % i, sp) for i, sp in enumerate(ex.late_spans)]
+                sums = [float(trainer.flat.flat[a:b].double().abs().sum()) for _, (a, b) in regions]
+                gsum = [float(trainer.flat.grad[a:b].double().abs().sum()) for _, (a, b) in regions]
+                box2 = [None] * world
+                dist.all_gather_object(box2, (sums, gsum, trainer.last_path, float(loss), float(rloss)), group=host)
+                if rank == 0:
+                    diff = [n for (n, _), x, y in zip(regions, box2[0][0], box2[1][0]) if x != y]
+                    gdiff = [n for (n, _), x, y in zip(regions, box2[0][1], box2[1][1]) if x != y]
+                    print('trace epoch %d step %d paths %s/%s loss %.6f/%.6f oracle %.6f/%.6f params differ in %s, exchanged grads differ in %s' % (
+                        e, steps, box2[0][2], box2[1][2], box2[0][3], box2[1][3], box2[0][4], box2[1][4], diff, gdiff), flush=True)
+    if args.trace2:
+        box3 = [None] * world
+        dist.all_gather_object(box3, (chk[:steps].cpu().numpy(), chk_paths), group=host)
+        if rank == 0:
+            for st_ in range(steps):
+                pd = [n for ri, (n, _) in enumerate(regions) if box3[0][0][st_, ri, 0] != box3[1][0][st_, ri, 0]]
+                gd = [n for ri, (n, _) in enumerate(regions) if box3[0][0][st_, ri, 1] != box3[1][0][st_, ri, 1]]
+                print('trace2 step %d paths %s/%s params differ in %s, exchanged grads differ in %s' % (st_ + 1, box3[0][1][st_], box3[1][1][st_], pd, gd), flush=True)
     rp = dict(oref.named_parameters())
     worst_param = max(float((p.detach().cpu() - rp[k].detach()).abs().max()) for k, p in trainer.model.named_parameters()
                       if not k.startswith('user_encoder.news_encoder.'))
@@ -203,12 +239,13 @@ if not args.skip_epoch:
              'ok': bool(samples_same and covered and max(b[0] for b in box) <= 5e-5 and max(b[1] for b in box) <= steps * 1e-2 * 1.01 + 1e-4)}
     epoch['ok'] = epoch['ok'] and epoch['parameters_identical_across_ranks']
 
-ok = err_prod <= 2e-5 and err_oracle <= 1e-4 and params_same and (epoch is None or epoch['ok'])
+tmo = ops.lstm_sync_timeouts()
+ok = err_prod <= 2e-5 and err_oracle <= 1e-4 and params_same and (epoch is None or epoch['ok']) and tmo == 0
 if rank == 0:
     print(json.dumps({'world': world, 'backend': args.backend, 'rccl_ranks': rccl_ranks, 'devices': torch.cuda.device_count(),
-                      'binding': tr.exchange.describe()['binding'], 'buckets': [b['name'] for b in tr.exchange.describe()['buckets']],
+                      'binding': (trainer if args.only_epoch else tr).exchange.describe()['binding'], 'buckets': [b['name'] for b in (trainer if args.only_epoch else tr).exchange.describe()['buckets']],
                       'grad_rel_err_vs_mean_of_shard_gradients': err_prod, 'grad_err_vs_oracle_mean_of_shard_gradients': err_oracle,
-                      'worst_gradient': worst_name, 'parameters_identical_across_ranks': params_same, 'epoch': epoch, 'ok': bool(ok)}))
+                      'worst_gradient': worst_name, 'recurrence_exchange_timeouts': tmo, 'parameters_identical_across_ranks': params_same, 'epoch': epoch, 'ok': bool(ok)}))
 dist.barrier()
 dist.destroy_process_group()
 sys.exit(0 if ok else 1)
