@@ -265,7 +265,7 @@ class Tape:
         seg = self.lib.nnr_tape_segment(self.h)
         if seg < 0:
             raise TapeError('nnr_tape_segment failed')
-        self.host_calls.append((fn, torch.cuda.current_stream().cuda_stream, torch.cuda.current_device()))
+        self.host_calls.append((fn, torch.cuda.current_stream(), torch.cuda.current_device()))       # (the Stream OBJECT: see replay)
         self._in_host_call = True
         try:
             return fn()
@@ -295,8 +295,8 @@ class Tape:
                 self.lib.nnr_tape_last_error(self.h, None, C.byref(call), name, 64)
                 raise L.NnrHipError('tape replay: call %d (%s) failed with code %d' % (call.value, name.value.decode(), rc))
             if seg < len(self.host_calls):
-                fn, raw, dev = self.host_calls[seg]
-                with torch.cuda.stream(torch.cuda.ExternalStream(raw, device=dev)):
+                fn, stream, dev = self.host_calls[seg]
+                with torch.cuda.stream(stream):          # the very stream object that was current when the callback was recorded
                     fn()
 
     def timings(self):

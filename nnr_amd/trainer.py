@@ -16,12 +16,12 @@ from .model import negative_log_softmax
 # NNR_REPLAY=0: the native step is issued call by call from Python every step (no tape).
 _NATIVE_STEP = os.environ.get('NNR_NATIVE_STEP', '1') != '0'
 _REPLAY = os.environ.get('NNR_REPLAY', '1') != '0'
-# Data parallelism: the native step is issued call by call unless NNR_REPLAY_DP=1.  With torch.distributed's all-reduce as host
-# callbacks between the tape's segments, 4 of 12 two-rank runs of a tiny-dimension epoch (tests/dp_rank_main.py part C, ranks sharing one
-# GPU through gloo) ended with parameters that differed between the ranks or from the oracle; 0 of 8 call by call, 0 of 8 through
-# autograd, 0 of 20 with any per-step read-back added, 0 of 12 single-rank replays (tools/dp_flaky.sh, dp_trace.sh, replay_loop.sh;
-# profiles/r03a_dp_flaky.txt).  Not understood yet, so not enabled: the replay buys no GPU time, correctness first.
-_REPLAY_DP = os.environ.get('NNR_REPLAY_DP', '0') == '1'
+# Data parallelism: NNR_REPLAY_DP=0 issues the native step call by call.  (Round 3: with the host callbacks of a replay -- torch.distributed's
+# all-reduce between the tape's segments -- re-entered under torch.cuda.ExternalStream(raw handle), 4 of 12 two-rank runs of a
+# tiny-dimension epoch ended with parameters that differed between the ranks or from the oracle: an ExternalStream is another stream
+# IDENTITY for the same hardware queue, and c10d / the caching allocator order their copies and buffer reuse per identity.  Re-entered
+# under the very Stream object that was current at recording time: 16 of 16 + the full two-rank test; profiles/r03a_dp_flaky.txt.)
+_REPLAY_DP = os.environ.get('NNR_REPLAY_DP', '1') != '0'
 _WARM_STEPS = 2          # eager steps before a tape is recorded (first-use allocations: workspaces, W^T copies, packed weights)
 
 
