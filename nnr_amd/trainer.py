@@ -18,7 +18,7 @@ _NATIVE_STEP = os.environ.get('NNR_NATIVE_STEP', '1') != '0'
 _REPLAY = os.environ.get('NNR_REPLAY', '1') != '0'
 # Data parallelism: NNR_REPLAY_DP=0 issues the native step call by call.  (Round 3: with the host callbacks of a replay -- torch.distributed's
 # all-reduce between the tape's segments -- re-entered under torch.cuda.ExternalStream(raw handle), 4 of 12 two-rank runs of a
-# tiny-dimension epoch ended with parameters that differed between the ranks or from the oracle: an ExternalStream is another stream
+# tiny-dimension epoch ended with parameters that differed between the ranks or from the CPU checker: an ExternalStream is another stream
 # IDENTITY for the same hardware queue, and c10d / the caching allocator order their copies and buffer reuse per identity.  Re-entered
 # under the very Stream object that was current at recording time: 16 of 16 + the full two-rank test; profiles/r03a_dp_flaky.txt.)
 _REPLAY_DP = os.environ.get('NNR_REPLAY_DP', '1') != '0'

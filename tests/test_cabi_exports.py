@@ -45,6 +45,35 @@ def test_ctypes_structs_match_c_layout(tmp_path):
     assert got == want
 
 
+def _params(name):
+    """Parameter list of an entry point as declared in the header (comments stripped)."""
+    src = re.sub(r'/\*.*?\*/', ' ', open(HEADER).read(), flags=re.S)
+    m = re.search(r'\b(?:int|size_t)\s+%s\s*\(([^;{]*?)\)\s*;' % re.escape(name), src, flags=re.S)
+    assert m, name
+    body = ' '.join(m.group(1).split())
+    return [] if body in ('', 'void') else [q.strip() for q in body.split(',')]
+
+
+def test_tape_registry_matches_the_header():
+    """csrc/tape.hip records and replays entry points through one generated thunk each (8-byte argument slots -> typed call):
+    every entry point that takes a trailing hipStream_t must be recordable, with exactly the header's argument count; host-only
+    queries must not be.  The pool struct's round-3 fields sit behind the round-2 ones (the Python mirror appends them)."""
+    from nnr_amd import _lib
+    lib = _lib.lib()
+    n_rec = 0
+    for name in _declared():
+        ps = _params(name)
+        fid = lib.nnr_tape_fn_id(name.encode())
+        if ps and ps[-1].startswith('hipStream_t') and not name.startswith('nnr_tape_'):
+            assert fid >= 0, '%s takes a stream but has no thunk in csrc/tape.hip REGISTRY' % name
+            assert lib.nnr_tape_fn_nargs(fid) == len(ps) - 1, (name, lib.nnr_tape_fn_nargs(fid), ps)
+            n_rec += 1
+        else:
+            assert fid < 0, '%s has no stream argument and must not be recordable' % name
+    assert n_rec >= 50
+    assert _lib.PoolArgs.th.offset > _lib.PoolArgs.lddv.offset and _lib.PoolArgs.w2.offset > _lib.PoolArgs.th.offset
+
+
 def test_product_path_refuses_cpu_tensors():
     import torch
     from nnr_amd import ops, _lib
