@@ -182,11 +182,13 @@ class Trainer:
     def _native_train_step_on_current(self, batch, native_step):
         key = tuple((tuple(t.shape), t.dtype) for t in batch)
         tape = self.tapes.get(key)
+        # scalars baked into the recorded arguments + the HIP stream the step is issued on (the tape replays on the recorded streams:
+        # a caller that switches its current stream gets a fresh tape, not launches that are unordered with its own work)
         hyper = (self.lr, self.weight_decay, self.gradient_clip_norm, dp.world_size(), float(self.model.news_encoder.dropout_rate),
-                 float(self.model.user_encoder.dropout_rate))
+                 float(self.model.user_encoder.dropout_rate), torch.cuda.current_stream(self.flat.grad.device).cuda_stream)
         if tape is not None and tape.hyper != hyper:
-            # scalars that are baked into the recorded arguments changed (learning rate, clip, weight decay, dropout rate, world size):
-            # drop the tape and record a fresh one on the next step
+            # something that is baked into the recording changed (learning rate, clip, weight decay, dropout rate, world size, the
+            # caller's current stream): drop the tape and record a fresh one on the next step
             tape.close()
             del self.tapes[key]
             tape = None
