@@ -37,6 +37,7 @@ def _dp_world():
     return dist.get_world_size() if dist.is_initialized() else 1
 
 
+_CN_SPLIT = os.environ.get('NNR_CN_SPLIT', '0') == '1'      # c_n projections of a union call as plain skinny GEMM + row gather: measured no gain (11.21-11.27 vs 11.24-11.26 ms)
 _DX_TILE = int(os.environ.get('NNR_DX_TILE', '0'))          # A/B: tile of the content streams' embedding-row gradient GEMM (0 = automatic: 9)
 
 
@@ -347,7 +348,13 @@ def _cne_fwd_post(mod, sv, par=False):
     def gate_and_self(st, other):
         plan, cap = st['plan'], st['plan'].cap
         # title_M(sorted_content_m): both indexed by sorted RANK (newsEncoders.py:128-129)
-        st['mproj'] = ops.linear_fwd(other['cn'], st['Mlin'].weight, st['Mlin'].bias, **({} if st['pm'] is None else {'a_idx': st['pm']}))
+        if st['pm'] is not None and _CN_SPLIT:
+            # rank pairing over a union of two calls: the plain (skinny, 16 x 80 tiles) projection of every c_n row, then a row gather
+            # through the pairing map -- the row-gathering 64 x 80 GEMM took 50-75 us here and 150 us in the backward pass (right in
+            # front of the backward recurrence, beside the leaf stream's weight-gradient GEMMs)
+            st['mproj'] = ops.embed_gather(ops.linear_fwd(other['cn'], st['Mlin'].weight, st['Mlin'].bias), st['pm'], 0.0, 0)
+        else:
+            st['mproj'] = ops.linear_fwd(other['cn'], st['Mlin'].weight, st['Mlin'].bias, **({} if st['pm'] is None else {'a_idx': st['pm']}))
         st['G'] = torch.empty((cap, H2), **f32)
         st['Ht'] = torch.empty((cap, H2), **f32)
         ops.gemm(st['hout'], st['Hlin'].weight, st['Ht'], M=cap, N=H2, K=H2, lda=H2, ldb=H2, ldc=H2, dyn=plan.total, dyn_dim=1,
@@ -502,7 +509,10 @@ def _cne_bwd_pre(mod, sv, drep, par=False, leaf=None):
         pm, opm = st['pm'], other['pm']                   # union of two calls: mproj[s] = M(cn_other[pm[s]])  (pm^-1 = other's pm)
         leaf(lambda: ops.linear_bwd_weight(dP, other['cn'], grad_of(st['Mlin'].weight), db=grad_of(st['Mlin'].bias),
                                            **({} if pm is None else {'b_idx': pm})), dP)
-        other['dcn'] = ops.linear_bwd_data(dP, st['Mlin'].weight, **({} if opm is None else {'a_idx': opm}))   # [n, H2], rank-indexed
+        if opm is not None and _CN_SPLIT:
+            other['dcn'] = ops.embed_gather(ops.linear_bwd_data(dP, st['Mlin'].weight), opm, 0.0, 0)            # [n, H2], rank-indexed
+        else:
+            other['dcn'] = ops.linear_bwd_data(dP, st['Mlin'].weight, **({} if opm is None else {'a_idx': opm}))   # [n, H2], rank-indexed
         st['dHt'] = None
 
     _two_chains(dev, par, lambda: self_gate_bwd(t_, c_, 0), lambda: self_gate_bwd(c_, t_, H2))
