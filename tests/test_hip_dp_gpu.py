@@ -27,7 +27,17 @@ def _launch(world, backend, port, native=False, extra=()):
         env['NNR_DP_NATIVE'] = '1'
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.join(ROOT, 'tests', 'dp_rank_main.py'), '--backend', backend, *extra]
-    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)          # (normally 80-170 s)
+    # own session: if the ranks ever hang, the whole process GROUP is killed (a timed-out subprocess.run would kill torchrun only
+    # and leave the ranks on the GPU); normally 80-170 s
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, start_new_session=True)
+    try:
+        so, se = p.communicate(timeout=600)
+    except subprocess.TimeoutExpired:
+        import signal
+        os.killpg(p.pid, signal.SIGKILL)
+        so, se = p.communicate()
+        so += '\n[ranks killed after 600 s]'
+    r = subprocess.CompletedProcess(cmd, p.returncode, so, se)
     if r.returncode != 0:                                       # keep the ranks' full output where a gpurun call brings it back
         os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
         with open(os.path.join(ROOT, 'gpurun_out', 'dp_rank_main_%s_%d.log' % (backend, world)), 'w') as f:
