@@ -25,6 +25,12 @@ def _launch(world, backend, port, native=False, extra=()):
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')           # dmabuf IPC: RCCL's intra-node transport needs it on this image
     if native:
         env['NNR_DP_NATIVE'] = '1'
+    if backend == 'gloo':
+        # two PROCESSES share GPU 0 here: the CU-pair recurrence needs both workgroups of a pair resident at once, which two processes
+        # dispatching into the same CUs cannot guarantee each other (bounded spins then run into their time-outs: one run of ~20 took
+        # 25 minutes).  The shared-GPU mode tests the exchange, not the recurrence: one-CU kernel (the pair kernel is covered by every
+        # single-process test, and by the RCCL variants below, one process per GPU)
+        env['NNR_LSTM_PAIR'] = '0'
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.join(ROOT, 'tests', 'dp_rank_main.py'), '--backend', backend, *extra]
     # own session: if the ranks ever hang, the whole process GROUP is killed (a timed-out subprocess.run would kill torchrun only

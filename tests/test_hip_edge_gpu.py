@@ -295,7 +295,7 @@ def test_bench_launcher_runs_two_ranks_on_one_gpu():
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
-    env.update(NNR_DP_BACKEND='gloo', NNR_SHARE_GPU='1')
+    env.update(NNR_DP_BACKEND='gloo', NNR_SHARE_GPU='1', NNR_LSTM_PAIR='0')      # (two processes on one GPU: one-CU recurrence, see tests/test_hip_dp_gpu.py)
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--no_cpu_baseline', '--batch_size', '8'],
                        capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
