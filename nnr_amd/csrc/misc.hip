@@ -194,22 +194,33 @@ __global__ __launch_bounds__(256) void small_embed_bwd_kernel(const int* __restr
 __global__ __launch_bounds__(256) void embed_gather_kernel(const float* __restrict__ table, const int* __restrict__ idx, long n,
                                                            const int* __restrict__ n_dev, int dim, float* __restrict__ out, uint32_t seed,
                                                            uint32_t thr, float scale) {
+  // FOUR rows per wave and trip (round 3): a row costs two dependent memory round trips (its index, then the table row), and with one
+  // row per trip a wave had a single one in flight -- 1.75 TB/s on the 84 k-row content stream of a batch-64 step, at the head of the
+  // step's dependent chain.  The four indices, then the four rows' segments are loaded before any of them is used.
+  constexpr int UR = 4;
   const int lane = threadIdx.x & 63;
   const int nv = dim >> 2;
   if (n_dev) n = min(n, (long)*n_dev);                 // live row count kept on the device (packed token streams)
-  for (long row = blockIdx.x * 4L + (threadIdx.x >> 6); row < n; row += gridDim.x * 4L) {
-    const int src = idx[row];
-    const f32x4* tp = reinterpret_cast<const f32x4*>(table + (long)src * dim);
-    f32x4* op = reinterpret_cast<f32x4*>(out + row * dim);
-    for (int c = lane; c < nv; c += 64) {
-      f32x4 v = (src >= 0) ? tp[c] : f32x4{0.f, 0.f, 0.f, 0.f};
-      if (thr) {
-        bool kp[4];
-        nnr_keep4(seed, (uint64_t)row * dim + 4 * c, thr, kp);       // dim % 4 == 0 is checked by the launcher
+  for (long row0 = (blockIdx.x * 4L + (threadIdx.x >> 6)) * UR; row0 < n; row0 += gridDim.x * 4L * UR) {
+    int src[UR];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = kp[e] ? v[e] * scale : 0.f;
+    for (int u = 0; u < UR; ++u) src[u] = (row0 + u < n) ? idx[row0 + u] : -1;
+    for (int c = lane; c < nv; c += 64) {
+      f32x4 v[UR];
+#pragma unroll
+      for (int u = 0; u < UR; ++u)
+        v[u] = (src[u] >= 0) ? reinterpret_cast<const f32x4*>(table + (long)src[u] * dim)[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < UR; ++u) {
+        if (row0 + u >= n) break;
+        if (thr) {
+          bool kp[4];
+          nnr_keep4(seed, (uint64_t)(row0 + u) * dim + 4 * c, thr, kp);       // dim % 4 == 0 is checked by the launcher
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[u][e] = kp[e] ? v[u][e] * scale : 0.f;
+        }
+        __builtin_nontemporal_store(v[u], reinterpret_cast<f32x4*>(out + (row0 + u) * dim) + c);
       }
-      __builtin_nontemporal_store(v, op + c);
     }
   }
 }
@@ -229,6 +240,8 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(const float* __restr
   if (n_dev) n = min(n, (long)*n_dev);                 // live row count kept on the device (packed token streams)
   if (use_hot) for (int i = threadIdx.x; i < SC_HOT * dim; i += 256) hot[i] = 0.f;
   __syncthreads();
+  // (four rows in flight per wave, as in embed_gather_kernel, measured 2x SLOWER here -- 245 -> 494 us on the content stream: the
+  // atomics of four rows issued back to back queue up behind each other; one row per trip it stays)
   for (long row = blockIdx.x * 4L + wv; row < n; row += gridDim.x * 4L) {
     const int dst = idx[row];
     if (dst < 0) continue;
@@ -861,7 +874,7 @@ extern "C" int nnr_embed_gather(const float* table, const int* idx, long n, cons
                                 hipStream_t stream) {
   if (dim & 3) return NNR_ERR_UNSUPPORTED;
   const float sc = p > 0.f ? 1.f / (1.f - p) : 1.f;
-  hipLaunchKernelGGL(embed_gather_kernel, dim3(ew_grid(n, 4)), dim3(256), 0, stream, table, idx, n, n_dev, dim, out, seed,
+  hipLaunchKernelGGL(embed_gather_kernel, dim3(ew_grid((n + 3) / 4, 4)), dim3(256), 0, stream, table, idx, n, n_dev, dim, out, seed,
                      nnr_drop_thresh(p), sc);
   NNR_CHECK_LAUNCH();
   return NNR_OK;
