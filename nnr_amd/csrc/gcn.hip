@@ -20,13 +20,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     const float* __restrict__ graph, const float* __restrict__ in, const float* __restrict__ bias, const float* __restrict__ aux_in,
     float* __restrict__ out0, float* __restrict__ out1, float* __restrict__ out2, int G, int D, int relu, uint32_t seed, uint32_t thr, float scale) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  constexpr int A_LD = MT * 16 + 1;             // odd row stride: the row-major fragment read (16 rows x 4 columns) spreads over the banks
+  // Only the GR = roundup4(G) rows that exist are kept in LDS (not the MT * 16 of the row tiles): G = 68 -> 36.4 KB instead of
+  // 46.6 KB, FOUR workgroups per CU instead of three, so the 15 x B workgroups of a batch-64 launch (960) are resident at once
+  // instead of 768 + a tail of 192.  Fragment rows / columns beyond GR are clamped onto GR - 1: they only feed accumulator rows
+  // >= G, which are never written back.
+  const int ks_n = (G + 3) >> 2, GR = ks_n * 4;
+  const int A_LD = GR | 1;                      // odd row stride: the row-major fragment read (16 rows x 4 columns) spreads over the banks
   constexpr int Z_LD = 68;                      // 64 columns + 4: rows stay 16-byte aligned
-  float* As = sm;                               // [MT * 16][A_LD], zero beyond G
-  float* Zs = sm + ((MT * 16 * A_LD + 3) & ~3); // [MT * 16][Z_LD]
+  float* As = sm;                               // [GR][A_LD], zero beyond G
+  float* Zs = sm + ((GR * A_LD + 3) & ~3);      // [GR][Z_LD]
   const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int r16 = lane & 15, kk = lane >> 4;
-  const int ks_n = (G + 3) >> 2;
   const float* A = graph + (long)b * G * G;
   if ((G & 3) == 0) {
     // float4 rows (G = 68: 17 per row); rows / columns beyond G are never read into a stored result (they only feed the
@@ -39,7 +43,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
       for (int e = 0; e < 4; ++e) As[row * A_LD + c + e] = v[e];
     }
   } else {
-    for (int i = tid; i < MT * 16 * A_LD; i += 256) {
+    for (int i = tid; i < GR * A_LD; i += 256) {
       const int row = i / A_LD, col = i - row * A_LD;
       As[i] = (row < G && col < G) ? A[row * G + col] : 0.f;
     }
@@ -69,21 +73,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
         *reinterpret_cast<f32x4*>(out0 + idx) = v;                     // dS
       }
     }
-    *reinterpret_cast<f32x4*>(&Zs[row * Z_LD + c4]) = v;
+    if (row < GR) *reinterpret_cast<f32x4*>(&Zs[row * Z_LD + c4]) = v;
   }
   __syncthreads();
   float bf[MT * 4];                                        // lane (column r16, kk): in[4 ks + kk][column] for every k-step
 #pragma unroll
-  for (int ks = 0; ks < MT * 4; ++ks) bf[ks] = Zs[(4 * ks + kk) * Z_LD + w * 16 + r16];
+  for (int ks = 0; ks < MT * 4; ++ks) bf[ks] = ks < ks_n ? Zs[(4 * ks + kk) * Z_LD + w * 16 + r16] : 0.f;
   f32x4 acc[MT];
+  int arow[MT];                                            // this lane's row (forward) / column (backward) of A per row tile, clamped
 #pragma unroll
-  for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int m = 0; m < MT; ++m) {
+    acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    arow[m] = min(m * 16 + r16, GR - 1);
+  }
 #pragma unroll
   for (int ks = 0; ks < MT * 4; ++ks) {
     if (ks < ks_n) {
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        const float a = MODE == 0 ? As[(m * 16 + r16) * A_LD + 4 * ks + kk] : As[(4 * ks + kk) * A_LD + m * 16 + r16];
+        const float a = MODE == 0 ? As[arow[m] * A_LD + 4 * ks + kk] : As[(4 * ks + kk) * A_LD + arow[m]];
         acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bf[ks], acc[m], 0, 0, 0);
       }
     }
@@ -92,7 +100,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) Zs[(m * 16 + 4 * kk + e) * Z_LD + w * 16 + r16] = acc[m][e];
+    for (int e = 0; e < 4; ++e)
+      if (m * 16 + 4 * kk + e < GR) Zs[(m * 16 + 4 * kk + e) * Z_LD + w * 16 + r16] = acc[m][e];
   __syncthreads();
   if (!cok) return;
   f32x4 bv = {0.f, 0.f, 0.f, 0.f};
@@ -132,8 +141,8 @@ extern "C" int nnr_gcn_aggregate_fwd(const float* graph, const float* z, const f
   if (!graph || !z || !y || B <= 0 || G <= 0 || D <= 0) return NNR_ERR_ARG;
   if (G > GCN_MAXG || (D & 3)) return NNR_ERR_UNSUPPORTED;          // float4 rows
   const float sc = p > 0.f ? 1.f / (1.f - p) : 1.f;
-  const int gp = (G + 15) / 16 * 16;
-#define GCN_CASE(MT_) case MT_: hipLaunchKernelGGL((gcn_aggregate_kernel<0, MT_>), dim3((D + 63) / 64, B), dim3(256), (size_t)(((gp * (gp + 1) + 3) & ~3) + gp * 68) * sizeof(float), \
+  const int gp = (G + 15) / 16 * 16, gr = (G + 3) / 4 * 4;
+#define GCN_CASE(MT_) case MT_: hipLaunchKernelGGL((gcn_aggregate_kernel<0, MT_>), dim3((D + 63) / 64, B), dim3(256), (size_t)(((gr * (gr | 1) + 3) & ~3) + gr * 68) * sizeof(float), \
                                                    stream, graph, z, bias, resid, y, r_out, nullptr, G, D, relu, seed, nnr_drop_thresh(p), sc); break;
   switch (gp / 16) { GCN_CASE(1) GCN_CASE(2) GCN_CASE(3) GCN_CASE(4) GCN_CASE(5) GCN_CASE(6) GCN_CASE(7) GCN_CASE(8) }
 #undef GCN_CASE
@@ -146,8 +155,8 @@ extern "C" int nnr_gcn_aggregate_bwd(const float* graph, const float* dy, const 
   if (!graph || !dy || !dz || B <= 0 || G <= 0 || D <= 0 || (r && !ds)) return NNR_ERR_ARG;
   if (G > GCN_MAXG || (D & 3)) return NNR_ERR_UNSUPPORTED;          // float4 rows
   const float sc = p > 0.f ? 1.f / (1.f - p) : 1.f;
-  const int gp = (G + 15) / 16 * 16;
-#define GCN_CASE(MT_) case MT_: hipLaunchKernelGGL((gcn_aggregate_kernel<1, MT_>), dim3((D + 63) / 64, B), dim3(256), (size_t)(((gp * (gp + 1) + 3) & ~3) + gp * 68) * sizeof(float), \
+  const int gp = (G + 15) / 16 * 16, gr = (G + 3) / 4 * 4;
+#define GCN_CASE(MT_) case MT_: hipLaunchKernelGGL((gcn_aggregate_kernel<1, MT_>), dim3((D + 63) / 64, B), dim3(256), (size_t)(((gr * (gr | 1) + 3) & ~3) + gr * 68) * sizeof(float), \
                                                    stream, graph, dy, nullptr, r, ds, dx0, dz, G, D, 0, seed, nnr_drop_thresh(p), sc); break;
   switch (gp / 16) { GCN_CASE(1) GCN_CASE(2) GCN_CASE(3) GCN_CASE(4) GCN_CASE(5) GCN_CASE(6) GCN_CASE(7) GCN_CASE(8) }
 #undef GCN_CASE

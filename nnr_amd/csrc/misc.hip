@@ -412,12 +412,24 @@ __global__ __launch_bounds__(256) void sue_intra_fwd_kernel(const float* __restr
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   for (int j = tid; j < Hn; j += 256) cid[j] = (int)cidx[(long)b * Hn + j];
   const float* q = qc + (long)bn * A;
-  for (int j = w; j < Hn; j += 4) {
-    const float* k = kf + ((long)b * Hn + j) * A;
-    float p = 0.f;
-    for (int x = lane; x < A; x += 64) p += k[x] * q[x];
-    p = wave_sum(p);
-    if (lane == 0) sc[j] = p * inv_scale;
+  for (int j0 = w; j0 < Hn; j0 += 16) {                     // 4 items per wave and trip: their loads are in flight together
+    float p[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* k[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) k[u] = kf + ((long)b * Hn + min(j0 + 4 * u, Hn - 1)) * A;
+    for (int x = lane; x < A; x += 64) {
+      const float qv = q[x];
+      float kv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) kv[u] = k[u][x];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) p[u] += kv[u] * qv;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float t = wave_sum(p[u]);
+      if (lane == 0 && j0 + 4 * u < Hn) sc[j0 + 4 * u] = t * inv_scale;
+    }
   }
   __syncthreads();
   sue_members(cid, Hn, C, ccnt, cstart, order);
@@ -439,58 +451,95 @@ __global__ __launch_bounds__(256) void sue_intra_fwd_kernel(const float* __restr
   if (col >= D) return;
   const float* gb = g + (long)b * Hn * D + col;
   float* fo = feat + (long)bn * C * D + col;
-  for (int c = 0; c < C; ++c) {
-    float acc = 0.f;
-    for (int k = 0; k < ccnt[c]; ++k) {
-      const int j = order[cstart[c] + k];
-      acc += al[j] * gb[(long)j * D];
+  // One walk over the cluster-sorted member list, 8 loads in flight per trip (cluster by cluster the walk was up to Hn dependent
+  // loads: clusters hold 2-3 members on average).  Every cluster still sums its members in ascending order.
+  for (int c = 0; c < C; ++c)
+    if (ccnt[c] == 0) fo[(long)c * D] = 0.f;            // empty cluster -> 0, as scatter_sum
+  const int total = cstart[C - 1] + ccnt[C - 1];
+  if (total == 0) return;
+  int cur = cid[order[0]];
+  float acc = 0.f;
+  for (int p0 = 0; p0 < total; p0 += 8) {
+    int jj[8];
+    float gv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      jj[u] = order[min(p0 + u, total - 1)];
+      gv[u] = gb[(long)jj[u] * D];
     }
-    fo[(long)c * D] = acc;              // empty cluster -> 0, as scatter_sum
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (p0 + u < total) {
+        const int cl = cid[jj[u]];
+        if (cl != cur) {
+          fo[(long)cur * D] = acc;
+          acc = 0.f;
+          cur = cl;
+        }
+        acc += al[jj[u]] * gv[u];
+      }
+    }
   }
+  fo[(long)cur * D] = acc;
 }
 
-// backward part 1, grid B*N: d alpha, segment-softmax backward -> ds[b, n, :] (workspace), dqc[b, n, :]
+// backward part 1, grid B*N: d alpha, segment-softmax backward -> ds[b, n, :] (workspace), dqc[b, n, :].
+// (B*N = 320 workgroups of 4 waves at batch 64.  16 waves per workgroup take the Hn items in one trip and are no faster alone
+// (30 vs 27 us) but 126 vs 82 us inside the step: a 1024-thread workgroup needs a whole CU at once, and the CUs are shared with the
+// weight-gradient GEMM of the other stream.  The kernel is written for any multiple of 64 threads.)
 __global__ __launch_bounds__(256) void sue_intra_bwd_ds_kernel(const float* __restrict__ kf, const float* __restrict__ g,
-                                                               const long* __restrict__ cidx, const float* __restrict__ alpha,
-                                                               const float* __restrict__ dfeat, int N, int Hn, int C, int A, int D,
-                                                               float inv_scale, float* __restrict__ ds_ws, float* __restrict__ dqc) {
+                                                                const long* __restrict__ cidx, const float* __restrict__ alpha,
+                                                                const float* __restrict__ dfeat, int N, int Hn, int C, int A, int D,
+                                                                float inv_scale, float* __restrict__ ds_ws, float* __restrict__ dqc) {
   __shared__ float al[SUE_MAXH], da[SUE_MAXH], ds[SUE_MAXH], csum[SUE_MAXC];
   __shared__ int cid[SUE_MAXH];
   const int bn = blockIdx.x, b = bn / N, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  for (int j = tid; j < Hn; j += 256) { cid[j] = (int)cidx[(long)b * Hn + j]; al[j] = alpha[(long)bn * Hn + j]; }
+  const int nt = blockDim.x, nw = nt >> 6;
+  for (int j = tid; j < Hn; j += nt) { cid[j] = (int)cidx[(long)b * Hn + j]; al[j] = alpha[(long)bn * Hn + j]; }
   __syncthreads();
   const float* gb = g + (long)b * Hn * D;
   const float* df = dfeat + (long)bn * C * D;
   // dalpha_j = <dfeat[cid_j], g_j>
   if (!(D & 3)) {
-    // 4 items per wave at a time, float4 lanes: 8 independent 16-byte loads in flight per trip, 4 trips per batch at D = 900
-    // (item-by-item with scalar lanes this phase was ~180 dependent trips per wave)
+    // 4 items per wave at a time, float4 lanes, two column trips per pass: 16 independent 16-byte loads in flight, 2 passes at D = 900
     const int D4 = D >> 2;
-    for (int j0 = w; j0 < Hn; j0 += 16) {
+    for (int j0 = w; j0 < Hn; j0 += 4 * nw) {
       float p[4] = {0.f, 0.f, 0.f, 0.f};
       const f32x4* dr[4];
       const f32x4* gr[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int j = min(j0 + 4 * u, Hn - 1);
+        const int j = min(j0 + nw * u, Hn - 1);
         dr[u] = reinterpret_cast<const f32x4*>(df + (long)cid[j] * D);
         gr[u] = reinterpret_cast<const f32x4*>(gb + (long)j * D);
       }
-      for (int x = lane; x < D4; x += 64) {
-        f32x4 a[4], c[4];
+      for (int x = lane; x < D4; x += 128) {
+        const int x2 = x + 64;
+        const bool two = x2 < D4;
+        f32x4 a[4], c[4], a2[4], c2[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) { a[u] = dr[u][x]; c[u] = gr[u][x]; }
 #pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          a2[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+          c2[u] = a2[u];
+          if (two) { a2[u] = dr[u][x2]; c2[u] = gr[u][x2]; }
+        }
+#pragma unroll
         for (int u = 0; u < 4; ++u) p[u] += a[u][0] * c[u][0] + a[u][1] * c[u][1] + a[u][2] * c[u][2] + a[u][3] * c[u][3];
+        if (two) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) p[u] += a2[u][0] * c2[u][0] + a2[u][1] * c2[u][1] + a2[u][2] * c2[u][2] + a2[u][3] * c2[u][3];
+        }
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const float t = wave_sum(p[u]);
-        if (lane == 0 && j0 + 4 * u < Hn) da[j0 + 4 * u] = t;
+        if (lane == 0 && j0 + nw * u < Hn) da[j0 + nw * u] = t;
       }
     }
   } else {
-    for (int j = w; j < Hn; j += 4) {
+    for (int j = w; j < Hn; j += nw) {
       const float* dr = df + (long)cid[j] * D;
       const float* gr = gb + (long)j * D;
       float p = 0.f;
@@ -506,14 +555,14 @@ __global__ __launch_bounds__(256) void sue_intra_bwd_ds_kernel(const float* __re
     csum[tid] = sm;
   }
   __syncthreads();
-  for (int j = tid; j < Hn; j += 256) {
+  for (int j = tid; j < Hn; j += nt) {
     const float v = al[j] * (da[j] - csum[cid[j]]) * inv_scale;
     ds[j] = v;
     ds_ws[(long)bn * Hn + j] = v;
   }
   __syncthreads();
   // dqc[b, n, :] = sum_j ds[j] * kf[b, j, :]
-  for (int x = tid; x < A; x += 256) {
+  for (int x = tid; x < A; x += nt) {
     float acc = 0.f;
     int j = 0;
     for (; j + 8 <= Hn; j += 8) {
@@ -545,6 +594,7 @@ __global__ __launch_bounds__(256) void sue_intra_bwd_dg_kernel(const float* __re
   for (int j = tid; j < Hn; j += 256) cid[j] = (int)cidx[(long)b * Hn + j];
   __syncthreads();
   if (last) {
+    if (blockIdx.z) return;
     for (int x = tid; x < A; x += 256) {
       float qv[8];
 #pragma unroll
@@ -561,11 +611,22 @@ __global__ __launch_bounds__(256) void sue_intra_bwd_dg_kernel(const float* __re
   sue_members(cid, Hn, C, ccnt, cstart, order);
   const int col = blockIdx.y * 256 + tid;
   if (col >= D) return;
-  for (int c = 0; c < C; ++c) {
-    if (ccnt[c] == 0) continue;
+  // blockIdx.z deals the clusters (c = z, z + Z, ...): B * slices workgroups alone are 1.25 waves per SIMD at batch 64, and their C
+  // dependent load groups were pure latency.  The next cluster's d feat values are loaded before this cluster's rows are stored.
+  const int Z = gridDim.z;
+  int c = blockIdx.z;
+  while (c < C && ccnt[c] == 0) c += Z;
+  float nx[8];
+#pragma unroll
+  for (int n = 0; n < 8; ++n) nx[n] = (n < N && c < C) ? dfeat[(((long)b * N + n) * C + c) * D + col] : 0.f;
+  while (c < C) {
     float dv[8];
 #pragma unroll
-    for (int n = 0; n < 8; ++n) dv[n] = n < N ? dfeat[(((long)b * N + n) * C + c) * D + col] : 0.f;
+    for (int n = 0; n < 8; ++n) dv[n] = nx[n];
+    int cn = c + Z;
+    while (cn < C && ccnt[cn] == 0) cn += Z;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) nx[n] = (n < N && cn < C) ? dfeat[(((long)b * N + n) * C + cn) * D + col] : 0.f;
     for (int k = 0; k < ccnt[c]; ++k) {
       const int j = order[cstart[c] + k];
       float acc = 0.f;
@@ -573,6 +634,7 @@ __global__ __launch_bounds__(256) void sue_intra_bwd_dg_kernel(const float* __re
       for (int n = 0; n < 8; ++n) if (n < N) acc += al[n][j] * dv[n];
       dg[((long)b * Hn + j) * D + col] = acc;
     }
+    c = cn;
   }
 }
 
@@ -981,7 +1043,7 @@ extern "C" int nnr_sue_intra_bwd(const float* kf, const float* qc, const float* 
   hipLaunchKernelGGL(sue_intra_bwd_ds_kernel, dim3(B * N), dim3(256), 0, stream, kf, g, cidx, alpha, dfeat, N, Hn, C, A, D,
                      1.f / sqrtf((float)A), ds_ws, dqc);
   NNR_CHECK_LAUNCH();
-  hipLaunchKernelGGL(sue_intra_bwd_dg_kernel, dim3(B, (D + 255) / 256 + 1), dim3(256), 0, stream, qc, cidx, alpha, dfeat, ds_ws, N, Hn, C,
+  hipLaunchKernelGGL(sue_intra_bwd_dg_kernel, dim3(B, (D + 255) / 256 + 1, C >= 3 ? 3 : 1), dim3(256), 0, stream, qc, cidx, alpha, dfeat, ds_ws, N, Hn, C,
                      A, D, dg, dkf);
   NNR_CHECK_LAUNCH();
   return NNR_OK;

@@ -539,7 +539,7 @@ def test_pair_recurrence_makes_progress_beside_a_cu_saturating_kernel(quad_T, mo
         assert torch.isfinite(b).all() and torch.equal(a, b), what
 
 
-@pytest.mark.parametrize('B,G,D', [(5, 68, 900), (3, 21, 52), (2, 128, 64), (4, 16, 20)])
+@pytest.mark.parametrize('B,G,D', [(5, 68, 900), (3, 21, 52), (2, 128, 64), (4, 16, 20), (3, 50, 132), (2, 66, 900), (2, 80, 72), (3, 5, 64)])
 def test_gcn_aggregate_forward_backward(B, G, D):
     """Per-user graph aggregate with GCNLayer's epilogue (csrc/gcn.hip) vs fp64, and the dropout mask of the forward, of the
     backward and of the batched-GEMM path (same counter-based mask over the flat [B, G, D] index)."""
@@ -688,10 +688,13 @@ def test_pool_dense_masked_dot():
 
 
 # ------------------------------------------------------------------------------------------------ SUE intra-cluster, misc
-def test_sue_intra_cluster_matches_scatter_semantics():
+@pytest.mark.parametrize('Bn,N,Hn,Cn,A,D', [(7, 5, 50, 19, 225, 900), (3, 2, 17, 2, 64, 52), (2, 8, 64, 32, 128, 50), (2, 1, 5, 7, 32, 260),
+                                            (66, 5, 50, 18, 128, 900)])
+def test_sue_intra_cluster_matches_scatter_semantics(Bn, N, Hn, Cn, A, D):
+    """Cluster attention of SUE (csrc/misc.hip sue_intra_*): the default shape, fewer clusters than the backward's cluster split, the
+    kernels' maxima (64 items, 32 clusters, 8 candidates, D not a multiple of 4), one candidate, and the headline launch shape."""
     from nnr_amd import ops
     d = dev()
-    Bn, N, Hn, Cn, A, D = 7, 5, 50, 19, 225, 900
     kf, qc, g = rnd(Bn, Hn, A, seed=1, scale=0.3), rnd(Bn, N, A, seed=2), rnd(Bn, Hn, D, seed=3)
     cidx = torch.randint(0, Cn, (Bn, Hn), generator=torch.Generator().manual_seed(4))
     cidx[0] = Cn - 1
