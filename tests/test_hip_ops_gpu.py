@@ -792,6 +792,21 @@ def test_elementwise_and_optimizer():
         close(dt, ref, what='small embed bwd, runs, n=%d' % n)
 
 
+@pytest.mark.parametrize('n', [1, 3, 1027, 1_048_579, 5_000_001, 25_600_003])
+def test_sumsq_is_accurate_and_deterministic(n):
+    """Global squared gradient norm (clip_grad_norm_, trainer.py:118): tail-only sizes, one unrolled trip + tail, and the CNE+SUE
+    buffer's size; the same bits on every call (the ranks of a data-parallel job must agree on the clip coefficient)."""
+    from nnr_amd import ops
+    d = dev()
+    g = (torch.randn(n, generator=torch.Generator().manual_seed(n)) * 0.1).to(d)
+    out = torch.full((2,), 7.0, device=d, dtype=torch.float32)
+    ops.sumsq(g, out[:1])
+    ops.sumsq(g, out[1:])
+    ref = float((g.double() ** 2).sum())
+    assert abs(float(out[0]) - ref) <= 1e-5 * ref + 1e-12, (float(out[0]), ref)
+    assert torch.equal(out[0], out[1])
+
+
 def test_slot_spread_column_sums():
     """Long reductions into a short vector (bias gradients, dw2 of the additive attention) go through the per-stream slot
     workspace (nnr_slot_workspace_floats): same sums as the direct form, and the workspace is left zeroed -- the second call,
