@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Headline benchmark of the hot path: training impressions/sec, CNE+SUE on MIND-200k-shaped synthetic data, batch 64
+"""Headline benchmark of the hot path: training impressions/sec, CNE+SUE on MIND-200k-shaped synthetic data, global batch 64
 (BASELINE.json), one process per GPU.
 
   python bench.py --gpus N --steps K --warmup W
@@ -9,19 +9,24 @@ With N > 1 and no WORLD_SIZE in the environment this process is only a LAUNCHER:
 process and exits with the child's return code (a fresh child, never an exec of a GPU-touched process).  Started by torchrun
 (RANK / LOCAL_RANK / WORLD_SIZE set) it is one rank of the job.
 
-One "step" = one optimizer step of trainer.py:105-120 (forward, loss, backward, [RCCL all-reduce of the flat gradient],
-clip_grad_norm_(4), Adam) on one batch that is already resident in HBM; dropout is ON (0.2, the reference's 200k setting).
+One "step" = one optimizer step of trainer.py:83-120 on one batch: batch delivery (the 21 tensors of trainer.py:83-103 are
+gathered / built in HBM from the device-resident corpus out of 256 bytes of behaviour ids -- nnr_corpus_batch +
+nnr_history_graph, a FRESH batch every step), forward, loss, backward, [RCCL all-reduce of the flat gradient],
+clip_grad_norm_(4), Adam; dropout is ON (0.2, the reference's 200k setting).  `--prebuilt` re-uses eight pre-built batches
+resident in HBM instead (the timed region of rounds 1-3).
 
-Scaling.  Impressions are independent units sharded over the ranks, so the headline line is WEAK scaling: every GPU
-processes the headline batch of 64 impressions per step (global batch 64*N), `value` = impressions of all ranks / time.
-For N > 1 the same run also times the reference's own flag semantics (`--batch_size` is the GLOBAL batch, per rank
-batch_size // world_size, trainer.py:218) = STRONG scaling at global batch 64, reported in the `strong_scaling` object of the
-same JSON line (per-GPU batch 8 at N = 8: a regime bound by the 128-step dependent chain of the Bi-LSTM and by launch
-latency, not by throughput).  `--global_batch G` makes the strong-scaling run the headline instead.
+Scaling.  `--batch_size 64` is the GLOBAL batch, exactly as the reference's flag (config.py:116): with N GPUs every rank
+processes batch_size // N impressions per step (trainer.py:218) and the gradients are averaged over the ranks -- the SAME
+optimisation problem at every N, so the headline line is STRONG scaling at global batch 64 (`scaling: "strong"`; BASELINE.json
+configs[3] = per-GPU batch 8 at N = 8: a regime bound by the 128-step dependent chain of the Bi-LSTM and by launch latency,
+not by throughput).  For N > 1 the same run also times WEAK scaling (64 impressions per GPU, global batch 64 N) and reports it
+in the secondary `weak_scaling` object; `--weak` makes that the headline instead (`--no_weak` skips the leg).
 
 Prints ONE JSON line (rank 0): throughput, the roofline of the dominant kernel measured live with HIP events on the launch
-stream, and a CPU baseline (the oracle with ATen's packed-sequence LSTM = the reference's nn.LSTM host path, timed on this
-box's cores on a bounded sample).  Exit code 3 if the CU-pair recurrence's exchange ever timed out (values poisoned)."""
+stream (+ `roofline.hbm`: the HBM-bound kernels of the step against the 8 TB/s peak), and a CPU baseline (the oracle with
+ATen's packed-sequence LSTM = the reference's nn.LSTM host path, timed on this box's cores on a bounded sample).
+`--config mhsa` runs BASELINE.json configs[1] (MHSA+MHSA) and adds the attention kernels' MFMA figures (`roofline.mhsa`).
+Exit code 3 if the CU-pair recurrence's exchange ever timed out (values poisoned)."""
 import argparse
 import json
 import os
@@ -41,15 +46,21 @@ def parse(argv=None):
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=6)
+    ap.add_argument('--config', choices=['cne_sue', 'mhsa'], default=None, help='shorthand for the encoder pair: cne_sue = BASELINE.json '
+                    'configs[2..4] (the headline), mhsa = configs[1] (MHSA+MHSA, MFMA attention kernel)')
     ap.add_argument('--news_encoder', default='CNE')
     ap.add_argument('--user_encoder', default='SUE')
-    ap.add_argument('--batch_size', type=int, default=64, help='impressions per GPU per step (weak scaling, the default)')
-    ap.add_argument('--global_batch', type=int, default=0, help='>0: strong scaling as the headline, this GLOBAL batch split over the GPUs')
-    ap.add_argument('--no_strong', action='store_true', help='N > 1: skip the additional strong-scaling (global batch 64) leg')
+    ap.add_argument('--batch_size', type=int, default=64, help='GLOBAL batch (the reference\'s flag, config.py:116); every rank processes '
+                    'batch_size // world_size impressions per step (trainer.py:218)')
+    ap.add_argument('--weak', action='store_true', help='headline = weak scaling: --batch_size impressions PER GPU (global batch_size x N)')
+    ap.add_argument('--no_weak', action='store_true', help='N > 1: skip the secondary weak-scaling (batch_size per GPU) leg')
+    ap.add_argument('--global_batch', type=int, default=0, help='deprecated alias of --batch_size (rounds 2-3)')
+    ap.add_argument('--prebuilt', action='store_true', help='re-use eight pre-built batches resident in HBM (rounds 1-3) instead of building a '
+                    'fresh batch from the device-resident corpus inside every timed step')
     ap.add_argument('--vocabulary_size', type=int, default=60000)
     ap.add_argument('--dense', action='store_true', help='all titles/abstracts at full length (worst-case roofline variant)')
-    ap.add_argument('--device_corpus', action='store_true', help='build every batch inside the timed step from the device-resident '
-                    'corpus (id-only batches: nnr_corpus_batch + nnr_history_graph) instead of re-using pre-built batches')
+    ap.add_argument('--device_corpus', action='store_true', help='(default since round 4; kept for old command lines) build every batch '
+                    'inside the timed step from the device-resident corpus (id-only batches: nnr_corpus_batch + nnr_history_graph)')
     ap.add_argument('--roofline_every', type=int, default=10, help='instrument every n-th timed step with HIP events (the two events per '
                     'launch cost ~5 %% of a step when all steps carry them)')
     ap.add_argument('--zipf_s', type=float, default=None, help='diagnostic: exponent of the synthetic word-id distribution (default: SynthSpec)')
@@ -61,7 +72,21 @@ def parse(argv=None):
     ap.add_argument('--cpu_baseline_steps', type=int, default=2)
     ap.add_argument('--plumbing_check', action='store_true', help='CPU only (gloo): run the launcher + the product\'s flat-buffer / '
                     'exchange plumbing (trainer.FlatParams, nnr_amd.dp) on a stand-in module and print one JSON line; no HIP call')
-    return ap.parse_args(argv)
+    a = ap.parse_args(argv)
+    if a.config == 'mhsa':
+        a.news_encoder = a.user_encoder = 'MHSA'
+    elif a.config == 'cne_sue':
+        a.news_encoder, a.user_encoder = 'CNE', 'SUE'
+    if a.global_batch > 0:
+        a.batch_size, a.weak = a.global_batch, False
+    return a
+
+
+def shard_sizes(batch_size, world, weak):
+    """(per-GPU batch, global batch) of a run: the reference's semantics (`--batch_size` global, per rank batch_size // world,
+    trainer.py:218; the remainder of an uneven division is dropped exactly as there) or, with --weak, batch_size per GPU."""
+    per = batch_size if weak else batch_size // world
+    return per, per * world
 
 
 def _free_port():
@@ -152,7 +177,7 @@ def plumbing_check(a):
     dp.broadcast_parameters(flat.flat)
     p0 = flat.flat.clone()
     ex = dp.GradientExchange(flat, early_modules=[tail])
-    per_gpu = a.batch_size if a.global_batch <= 0 else a.global_batch // world
+    per_gpu, global_batch = shard_sizes(a.batch_size, world, a.weak)
     t0 = time.perf_counter()
     for step in range(a.steps):
         flat.zero_grad()
@@ -170,7 +195,7 @@ def plumbing_check(a):
         ok = ok and all(torch.equal(same[0], s) for s in same)
     if rank == 0:
         print(json.dumps({'metric': 'plumbing check (CPU, gloo)', 'n_gpus': world, 'steps': a.steps, 'per_gpu_batch': per_gpu,
-                          'global_batch': per_gpu * world, 'scaling': 'weak' if a.global_batch <= 0 else 'strong',
+                          'global_batch': global_batch, 'scaling': 'weak' if a.weak else 'strong',
                           'buckets': ex.describe(), 'params_equal_on_all_ranks_and_expected': ok, 'seconds': round(dt, 4)}))
     if world > 1:
         torch.distributed.destroy_process_group()
@@ -281,10 +306,9 @@ def main():
     assert world == a.gpus, 'world size %d != --gpus %d (launch with torch.distributed.run --nproc-per-node %d, or let bench.py do it)' % (world, a.gpus, a.gpus)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    weak = a.global_batch <= 0
-    per_gpu = a.batch_size if weak else a.global_batch // world
-    assert per_gpu >= 1, 'global batch %d cannot be split over %d GPUs' % (a.global_batch, world)
-    global_batch = per_gpu * world
+    weak = bool(a.weak)
+    per_gpu, global_batch = shard_sizes(a.batch_size, world, weak)
+    assert per_gpu >= 1, 'global batch %d cannot be split over %d GPUs' % (a.batch_size, world)
     cfg = make_config(['--news_encoder=' + a.news_encoder, '--user_encoder=' + a.user_encoder, '--dataset=200k',
                        '--batch_size=%d' % global_batch, '--world_size=%d' % world],
                       corpus_sizes=dict(vocabulary_size=a.vocabulary_size))
@@ -300,14 +324,20 @@ def main():
 
     corpus = SynthCorpus(spec)
     rng = np.random.default_rng(100 + rank)
-    nb = min(8, a.steps + a.warmup)
+    device_corpus = not a.prebuilt
+    nb = min(256, a.steps + a.warmup) if device_corpus else min(8, a.steps + a.warmup)
+    dcorpus = []
 
     def batch_source(per_rank):
-        if a.device_corpus:
+        if device_corpus:
+            # a1's batch delivery inside the step: every step gathers / builds its 21 tensors in HBM from the device-resident corpus
+            # (nnr_corpus_batch + nnr_history_graph) out of `per_rank` behaviour ids; steps + warmup DISTINCT id sets, a fresh batch
+            # each step (the sustained leg cycles through the same sets: other draws are another workload, +-6 % in tokens)
             from nnr_amd.corpus import from_synth
-            dcorpus = from_synth(corpus, 4096, rng, dev, graph='build')
+            if not dcorpus:
+                dcorpus.append(from_synth(corpus, 4096, rng, dev, graph='build'))
             order = [torch.from_numpy(rng.permutation(4096)[:per_rank].astype(np.int32)).to(dev) for _ in range(nb)]
-            return lambda i: dcorpus.train_batch(order[i % nb])      # 256 bytes of behaviour ids per batch; the 21 tensors are gathered / built in HBM
+            return lambda i: dcorpus[0].train_batch(order[i % nb])
         batches = [to_torch(corpus.batch(per_rank, rng), dev) for _ in range(nb)]
         return lambda i: batches[i % nb]        # masks are mutated in place by the model; mutation is idempotent, so batches can be reused
 
@@ -319,6 +349,10 @@ def main():
     headline = (a.news_encoder, a.user_encoder, per_gpu, a.dense) == ('CNE', 'SUE', 64, False)
     if roof and not headline:
         roof['traffic'] = None            # the committed PMC passes (profiles/pmc_traffic.json) are of the headline command only
+        for v in (roof.get('hbm') or {}).values():
+            v['traffic'] = v['traffic_over_algorithmic'] = None
+    if roof and a.news_encoder == 'MHSA':
+        roof['mhsa'] = prof.mhsa_roofline(PEAK_F32_TFLOPS)
     if roof and headline:
         # counter bytes (same PMC passes) over ALGORITHMIC operand bytes of the weight-gradient (token-reduction) GEMM launches
         roof['weight_gradient_traffic'] = prof.weight_gradient_traffic()
@@ -361,13 +395,15 @@ def main():
     if world > 1:
         exchange = measure_exchange(trainer, torch, dev, world, a)
 
-    strong = None
-    if world > 1 and weak and not a.no_strong and a.batch_size % world == 0:
-        # the reference's semantics for the SAME command line on N GPUs: --batch_size 64 is the global batch (trainer.py:218)
-        sp = a.batch_size // world
-        sdt, scalls = timed_run(a, trainer, batch_source(sp), a.steps, max(2, a.warmup // 2), prof, dp, torch, dev, world, False)
-        strong = {'scaling': 'strong', 'global_batch': a.batch_size, 'per_gpu_batch': sp, 'value': round(a.steps * a.batch_size / sdt, 2),
-                  'unit': 'impressions/s', 'ms_per_step': round(1000 * sdt / a.steps, 3), 'abi_calls_per_step': round(scalls, 1)}
+    other = None
+    if world > 1 and not a.no_weak:
+        # the OTHER scaling mode of the same job, as a secondary object: weak scaling (batch_size impressions per GPU) beside the
+        # strong-scaling headline, or -- under --weak -- the reference's global-batch semantics beside the weak headline
+        op_, og_ = shard_sizes(a.batch_size, world, not weak)
+        if op_ >= 1 and op_ != per_gpu:
+            odt, ocalls = timed_run(a, trainer, batch_source(op_), a.steps, max(3, a.warmup // 2), prof, dp, torch, dev, world, False)
+            other = {'scaling': 'strong' if weak else 'weak', 'global_batch': og_, 'per_gpu_batch': op_, 'value': round(a.steps * og_ / odt, 2),
+                     'unit': 'impressions/s', 'ms_per_step': round(1000 * odt / a.steps, 3), 'abi_calls_per_step': round(ocalls, 1)}
 
     exchange_timeouts = ops.lstm_sync_timeouts()      # persistent device counter over EVERY pair-kernel launch of this process
     tmo = torch.tensor([exchange_timeouts], device=dev, dtype=torch.int64)
@@ -380,8 +416,8 @@ def main():
 
     if rank == 0:
         out = {
-            'metric': 'training impressions/sec on MIND-200k (CNE+SUE, bs=64)' if (a.news_encoder, a.user_encoder) == ('CNE', 'SUE')
-                      else 'training impressions/sec (%s+%s)' % (a.news_encoder, a.user_encoder),
+            'metric': ('training impressions/sec on MIND-200k (%s+%s, bs=%d)' % (a.news_encoder, a.user_encoder, a.batch_size)) +
+                      (' per GPU, weak scaling' if (weak and world > 1) else ''),
             'value': round(a.steps * global_batch / dt, 2), 'unit': 'impressions/s', 'n_gpus': world, 'steps': a.steps,
             'warmup': a.warmup, 'ms_per_step': round(1000 * dt / a.steps, 3), 'higher_is_better': True,
             'scaling': 'weak' if weak else 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
@@ -389,7 +425,8 @@ def main():
                                    (a.news_encoder, a.user_encoder, cfg.dropout_rate, cfg.gcn_layer_num, ', dense lengths' if a.dense else ''),
                        'global_batch': global_batch, 'per_gpu_batch': per_gpu, 'parallelism': 'dp%d' % world,
                        'synth': {k: v for k, v in spec.describe().items() if k in ('vocabulary_size', 'title_len_mean', 'content_len_mean', 'news_pool', 'dense')},
-                       'batches': 'device-resident corpus, id-only' if a.device_corpus else 'pre-built, resident in HBM',
+                       'batches': ('device-resident corpus, id-only: a fresh batch is gathered / built in HBM inside every timed step (%d distinct id sets)' % nb)
+                                  if device_corpus else 'pre-built, %d batches resident in HBM, re-used' % nb,
                        'peak_hbm_reserved_gb': round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 2),
                        'abi_calls_per_step': round(calls, 1),
                        'launch_path': launch_path(trainer),
@@ -401,8 +438,8 @@ def main():
             out['sustained'] = sustained
         if exchange is not None:
             out['exchange'] = exchange
-        if strong is not None:
-            out['strong_scaling'] = strong
+        if other is not None:
+            out['weak_scaling' if other['scaling'] == 'weak' else 'strong_scaling'] = other
         if not a.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(cfg, spec, a.cpu_baseline_batch, a.cpu_baseline_steps)
         print(json.dumps(out))

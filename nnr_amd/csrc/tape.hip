@@ -122,11 +122,14 @@ extern "C" int nnr_tape_call(nnr_tape* t, int fn, hipStream_t stream, const uint
                              const void* const* blob_ptr, const size_t* blob_bytes, int nblobs, int tag, size_t* slot_off_out,
                              size_t* blob_off_out) {
   if (!t || t->final || fn < 0 || fn >= NREG || nslots != REGISTRY[fn].nargs || (nslots > 0 && !slots)) return NNR_ERR_ARG;
+  // every blob is validated BEFORE the arena is touched: a rejected call leaves no orphaned slots / blob references behind
+  if (nblobs < 0 || (nblobs > 0 && (!blob_slot || !blob_ptr || !blob_bytes))) return NNR_ERR_ARG;
+  for (int i = 0; i < nblobs; ++i)
+    if (blob_slot[i] < 0 || blob_slot[i] >= nslots || !blob_ptr[i]) return NNR_ERR_ARG;
   Call c;
   c.fn = fn; c.stream = stream_index(t, stream); c.nslots = nslots; c.tag = tag; c.slot_off = t->arena.size();
   t->arena.insert(t->arena.end(), slots, slots + nslots);
   for (int i = 0; i < nblobs; ++i) {
-    if (blob_slot[i] < 0 || blob_slot[i] >= nslots || !blob_ptr[i]) return NNR_ERR_ARG;
     const size_t units = (blob_bytes[i] + 7) / 8, off = t->arena.size();
     t->arena.resize(off + units, 0);
     std::memcpy(&t->arena[off], blob_ptr[i], blob_bytes[i]);
@@ -218,8 +221,19 @@ extern "C" int nnr_tape_replay(nnr_tape* t, int segment, const uint64_t* values,
     if ((int)t->tset.size() <= timing_set) t->tset.resize(timing_set + 1);
     ts = &t->tset[timing_set];
     if (ts->empty()) {
-      ts->resize(2 * (size_t)t->ntagged);
-      for (hipEvent_t& e : *ts) if (hipEventCreate(&e) != hipSuccess) return NNR_ERR_LAUNCH;
+      // built aside and moved in only when EVERY create succeeded: a half-built set would be taken for a usable one by the next
+      // timing replay and destroyed (uninitialised handles) by nnr_tape_destroy
+      std::vector<hipEvent_t> fresh;
+      fresh.reserve(2 * (size_t)t->ntagged);
+      for (int i = 0; i < 2 * t->ntagged; ++i) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) {
+          for (hipEvent_t d : fresh) (void)hipEventDestroy(d);
+          return NNR_ERR_LAUNCH;
+        }
+        fresh.push_back(e);
+      }
+      *ts = std::move(fresh);
     }
   }
   for (size_t i = t->seg_begin[segment]; i < t->seg_begin[segment + 1]; ++i) {

@@ -34,7 +34,8 @@ def world_size():
 class NativeExchange:
     """The same exchange through the C-ABI (`nnr_dp_*`, csrc/dp.hip: RCCL called directly on the launch stream, no
     ProcessGroup in between).  The 128-byte communicator id travels over the already-initialised torch.distributed group
-    (any backend) when world > 1.  Opt-in: NNR_DP_NATIVE=1; `torch.distributed` ("nccl" = the same RCCL) is the default."""
+    (any backend) when world > 1.  Default when the job's backend is "nccl" and world > 1 (see _native_wanted); NNR_DP_NATIVE=0 keeps
+    `torch.distributed`'s all_reduce ("nccl" = the same RCCL)."""
 
     def __init__(self, rank, world):
         from . import _lib as L
@@ -65,14 +66,49 @@ class NativeExchange:
 
 
 _native = None
+_native_state = {'decided': False, 'why': ''}
+
+
+def _native_wanted():
+    """The C-ABI binding (RCCL called directly, `nnr_dp_allreduce` part of the recorded launch sequence: ONE tape segment, no host
+    callback in the step) is the DEFAULT whenever the job exchanges over RCCL (backend "nccl", world > 1); `torch.distributed`'s
+    all_reduce is the fallback (NNR_DP_NATIVE=0, the gloo test backend, or a box whose RCCL cannot be resolved).  NNR_DP_NATIVE=1
+    forces it (one-rank ordering tests)."""
+    e = os.environ.get('NNR_DP_NATIVE')
+    if e is not None:
+        return e == '1'
+    return dist.is_initialized() and dist.get_backend() == 'nccl' and dist.get_world_size() > 1
 
 
 def _native_exchange():
+    """The process's NativeExchange, or None (torch.distributed binding).  Decided ONCE, identically on every rank: ncclCommInitRank
+    is a blocking collective, so the ranks first agree (over the torch.distributed group) that each of them can resolve RCCL, and
+    fall back together otherwise."""
     global _native
-    if _native is None and os.environ.get('NNR_DP_NATIVE') == '1' and torch.cuda.is_available():
-        rank = dist.get_rank() if dist.is_initialized() else 0
-        _native = NativeExchange(rank, world_size())
+    if _native_state['decided']:
+        return _native
+    if not (_native_wanted() and torch.cuda.is_available()):
+        return None                                   # (not latched: the process group may not be up yet)
+    _native_state['decided'] = True
+    from . import _lib as L
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    probe = (C.c_ubyte * 128)()
+    ok = 1 if L.lib().nnr_dp_unique_id(probe) == 0 else 0
+    if world_size() > 1:
+        flag = torch.tensor([ok], device='cuda' if dist.get_backend() == 'nccl' else 'cpu', dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = int(flag.item())
+    if not ok:
+        _native_state['why'] = 'RCCL could not be resolved by libnnr_hip.so on every rank: torch.distributed binding'
+        import warnings
+        warnings.warn('nnr_amd.dp: ' + _native_state['why'])
+        return None
+    _native = NativeExchange(rank, world_size())
     return _native
+
+
+def native_active(is_cuda=True):
+    return bool(is_cuda) and _native_exchange() is not None
 
 
 def broadcast_parameters(flat_params):
@@ -159,7 +195,7 @@ class GradientExchange:
         return {'buckets': ([{'name': 'early (user encoder)', 'floats': es[1] - es[0]}] if es else []) +
                            ([{'name': 'table (word embedding)', 'floats': ts[1] - ts[0]}] if ts else []) +
                            [{'name': 'late', 'floats': sum(b - a for a, b in self.late_spans)}],
-                'binding': 'C-ABI nnr_dp_allreduce' if (os.environ.get('NNR_DP_NATIVE') == '1' and self.grad.is_cuda) else 'torch.distributed all_reduce',
+                'binding': 'C-ABI nnr_dp_allreduce (RCCL, recorded in the launch tape)' if native_active(self.grad.is_cuda) else 'torch.distributed all_reduce',
                 'overlap': ('early bucket is reduced while the news-encoder backward runs' if es else 'none (single bucket)') +
                            ('; table bucket while the LSTM weight-gradient GEMMs of the tail run' if ts else '')}
 
@@ -179,7 +215,7 @@ class GradientExchange:
         return self._comm
 
     def _native(self):
-        return os.environ.get('NNR_DP_NATIVE') == '1' and self.grad.is_cuda
+        return native_active(self.grad.is_cuda)
 
     def early_ready(self):
         """The early bucket's gradients are final on the CURRENT stream: start reducing them."""

@@ -14,6 +14,38 @@ ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
 K_CHUNK = 1024      # reduction rows per slice of the token-reduction (weight-gradient) GEMMs, see nnr_gemm_args.k_chunk
 
 
+class _NoSpan:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+_NOSPAN = _NoSpan()
+
+
+def _hbm_span(family, per_row, rows, dyn=None, fixed=0.0, tag=''):
+    """Live-profile span of an HBM-bound launch (bench.py `roofline.hbm`): ALGORITHMIC bytes = fixed + per_row x live rows, every
+    operand read once and every result written once; `dyn` = device int32 holding the live row count (read after the timed region)."""
+    if not _prof.active():
+        return _NOSPAN
+
+    def flops(vals=None):
+        return 0.0
+
+    def nbytes(vals=None, rows=rows, dyn=dyn):
+        r = rows
+        if dyn is not None:
+            r = min(rows, int(vals[dyn.data_ptr()]) if vals is not None else int(dyn.reshape(-1)[0].item()))
+        return float(fixed) + float(per_row) * r
+    flops.dyn = [dyn] if dyn is not None else []
+    flops.bytes_fn = nbytes
+    flops.hbm = True
+    flops.tag = tag or 'rows%d%s' % (rows, ' dyn' if dyn is not None else '')
+    return _prof.span(family, flops)
+
+
 def _p(t):
     if t is None:
         return None
@@ -661,12 +693,25 @@ def _pool_args(x, ldx, D, n, Lx, plan=None, mask=None, mask_div=1, score=None, v
     return a
 
 
+def _pool_span(family, kw, per_token_arrays):
+    """x [tokens, D] is the operand that matters: forward reads it once (+ the tanh projection when the score is fused), backward
+    reads it and writes dx (+ reads dx when it accumulates); per-sequence vectors are n x D."""
+    if not _prof.active():
+        return _NOSPAN
+    plan, D, n, Lx = kw.get('plan'), kw['D'], kw['n'], kw['Lx']
+    th = kw.get('th')
+    per_row = 4.0 * (D * per_token_arrays + (th.shape[1] if th is not None else 0) + 2)
+    return _hbm_span(family, per_row, n * Lx, dyn=plan.total if plan is not None else None, fixed=4.0 * n * D * 3)
+
+
 def pool_fwd(**kw):
-    L.check(L.lib().nnr_attn_pool_fwd(C.byref(_pool_args(**kw)), _s()), 'nnr_attn_pool_fwd')
+    with _pool_span('pool_fwd', kw, 1):
+        L.check(L.lib().nnr_attn_pool_fwd(C.byref(_pool_args(**kw)), _s()), 'nnr_attn_pool_fwd')
 
 
 def pool_bwd(**kw):
-    L.check(L.lib().nnr_attn_pool_bwd(C.byref(_pool_args(**kw)), _s()), 'nnr_attn_pool_bwd')
+    with _pool_span('pool_bwd', kw, 3 if kw.get('dx_accumulate') else 2):
+        L.check(L.lib().nnr_attn_pool_bwd(C.byref(_pool_args(**kw)), _s()), 'nnr_attn_pool_bwd')
 
 
 # ---------------------------------------------------------------------------------------------- elementwise
@@ -687,6 +732,11 @@ def add2d(y, ldy, x, ldx, rows, cols, alpha=1.0, accumulate=False):
 
 
 def gate_bwd(dHt, H, G, dH, dpre, plan, cols):
+    with _hbm_span('gate_bwd', 5 * 4.0 * cols, plan.cap, dyn=plan.total):      # reads dHt, H, G; writes dH, dpre
+        return _gate_bwd(dHt, H, G, dH, dpre, plan, cols)
+
+
+def _gate_bwd(dHt, H, G, dH, dpre, plan, cols):
     L.check(L.lib().nnr_gate_bwd(_p(dHt), _p(H), _p(G), _p(dH), _p(dpre), _p(plan.total), plan.cap, cols, _s()), 'nnr_gate_bwd')
 
 
@@ -746,13 +796,17 @@ def relu_drop_bwd(dy, r, ds, dx, p, seed):
 
 # ---------------------------------------------------------------------------------------------- SUE / loss / optimiser
 def gcn_aggregate_fwd(graph, z, bias, resid, r_out, y, B, G, D, relu, p, seed):
-    L.check(L.lib().nnr_gcn_aggregate_fwd(_p(graph), _p(z), _p(bias), _p(resid), _p(r_out), _p(y), B, G, D, int(relu), C.c_float(p),
-                                          C.c_uint32(int(seed) & 0xFFFFFFFF), _s()), 'nnr_gcn_aggregate_fwd')
+    arrays = 3 + (1 if resid is not None else 0)                                  # z, (resid) read; r, y written
+    with _hbm_span('gcn_aggregate_fwd', 4.0 * (G * D * arrays + G * G), B):
+        L.check(L.lib().nnr_gcn_aggregate_fwd(_p(graph), _p(z), _p(bias), _p(resid), _p(r_out), _p(y), B, G, D, int(relu), C.c_float(p),
+                                              C.c_uint32(int(seed) & 0xFFFFFFFF), _s()), 'nnr_gcn_aggregate_fwd')
 
 
 def gcn_aggregate_bwd(graph, dy, r, ds, dx0, dz, B, G, D, p, seed):
-    L.check(L.lib().nnr_gcn_aggregate_bwd(_p(graph), _p(dy), _p(r), _p(ds), _p(dx0), _p(dz), B, G, D, C.c_float(p),
-                                          C.c_uint32(int(seed) & 0xFFFFFFFF), _s()), 'nnr_gcn_aggregate_bwd')
+    arrays = 4 + (1 if dx0 is not None else 0)                                    # dy, r read; dS, dz, (dx0) written
+    with _hbm_span('gcn_aggregate_bwd', 4.0 * (G * D * arrays + G * G), B):
+        L.check(L.lib().nnr_gcn_aggregate_bwd(_p(graph), _p(dy), _p(r), _p(ds), _p(dx0), _p(dz), B, G, D, C.c_float(p),
+                                              C.c_uint32(int(seed) & 0xFFFFFFFF), _s()), 'nnr_gcn_aggregate_bwd')
 
 
 def sue_x0_fwd(hist, proxy, x0, B, Hn, Kc, D, p, seed, cmask_fix=None):
@@ -777,11 +831,23 @@ def sue_slice_bwd(dgfeat, dpad, B, Hn, G, D):
 
 
 def sue_intra_fwd(kf, qc, g, cidx, B, N, Hn, Cn, A, D, alpha, feat):
+    # per user: keys [Hn, A] + queries [N, A] + features [Hn, D] + indices read; weights [N, Hn] + cluster features [N, Cn, D] written
+    with _hbm_span('sue_intra_fwd', 4.0 * (Hn * A + N * A + Hn * D + N * Hn + N * Cn * D) + 8.0 * Hn, B):
+        return _sue_intra_fwd(kf, qc, g, cidx, B, N, Hn, Cn, A, D, alpha, feat)
+
+
+def _sue_intra_fwd(kf, qc, g, cidx, B, N, Hn, Cn, A, D, alpha, feat):
     L.check(L.lib().nnr_sue_intra_fwd(_p(kf), _p(qc), _p(g), _p(cidx), B, N, Hn, Cn, A, D, _p(alpha), _p(feat), _s()), 'nnr_sue_intra_fwd')
 
 
 def sue_intra_bwd(kf, qc, g, cidx, alpha, dfeat, B, N, Hn, Cn, A, D, dg, dkf, dqc):
     ws = torch.empty(B * N * Hn, device=kf.device, dtype=torch.float32)
+    # per user: d cluster features [N, Cn, D], features [Hn, D], keys, queries, weights read; d features [Hn, D], d keys, d queries written
+    with _hbm_span('sue_intra_bwd', 4.0 * (N * Cn * D + 2 * Hn * D + 2 * Hn * A + 2 * N * A + N * Hn) + 8.0 * Hn, B):
+        return _sue_intra_bwd(kf, qc, g, cidx, alpha, dfeat, B, N, Hn, Cn, A, D, dg, dkf, dqc, ws)
+
+
+def _sue_intra_bwd(kf, qc, g, cidx, alpha, dfeat, B, N, Hn, Cn, A, D, dg, dkf, dqc, ws):
     L.check(L.lib().nnr_sue_intra_bwd(_p(kf), _p(qc), _p(g), _p(cidx), _p(alpha), _p(dfeat), B, N, Hn, Cn, A, D, _p(dg), _p(dkf), _p(dqc),
                                       _p(ws), _s()), 'nnr_sue_intra_bwd')
 
@@ -804,6 +870,11 @@ def logits_bwd(dlogits, user, cand, B, N, D, duser, dcand, accumulate=False):
 
 def sumsq(g, out):
     """out[0] = sum g^2 (stored; fixed-order sum)."""
+    with _hbm_span('sumsq', 4.0, g.numel()):
+        return _sumsq(g, out)
+
+
+def _sumsq(g, out):
     L.check(L.lib().nnr_sumsq(_p(g), C.c_long(g.numel()), _p(out), _s()), 'nnr_sumsq')
 
 
@@ -828,6 +899,11 @@ def click_loss(user, cand, B, N, D, logits, loss, dlogits, duser, dcand, terms_w
 
 
 def clip_adam(p, g, m, v, sumsq_buf, grad_scale, clip, lr, beta1, beta2, eps, wd, step):
+    with _hbm_span('clip_adam', 7 * 4.0, p.numel()):                              # p, g, m, v read; p, m, v written
+        return _clip_adam(p, g, m, v, sumsq_buf, grad_scale, clip, lr, beta1, beta2, eps, wd, step)
+
+
+def _clip_adam(p, g, m, v, sumsq_buf, grad_scale, clip, lr, beta1, beta2, eps, wd, step):
     L.check(L.lib().nnr_clip_adam(_p(p), _p(g), _p(m), _p(v), C.c_long(p.numel()), _p(sumsq_buf), C.c_float(grad_scale), C.c_float(clip),
                                   C.c_float(lr), C.c_float(beta1), C.c_float(beta2), C.c_float(eps), C.c_float(wd), int(step), _s()),
             'nnr_clip_adam')
@@ -837,6 +913,26 @@ def mhsa_fwd(qkv, mask, n, Lq, heads, dh, out, prob, p=0.0, seed=0):
     """p > 0: the dropout that follows the attention is applied in the output stage (== ops.dropout(out, p, seed))."""
     if mask is not None and mask.dtype == torch.bool:
         mask = mask.view(torch.uint8)
+    with _mhsa_span('mhsa_fwd', n, Lq, heads, dh, 4.0, 4.0):          # S = Q K^T and O = P V: 4 L^2 d FLOP per head; Q, K, V read, O written
+        return _mhsa_fwd(qkv, mask, n, Lq, heads, dh, out, prob, p, seed)
+
+
+def _mhsa_span(family, n, Lq, heads, dh, flop_units, arrays):
+    if not _prof.active():
+        return _NOSPAN
+
+    def flops(vals=None):
+        return flop_units * Lq * Lq * dh * heads * n
+
+    def nbytes(vals=None):
+        return arrays * 4.0 * n * Lq * heads * dh
+    flops.dyn = []
+    flops.bytes_fn = nbytes
+    flops.tag = 'n%d L%d h%d d%d' % (n, Lq, heads, dh)
+    return _prof.span(family, flops)
+
+
+def _mhsa_fwd(qkv, mask, n, Lq, heads, dh, out, prob, p, seed):
     L.check(L.lib().nnr_mhsa_fwd(_p(qkv), _p(mask), n, Lq, heads, dh, C.c_float(1.0 / math.sqrt(dh)), _p(out), _p(prob),
                                  C.c_float(p), C.c_uint32(seed & 0xFFFFFFFF), _s()), 'nnr_mhsa_fwd')
 
@@ -844,6 +940,12 @@ def mhsa_fwd(qkv, mask, n, Lq, heads, dh, out, prob, p=0.0, seed=0):
 def mhsa_bwd(qkv, mask, prob, dout, n, Lq, heads, dh, dqkv, p=0.0, seed=0):
     if mask is not None and mask.dtype == torch.bool:
         mask = mask.view(torch.uint8)
+    # P recomputed (2), dP = dO V^T (2), dV = P^T dO (2), dQ = dS K (2), dK = dS^T Q (2): 10 L^2 d FLOP per head; Q, K, V, dO read, dQ, dK, dV written
+    with _mhsa_span('mhsa_bwd', n, Lq, heads, dh, 10.0, 7.0):
+        return _mhsa_bwd(qkv, mask, prob, dout, n, Lq, heads, dh, dqkv, p, seed)
+
+
+def _mhsa_bwd(qkv, mask, prob, dout, n, Lq, heads, dh, dqkv, p, seed):
     L.check(L.lib().nnr_mhsa_bwd(_p(qkv), _p(mask), _p(prob), _p(dout), n, Lq, heads, dh, C.c_float(1.0 / math.sqrt(dh)), _p(dqkv),
                                  C.c_float(p), C.c_uint32(seed & 0xFFFFFFFF), _s()), 'nnr_mhsa_bwd')
 
@@ -858,6 +960,11 @@ def embed_gather(table, idx, p, seed, out=None, dyn=None):
     n, dim = idx.numel(), table.shape[1]
     if out is None:
         out = torch.empty((n, dim), device=table.device, dtype=torch.float32)
+    with _hbm_span('embed_gather', 2 * 4.0 * dim + 4.0, n, dyn=dyn):              # a table row read, a row written, an id read
+        return _embed_gather(table, idx, p, seed, out, dyn, n, dim)
+
+
+def _embed_gather(table, idx, p, seed, out, dyn, n, dim):
     L.check(L.lib().nnr_embed_gather(_p(table), _p(idx), C.c_long(n), _p(dyn), dim, _p(out), C.c_float(p), C.c_uint32(seed & 0xFFFFFFFF), _s()),
             'nnr_embed_gather')
     return out
@@ -865,6 +972,11 @@ def embed_gather(table, idx, p, seed, out=None, dyn=None):
 
 def embed_scatter(dout, idx, dtable, p, seed, dyn=None):
     n, dim = idx.numel(), dtable.shape[1]
+    with _hbm_span('embed_scatter', 2 * 4.0 * dim + 4.0, n, dyn=dyn):             # a gradient row read, a table-gradient row added to, an id read
+        return _embed_scatter(dout, idx, dtable, p, seed, dyn, n, dim)
+
+
+def _embed_scatter(dout, idx, dtable, p, seed, dyn, n, dim):
     if dyn is not None:
         L.check(L.lib().nnr_embed_scatter_dyn(_p(dout), _p(idx), C.c_long(n), _p(dyn), dim, _p(dtable), C.c_float(p), C.c_uint32(seed & 0xFFFFFFFF),
                                               _s()), 'nnr_embed_scatter_dyn')

@@ -103,14 +103,115 @@ def _all_records():
         yield family, fn, ms
 
 
-def summary():
+def _bytes_of(fn):
+    if hasattr(fn, 'op_bytes'):
+        return float(fn.op_bytes)
+    if hasattr(fn, 'bytes_fn'):
+        return float(fn.bytes_fn())
+    return None
+
+
+def summary(hbm=False):
+    """Per family: summed HIP-event time, algorithmic FLOPs and launches.  hbm=False: the MFMA-bound families (GEMMs, recurrences);
+    hbm=True: the HBM-bound ones (ops._hbm_span: gathers / scatters / pools / element-wise / optimizer), with their algorithmic bytes."""
     fam = {}
     for family, fn, ms in _all_records():
-        d = fam.setdefault(family, dict(ms=0.0, flops=0.0, launches=0))
+        if bool(getattr(fn, 'hbm', False)) != bool(hbm):
+            continue
+        d = fam.setdefault(family, dict(ms=0.0, flops=0.0, launches=0, bytes=0.0))
         d['ms'] += ms
         d['flops'] += float(fn())
         d['launches'] += 1
+        if hbm:
+            d['bytes'] += _bytes_of(fn) or 0.0
     return fam
+
+
+# HBM-bound families -> the kernels one call launches (names as tools/pmc_traffic.py shortens them; prefix match), kernels per call
+HBM_KERNELS = {
+    'embed_gather': (('embed_gather_kernel',), 1), 'embed_scatter': (('embed_scatter_kernel', 'embed_scatter_sorted_kernel'), 1),
+    'pool_fwd': (('pool_kernel<false',), 1), 'pool_bwd': (('pool_kernel<true',), 1), 'gate_bwd': (('gate_bwd_kernel',), 1),
+    'gcn_aggregate_fwd': (('gcn_aggregate_kernel<0',), 1), 'gcn_aggregate_bwd': (('gcn_aggregate_kernel<1',), 1),
+    'sue_intra_fwd': (('sue_intra_fwd_kernel',), 1), 'sue_intra_bwd': (('sue_intra_bwd_ds_kernel', 'sue_intra_bwd_dg_kernel'), 2),
+    'clip_adam': (('adam_kernel',), 1), 'sumsq': (('sumsq_kernel',), 1),
+}
+PEAK_HBM_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable by a float4 copy)
+
+
+def pmc_traffic_family(family):
+    """Counter HBM bytes per CALL of an HBM-bound family from the committed PMC passes (same build only), or None."""
+    d = _pmc_file()
+    spec = HBM_KERNELS.get(family)
+    if d is None or spec is None:
+        return None
+    names, per_call = spec
+    tot = launches = 0.0
+    for k in d.get('kernels', []):
+        if any(k['kernel'].startswith(n) for n in names):
+            tot += k['hbm_bytes_per_launch'] * k['launches']
+            launches += k['launches']
+    return round(tot / (launches / per_call)) if launches else None
+
+
+def mfma_busy(kernel_prefix):
+    """Matrix-pipe busy fraction of the kernels whose name starts with `kernel_prefix` from the committed counter pass
+    (profiles/pmc_mfma_busy.json, written by tools/pmc_mfma_busy.py from `rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE`
+    of bench.py --config mhsa), quoted only when that file was collected on THIS build; else None."""
+    import json
+    import os
+    from . import _lib
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'pmc_mfma_busy.json')
+    try:
+        d = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    have, now = d.get('build_id') or {}, _lib.build_id()
+    if not (have.get('src_sha256') == now['src_sha256'] or (have.get('lib_sha256') and have.get('lib_sha256') == now['lib_sha256'])):
+        return None
+    for k in d.get('kernels', []):
+        if k['kernel'].startswith(kernel_prefix):
+            return k
+    return None
+
+
+def mhsa_roofline(peak_tflops):
+    """bench.py --config mhsa, `roofline.mhsa`: the MFMA attention core (csrc/mhsa.hip) per direction -- algorithmic FLOPs of the
+    Q K^T / P V contractions over live HIP-event time against the fp32 MFMA peak (= the arithmetic MFMA utilisation), its algorithmic
+    bytes against the HBM peak (the kernel is HBM-bound: 32 x 32 x 20 attention matrices), and the matrix-pipe busy counter."""
+    fam = summary()
+    out = {}
+    for k, kern in (('mhsa_fwd', 'mhsa_fwd_kernel'), ('mhsa_bwd', 'mhsa_bwd_kernel')):
+        v = fam.get(k)
+        if not v or v['ms'] <= 0:
+            continue
+        tf = v['flops'] / (v['ms'] * 1e-3) / 1e12
+        nbytes = sum((_bytes_of(fn) or 0.0) for f, fn, _ in _all_records() if f == k)
+        gbs = nbytes / (v['ms'] * 1e-3) / 1e9
+        busy = mfma_busy(kern)
+        out[k] = {'kernel': kern, 'launches': v['launches'], 'avg_launch_us': round(1000 * v['ms'] / v['launches'], 2),
+                  'mfma_tflops': round(tf, 2), 'mfma_utilisation': round(tf / peak_tflops, 4),
+                  'hbm_gb_s': round(gbs, 1), 'hbm_frac': round(gbs / PEAK_HBM_GBS, 4),
+                  'mfma_busy_counter': None if busy is None else busy.get('mfma_busy'),
+                  'mfma_busy_source': 'profiles/pmc_mfma_busy.json (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), same build only)'}
+    return out or None
+
+
+def hbm_roofline():
+    """bench.py `roofline.hbm`: per HBM-bound family of the step, algorithmic bytes / live HIP-event time against the 8 TB/s peak,
+    beside the counter bytes of the committed PMC passes.  The durations are IN-STEP (the launch shares the chip with up to three
+    other streams), so `frac` is a lower bound of what the kernel reaches alone."""
+    fam = summary(hbm=True)
+    out = {}
+    for k, v in sorted(fam.items(), key=lambda kv: -kv[1]['ms']):
+        if v['ms'] <= 0 or not v['launches']:
+            continue
+        gbs = v['bytes'] / (v['ms'] * 1e-3) / 1e9
+        t = pmc_traffic_family(k)
+        per = v['bytes'] / v['launches']
+        out[k] = {'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 4), 'launches': v['launches'],
+                  'avg_launch_us': round(1000 * v['ms'] / v['launches'], 2), 'algorithmic_bytes_per_launch': round(per),
+                  'traffic': t, 'traffic_over_algorithmic': None if not t else round(t / per, 2)}
+    return out or None
 
 
 _PMC = {}
@@ -213,6 +314,7 @@ def roofline(peak_tflops, sampled_steps=None, ms_per_step=None):
                          'launches': v['launches']} for k, v in sorted(fam.items(), key=lambda kv: -kv[1]['ms'])},
         # whole-step view: the launches of several HIP streams overlap, so per-kernel wall durations double-count the chip;
         # algorithmic FLOPs of all instrumented GEMM / recurrence launches of one step over the step time do not
+        'hbm': hbm_roofline(),
         'step': (None if not (sampled_steps and ms_per_step) else (lambda tf: {'gflop': round(sum(v['flops'] for v in fam.values()) / sampled_steps / 1e9, 1),
                  'tflops': round(tf, 2), 'frac': round(tf / peak_tflops, 4)})(sum(v['flops'] for v in fam.values()) / sampled_steps / (ms_per_step * 1e-3) / 1e12)),
     }

@@ -19,6 +19,18 @@ def supported(model):
             and model.news_encoder.tie_order == 'stable' and NE._CNE_UNION and model.training)
 
 
+_ID_INPUTS = (1, 2, 3, 6, 13, 14, 15, 18)       # category / subCategory / title / content ids of the history and the candidate call
+
+
+def recordable(batch):
+    """May a launch tape be recorded from a step on `batch`?  Every tensor must be used where it lies: a non-contiguous tensor or an
+    int64 id tensor would be converted by a torch op outside the library (news_encoders._i32 / .contiguous()) into a temporary the
+    tape knows nothing about.  Such batches (not what the reference's DataLoader or DeviceCorpus produce: SURVEY.md appendix C) run
+    the native step call by call."""
+    return (all(t.is_cuda and t.is_contiguous() for t in batch) and all(batch[i].dtype == torch.int32 for i in _ID_INPUTS)
+            and batch[11].dim() == 2 and batch[11].element_size() == 1 and batch[12].dtype == torch.int64)
+
+
 def forward_backward(trainer, batch):
     """Forward + loss + backward of one batch (21 device tensors, Model.forward order) into the trainer's flat gradient buffer.
     Returns (logits [B, N], loss []) -- fresh tensors of this call."""

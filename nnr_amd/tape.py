@@ -28,6 +28,7 @@ _INT_TYPES = (C.c_int, C.c_long, C.c_size_t, C.c_uint32, C.c_ulong, C.c_int64, C
 ACTIVE = [None]            # the tape that is recording right now
 VALUE_KINDS = {'news_seed': 0, 'user_seed': 1, 'adam_step': 2}
 _VALUE_ARGS = {('nnr_clip_adam', 13): 'adam_step'}            # (entry point, argument index) -> value kind, for plain integers
+_HANDLE_ARGS = {'nnr_dp_allreduce', 'nnr_dp_broadcast'}       # their FIRST pointer is an opaque host handle (the communicator), not device memory
 
 
 TAG_ALL = [False]
@@ -79,10 +80,23 @@ class _Proxy:
 
 
 class Tape:
-    def __init__(self, inputs, seeds):
+    def __init__(self, inputs, seeds, known=()):
         """inputs: the batch tensors of the recorded step (pointers into them become input patches); seeds: {'news_seed': int,
-        'user_seed': int} of the recorded step (uint32 arguments within 64 of one of them become value patches)."""
+        'user_seed': int} of the recorded step (uint32 arguments within 64 of one of them become value patches); known: tensors that
+        outlive the tape by construction (the trainer's flat parameter / gradient / moment buffers, of which every parameter is a
+        view).  Every device pointer that reaches a recorded call must resolve to an input, a `known` buffer or a buffer the tape
+        itself keeps alive (torch.empty* results of the step, ops.tape_keep'd caches): anything else -- a temporary made by a torch
+        op outside the library, e.g. an int64 -> int32 id conversion or a .contiguous() copy -- is listed in `violations` and the
+        trainer discards the recording (round-3 advisor: such a pointer would be baked in as a constant and read stale memory)."""
+        d = (int(seeds['news_seed']) - int(seeds['user_seed'])) & 0xFFFFFFFF
+        if min(d, (1 << 32) - d) < 128:
+            # the two per-step seeds advance by different strides; this close together a derived seed (base + small offset) of one
+            # encoder would be attributed to the other's base and replays would draw wrong masks: record on another step
+            raise TapeError('news / user dropout seeds of this step are within 128 of each other: not recordable (record the next step)')
         self.lib = L.lib()
+        self.known = [t for t in known if torch.is_tensor(t)]
+        self.violations = []                # (entry point, argument / field, pointer) that resolved to nothing the tape can vouch for
+        self._ranges, self._ranged = [], 0
         self.h = C.c_void_p()
         L.check(self.lib.nnr_tape_create(C.byref(self.h)), 'nnr_tape_create')
         self.inputs = [(t.data_ptr(), t.data_ptr() + t.numel() * t.element_size(), tuple(t.shape), t.dtype) for t in inputs]
@@ -174,6 +188,29 @@ class Tape:
                 return k, ptr - lo
         return None
 
+    def _vouched(self, ptr):
+        """Is `ptr` inside a buffer that stays valid for the tape's lifetime (kept by the tape, or `known`)?"""
+        if self._ranged == 0:
+            for t in self.known:
+                st = t.untyped_storage()
+                self._ranges.append((st.data_ptr(), st.data_ptr() + st.nbytes()))
+        keep = self.keep
+        while self._ranged < len(keep):
+            t = keep[self._ranged]
+            self._ranged += 1
+            if torch.is_tensor(t):
+                st = t.untyped_storage()
+                self._ranges.append((st.data_ptr(), st.data_ptr() + st.nbytes()))
+        self._ranged = max(self._ranged, 1)
+        for lo, hi in reversed(self._ranges):          # the most recent allocations are the likeliest hits
+            if lo <= ptr < hi:
+                return True
+        return False
+
+    def _check_ptr(self, name, where, ptr):
+        if ptr and self._input_of(ptr) is None and not self._vouched(ptr):
+            self.violations.append((name, where, ptr))
+
     def _seed_kind(self, v):
         for name in ('news_seed', 'user_seed'):
             d = (v - self.seeds[name]) & 0xFFFFFFFF
@@ -202,6 +239,8 @@ class Tape:
                 hit = self._input_of(v) if v else None
                 if hit is not None:
                     patches.append(('slot', 8 * i, 1000 + hit[0], 8, hit[1]))
+                elif v and not (i == 0 and name in _HANDLE_ARGS):
+                    self._check_ptr(name, i, v)
             elif isinstance(a, C.c_float):
                 v = struct.unpack('<I', struct.pack('<f', a.value))[0]
             elif isinstance(a, C.c_uint32):
@@ -216,7 +255,7 @@ class Tape:
                 v = 0
                 bi = len(blobs)
                 blobs.append((i, obj, C.sizeof(obj)))
-                self._blob_patches(obj, 0, bi, patches)
+                self._blob_patches(obj, 0, bi, patches, name)
             else:
                 raise TapeError('%s: argument %d of type %s cannot be recorded' % (name, i, type(a).__name__))
             slots[i] = v
@@ -241,12 +280,12 @@ class Tape:
             L.check(self.lib.nnr_tape_patch(self.h, C.c_size_t(base + off), kind, width, C.c_int64(addend)), 'nnr_tape_patch')
         self.calls += 1
 
-    def _blob_patches(self, obj, base, bi, patches):
+    def _blob_patches(self, obj, base, bi, patches, name=''):
         if isinstance(obj, C.Array):
             step = C.sizeof(obj._type_)
             if issubclass(obj._type_, C.Structure):
                 for j in range(len(obj)):
-                    self._blob_patches(obj[j], base + j * step, bi, patches)
+                    self._blob_patches(obj[j], base + j * step, bi, patches, name)
             return
         for fname, ftype in obj._fields_:
             off = base + getattr(type(obj), fname).offset
@@ -255,6 +294,8 @@ class Tape:
                 hit = self._input_of(v) if v else None
                 if hit is not None:
                     patches.append((bi, off, 1000 + hit[0], 8, hit[1]))
+                elif v:
+                    self._check_ptr(name, fname, v)
             elif ftype is C.c_uint32 and fname.endswith('seed'):
                 v = getattr(obj, fname)
                 if v and (not hasattr(obj, 'drop_target') or obj.drop_target):

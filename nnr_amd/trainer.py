@@ -82,7 +82,7 @@ class _Const:
 
     def __init__(self, fn, value):
         self.value = value
-        for k in ('tag', 'tn_dims', 'op_bytes'):
+        for k in ('tag', 'tn_dims', 'op_bytes', 'hbm'):
             if hasattr(fn, k):
                 setattr(self, k, getattr(fn, k))
 
@@ -99,6 +99,8 @@ class Trainer:
         self.native = _NATIVE_STEP if native is None else bool(native)
         self.replay = (_REPLAY and (dp.world_size() == 1 or _REPLAY_DP)) if replay is None else bool(replay)
         self.tapes = {}              # batch-shape key -> nnr_amd.tape.Tape
+        self.unrecordable = set()    # batch-shape keys whose recording was discarded (tape.violations): they stay call by call
+        self.tape_violations = []    # diagnostics: the violations of the last discarded recording
         self.native_steps = {}       # batch-shape key -> eager native steps run so far
         self.timing = False          # set by the caller (bench.py): the next step carries HIP events around its GEMM / recurrence calls
         self._snaps = {}             # tape -> [snapshot of the device-side sizes per timing replay]
@@ -205,26 +207,46 @@ class Trainer:
                 self._snapshot_sizes(tape)
             PARAM_EPOCH[0] += 1
             self.last_path = 'replay'
-            return tape.out
+            # tape.out are the recorded step's OWN logits / loss buffers, overwritten by the next replay: hand out copies, as the
+            # call-by-call and autograd paths hand out fresh tensors (a loop that keeps `loss` for later -- epoch-loss lists, logging
+            # every k steps -- would otherwise read the last step's values; round-3 advisor).  Two device-to-device copies of 1.3 KB.
+            return tuple(ops.copy_bytes(torch.empty_like(t), t) for t in tape.out)
         n = self.native_steps.get(key, 0)
         self.native_steps[key] = n + 1
         can_record = (self.replay and tape is None and n >= _WARM_STEPS and not eager_profile and not ops.ONE_STREAM[0] and len(self.tapes) < 4
-                      and not torch.cuda.is_current_stream_capturing())
-        if not can_record:
+                      and not torch.cuda.is_current_stream_capturing() and key not in self.unrecordable and native_step.recordable(batch))
+        tape = None
+        if can_record:
+            from .tape import Tape, TapeError
+            try:
+                tape = Tape(batch, self._next_seeds(), known=(self.flat.flat, self.flat.grad, self.m, self.v, self.sumsq))
+            except TapeError:
+                tape = None                             # (this step's two dropout seeds are too close to tell apart: record the next one)
+        if tape is None:
             self.last_path = 'native'
             logits, loss = self._body(batch, native_step)
             return logits, loss
-        from .tape import Tape
-        tape = Tape(batch, self._next_seeds())
         tape.hyper = hyper
         try:
-            tape.out = tape.record(lambda: self._body(batch, native_step))
+            out = tape.record(lambda: self._body(batch, native_step))
         except Exception:
             tape.close()
             raise
+        if tape.violations:
+            # the step itself ran eagerly and is complete; only the recording is unusable (a device pointer that belongs to neither the
+            # batch, nor a buffer the tape keeps alive, nor the flat parameter / gradient / moment buffers reached a call): stay call by call
+            import warnings
+            warnings.warn('nnr_amd: launch tape discarded, %d recorded pointer(s) of unknown provenance (first: %s argument %s); this batch '
+                          'shape stays on the call-by-call native step' % (len(tape.violations), tape.violations[0][0], tape.violations[0][1]))
+            self.tape_violations = list(tape.violations)
+            tape.close()
+            self.unrecordable.add(key)
+            self.last_path = 'native'
+            return out
+        tape.out = out
         self.tapes[key] = tape
         self.last_path = 'record'
-        return tape.out
+        return tuple(ops.copy_bytes(torch.empty_like(t), t) for t in tape.out)
 
     def _snapshot_sizes(self, tape):
         """After a timing replay: copy the device-side sizes (live token counts) the timed launches depended on; the buffers are

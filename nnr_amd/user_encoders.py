@@ -117,7 +117,7 @@ def gcn_backward(gcn, gsv, dy, graph, leaf):
             continue
         ops.relu_drop_bwd(dy, gsv['rs'][l], dS, dx, pl, gsv['seed0'] + l)        # dx = masked dy (residual branch)
         if not gcn.residual:
-            dx.zero_()
+            ops.fill_zero(dx)            # (a C-ABI call, not dx.zero_(): a torch fill is not part of a recorded launch tape -- round-3 advisor)
         if gsv['lns'][l] is not None:                                              # through the LayerNorm: dS := d(A z + b)
             xhat, rstd = gsv['lns'][l]
             ln = layer.layer_normalization
@@ -168,7 +168,10 @@ def sue_forward(mod, hist, cand, graph, cmask, cidx):
     # (+ the in-place `user_history_category_mask[:, -1] = 1` of userEncoders.py:73 in the same launch)
     fix = cmask if (cmask.is_cuda and cmask.dim() == 2 and cmask.is_contiguous() and tuple(cmask.shape) == (B, Kc + 1)) else None
     if fix is None:
-        cmask[:, -1] = 1
+        if cmask.is_cuda and cmask.dim() == 2 and cmask.is_contiguous() and cmask.element_size() == 1:
+            ops.fill_column_u8(cmask, -1, 1)            # (a C-ABI call: recordable)
+        else:
+            cmask[:, -1] = 1
     ops.sue_x0_fwd(hist, mod.proxy_node_embedding, x0, B, Hn, Kc, D, p, seed + 1, cmask_fix=fix)
     # ---- GCN
     x, gsv = gcn_forward(mod.gcn, x0, graph, seed + 10, mod.training)

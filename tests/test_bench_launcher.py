@@ -27,16 +27,30 @@ def test_bench_self_launches_ranks_and_exchanges_gradients(n):
     r, out = _run(['--gpus', str(n), '--plumbing_check', '--steps', '3'])
     assert r.returncode == 0, r.stderr[-2000:]
     assert out is not None and out['n_gpus'] == n and out['params_equal_on_all_ranks_and_expected'] is True
-    assert out['scaling'] == 'weak' and out['global_batch'] == 64 * n
+    # the headline follows the reference's flag semantics: --batch_size (default 64) is the GLOBAL batch, every rank takes
+    # batch_size // world_size impressions (config.py:116, trainer.py:218) -- the same optimisation problem at every N
+    assert out['scaling'] == 'strong' and out['global_batch'] == 64 and out['per_gpu_batch'] == 64 // n
     names = [b['name'] for b in out['buckets']['buckets']]
     assert names == ['early (user encoder)', 'late']
 
 
-def test_bench_strong_scaling_flag_follows_the_reference_batch_semantics():
-    """--global_batch G == the reference's `--batch_size G --world_size N`: per-rank batch G // N (trainer.py:218)."""
+def test_bench_batch_flags_follow_the_reference_batch_semantics():
+    """`--batch_size G` on N GPUs = the reference's `--batch_size G --world_size N`: per-rank batch G // N (trainer.py:218), an uneven
+    remainder dropped as there; --weak makes G the per-GPU batch; --global_batch is the old spelling of --batch_size."""
+    r, out = _run(['--gpus', '2', '--plumbing_check', '--steps', '1', '--batch_size', '48'])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert out['scaling'] == 'strong' and out['per_gpu_batch'] == 24 and out['global_batch'] == 48
     r, out = _run(['--gpus', '2', '--plumbing_check', '--steps', '1', '--global_batch', '64'])
     assert r.returncode == 0, r.stderr[-2000:]
     assert out['scaling'] == 'strong' and out['per_gpu_batch'] == 32 and out['global_batch'] == 64
+    r, out = _run(['--gpus', '2', '--plumbing_check', '--steps', '1', '--weak'])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert out['scaling'] == 'weak' and out['per_gpu_batch'] == 64 and out['global_batch'] == 128
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.shard_sizes(64, 8, False) == (8, 64) and bench.shard_sizes(64, 3, False) == (21, 63) and bench.shard_sizes(64, 8, True) == (64, 512)
+    a = bench.parse(['--config', 'mhsa', '--gpus', '4'])
+    assert (a.news_encoder, a.user_encoder, a.batch_size, a.weak) == ('MHSA', 'MHSA', 64, False)
 
 
 def test_gradient_exchange_buckets_cover_the_flat_buffer_exactly_once():

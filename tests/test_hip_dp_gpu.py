@@ -20,11 +20,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _launch(world, backend, port, native=False, extra=()):
+def _launch(world, backend, port, native=None, extra=()):
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'NNR_DP_NATIVE')}
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')           # dmabuf IPC: RCCL's intra-node transport needs it on this image
-    if native:
-        env['NNR_DP_NATIVE'] = '1'
+    if native is not None:
+        env['NNR_DP_NATIVE'] = '1' if native else '0'           # (None: the product's default -- the C-ABI binding on an "nccl" job)
     if backend == 'gloo':
         # two PROCESSES share GPU 0 here: the CU-pair recurrence needs both workgroups of a pair resident at once, which two processes
         # dispatching into the same CUs cannot guarantee each other (bounded spins then run into their time-outs: one run of ~20 took
@@ -78,7 +78,7 @@ def test_rccl_ranks_one_per_gpu(binding):
     out = _launch(2, 'nccl', 29581 + (binding == 'native'), native=(binding == 'native'))
     _check(out, 2)
     assert out['rccl_ranks'] == 2 and out['backend'] == 'nccl'
-    assert out['binding'] == ('C-ABI nnr_dp_allreduce' if binding == 'native' else 'torch.distributed all_reduce')
+    assert out['binding'].startswith('C-ABI nnr_dp_allreduce' if binding == 'native' else 'torch.distributed all_reduce')
 
 
 def test_rccl_all_visible_gpus():
@@ -89,3 +89,4 @@ def test_rccl_all_visible_gpus():
     w = 8 if n >= 8 else 4
     out = _launch(w, 'nccl', 29591, extra=('--skip_epoch',))
     assert out['ok'] and out['rccl_ranks'] == w and out['grad_err_vs_oracle_mean_of_shard_gradients'] <= 1e-4
+    assert out['binding'].startswith('C-ABI nnr_dp_allreduce')             # the default binding of an RCCL job

@@ -300,5 +300,8 @@ def test_bench_launcher_runs_two_ranks_on_one_gpu():
                        capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
-    assert out['n_gpus'] == 2 and out['scaling'] == 'weak' and out['config']['global_batch'] == 16 and out['value'] > 0
-    assert out['strong_scaling']['per_gpu_batch'] == 4 and out['config']['recurrence_exchange_timeouts'] == 0
+    # headline = the reference's batch semantics (--batch_size is the GLOBAL batch, trainer.py:218); weak scaling is the secondary object
+    assert out['n_gpus'] == 2 and out['scaling'] == 'strong' and out['config']['global_batch'] == 8 and out['config']['per_gpu_batch'] == 4 and out['value'] > 0
+    assert 'bs=8' in out['metric'] and out['weak_scaling']['per_gpu_batch'] == 8 and out['weak_scaling']['global_batch'] == 16
+    assert out['config']['recurrence_exchange_timeouts'] == 0 and 'device-resident corpus' in out['config']['batches']
+    assert out['config']['gradient_exchange']['binding'].startswith('torch.distributed')         # gloo test mode: never the RCCL binding

@@ -83,7 +83,7 @@ def test_recording_refuses_what_it_cannot_replay():
     from nnr_amd import ops
     from nnr_amd.tape import Tape, TapeError
     x = torch.randn(64, device='cuda')
-    t = Tape([x], {'news_seed': 10, 'user_seed': 20})
+    t = Tape([x], {'news_seed': 10, 'user_seed': 1 << 20})
     with pytest.raises(TapeError):
         t.record(lambda: torch.zeros(8, device='cuda'))                # a framework fill kernel would be missing from the tape
     t.close()
@@ -116,23 +116,24 @@ def test_native_step_equals_autograd_step():
     assert float((ga - gn).abs().max()) <= 2e-5 * float(ga.abs().max())
 
 
-@pytest.mark.parametrize('batch_size', [4, 9])
-def test_warmup_record_replay_against_oracle_dropout_on(batch_size):
+@pytest.mark.parametrize('batch_size,flags', [(4, []), (9, []), (5, ['--gcn_layer_norm', '--no_gcn_residual']), (5, ['--no_gcn_residual'])])
+def test_warmup_record_replay_against_oracle_dropout_on(batch_size, flags):
     """Seven consecutive optimizer steps, dropout 0.2 ON, each compared with the oracle (masks of that step injected): steps 0-1 are
     issued call by call, step 2 records the tape, steps 3-6 are native replays -- on different batches (input patches), with advancing
-    seeds and Adam step numbers (value patches)."""
+    seeds and Adam step numbers (value patches).  With --gcn_layer_norm --no_gcn_residual the GCN backward takes its non-fused branch,
+    whose residual-gradient fill used to be a torch op outside the tape (round-3 advisor, high): every replayed step was wrong."""
     import hip_masks
     from nnr_amd import _lib
     from nnr_amd.trainer import Trainer
     from oracle import nnr_oracle as O
-    cfg = make_config(['--news_encoder=CNE', '--user_encoder=SUE'], corpus_sizes=dict(vocabulary_size=900), tie_order='stable', batch_size=batch_size)
+    cfg = make_config(['--news_encoder=CNE', '--user_encoder=SUE'] + flags, corpus_sizes=dict(vocabulary_size=900), tie_order='stable', batch_size=batch_size)
     assert cfg.dropout_rate == 0.2
     model, ref = _models(cfg, seed=batch_size)
     tr = Trainer(model, cfg, native=True, replay=True)
     opt = O.make_optimizer(ref, cfg)
     corpus = SynthCorpus(SynthSpec(vocabulary_size=900, news_pool=500, seed=4))
     rng = np.random.default_rng(2)
-    paths, calls = [], []
+    paths, calls, kept = [], [], []
     for step in range(7):
         batch = corpus.batch(batch_size, rng)
         dev = to_torch(batch, 'cuda')
@@ -148,9 +149,15 @@ def test_warmup_record_replay_against_oracle_dropout_on(batch_size):
         err = float((logits.cpu() - rl).abs().max())
         bar = 1e-4 * max(1.0, float(rl.abs().max()))
         assert err <= bar and abs(float(loss) - rloss) <= bar, (step, paths, err, bar, float(loss), rloss)
+        kept.append((loss, logits, rloss, rl))
         assert bool((dev[16][:, :, 0]).all()) and bool(dev[11][:, -1].all())          # the in-place mask mutations reached THIS batch's tensors
     assert paths == ['native', 'native', 'record', 'replay', 'replay', 'replay', 'replay'], paths
     assert max(calls[3:]) <= 10 and min(calls[:2]) > 100, calls
+    assert not tr.tape_violations
+    # the tensors a step returned still hold THAT step's values after later replays (they are copies, not the tape's own buffers)
+    for step, (loss, logits, rloss, rl) in enumerate(kept):
+        bar = 1e-4 * max(1.0, float(rl.abs().max()))
+        assert abs(float(loss) - rloss) <= bar and float((logits.cpu() - rl).abs().max()) <= bar, step
     rp = dict(ref.named_parameters())
     for k, p in model.named_parameters():
         assert float((p.detach().cpu() - rp[k].detach()).abs().max()) <= 7 * 1e-4 * 1.01 + 1e-4, k       # Adam: <= lr per step per element
@@ -182,6 +189,57 @@ def test_other_shapes_and_modes_fall_back():
     for _ in range(4):
         tr2.train_step(to_torch(corpus.batch(4, rng), 'cuda'))
     assert tr2.last_path == 'autograd' and not tr2.tapes
+
+
+def test_batches_the_library_cannot_use_in_place_are_never_recorded():
+    """Round-3 advisor: an int64 id tensor (or a non-contiguous one) is converted by a torch op outside the library into a temporary
+    the tape cannot vouch for.  Such batches run the native step call by call -- correct results, no tape.  And a recording that does
+    meet a pointer of unknown provenance is discarded, not replayed."""
+    from nnr_amd import ops, step as native_step
+    from nnr_amd.trainer import Trainer
+    cfg = make_config(['--news_encoder=CNE', '--user_encoder=SUE'], corpus_sizes=dict(vocabulary_size=900), tie_order='stable', batch_size=4,
+                      dropout_rate=0.0)
+    model, _ = _models(cfg, seed=9)
+    tr = Trainer(model, cfg)
+    corpus = SynthCorpus(SynthSpec(vocabulary_size=900, news_pool=500, seed=10))
+    b = corpus.batch(4, np.random.default_rng(8))
+    good = to_torch(b, 'cuda')
+    wide = [t.long() if i in native_step._ID_INPUTS else t for i, t in enumerate(good)]
+    assert native_step.recordable(good) and not native_step.recordable(wide)
+    ref_logits = None
+    tr.lr = 0.0
+    for i in range(5):
+        logits, _ = tr.train_step([t.clone() for t in wide])
+        assert tr.last_path == 'native' and not tr.tapes
+        ref_logits = logits if ref_logits is None else ref_logits
+        assert torch.equal(logits, ref_logits)
+    for i in range(4):
+        logits, _ = tr.train_step([t.clone() for t in good])
+    assert tr.last_path == 'replay' and torch.equal(logits, ref_logits)            # same batch, lr 0, dropout 0: same logits either way
+    # a foreign pointer inside a recording: the tape is discarded and the shape stays call by call
+    tr2 = Trainer(model, cfg)
+    tr2.lr = 0.0
+    stray = torch.zeros(64, device='cuda')                                         # allocated OUTSIDE the step: the tape does not keep it
+    orig = native_step.forward_backward
+
+    def with_stray(trainer, batch):
+        ops.fill_zero(stray)
+        return orig(trainer, batch)
+    native_step.forward_backward = with_stray
+    try:
+        import warnings
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter('always')
+            paths = []
+            for i in range(5):
+                logits, _ = tr2.train_step([t.clone() for t in good])
+                paths.append(tr2.last_path)
+        assert paths == ['native'] * 5 and not tr2.tapes and len(tr2.unrecordable) == 1, paths
+        assert tr2.tape_violations and tr2.tape_violations[0][0] == 'nnr_fill_zero'
+        assert any('unknown provenance' in str(x.message) for x in w)
+        assert torch.equal(logits, ref_logits)
+    finally:
+        native_step.forward_backward = orig
 
 
 def test_changed_hyperparameters_invalidate_the_tape():

@@ -90,3 +90,33 @@ def test_committed_counter_file_is_well_formed():
         assert k['launches'] > 0 and k['hbm_bytes_per_launch'] == pytest.approx(k['fetch_bytes_per_launch'] + k['write_bytes_per_launch'], abs=2)
     names = {k['kernel'] for k in d['kernels']}
     assert {'gemm_tn_pipe2_kernel<2, 13, 3, 2>', 'gemm_nt_pipe2_kernel<2, 5, 3, 2>', 'lstm_bwd_pair_kernel<13>'} <= names
+
+
+def test_hbm_families_get_their_own_roofline_and_stay_out_of_the_mfma_one(records, monkeypatch):
+    """`roofline.hbm`: gathers / scatters / pools / element-wise / optimizer launches carry ALGORITHMIC bytes instead of FLOPs; they are
+    priced against the 8 TB/s HBM peak, listed by time, and never become the `dominant` (MFMA) family or add to the step's FLOPs."""
+    def hb(nbytes):
+        f = _fn(0.0, op_bytes=nbytes)
+        f.hbm = True
+        return f
+    profile.TAPE_RECORDS.extend([('embed_gather', hb(2.0e8), 0.05), ('embed_gather', hb(0.5e8), 0.02), ('clip_adam', hb(7.17e8), 5.0),
+                                 ('sue_intra_bwd', hb(1.0e8), 0.1)])
+    r = profile.roofline(PEAK, sampled_steps=1, ms_per_step=2.0)
+    assert r['family'] == 'gemm_tn_pipe2_128x208' and list(r['families']) == ['gemm_tn_pipe2_128x208', 'gemm_nt_pipe2_128x80', 'lstm_bwd']
+    assert r['share_of_instrumented_time'] == round(1.2 / 1.7, 3)
+    h = r['hbm']
+    assert list(h) == ['clip_adam', 'sue_intra_bwd', 'embed_gather']
+    g = h['embed_gather']
+    assert g['launches'] == 2 and g['avg_launch_us'] == 35.0 and g['algorithmic_bytes_per_launch'] == round(1.25e8)
+    assert g['achieved'] == round(2.5e8 / 0.07e-3 / 1e9, 1) and g['peak'] == 8000.0 and g['unit'] == 'GB/s'
+    assert g['frac'] == round(2.5e8 / 0.07e-3 / 1e9 / 8000.0, 4) and g['traffic'] is None          # (no PMC file for this fake build)
+    # counter bytes per CALL from the committed file when the build matches: one call of sue_intra_bwd launches two kernels
+    d = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
+    profile._PMC.clear()
+    monkeypatch.setattr(_lib, 'build_id', lambda: d['build_id'])
+    per = {k['kernel']: (k['hbm_bytes_per_launch'], k['launches']) for k in d['kernels']}
+    names = [n for n in per if n.startswith(('sue_intra_bwd_ds_kernel', 'sue_intra_bwd_dg_kernel'))]
+    if len(names) == 2:
+        want = sum(per[n][0] * per[n][1] for n in names) / (sum(per[n][1] for n in names) / 2)
+        assert profile.pmc_traffic_family('sue_intra_bwd') == round(want)
+    assert profile.pmc_traffic_family('no_such_family') is None

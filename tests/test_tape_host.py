@@ -160,3 +160,59 @@ def test_tape_class_classifies_seeds_and_input_pointers():
         t2.record(bad_seed)
     assert not T.recording() and type(L.lib()).__name__ == 'CDLL'                  # a failed recording leaves nothing patched
     t2.close()
+
+
+def test_pointer_provenance_guard_and_seed_separation():
+    """Round-3 advisor: (1) a device pointer that is neither inside a batch tensor, nor inside a buffer the tape keeps alive, nor inside
+    a `known` long-lived buffer (the trainer's flat parameter / gradient / moment buffers) must not be baked into a recording silently:
+    it is listed in `violations` (the trainer then discards the tape and stays call by call); (2) a step whose two dropout seeds lie
+    within 128 of each other cannot be recorded (derived seeds of one encoder would be attributed to the other)."""
+    from nnr_amd import tape as T
+    batch, flat, cache = torch.zeros(64), torch.zeros(256), torch.zeros(32)
+    t = T.Tape([batch], {'news_seed': 1000, 'user_seed': 5000}, known=[flat])
+
+    def step():
+        lib = L.lib()
+        t.keep.append(cache)                                                       # what ops.tape_keep / the torch.empty wrapper do
+        g = L.GemmArgs()
+        g.A, g.B, g.C, g.M, g.N, g.K = batch.data_ptr() + 8, flat.data_ptr() + 512, cache.data_ptr(), 0, 8, 8
+        L.check(lib.nnr_gemm_f32(C.byref(g), C.c_void_p(0)), 'nnr_gemm_f32')      # input + known + kept: all vouched for
+        g2 = L.GemmArgs()
+        g2.A, g2.B, g2.C, g2.M, g2.N, g2.K = batch.data_ptr(), flat.data_ptr(), 0x7f0000001000, 0, 8, 8
+        g2.bias = flat.data_ptr() + 4 * flat.numel()                               # one past the end of the known buffer
+        L.check(lib.nnr_gemm_f32(C.byref(g2), C.c_void_p(0)), 'nnr_gemm_f32')
+        L.check(lib.nnr_fill_zero(C.c_void_p(0x7f0000002000), C.c_size_t(0), C.c_void_p(0)), 'nnr_fill_zero')
+        L.check(lib.nnr_fill_zero(C.c_void_p(cache.data_ptr() + 64), C.c_size_t(0), C.c_void_p(0)), 'nnr_fill_zero')
+
+    t.record(step)
+    assert sorted((n, str(w)) for n, w, _ in t.violations) == [('nnr_fill_zero', '0'), ('nnr_gemm_f32', 'C'), ('nnr_gemm_f32', 'bias')]
+    assert {p for _, _, p in t.violations} == {0x7f0000001000, 0x7f0000002000, flat.data_ptr() + 4 * flat.numel()}
+    t.close()
+    for a, b in ((1000, 1100), (1100, 1000), (5, 0xFFFFFFF0), (7, 7)):
+        with pytest.raises(T.TapeError, match='within 128'):
+            T.Tape([batch], {'news_seed': a, 'user_seed': b})
+    T.Tape([batch], {'news_seed': 1000, 'user_seed': 1128}).close()
+
+
+def test_rejected_call_leaves_the_tape_untouched():
+    """Round-3 advisor: nnr_tape_call validates every blob BEFORE it appends anything -- a refused call must not leave orphaned slots
+    or blob references that finalize would later patch."""
+    lib = _lib()
+    h = C.c_void_p()
+    assert lib.nnr_tape_create(C.byref(h)) == 0
+    g = L.GemmArgs()
+    g.A, g.B, g.C, g.M = 0x1000, 0x2000, 0x3000, 0
+    before = _info(lib, h)
+    fid = lib.nnr_tape_fn_id(b'nnr_gemm_f32')
+    arr = (C.c_uint64 * 1)(0)
+    bslot = (C.c_int * 2)(0, 5)                                                    # second blob names a slot the call does not have
+    bptr = (C.c_void_p * 2)(C.addressof(g), C.addressof(g))
+    bbytes = (C.c_size_t * 2)(C.sizeof(g), C.sizeof(g))
+    assert lib.nnr_tape_call(h, fid, C.c_void_p(0), arr, 1, bslot, bptr, bbytes, 2, -1, None, None) == ERR_ARG
+    bptr2 = (C.c_void_p * 2)(C.addressof(g), None)
+    bslot2 = (C.c_int * 2)(0, 0)
+    assert lib.nnr_tape_call(h, fid, C.c_void_p(0), arr, 1, bslot2, bptr2, bbytes, 2, -1, None, None) == ERR_ARG
+    assert _info(lib, h) == before                                                 # no call, no op, no argument bytes were added
+    assert _call(lib, h, 'nnr_gemm_f32', [0], blobs=[(0, g)])[0] == 0
+    assert lib.nnr_tape_finalize(h) == 0 and _replay(lib, h, 0) == 0
+    assert lib.nnr_tape_destroy(h) == 0
