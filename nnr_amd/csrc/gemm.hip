@@ -1583,6 +1583,8 @@ extern "C" int nnr_gemm_f32(const nnr_gemm_args* a, hipStream_t stream) {
     case 29: if (!tn_pipe_ok(g) || g.b_idx) return NNR_ERR_ARG; return launch_tn_pipe2<4, 5, 3, 2>(g, stream);    // gen-2 TN 256 x 80
     case 30: if (!tn_pipe_ok(g)) return NNR_ERR_ARG; return launch_tn_pipe2<2, 10, 3, 2>(g, stream);              // gen-2 TN 128 x 160 (N = 300 in two column blocks)
     case 31: if (!pipe_ok(g) || g.a_idx) return NNR_ERR_ARG; return launch_pipe2<2, 4, 3, 2>(g, stream);          // gen-2 NT 128 x 64, 3 x 24 KB stages, 2 workgroups / CU
+    case 32: if (!tn_pipe_ok(g)) return NNR_ERR_ARG; return launch_tn_pipe2<1, 13, 3, 2>(g, stream);              // gen-2 TN 64 x 208, 3 x 20 KB stages: row tiles of 64 fit M = 200 / 400 / 832
+                                                                                                                  // (256 / 448 / 832 rows of MFMA work instead of 256 / 512 / 896)
     case 7:
       if (g.trans_a || g.a_idx || g.b_idx || g.c_idx || g.dyn_dev || g.split_k > 1 || g.k_chunk > 0 || g.rowdot_w || g.colsum_out || g.atomic ||
           (g.drop_target != 0 && g.drop_target != 3)) return NNR_ERR_ARG;

@@ -297,6 +297,9 @@ _TN_SMALL_LDS = os.environ.get('NNR_TN_SMALL_LDS', '0') == '1'      # 1: 53 KB 1
                                                                     # tile for N = 200 / 400 is ahead again (11.38 vs 11.43 ms, 4 rounds each)
 
 
+_TN_T64 = int(os.environ.get('NNR_TN_T64', '0'))      # A/B (round 4): bit 0 = 64 x 208 tile for the M = 200 / 400 gate / attention weight gradients, bit 1 = for the gathered dW_hh (M = 832)
+
+
 def tn_tile(M, N, K, gather=False):
     """Tile of a token-reduction (weight-gradient) GEMM C[M,N] += A[K,M]^T B[K,N] and the tile dims its split-K factor is sized
     for.  Measured on the step's shapes (tools/gemm_pipe_bench.py tn, TFLOP/s old -> new): 1664x300 82 -> 96 (128x80),
@@ -311,6 +314,8 @@ def tn_tile(M, N, K, gather=False):
     if _TN_SMALL_LDS:
         return (20 if gather else 26), 128, 80, 2048
     if N <= 208 or (N > 320 and N <= 416):
+        if (_TN_T64 & 2) if gather else ((_TN_T64 & 1) and M % 128 != 0):
+            return 32, 64, 208, 640       # gen-2 loop, 64 x 208: M = 200 / 400 / 832 in 4 / 7 / 13 row tiles (256 / 448 / 832 rows of MFMA work, not 256 / 512 / 896)
         return 27, 128, 208, 640          # gen-2 loop, 128 x 208 (one token row per DMA instruction: takes gathered rows)
     if gather:
         return 20, 128, 80, 2048          # gathered rows wider than 208 columns (dW_hh at --hidden_dim 212..256): tile 26 has no gather path
@@ -414,7 +419,7 @@ def gemm(A, B, C_=None, *, M, N, K, lda, ldb, ldc=0, trans_a=False, trans_b=Fals
         t = 5 if not trans_b else 4
     fam = 'gemm_%s_%s' % ('tn' if trans_a else ('nn' if trans_b else 'nt'),
                           {1: '256x80', 2: '64x80', 3: '128x208', 4: '128x80', 5: '128x80k32', 6: '64x80k64', 7: '16x80skinny', 8: 'pipe128x80k32', 9: 'pipe2_128x80', 13: 'pipe128x80s4',
-                           15: 'pipe128x80', 16: 'pipe128x80s2', 20: 'pipe128x80', 26: 'pipe2_128x80', 27: 'pipe2_128x208', 30: 'pipe2_128x160', 31: 'pipe2_128x64', 22: 'pipe64x80', 23: 'pipe256x80', 24: 'pipe128x208', 25: 'pipe128x128'}.get(t, 'tile%d' % t))
+                           15: 'pipe128x80', 16: 'pipe128x80s2', 20: 'pipe128x80', 26: 'pipe2_128x80', 27: 'pipe2_128x208', 30: 'pipe2_128x160', 31: 'pipe2_128x64', 32: 'pipe2_64x208', 22: 'pipe64x80', 23: 'pipe256x80', 24: 'pipe128x208', 25: 'pipe128x128'}.get(t, 'tile%d' % t))
 
     def flops(vals=None, M=M, N=N, K=K, dyn=dyn, dyn_dim=dyn_dim, batch=batch):
         # vals: {data_ptr of a device-side size: its value at the time of the launch} (replayed launches: the size buffers are

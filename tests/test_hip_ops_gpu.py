@@ -915,7 +915,7 @@ def test_gemm_fused_bias_gradient():
     close(db, 0.25 + dy[:used].double().sum(0), tol=5e-5, what='fused db')
 
 
-TN_PIPE_TILES = [20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30]
+TN_PIPE_TILES = [20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 32]
 TN_NO_GATHER = [26, 28, 29]          # gen-2 loop: gathered B rows only with the 256-float pitch (tile 27)
 
 
