@@ -84,6 +84,12 @@ typedef struct nnr_gemm_args {
   int vec_epi;
   int sched;                /* token-reduction (split-K) launches: bits 0-1 how workgroups are dealt to the XCDs, bits 2-7 / 8+ tuning
                              * overrides of the device-side slice count (NNR_TN_DEAL / NNR_TN_WANT / NNR_TN_STAGES) */
+  /* reproducible split-K (trans_a = trans_b = 1, split_k > 1, N % 4 == 0): with `slab` set, slice z STORES its partial M x N result to
+   * slab[z] and a second launch adds the live slices in slice order into C (and the fused column sums into colsum_out): no f32
+   * atomics inside the reduction, bit-identical gradients from run to run (config.py:125-130).  slab_floats >= split_k * (M * N + M). */
+  float* slab;
+  long slab_floats;
+  int slab_mode;            /* filled by the library */
 } nnr_gemm_args;
 
 int nnr_gemm_f32(const nnr_gemm_args* args, hipStream_t stream);
@@ -183,9 +189,10 @@ int nnr_attn_pool_bwd(const nnr_pool_args* a, hipStream_t stream);
 int nnr_gate_bwd(const float* dHt, const float* H, const float* G, float* dH, float* dpre, const int* rows_dev, int rows, int cols,
                  hipStream_t stream);                                            /* newsEncoders.py:128-131 backward */
 int nnr_packed_seq_sum(const float* x, int D, const int* off, const int* slen, int n, float* out, hipStream_t stream);
-/* `ws`: NULL, or a ZEROED workspace of nnr_slot_workspace_floats(N) floats owned by the calling stream: many workgroups adding
- * into one short vector serialise on its few cache lines, so they add into 32 slots of the workspace first and a second tiny
- * launch folds the slots into the destination and leaves the workspace zeroed (reusable by the next call on that stream). */
+/* `ws`: NULL (f32 atomics straight into the destination: arrival order, not reproducible), or a workspace of
+ * nnr_slot_workspace_floats(N) floats owned by the calling stream: every workgroup stores the column sums of its share of the live
+ * rows to its own slot row, and a second tiny launch adds the slot rows in a fixed order into the destination (one f32 atomic per
+ * column and call) -- bit-identical from run to run, and no serialisation on the destination's few cache lines. */
 int nnr_slot_workspace_floats(int N);
 int nnr_tanh_score_bwd(float* th, const float* ds, const float* w2, float* dw2, const int* rows_dev, int rows, int A, float* ws,
                        hipStream_t stream);                                      /* layers.py:168-169 backward */
@@ -205,6 +212,20 @@ int nnr_embed_scatter(const float* dout, const int* idx, long n, int dim, float*
 /* the same over the first min(n, *n_dev) rows (packed token streams: the live row count stays on the device) */
 int nnr_embed_scatter_dyn(const float* dout, const int* idx, long n, const int* n_dev, int dim, float* dtable, float p, uint32_t seed,
                           hipStream_t stream);
+/* Reproducible form of the embedding-row gradient (the reference's runs are seeded and deterministic: config.py:125-130; autograd's
+ * nn.Embedding backward at newsEncoders.py:117-118).  nnr_token_sort: stable sort of the live packed rows by word id (rows beyond
+ * min(cap, *n_dev) and ids outside [0, vocab) get the pad key `vocab` and sort to the end); keys_tmp / rows_tmp / keys_sorted /
+ * rows_sorted: `cap` entries each, temp: nnr_token_sort_workspace_bytes(cap, vocab) bytes.  It needs nothing but the planned token
+ * stream, so the host side issues it on a side stream under the forward pass.  nnr_embed_scatter_sorted: dtable[w,:] += sum of
+ * mask * dout[row,:] over the rows of word w IN LIST ORDER -- every word receives ONE f32 atomic add per element and launch, so
+ * with at most two launches per step into a zeroed table gradient (title stream, content stream) the result is bit-reproducible;
+ * partial_ws: nnr_embed_scatter_sorted_workspace_floats(cap) floats; dim <= 320. */
+size_t nnr_token_sort_workspace_bytes(long cap, int vocab);
+int nnr_token_sort(const int* tok, long cap, const int* n_dev, int vocab, unsigned* keys_tmp, int* rows_tmp, unsigned* keys_sorted,
+                   int* rows_sorted, void* temp, size_t temp_bytes, hipStream_t stream);
+size_t nnr_embed_scatter_sorted_workspace_floats(long cap);
+int nnr_embed_scatter_sorted(const float* dout, const unsigned* keys_sorted, const int* rows_sorted, long cap, int vocab, int dim,
+                             float* dtable_accum, float p, uint32_t seed, float* partial_ws, hipStream_t stream);
 int nnr_transpose2d(const float* in, float* out, long rows, int cols, int accumulate, hipStream_t stream);
 /* `count` independent transposes out[c][r] = in[r][c] in ONE launch; the descriptors live in device memory (the host side keeps
  * them for the W^T copies of the weights that the data-gradient GEMMs multiply by: refreshed once per optimizer step). */
@@ -340,6 +361,11 @@ int nnr_fusion_rows_fwd(const float* cat_table, const float* sub_table, const in
 int nnr_fusion_rows_bwd(const int* cat0, const int* sub0, int n0, const int* cat1, const int* sub1, int n1, int cd, int sd, const float* dout,
                         int lddo, float* dcat_table_accum, float* dsub_table_accum, float p, uint32_t seed_cat, uint32_t seed_sub,
                         hipStream_t stream);
+/* The same gradients, reproducibly (one workgroup per table row scans the ids in order: no run merging, no arrival-order atomics);
+ * ncat / nsub = rows of the two tables; cd, sd <= 128. */
+int nnr_fusion_rows_bwd_det(const int* cat0, const int* sub0, int n0, const int* cat1, const int* sub1, int n1, int cd, int sd, int ncat,
+                            int nsub, const float* dout, int lddo, float* dcat_table_accum, float* dsub_table_accum, float p,
+                            uint32_t seed_cat, uint32_t seed_sub, hipStream_t stream);
 /* Click predictor + loss + their backward in one launch (model.py:126-127, trainer.py:64-66): logits [B, N], loss (scalar, a fixed-order
  * mean), dlogits [B, N] (optional), duser / dcand [B, N, D] (both or neither); terms_ws: B floats of scratch.  N <= 64. */
 int nnr_click_loss(const float* user, const float* cand, int B, int N, int D, float* logits, float* loss, float* dlogits, float* duser,

@@ -20,7 +20,7 @@ class GemmArgs(C.Structure):
                 ('ldmul', ci), ('resid', vp), ('ldres', ci), ('accumulate', ci), ('atomic', ci), ('c_idx', vp),
                 ('split_k', ci), ('rowdot_w', vp), ('rowdot_out', vp), ('batch', ci), ('strideA', cl), ('strideB', cl),
                 ('strideC', cl), ('stride_aux', cl), ('stride_res', cl), ('k_chunk', ci), ('colsum_out', vp), ('tile', ci), ('drop_thresh', cu32),
-                ('drop_scale', cf), ('vec_epi', ci), ('sched', ci)]
+                ('drop_scale', cf), ('vec_epi', ci), ('sched', ci), ('slab', vp), ('slab_floats', cl), ('slab_mode', ci)]
 
 
 class LstmProblem(C.Structure):
@@ -64,6 +64,7 @@ SYMBOLS = [
     'nnr_tape_create', 'nnr_tape_destroy', 'nnr_tape_fn_id', 'nnr_tape_fn_nargs', 'nnr_tape_call', 'nnr_tape_wait_stream', 'nnr_tape_event_record',
     'nnr_tape_event_wait', 'nnr_tape_segment', 'nnr_tape_patch', 'nnr_tape_finalize', 'nnr_tape_info', 'nnr_tape_replay', 'nnr_tape_timings', 'nnr_tape_timeline',
     'nnr_tape_last_error',
+    'nnr_token_sort_workspace_bytes', 'nnr_token_sort', 'nnr_embed_scatter_sorted_workspace_floats', 'nnr_embed_scatter_sorted', 'nnr_fusion_rows_bwd_det',
 ]
 
 
@@ -98,6 +99,8 @@ def lib():
             getattr(_lib, s).restype = ci
         _lib.nnr_lstm_sync_bytes.restype = C.c_size_t
         _lib.nnr_lstm_sync_diag_offset.restype = C.c_size_t
+        _lib.nnr_token_sort_workspace_bytes.restype = C.c_size_t
+        _lib.nnr_embed_scatter_sorted_workspace_floats.restype = C.c_size_t
     return _lib
 
 

@@ -6,7 +6,7 @@ OUT=../libnnr_hip.so
 FLAGS="${NNR_EXTRA_FLAGS} --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-pass-failed"
 mkdir -p build
 pids=()
-for f in gemm seq_plan lstm pool misc mhsa corpus dp gcn tape fuse; do
+for f in gemm seq_plan lstm pool misc mhsa corpus dp gcn tape fuse sort; do
   [ -f $f.hip ] || continue
   if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ ../../include/nnr_hip.h -nt build/$f.o ]; then
     hipcc $FLAGS -c $f.hip -o build/$f.o &

@@ -62,6 +62,57 @@ __global__ __launch_bounds__(256) void fusion_rows_bwd_kernel(const int* __restr
   }
 }
 
+// Reproducible form (round 4; config.py:125-130): one workgroup per TABLE ROW t.  Its four waves scan the id list in 64-row chunks
+// (wave w takes chunks w, w + 4, ...: one coalesced id load, a ballot, then the matching rows in ascending order), lane = column; the four
+// partial sums are added in wave order and the table row gets ONE f32 atomic per element (a second launch -- the other encoder call
+// of the plugin API -- may add into the same gradient: two addends into a zeroed buffer commute).  No run merging, no arrival order.
+__global__ __launch_bounds__(256) void fusion_rows_bwd_det_kernel(const int* __restrict__ cat0, const int* __restrict__ sub0, int n0,
+                                                                  const int* __restrict__ cat1, const int* __restrict__ sub1, int n, int cd,
+                                                                  int sd, int ncat, const float* __restrict__ dout, int lddo,
+                                                                  float* __restrict__ dctab, float* __restrict__ dstab, uint32_t seed_cat,
+                                                                  uint32_t seed_sub, uint32_t thr, float scale) {
+  __shared__ float part[4][128];
+  const bool is_cat = (int)blockIdx.x < ncat;
+  const int t = is_cat ? blockIdx.x : blockIdx.x - ncat;
+  const int dim = is_cat ? cd : sd, col0 = is_cat ? 0 : cd;
+  const int* i0 = is_cat ? cat0 : sub0;
+  const int* i1 = is_cat ? cat1 : sub1;
+  float* dtab = is_cat ? dctab : dstab;
+  const uint32_t seed = is_cat ? seed_cat : seed_sub;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float acc0 = 0.f, acc1 = 0.f;                       // columns lane and lane + 64 (dim <= 128, checked by the launcher)
+  for (int base = w * 64; base < n; base += 256) {
+    const int row = base + lane;
+    int id = -1;
+    if (row < n) id = row < n0 ? i0[row] : i1[row - n0];
+    unsigned long long m = __ballot(id == t);
+    while (m) {                                         // eight matching rows in flight, added in ascending row order
+      float v0[8], v1[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        v0[q] = v1[q] = 0.f;
+        if (m) {                                        // (wave-uniform)
+          const long r = base + __builtin_ctzll(m);
+          m &= m - 1;
+          if (lane < dim) v0[q] = dout[r * lddo + col0 + lane] * (nnr_keep(seed, (uint64_t)(r * dim + lane), thr) ? scale : 0.f);
+          if (lane + 64 < dim) v1[q] = dout[r * lddo + col0 + lane + 64] * (nnr_keep(seed, (uint64_t)(r * dim + lane + 64), thr) ? scale : 0.f);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { acc0 += v0[q]; acc1 += v1[q]; }
+    }
+  }
+  part[w][lane] = acc0;
+  part[w][lane + 64] = acc1;
+  __syncthreads();
+  if (w == 0) {
+    for (int c = lane; c < dim; c += 64) {
+      const float v = ((part[0][c] + part[1][c]) + part[2][c]) + part[3][c];
+      if (v != 0.f) atomicAdd(&dtab[(long)t * dim + c], v);
+    }
+  }
+}
+
 // ---- click predictor + loss + their backward in ONE launch (model.py:126-127, trainer.py:64-66): one workgroup per sample.
 //   logits[b, n] = <user[b, n], cand[b, n]>;  loss = mean_b(-log_softmax(logits[b])[0]);  dlogits = (softmax - onehot_0) / B
 //   duser[b, n] = dlogits[b, n] * cand[b, n];  dcand[b, n] = dlogits[b, n] * user[b, n]
@@ -156,6 +207,20 @@ extern "C" int nnr_fusion_rows_bwd(const int* cat0, const int* sub0, int n0, con
   const int rpw = n >= 16 * 1024 ? 16 : (n >= 2048 ? 8 : 4);
   hipLaunchKernelGGL(fusion_rows_bwd_kernel, dim3((n + 4 * rpw - 1) / (4 * rpw), 2), dim3(256), 0, stream, cat0, sub0, n0, cat1, sub1, n, cd, sd,
                      dout, lddo, dcat_table, dsub_table, seed_cat, seed_sub, nnr_drop_thresh(p), sc, rpw);
+  NNR_CHECK_LAUNCH();
+  return NNR_OK;
+}
+
+extern "C" int nnr_fusion_rows_bwd_det(const int* cat0, const int* sub0, int n0, const int* cat1, const int* sub1, int n1, int cd, int sd,
+                                       int ncat, int nsub, const float* dout, int lddo, float* dcat_table, float* dsub_table, float p,
+                                       uint32_t seed_cat, uint32_t seed_sub, hipStream_t stream) {
+  if (!cat0 || !sub0 || !dout || !dcat_table || !dsub_table || n0 < 0 || n1 < 0 || (n1 > 0 && (!cat1 || !sub1)) || ncat < 0 || nsub < 0 || cd > 128 || sd > 128)
+    return NNR_ERR_ARG;
+  const int n = n0 + n1;
+  if (n == 0 || ncat + nsub == 0) return NNR_OK;
+  const float sc = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  hipLaunchKernelGGL(fusion_rows_bwd_det_kernel, dim3(ncat + nsub), dim3(256), 0, stream, cat0, sub0, n0, cat1, sub1, n, cd, sd, ncat, dout, lddo,
+                     dcat_table, dsub_table, seed_cat, seed_sub, nnr_drop_thresh(p), sc);
   NNR_CHECK_LAUNCH();
   return NNR_OK;
 }

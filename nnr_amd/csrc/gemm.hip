@@ -43,7 +43,7 @@ __device__ __forceinline__ void gemm_epilogue(const nnr_gemm_args& g, f32x4 (&ac
   // Accumulators go through LDS in TM passes of 64 rows (tiny fully-unrolled store loop: the MFMA registers are only
   // ever indexed statically), then a rolled, runtime-flagged loop applies the epilogue with consecutive lanes on
   // consecutive columns: every global access (C, aux, mul, resid, atomics) is a contiguous 256-B wave access.
-  const bool use_atomic = g.atomic || g.split_k > 1 || g.k_chunk > 0;
+  const bool use_atomic = !g.slab_mode && (g.atomic || g.split_k > 1 || g.k_chunk > 0);      // (slab mode: a slice stores its tile plainly)
   float* aux = g.aux_out;
   const float* res = g.resid;
   const float* mulp = g.mul;
@@ -425,23 +425,28 @@ __global__ __launch_bounds__(256) void gemm_kernel(nnr_gemm_args g) {
   }
 
   if (do_colsum) {
-    // thread (kr, mq) holds partial sums for columns 4*mq..4*mq+3; threads with equal mq differ in kr: reduce through LDS
-    float* red = lds;                                   // [BM] floats, the tile buffers are free now
-    for (int i = tid; i < BM; i += 256) red[i] = 0.f;
-    __syncthreads();
+    // thread (kr, mq) holds partial sums for columns 4*mq..4*mq+3; threads with equal mq differ in kr (0 .. BK-1): every partial goes
+    // to its own LDS word [kr][BM] (the tile buffers are free now: BK x BM floats <= A_SZ) and is summed over kr in FIXED order -- LDS
+    // float atomics here would add in arrival order, i.e. round differently from run to run
+    float* red = lds;
 #pragma unroll
     for (int j = 0; j < NAL; ++j) {
       const int f = tid + 256 * j, kr = f / (BM / 4), mq = f - kr * (BM / 4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) atomicAdd(&red[4 * mq + e], csum[j][e]);
+      *reinterpret_cast<f32x4*>(&red[kr * BM + 4 * mq]) = csum[j];
     }
     __syncthreads();
-    for (int i = tid; i < BM; i += 256)
-      if (m0 + i < M) atomicAdd(&g.colsum_out[m0 + i], red[i]);
+    for (int i = tid; i < BM; i += 256) {
+      float t = 0.f;
+      for (int kr = 0; kr < BK; ++kr) t += red[kr * BM + i];
+      if (m0 + i < M) {
+        if (g.slab_mode) g.colsum_out[(long)z * M + m0 + i] = t;      // slice z's own row of the column-sum slab
+        else atomicAdd(&g.colsum_out[m0 + i], t);
+      }
+    }
     __syncthreads();
   }
 
-  gemm_epilogue<TM, TN>(g, acc, lds, C, m0, n0, M, N, z);
+  gemm_epilogue<TM, TN>(g, acc, lds, g.slab_mode ? C + (long)z * M * N : C, m0, n0, M, N, z);
 }
 
 template <int TM, int TN, int BK>
@@ -877,6 +882,26 @@ static bool pipe_ok(const nnr_gemm_args& g) {
 //  * NS stage buffers, one counted vmcnt wait + one raw barrier per stage (as gemm_nt_pipe_kernel).
 //  * split-K over blockIdx.z, f32 atomics in the epilogue; the fused bias gradient (column sums of A) of the column-block-0
 //    workgroups is one extra MFMA per row tile and step against a fragment of ones -- no LDS traffic, no extra pass over A.
+// Slices a token-reduction launch uses for a LIVE reduction length K (the host sizes split_k for the capacity of the token buffers):
+// as many as keep a slice long enough to amortise its prologue and its epilogue (~96 stages of 16 rows) while still giving every CU a
+// workgroup or two, rounded so that eff x nblk is a whole number of waves of resident workgroups (400 x 400 x 77 k tokens: 1 000
+// workgroups on 768 slots = 379 us, 740 or 1 520 = 279 / 293 us).  Shared by the kernels and by the slab reduction (same arithmetic,
+// same K: they agree on which slices exist).
+__device__ __forceinline__ int tn_eff_slices(int split_k, int sched, int K, int nblk, int slots) {
+  const int deal_mode = sched & 3;
+  const int want_wg = ((sched >> 2) & 63) ? ((sched >> 2) & 63) * 64 : 512;      // workgroups wanted at least (tuning knob, default 512)
+  const int slice_stages = (sched >> 8) ? (sched >> 8) : 96;                     // stages per slice aimed at (tuning knob)
+  const int ktiles = (K + 15) / 16;
+  const int want = (want_wg + nblk - 1) / nblk;
+  int eff = max(1, min(min(split_k, max(want, ktiles / slice_stages)), max(1, ktiles / 12)));
+  if (deal_mode != 2) {
+    const int W = eff * nblk, wv = W / slots;
+    const int target = W < slots ? slots : (((W - wv * slots) * 2 < slots) ? wv * slots : (wv + 1) * slots);
+    eff = max(1, min(target / nblk, min(split_k, max(1, ktiles / 12))));
+  }
+  return eff;
+}
+
 template <int TM, int TN, int NS, int OCC, int PRIO = 0>
 __global__ __launch_bounds__(256, OCC) void gemm_tn_pipe_kernel(nnr_gemm_args g) {
   if (PRIO == 1) set_prio_dyn((blockIdx.x + gridDim.x * blockIdx.z) >> 8);
@@ -910,19 +935,8 @@ __global__ __launch_bounds__(256, OCC) void gemm_tn_pipe_kernel(nnr_gemm_args g)
   int kbeg = 0, kend = K;
   if (g.split_k > 1) {
     const int deal_mode = g.sched & 3;                // set by the launcher
-    const int want_wg = ((g.sched >> 2) & 63) ? ((g.sched >> 2) & 63) * 64 : 512;      // workgroups wanted at least (tuning knob, default 512)
-    const int slice_stages = (g.sched >> 8) ? (g.sched >> 8) : 96;                     // stages per slice aimed at (tuning knob)
     const int ktiles = (K + BK - 1) / BK;
-    const int want = (want_wg + nblk - 1) / nblk;
-    int eff = max(1, min(min(g.split_k, max(want, ktiles / slice_stages)), max(1, ktiles / 12)));
-    if (deal_mode != 2) {
-      // whole waves of workgroups: eff x nblk just above a multiple of the chip's resident slots leaves a last wave that is mostly
-      // empty (400 x 400 x 77 k tokens: 1 000 workgroups on 768 slots = 379 us, 740 or 1 520 workgroups = 279 / 293 us)
-      constexpr int slots = OCC * 256;
-      const int W = eff * nblk, wv = W / slots;
-      const int target = W < slots ? slots : (((W - wv * slots) * 2 < slots) ? wv * slots : (wv + 1) * slots);
-      eff = max(1, min(target / nblk, min(g.split_k, max(1, ktiles / 12))));
-    }
+    const int eff = tn_eff_slices(g.split_k, g.sched, K, nblk, OCC * 256);
     if (deal_mode) {
       const int W = eff * nblk, per = (W + 7) >> 3;
       const int L = blockIdx.x, x = L & 7, slot = L >> 3;
@@ -1075,11 +1089,22 @@ __global__ __launch_bounds__(256, OCC) void gemm_tn_pipe_kernel(nnr_gemm_args g)
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int row = m0 + (w * TM + m) * 16 + kk * 4 + reg;
-        if (row < M) atomicAdd(&g.colsum_out[row], cs[m][reg]);
+        if (row < M) {
+          if (g.slab_mode) g.colsum_out[(long)z * M + row] = cs[m][reg];      // slice z's own row of the column-sum slab
+          else atomicAdd(&g.colsum_out[row], cs[m][reg]);
+        }
       }
   }
   __syncthreads();
-  gemm_epilogue<TM, TN>(g, acc, lds, g.C, m0, n0, M, N, z);
+  gemm_epilogue<TM, TN>(g, acc, lds, g.slab_mode ? g.C + (long)z * M * N : g.C, m0, n0, M, N, z);
+}
+
+// deal mode / slice-count tuning knobs of the split-K token reductions, as the kernels and the slab reduction read them from g.sched
+static int tn_sched_bits() {
+  static const int deal_mode = [] { const char* e = getenv("NNR_TN_DEAL"); return e ? atoi(e) : 1; }();      // A/B: 0 = tiles of a slice spread over the XCDs
+  static const int want_code = [] { const char* e = getenv("NNR_TN_WANT"); return e ? atoi(e) / 64 : 0; }();    // tuning: minimum workgroup count (default 512)
+  static const int stage_code = [] { const char* e = getenv("NNR_TN_STAGES"); return e ? atoi(e) : 0; }();       // tuning: stages per split-K slice (default 96)
+  return (deal_mode & 3) | ((want_code & 63) << 2) | (stage_code << 8);
 }
 
 template <int TM, int TN, int NS, int OCC, int PRIO = 0>
@@ -1087,11 +1112,8 @@ int launch_tn_pipe(const nnr_gemm_args& g, hipStream_t s) {
   constexpr int BM = 64 * TM, BN = 16 * TN;
   const int nbm = (g.M + BM - 1) / BM, nbn = (g.N + BN - 1) / BN;
   dim3 grid(g.split_k > 1 ? nbm * nbn * ((g.split_k + 7) / 8) * 8 : nbm * nbn), block(256);      // split-K: slices are dealt to XCDs (see the kernel)
-  static const int deal_mode = [] { const char* e = getenv("NNR_TN_DEAL"); return e ? atoi(e) : 1; }();      // A/B: 0 = tiles of a slice spread over the XCDs
-  static const int want_code = [] { const char* e = getenv("NNR_TN_WANT"); return e ? atoi(e) / 64 : 0; }();    // tuning: minimum workgroup count (default 512)
   nnr_gemm_args gg = g;
-  static const int stage_code = [] { const char* e = getenv("NNR_TN_STAGES"); return e ? atoi(e) : 0; }();       // tuning: stages per split-K slice (default 96)
-  gg.sched = (deal_mode & 3) | ((want_code & 63) << 2) | (stage_code << 8);
+  gg.sched = tn_sched_bits();
   hipLaunchKernelGGL((gemm_tn_pipe_kernel<TM, TN, NS, OCC, PRIO>), grid, block, 0, s, gg);
   NNR_CHECK_LAUNCH();
   return NNR_OK;
@@ -1150,19 +1172,8 @@ __global__ __launch_bounds__(256, OCC) void gemm_tn_pipe2_kernel(nnr_gemm_args g
   int kbeg = 0, kend = K;
   if (g.split_k > 1) {
     const int deal_mode = g.sched & 3;                // set by the launcher
-    const int want_wg = ((g.sched >> 2) & 63) ? ((g.sched >> 2) & 63) * 64 : 512;      // workgroups wanted at least (tuning knob, default 512)
-    const int slice_stages = (g.sched >> 8) ? (g.sched >> 8) : 96;                     // stages per slice aimed at (tuning knob)
     const int ktiles = (K + BK - 1) / BK;
-    const int want = (want_wg + nblk - 1) / nblk;
-    int eff = max(1, min(min(g.split_k, max(want, ktiles / slice_stages)), max(1, ktiles / 12)));
-    if (deal_mode != 2) {
-      // whole waves of workgroups: eff x nblk just above a multiple of the chip's resident slots leaves a last wave that is mostly
-      // empty (400 x 400 x 77 k tokens: 1 000 workgroups on 768 slots = 379 us, 740 or 1 520 workgroups = 279 / 293 us)
-      constexpr int slots = OCC * 256;
-      const int W = eff * nblk, wv = W / slots;
-      const int target = W < slots ? slots : (((W - wv * slots) * 2 < slots) ? wv * slots : (wv + 1) * slots);
-      eff = max(1, min(target / nblk, min(g.split_k, max(1, ktiles / 12))));
-    }
+    const int eff = tn_eff_slices(g.split_k, g.sched, K, nblk, OCC * 256);
     if (deal_mode) {
       const int W = eff * nblk, per = (W + 7) >> 3;
       const int L = blockIdx.x, x = L & 7, slot = L >> 3;
@@ -1346,11 +1357,14 @@ __global__ __launch_bounds__(256, OCC) void gemm_tn_pipe2_kernel(nnr_gemm_args g
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int row = m0 + (w * TM + m) * 16 + kk * 4 + reg;
-        if (row < M) atomicAdd(&g.colsum_out[row], cs[m][reg]);
+        if (row < M) {
+          if (g.slab_mode) g.colsum_out[(long)z * M + row] = cs[m][reg];      // slice z's own row of the column-sum slab
+          else atomicAdd(&g.colsum_out[row], cs[m][reg]);
+        }
       }
   }
   __syncthreads();
-  gemm_epilogue<TM, TN>(g, acc, lds, g.C, m0, n0, M, N, z);
+  gemm_epilogue<TM, TN>(g, acc, lds, g.slab_mode ? g.C + (long)z * M * N : g.C, m0, n0, M, N, z);
 }
 
 template <int TM, int TN, int NS, int OCC>
@@ -1358,11 +1372,8 @@ int launch_tn_pipe2(const nnr_gemm_args& g, hipStream_t s) {
   constexpr int BM = 64 * TM, BN = 16 * TN;
   const int nbm = (g.M + BM - 1) / BM, nbn = (g.N + BN - 1) / BN;
   dim3 grid(g.split_k > 1 ? nbm * nbn * ((g.split_k + 7) / 8) * 8 : nbm * nbn), block(256);      // split-K: slices are dealt to XCDs (see the kernel)
-  static const int deal_mode = [] { const char* e = getenv("NNR_TN_DEAL"); return e ? atoi(e) : 1; }();      // A/B: 0 = tiles of a slice spread over the XCDs
-  static const int want_code = [] { const char* e = getenv("NNR_TN_WANT"); return e ? atoi(e) / 64 : 0; }();    // tuning: minimum workgroup count (default 512)
   nnr_gemm_args gg = g;
-  static const int stage_code = [] { const char* e = getenv("NNR_TN_STAGES"); return e ? atoi(e) : 0; }();       // tuning: stages per split-K slice (default 96)
-  gg.sched = (deal_mode & 3) | ((want_code & 63) << 2) | (stage_code << 8);
+  gg.sched = tn_sched_bits();
   hipLaunchKernelGGL((gemm_tn_pipe2_kernel<TM, TN, NS, OCC>), grid, block, 0, s, gg);
   NNR_CHECK_LAUNCH();
   return NNR_OK;
@@ -1492,66 +1503,73 @@ int launch_skinny(const nnr_gemm_args& g, hipStream_t s) {
   return NNR_OK;
 }
 
+// ---------------------------------------------------------------------------------------------- split-K slabs: fixed-order reduction
+// Reproducible weight gradients (the reference's runs are seeded and deterministic: config.py:125-130): with `slab` set, slice z of a
+// split-K launch STORES its M x N partial tile-by-tile into slab[z] (plain float4 stores at ~6 TB/s instead of f32 atomics at the
+// memory-side units' ~1.3 TB/s, all of them at the end of a wave of workgroups) and this kernel adds the live slices in slice order:
+// C[m][n] += sum_z slab[z][m][n], colsum_out[m] += sum_z colsum_slab[z][m].  Which slices exist for the live reduction length is
+// decided by the same arithmetic as in the GEMM kernel (kind 1: the LDS-DMA TN tiles' device-side slice count; kind 0: the
+// register-staged tiles' static split).  The final add is ONE f32 atomic per element and launch (a parameter gradient receives at
+// most two such launches per step -- the two encoder calls of the plugin API -- and two addends into a zeroed buffer commute).
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ cs_slab, float* __restrict__ C,
+                                                            int ldc, float* __restrict__ colsum_out, int M, int N, int K, const int* __restrict__ dyn_dev,
+                                                            int split_k, int sched, int nblk, int slots, int bk, int kind) {
+  if (dyn_dev) K = min(K, *dyn_dev);
+  int live;
+  const int ktiles = (K + bk - 1) / bk;
+  if (ktiles <= 0) {
+    live = 0;
+  } else if (kind == 1) {
+    const int eff = tn_eff_slices(split_k, sched, K, nblk, slots);
+    const int per_k = (ktiles + eff - 1) / eff;
+    live = min(eff, (ktiles + per_k - 1) / per_k);
+  } else {
+    const int per = (ktiles + split_k - 1) / split_k;
+    live = per > 0 ? min(split_k, (ktiles + per - 1) / per) : 0;
+  }
+  const long MN = (long)M * N, MN4 = MN >> 2;               // (N % 4 == 0 is checked by the dispatcher)
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < MN4; i += stride) {
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    int z = 0;
+    for (; z + 4 <= live; z += 4) {                          // four slices in flight, added in slice order
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = reinterpret_cast<const f32x4*>(slab + (long)(z + u) * MN)[i];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) t += v[u];
+    }
+    for (; z < live; ++z) t += reinterpret_cast<const f32x4*>(slab + (long)z * MN)[i];
+    const long e = i << 2;
+    const int m = (int)(e / N), n = (int)(e - (long)m * N);
+    float* cp = C + (long)m * ldc + n;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) atomicAdd(cp + q, t[q]);
+  }
+  if (colsum_out != nullptr && cs_slab != nullptr) {
+    for (long m = blockIdx.x * (long)blockDim.x + threadIdx.x; m < M; m += stride) {
+      float t = 0.f;
+      for (int z = 0; z < live; ++z) t += cs_slab[(long)z * M + m];
+      atomicAdd(&colsum_out[m], t);
+    }
+  }
+}
+
 }  // namespace
 
-extern "C" int nnr_gemm_f32(const nnr_gemm_args* a, hipStream_t stream) {
-  if (!a || !a->A || !a->B) return NNR_ERR_ARG;
-  if (!a->C && !a->rowdot_out && !a->aux_out) return NNR_ERR_ARG;
-  if (a->M <= 0 || a->N <= 0 || a->K <= 0) return NNR_OK;
-  nnr_gemm_args g = *a;
-  g.drop_thresh = nnr_drop_thresh(g.drop_target ? g.drop_p : 0.f);
-  g.drop_scale = (g.drop_target && g.drop_p > 0.f) ? 1.f / (1.f - g.drop_p) : 1.f;
-  if (g.drop_thresh == 0u) g.drop_target = 0;
-  if (g.k_chunk > 0) { if ((g.k_chunk & 31) || g.batch > 1) return NNR_ERR_ARG; g.split_k = 2; }   // shares split-K's restrictions below
-  if (g.split_k > 1 && (g.bias || g.rowvec || g.act || g.aux_out || g.mul || g.resid || g.batch > 1 || g.rowdot_w))
-    return NNR_ERR_ARG;
-  if ((g.a_idx && g.trans_a) || (g.b_idx && !g.trans_b)) return NNR_ERR_ARG;
-  if (g.colsum_out && !g.trans_a) return NNR_ERR_ARG;
-  if ((g.dyn_dim != 0) != (g.dyn_dev != nullptr)) return NNR_ERR_ARG;
-  {
-    auto ok = [](const void* p, int ld) { return p == nullptr || ((((uintptr_t)p) & 15) == 0 && (ld & 3) == 0); };
-    const bool strides = g.batch <= 1 || (((g.strideC | g.stride_aux | g.stride_res) & 3) == 0);
-    g.vec_epi = (!g.c_idx && !g.atomic && g.split_k <= 1 && !g.rowdot_w && (g.N & 3) == 0 && ok(g.C, g.ldc) && ok(g.bias, 0) &&
-                 ok(g.rowvec, g.ldrv) && ok(g.aux_out, g.ldaux) && ok(g.mul, g.ldmul) && ok(g.resid, g.ldres) && strides &&
-                 (g.drop_target != 3 || (g.drop_cols & 3) == 0)) ? 1 : 0;
-  }
-  int tile = g.tile;
-  if (tile == 0) {
-    const long wg128 = (long)((g.M + 127) / 128) * ((g.N + 79) / 80) * (g.k_chunk > 0 ? (g.K + g.k_chunk - 1) / g.k_chunk : (g.split_k > 1 ? g.split_k : (g.batch > 1 ? g.batch : 1)));
-    const long wg64 = (long)((g.M + 63) / 64) * ((g.N + 79) / 80) * (g.split_k > 1 ? g.split_k : (g.batch > 1 ? g.batch : 1));
-    const bool plain = !g.trans_a && !g.a_idx && !g.b_idx && !g.c_idx && !g.dyn_dev && g.split_k <= 1 && g.k_chunk <= 0 && !g.rowdot_w &&
-                       !g.colsum_out && !g.atomic && (g.drop_target == 0 || g.drop_target == 3);
-    static const bool use_t9 = [] { const char* e = getenv("NNR_NT9"); return !(e && atoi(e) == 0); }();   // A/B
-    static const bool use_pipe = [] { const char* e = getenv("NNR_GEMM_PIPE"); return !(e && atoi(e) == 0); }();   // A/B switch
-    if (g.rowdot_w) tile = 3;
-    else if (plain && wg64 <= 512 && g.K >= 64) tile = 7;   // small row-parallel launch: 16 x 80 tiles, K split over the 4 waves
-    else if (use_pipe && use_t9 && pipe_ok(g) && !g.a_idx && g.K >= 800 && wg64 > 512) {
-      tile = 9;              // long reductions (dX: K = 1664, SUE: K = 900): the
-                             // software-pipelined loop with the lean DMA issue, 2 workgroups / CU (130 vs 112 TF, 93 vs 79 TF)
-      // Launches of one or two waves of workgroups (SUE: 4 352 / 6 080 rows x 900 columns) are bound by the CU that carries the most
-      // tiles: 4 352 x 900 is 408 tiles of 128 x 80 (the busiest CU works through 2 x 80 columns of a 128-row stripe) but 510 tiles of
-      // 128 x 64 (2 x 64 columns, and no column padding: 900 = 14.06 x 64 vs 11.25 x 80) -- take the narrower tile when that wins by > 8 %.
-      static const bool use_n64 = [] { const char* e = getenv("NNR_NT64"); return e && atoi(e) == 1; }();   // opt-in: measured no better in the step (11.38-11.44 vs 11.27-11.31 ms, sustained equal)
-      if (use_n64 && !g.dyn_dev && g.batch <= 1) {
-        const long nbm = (g.M + 127) / 128, t80 = nbm * ((g.N + 79) / 80), t64 = nbm * ((g.N + 63) / 64);
-        const long load80 = ((t80 + 255) / 256) * 80, load64 = ((t64 + 255) / 256) * 64;
-        if (t80 < 1024 && load64 * 100 < load80 * 92) tile = 31;
-      }
-    }
-    else if (use_pipe && pipe_ok(g) && (g.dyn_dev || wg128 >= 640)) tile = 15;   // GPU-filling NT: LDS-DMA staged 128 x 80, BK 16, 4 workgroups / CU
-                             // (112 vs 98 TF on the 131 072-row CNE shapes, tools/gemm_pipe_bench.py)
-    else if (use_pipe && pipe_ok(g) && wg64 > 512 && g.K >= 128) tile = 16;      // mid-size NT (SUE: 4 352 x 900 x 900): same tile, two 13 KB stages,
-                             // 5-6 workgroups / CU cover the round trips (79 vs 65-72 TF)
-    else if (wg64 <= 512 && !g.dyn_dev && g.k_chunk <= 0 && g.K >= 128 && !g.trans_a) tile = 6;   // (not for TN: the small weight-gradient
-                             // launches run on the leaf stream BESIDE the recurrence, whose workgroups hold 98 KB of LDS per CU; a 74 KB tile cannot
-                             // move in next to them and waits for free CUs, the 19 KB tile can: 12.60 vs 12.70 ms/step)   // at most 2 workgroups per CU: nothing hides the
-                             // memory round trip each k-stage pays with a one-stage prefetch -> BK = 64, 4x fewer stages
-    else if (g.M <= 512 || (wg128 < 640 && !g.dyn_dev)) tile = 2;   // too few 128-row tiles to fill 256 CUs x 4: use 64-row tiles
-    else if (g.trans_a) tile = 2;   // TN (token-reduction dW): callers pick the LDS-DMA tiles 20 / 24 explicitly (their split-K factor
-                                    // depends on the tile); this is the register-staged fallback
-    else if (!g.trans_a && !g.trans_b) tile = 5;   // NT that the pipelined kernel cannot take (unaligned operands)
-    else tile = 4;           // NN with a K-major B (activations on both sides, or a weight the caller did not transpose)
-  }
+// tile id -> (rows, columns, stage depth, workgroups per CU the kernel is built for, 1 = LDS-DMA TN tile with the device-side slice count)
+static bool tile_shape(int tile, int* bm, int* bn, int* bk, int* occ, int* kind) {
+  struct T { int tile, bm, bn, bk, occ, kind; };
+  static const T tab[] = {{1, 256, 80, 16, 1, 0}, {2, 64, 80, 16, 1, 0}, {3, 128, 208, 16, 1, 0}, {4, 128, 80, 16, 1, 0}, {5, 128, 80, 32, 1, 0}, {6, 64, 80, 64, 1, 0},
+                          {20, 128, 80, 16, 3, 1}, {21, 128, 80, 16, 3, 1}, {22, 64, 80, 16, 4, 1}, {23, 256, 80, 16, 2, 1}, {24, 128, 208, 16, 2, 1},
+                          {25, 128, 128, 16, 2, 1}, {26, 128, 80, 16, 3, 1}, {27, 128, 208, 16, 2, 1}, {28, 128, 80, 16, 2, 1}, {29, 256, 80, 16, 2, 1},
+                          {30, 128, 160, 16, 2, 1}, {32, 64, 208, 16, 2, 1}};
+  for (const T& t : tab)
+    if (t.tile == tile) { *bm = t.bm; *bn = t.bn; *bk = t.bk; *occ = t.occ; *kind = t.kind; return true; }
+  return false;
+}
+
+static int dispatch_tile(int tile, const nnr_gemm_args& g, hipStream_t stream) {
   switch (tile) {
     case 1: return launch_cfg<4, 5, 16>(g, stream);    // 256 x 80
     case 2: return launch_cfg<1, 5, 16>(g, stream);    //  64 x 80
@@ -1591,4 +1609,89 @@ extern "C" int nnr_gemm_f32(const nnr_gemm_args* a, hipStream_t stream) {
       return launch_skinny(g, stream);
     default: return NNR_ERR_ARG;
   }
+}
+
+extern "C" int nnr_gemm_f32(const nnr_gemm_args* a, hipStream_t stream) {
+  if (!a || !a->A || !a->B) return NNR_ERR_ARG;
+  if (!a->C && !a->rowdot_out && !a->aux_out) return NNR_ERR_ARG;
+  if (a->M <= 0 || a->N <= 0 || a->K <= 0) return NNR_OK;
+  nnr_gemm_args g = *a;
+  g.drop_thresh = nnr_drop_thresh(g.drop_target ? g.drop_p : 0.f);
+  g.drop_scale = (g.drop_target && g.drop_p > 0.f) ? 1.f / (1.f - g.drop_p) : 1.f;
+  if (g.drop_thresh == 0u) g.drop_target = 0;
+  if (g.k_chunk > 0) { if ((g.k_chunk & 31) || g.batch > 1) return NNR_ERR_ARG; g.split_k = 2; }   // shares split-K's restrictions below
+  if (g.split_k > 1 && (g.bias || g.rowvec || g.act || g.aux_out || g.mul || g.resid || g.batch > 1 || g.rowdot_w))
+    return NNR_ERR_ARG;
+  if ((g.a_idx && g.trans_a) || (g.b_idx && !g.trans_b)) return NNR_ERR_ARG;
+  if (g.colsum_out && !g.trans_a) return NNR_ERR_ARG;
+  if ((g.dyn_dim != 0) != (g.dyn_dev != nullptr)) return NNR_ERR_ARG;
+  {
+    auto ok = [](const void* p, int ld) { return p == nullptr || ((((uintptr_t)p) & 15) == 0 && (ld & 3) == 0); };
+    const bool strides = g.batch <= 1 || (((g.strideC | g.stride_aux | g.stride_res) & 3) == 0);
+    g.vec_epi = (!g.c_idx && !g.atomic && g.split_k <= 1 && !g.rowdot_w && (g.N & 3) == 0 && ok(g.C, g.ldc) && ok(g.bias, 0) &&
+                 ok(g.rowvec, g.ldrv) && ok(g.aux_out, g.ldaux) && ok(g.mul, g.ldmul) && ok(g.resid, g.ldres) && strides &&
+                 (g.drop_target != 3 || (g.drop_cols & 3) == 0)) ? 1 : 0;
+  }
+  // reproducible split-K: the slices store into the caller's slab, a second launch adds them in slice order (splitk_reduce_kernel)
+  float* slab_C = nullptr;
+  float* slab_cs = nullptr;
+  int slab_ldc = 0;
+  if (g.slab != nullptr) {
+    if (!(g.trans_a && g.trans_b) || g.split_k <= 1 || g.k_chunk > 0 || g.c_idx || (g.N & 3) || (((uintptr_t)g.slab) & 15) || !g.C || g.accumulate == 2 ||
+        g.slab_floats < (long)g.split_k * ((long)g.M * g.N + g.M))
+      return NNR_ERR_ARG;
+    slab_C = g.C; slab_ldc = g.ldc; slab_cs = g.colsum_out;
+    g.C = g.slab; g.ldc = g.N; g.atomic = 0; g.accumulate = 0; g.slab_mode = 1; g.vec_epi = 1;
+    if (g.colsum_out) g.colsum_out = g.slab + (long)g.split_k * g.M * g.N;
+  } else {
+    g.slab_mode = 0;
+  }
+  int tile = g.tile;
+  if (tile == 0) {
+    const long wg128 = (long)((g.M + 127) / 128) * ((g.N + 79) / 80) * (g.k_chunk > 0 ? (g.K + g.k_chunk - 1) / g.k_chunk : (g.split_k > 1 ? g.split_k : (g.batch > 1 ? g.batch : 1)));
+    const long wg64 = (long)((g.M + 63) / 64) * ((g.N + 79) / 80) * (g.split_k > 1 ? g.split_k : (g.batch > 1 ? g.batch : 1));
+    const bool plain = !g.trans_a && !g.a_idx && !g.b_idx && !g.c_idx && !g.dyn_dev && g.split_k <= 1 && g.k_chunk <= 0 && !g.rowdot_w &&
+                       !g.colsum_out && !g.atomic && (g.drop_target == 0 || g.drop_target == 3);
+    static const bool use_t9 = [] { const char* e = getenv("NNR_NT9"); return !(e && atoi(e) == 0); }();   // A/B
+    static const bool use_pipe = [] { const char* e = getenv("NNR_GEMM_PIPE"); return !(e && atoi(e) == 0); }();   // A/B switch
+    if (g.rowdot_w) tile = 3;
+    else if (plain && wg64 <= 512 && g.K >= 64) tile = 7;   // small row-parallel launch: 16 x 80 tiles, K split over the 4 waves
+    else if (use_pipe && use_t9 && pipe_ok(g) && !g.a_idx && g.K >= 800 && wg64 > 512) {
+      tile = 9;              // long reductions (dX: K = 1664, SUE: K = 900): the
+                             // software-pipelined loop with the lean DMA issue, 2 workgroups / CU (130 vs 112 TF, 93 vs 79 TF)
+      // Launches of one or two waves of workgroups (SUE: 4 352 / 6 080 rows x 900 columns) are bound by the CU that carries the most
+      // tiles: 4 352 x 900 is 408 tiles of 128 x 80 (the busiest CU works through 2 x 80 columns of a 128-row stripe) but 510 tiles of
+      // 128 x 64 (2 x 64 columns, and no column padding: 900 = 14.06 x 64 vs 11.25 x 80) -- take the narrower tile when that wins by > 8 %.
+      static const bool use_n64 = [] { const char* e = getenv("NNR_NT64"); return e && atoi(e) == 1; }();   // opt-in: measured no better in the step (11.38-11.44 vs 11.27-11.31 ms, sustained equal)
+      if (use_n64 && !g.dyn_dev && g.batch <= 1) {
+        const long nbm = (g.M + 127) / 128, t80 = nbm * ((g.N + 79) / 80), t64 = nbm * ((g.N + 63) / 64);
+        const long load80 = ((t80 + 255) / 256) * 80, load64 = ((t64 + 255) / 256) * 64;
+        if (t80 < 1024 && load64 * 100 < load80 * 92) tile = 31;
+      }
+    }
+    else if (use_pipe && pipe_ok(g) && (g.dyn_dev || wg128 >= 640)) tile = 15;   // GPU-filling NT: LDS-DMA staged 128 x 80, BK 16, 4 workgroups / CU
+                             // (112 vs 98 TF on the 131 072-row CNE shapes, tools/gemm_pipe_bench.py)
+    else if (use_pipe && pipe_ok(g) && wg64 > 512 && g.K >= 128) tile = 16;      // mid-size NT (SUE: 4 352 x 900 x 900): same tile, two 13 KB stages,
+                             // 5-6 workgroups / CU cover the round trips (79 vs 65-72 TF)
+    else if (wg64 <= 512 && !g.dyn_dev && g.k_chunk <= 0 && g.K >= 128 && !g.trans_a) tile = 6;   // (not for TN: the small weight-gradient
+                             // launches run on the leaf stream BESIDE the recurrence, whose workgroups hold 98 KB of LDS per CU; a 74 KB tile cannot
+                             // move in next to them and waits for free CUs, the 19 KB tile can: 12.60 vs 12.70 ms/step)   // at most 2 workgroups per CU: nothing hides the
+                             // memory round trip each k-stage pays with a one-stage prefetch -> BK = 64, 4x fewer stages
+    else if (g.M <= 512 || (wg128 < 640 && !g.dyn_dev)) tile = 2;   // too few 128-row tiles to fill 256 CUs x 4: use 64-row tiles
+    else if (g.trans_a) tile = 2;   // TN (token-reduction dW): callers pick the LDS-DMA tiles 20 / 24 explicitly (their split-K factor
+                                    // depends on the tile); this is the register-staged fallback
+    else if (!g.trans_a && !g.trans_b) tile = 5;   // NT that the pipelined kernel cannot take (unaligned operands)
+    else tile = 4;           // NN with a K-major B (activations on both sides, or a weight the caller did not transpose)
+  }
+  const int rc = dispatch_tile(tile, g, stream);
+  if (rc != NNR_OK || !g.slab_mode) return rc;
+  int bm, bn, bk, occ, kind;
+  if (!tile_shape(tile, &bm, &bn, &bk, &occ, &kind)) return NNR_ERR_ARG;
+  const int nblk = ((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn);
+  const long mn4 = ((long)g.M * g.N) >> 2;
+  const int blocks = (int)(mn4 / 256 + 1 > 2048 ? 2048 : mn4 / 256 + 1);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)g.slab, (const float*)g.colsum_out, slab_C, slab_ldc, slab_cs,
+                     g.M, g.N, g.K, g.dyn_dim == 2 ? g.dyn_dev : (const int*)nullptr, g.split_k, tn_sched_bits(), nblk, occ * 256, bk, kind);
+  NNR_CHECK_LAUNCH();
+  return NNR_OK;
 }

@@ -61,25 +61,43 @@ __global__ __launch_bounds__(256) void packed_seq_sum_kernel(const float* __rest
 // L2 whatever the address within the line (measured: 1 600 workgroups x 200 columns = 93 us, 800 x 400 = 66 us, both far above
 // their HBM time), so with a workspace the workgroups add into slot (blockIdx.x % NNR_SLOTS) of `ws` [NNR_SLOTS, N] -- 32x
 // more lines -- and slot_reduce_kernel folds the slots into the destination and leaves the workspace zeroed for the next call.
-constexpr int NNR_SLOTS = 32;
-__global__ __launch_bounds__(256) void slot_reduce_kernel(float* __restrict__ ws, int N, float* __restrict__ out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= N) return;
+// Round 4: the result must also be REPRODUCIBLE (config.py:125-130), and atomics into shared slots add in arrival order.  Now every
+// workgroup b of the (at most NNR_SLOTS) workgroups of a launch owns a contiguous range of the LIVE rows and stores its column sums to
+// ITS row ws[b][N]; slot_reduce_kernel adds the rows in a fixed tree order (thread (column, s) sums rows s, s + 32, ... in order, then
+// the 32 partial sums are added in order) and issues ONE atomic add per column (the destination is a parameter gradient that a
+// second launch -- the other encoder call of the plugin API -- may add into: two addends into a zeroed buffer commute).
+constexpr int NNR_SLOTS = 1024;
+__global__ __launch_bounds__(256) void slot_reduce_kernel(const float* __restrict__ ws, int nb, int N, float* __restrict__ out) {
+  __shared__ float part[32][8];
+  const int cl = threadIdx.x & 7, sg = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + cl;
   float acc = 0.f;
-#pragma unroll 8
-  for (int s = 0; s < NNR_SLOTS; ++s) {
-    acc += ws[s * N + c];
-    ws[s * N + c] = 0.f;
+  if (c < N)
+    for (int b = sg; b < nb; b += 32) acc += ws[(long)b * N + c];
+  part[sg][cl] = acc;
+  __syncthreads();
+  if (sg == 0 && c < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) t += part[q][cl];
+    atomicAdd(&out[c], t);
   }
-  atomicAdd(&out[c], acc);               // the destination is a parameter gradient other streams may add into
 }
 
 __global__ __launch_bounds__(256) void tanh_score_bwd_kernel(float* __restrict__ th, const float* __restrict__ ds,
                                                              const float* __restrict__ w2, float* __restrict__ dw2,
                                                              const int* rows_dev, int rows, int A, int rows_per_block, float* ws) {
   const int R = dyn_rows(rows_dev, rows);
-  const int r0 = blockIdx.x * rows_per_block, r1 = min(R, r0 + rows_per_block);
-  if (ws) dw2 = ws + (blockIdx.x % NNR_SLOTS) * A;
+  int r0, r1;
+  if (ws) {                                   // reproducible form: gridDim.x workgroups share the LIVE rows, each stores to its own slot row
+    const int chunk = (R + (int)gridDim.x - 1) / (int)gridDim.x;
+    r0 = min(R, (int)blockIdx.x * chunk);
+    r1 = min(R, r0 + chunk);
+    dw2 = ws + (long)blockIdx.x * A;
+  } else {
+    r0 = blockIdx.x * rows_per_block;
+    r1 = min(R, r0 + rows_per_block);
+  }
   for (int a = threadIdx.x; a < A; a += blockDim.x) {
     const float w = w2[a];
     float acc = 0.f;
@@ -100,7 +118,8 @@ __global__ __launch_bounds__(256) void tanh_score_bwd_kernel(float* __restrict__
       acc += d * t;
       th[(long)row * A + a] = d * w * (1.f - t * t);
     }
-    if (r0 < r1) atomicAdd(&dw2[a], acc);
+    if (ws) dw2[a] = acc;
+    else if (r0 < r1) atomicAdd(&dw2[a], acc);
   }
 }
 
@@ -128,9 +147,17 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ x
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int ld, const int* rows_dev, int rows, int N,
                                                      float* __restrict__ out, int rows_per_block, float* ws) {
   const int R = dyn_rows(rows_dev, rows);
-  const int r0 = blockIdx.x * rows_per_block, r1 = min(R, r0 + rows_per_block);
-  if (r0 >= r1) return;
-  if (ws) out = ws + (blockIdx.x % NNR_SLOTS) * N;
+  int r0, r1;
+  if (ws) {                                   // reproducible form (see slot_reduce_kernel): own slot row, written even when empty
+    const int chunk = (R + (int)gridDim.x - 1) / (int)gridDim.x;
+    r0 = min(R, (int)blockIdx.x * chunk);
+    r1 = min(R, r0 + chunk);
+    out = ws + (long)blockIdx.x * N;
+  } else {
+    r0 = blockIdx.x * rows_per_block;
+    r1 = min(R, r0 + rows_per_block);
+    if (r0 >= r1) return;
+  }
   for (int c = blockIdx.y * blockDim.x + threadIdx.x; c < N; c += gridDim.y * blockDim.x) {
     float acc = 0.f;
     int row = r0;
@@ -142,7 +169,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
       for (int u = 0; u < 8; ++u) acc += v[u];
     }
     for (; row < r1; ++row) acc += x[(long)row * ld + c];
-    atomicAdd(&out[c], acc);
+    if (ws) out[c] = acc;
+    else atomicAdd(&out[c], acc);
   }
 }
 
@@ -332,9 +360,25 @@ __global__ void sue_x0_kernel(const float* __restrict__ hist, const float* __res
       if (dhist) dhist[((long)b * Hn + j) * D + c] = up;
     } else {
       const int k = j - Hn;
-      const float m = nnr_keep(seed, (uint64_t)((long)b * Kc + k) * D + c, thr) ? scale : 0.f;
-      if (x0) x0[i] = proxy[(long)k * D + c] * m;
-      if (dproxy) atomicAdd(&dproxy[(long)k * D + c], up * m);
+      if (x0) {
+        const float m = nnr_keep(seed, (uint64_t)((long)b * Kc + k) * D + c, thr) ? scale : 0.f;
+        x0[i] = proxy[(long)k * D + c] * m;
+      }
+    }
+  }
+  if (dproxy) {
+    // dproxy[k, c] += sum_b mask * dX0[b, Hn + k, c]: one thread per (k, c) adds the B samples IN ORDER (reproducible; f32 atomics from
+    // B x Kc x D threads added in arrival order) and issues one atomic add (the destination is a parameter gradient)
+    for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < (long)Kc * D; t += (long)gridDim.x * blockDim.x) {
+      const int c = t % D, k = t / D;
+      float acc = 0.f;
+      for (int b = 0; b < B; ++b) {
+        const long i = ((long)b * G + Hn + k) * D + c;
+        const float up = dx0_add ? dx0[i] + dx0_add[i] : dx0[i];
+        const float m = nnr_keep(seed, (uint64_t)((long)b * Kc + k) * D + c, thr) ? scale : 0.f;
+        acc += up * m;
+      }
+      atomicAdd(&dproxy[t], acc);
     }
   }
 }
@@ -877,12 +921,12 @@ extern "C" int nnr_slot_workspace_floats(int N) { return NNR_SLOTS * N; }
 extern "C" int nnr_tanh_score_bwd(float* th, const float* ds, const float* w2, float* dw2, const int* rows_dev, int rows, int A,
                                   float* ws, hipStream_t stream) {
   const int rpb = 64;
-  const int blocks = (rows + rpb - 1) / rpb;
-  if (blocks < 4 * NNR_SLOTS) ws = nullptr;                     // few workgroups: the direct atomics are cheaper than a second launch
+  int blocks = (rows + rpb - 1) / rpb;
+  if (ws) blocks = blocks > NNR_SLOTS ? NNR_SLOTS : (blocks < 1 ? 1 : blocks);      // (the live rows are shared out on the device)
   hipLaunchKernelGGL(tanh_score_bwd_kernel, dim3(blocks), dim3(256), 0, stream, th, ds, w2, dw2, rows_dev, rows, A, rpb, ws);
   NNR_CHECK_LAUNCH();
   if (ws) {
-    hipLaunchKernelGGL(slot_reduce_kernel, dim3((A + 255) / 256), dim3(256), 0, stream, ws, A, dw2);
+    hipLaunchKernelGGL(slot_reduce_kernel, dim3((A + 7) / 8), dim3(256), 0, stream, (const float*)ws, blocks, A, dw2);
     NNR_CHECK_LAUNCH();
   }
   return NNR_OK;
@@ -903,12 +947,12 @@ extern "C" int nnr_colsum(const float* x, int ld, const int* rows_dev, int rows,
   // per block a [3200, 200] bias gradient was 25 workgroups walking 128 rows each (43 us); many enough to bound the atomics
   int rpb = rows / 512;
   rpb = rpb < 8 ? 8 : (rpb > 128 ? 128 : rpb);
-  const int blocks = (rows + rpb - 1) / rpb;
-  if (blocks < 4 * NNR_SLOTS) ws = nullptr;
+  int blocks = (rows + rpb - 1) / rpb;
+  if (ws) blocks = blocks > NNR_SLOTS ? NNR_SLOTS : blocks;
   hipLaunchKernelGGL(colsum_kernel, dim3(blocks, (N + 255) / 256), dim3(256), 0, stream, x, ld, rows_dev, rows, N, out, rpb, ws);
   NNR_CHECK_LAUNCH();
   if (ws) {
-    hipLaunchKernelGGL(slot_reduce_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, ws, N, out);
+    hipLaunchKernelGGL(slot_reduce_kernel, dim3((N + 7) / 8), dim3(256), 0, stream, (const float*)ws, blocks, N, out);
     NNR_CHECK_LAUNCH();
   }
   return NNR_OK;

@@ -293,6 +293,10 @@ def _cne_fwd_pre(mod, title_text, title_mask, content_text, content_mask, catego
         # dropout(embedding rows) materialised ONCE per token (6 TB/s gather): fused into the GEMM's A loader the counter hash
         # is recomputed by each of the 21 column blocks (-16 % on this GEMM and on the dW_ih GEMM of the backward)
         st['xd'] = ops.embed_gather(emb, plan.tok, p, st['seed'], dyn=plan.total)
+        if ops.SCATTER_SORTED and mod.training and E <= 320:
+            # the backward's embedding-row gradient is a segmented reduction over the rows sorted by word id (reproducible, no atomic
+            # ceiling): the sort needs only the planned ids and runs on the leaf stream under the forward pass
+            st['tsort'] = ops.TokenSort(plan.tok, plan.total, emb.shape[0])
         ops.gemm(st['xd'], w.w_ihp, st['gates'], M=cap, N=2 * w.NP, K=E, lda=E, ldb=E, ldc=2 * w.NP, dyn=plan.total, dyn_dim=1, bias=w.b_p,
                  flop_scale=4.0 * H / w.NP)
         st['cell'] = torch.empty((cap, 2 * w.HP), **f32)
@@ -468,8 +472,9 @@ def _cne_bwd_pre(mod, sv, drep, par=False, leaf=None):
     drep = drep.reshape(n, D)
     emb = mod.word_embedding.weight
 
-    ops.fusion_rows_bwd(*sv['cats'], sv['cd'], sv['sd'], drep[:, 2 * H2:], D, grad_of(mod.category_embedding.weight),
-                        grad_of(mod.subCategory_embedding.weight), p, seed + _SITE['cat'], seed + _SITE['sub'])
+    # (a leaf of the backward pass: nothing downstream reads the two table gradients -- on the leaf stream, off the dependent chain)
+    leaf(lambda: ops.fusion_rows_bwd(*sv['cats'], sv['cd'], sv['sd'], drep[:, 2 * H2:], D, grad_of(mod.category_embedding.weight),
+                                     grad_of(mod.subCategory_embedding.weight), p, seed + _SITE['cat'], seed + _SITE['sub']), drep)
 
     # ---- cross attention pools: dHt (overwrite), dv -> K / Q params and the gradient of the OTHER stream's self vector
     def cross_bwd(st, other, col0):
@@ -573,7 +578,10 @@ def _cne_bwd_post(mod, sv, st, leaf=None):
             dx = st['cell'].view(-1)[:cap * E].view(cap, E) if st['cell'].numel() >= cap * E else torch.empty((cap, E), **f32)
             ops.gemm(dg, w.w_ihp_t, dx, M=cap, N=E, K=2 * NP, lda=2 * NP, ldb=2 * NP, ldc=E, dyn=plan.total, dyn_dim=1,
                      tile=_DX_TILE if leaf is not None else _TITLE_DX_TILE, flop_scale=4.0 * H / NP)
-            ops.embed_scatter(dx, plan.tok, grad_of(emb), p, st['seed'], dyn=plan.total)
+            if st.get('tsort') is not None:
+                ops.embed_scatter_sorted(dx, st['tsort'], grad_of(emb), p, st['seed'])
+            else:
+                ops.embed_scatter(dx, plan.tok, grad_of(emb), p, st['seed'], dyn=plan.total)
             return
         ops.gemm(dg, w.w_ihp_t, grad_of(emb), M=cap, N=E, K=2 * NP, lda=2 * NP, ldb=2 * NP, ldc=E, c_idx=plan.tok, atomic=True,
                  drop=(4, p, st['seed'], E), dyn=plan.total, dyn_dim=1, tile=0 if leaf is not None else _TITLE_DX_TILE, flop_scale=4.0 * H / NP)

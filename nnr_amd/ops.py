@@ -297,7 +297,7 @@ _TN_SMALL_LDS = os.environ.get('NNR_TN_SMALL_LDS', '0') == '1'      # 1: 53 KB 1
                                                                     # tile for N = 200 / 400 is ahead again (11.38 vs 11.43 ms, 4 rounds each)
 
 
-_TN_T64 = int(os.environ.get('NNR_TN_T64', '0'))      # A/B (round 4): bit 0 = 64 x 208 tile for the M = 200 / 400 gate / attention weight gradients, bit 1 = for the gathered dW_hh (M = 832)
+_TN_T64 = int(os.environ.get('NNR_TN_T64', '3'))      # A/B (round 4): bit 0 = 64 x 208 tile for the M = 200 / 400 gate / attention weight gradients, bit 1 = for the gathered dW_hh (M = 832)
 
 
 def tn_tile(M, N, K, gather=False):
@@ -332,7 +332,7 @@ def split_for(m, n, k, tile_m=64, tile_n=80, target_blocks=2048, kmin=256):
 def gemm(A, B, C_=None, *, M, N, K, lda, ldb, ldc=0, trans_a=False, trans_b=False, dyn=None, dyn_dim=0, a_idx=None, b_idx=None,
          drop=None, alpha=1.0, bias=None, rowvec=None, ldrv=0, rowvec_map=None, act=0, aux_out=None, ldaux=0, mul=None, ldmul=0,
          resid=None, ldres=0, accumulate=False, atomic=False, c_idx=None, split_k=1, rowdot_w=None, rowdot_out=None, batch=1,
-         strideA=0, strideB=0, strideC=0, stride_aux=0, stride_res=0, tile=0, colsum_out=None, k_chunk=0, flop_scale=1.0):
+         strideA=0, strideB=0, strideC=0, stride_aux=0, stride_res=0, tile=0, colsum_out=None, k_chunk=0, flop_scale=1.0, slab=None):
     # flop_scale: algorithmic / padded work of this launch (the LSTM gate columns are padded 800 -> 832 per direction; the live
     # profile counts the true 8H columns, not the padded 2*NP)
     # ctypes zero-initialises the struct: only the fields a call actually uses are written (a field store costs ~0.2 us of host
@@ -383,6 +383,10 @@ def gemm(A, B, C_=None, *, M, N, K, lda, ldb, ldc=0, trans_a=False, trans_b=Fals
         g.colsum_out = colsum_out.data_ptr()
     if k_chunk:
         g.k_chunk = int(k_chunk)
+    if slab is None and TN_SLAB and trans_a and trans_b and split_k > 1 and not k_chunk and c_idx is None and (N & 3) == 0 and C_ is not None:
+        slab = _slab_ws(A.device, int(split_k) * (M * N + M))      # reproducible split-K: partial results to a slab + fixed-order reduction
+    if slab is not None:
+        g.slab, g.slab_floats = slab.data_ptr(), slab.numel()
     if not (A.is_cuda and B.is_cuda):
         raise L.NnrHipError('nnr_amd ops need device tensors (no CPU fallback on the product path)')
     if not _prof.active():
@@ -493,11 +497,27 @@ def rowdot(x, w, out, dyn=None, rows=None):
 
 
 _SLOT_WS = {}
+_SLAB_WS = {}
+TN_SLAB = os.environ.get('NNR_TN_SLAB', '1') != '0'      # split-K weight gradients through slabs + a fixed-order reduction (0: f32 atomics)
+
+
+def _slab_ws(dev, floats):
+    """Split-K slab workspace of the CURRENT stream (nnr_gemm_args.slab): a launch's slices store their partial results there and the
+    reduction that follows it on the same stream consumes them, so launches of one stream share one buffer (grown when a bigger
+    launch comes along; a recording tape keeps every buffer it has seen alive)."""
+    key = torch._C._cuda_getCurrentRawStream(dev.index if dev.index is not None else torch.cuda.current_device())
+    ws = _SLAB_WS.get(key)
+    if ws is None or ws.numel() < floats:
+        ws = torch.empty(max(int(floats), 1 << 22), device=dev, dtype=torch.float32)
+        _SLAB_WS[key] = ws
+    tape_keep(ws)
+    return ws
+
 
 
 def _slot_ws(dev, n):
-    """Zeroed slot workspace of the CURRENT stream (see nnr_slot_workspace_floats): kernels of one stream run in order and each
-    call leaves it zeroed, so one buffer per stream serves every call; grown (fresh zeros) when a wider vector comes along."""
+    """Slot workspace of the CURRENT stream (see nnr_slot_workspace_floats): kernels of one stream run in order and each call
+    overwrites the slot rows it reads, so one buffer per stream serves every call; grown when a wider vector comes along."""
     key = torch._C._cuda_getCurrentRawStream(dev.index if dev.index is not None else torch.cuda.current_device())
     need = L.lib().nnr_slot_workspace_floats(int(n))
     ws = _SLOT_WS.get(key)
@@ -510,7 +530,7 @@ def _slot_ws(dev, n):
 
 def bias_grad(dy, db, dyn=None, rows=None):
     R = dy.shape[0] if rows is None else rows
-    ws = _slot_ws(dy.device, db.numel()) if R >= 1024 else None
+    ws = _slot_ws(dy.device, db.numel())         # per-workgroup slot rows + fixed-order reduction (reproducible; round 3: only for R >= 1024)
     L.check(L.lib().nnr_colsum(_p(dy), dy.stride(0), _p(dyn), R, db.numel(), _p(db), _p(ws), _s()), 'nnr_colsum')
 
 
@@ -751,7 +771,7 @@ def packed_seq_sum(x, D, plan, out):
 
 def tanh_score_bwd(th, ds, w2, dw2, plan, A):
     rows = plan.cap if plan is not None else th.shape[0]
-    ws = _slot_ws(th.device, A) if rows >= 8192 else None
+    ws = _slot_ws(th.device, A)                  # (reproducible dw2: see csrc/misc.hip slot_reduce_kernel)
     L.check(L.lib().nnr_tanh_score_bwd(_p(th), _p(ds), _p(w2), _p(dw2), _p(plan.total) if plan is not None else None, rows, A, _p(ws),
                                        _s()), 'nnr_tanh_score_bwd')
 
@@ -891,8 +911,16 @@ def fusion_rows_fwd(cat_table, sub_table, cat0, sub0, cat1, sub1, out_view, ldo,
                                         C.c_uint32(seed_sub & 0xFFFFFFFF), _s()), 'nnr_fusion_rows_fwd')
 
 
+DETERMINISTIC = os.environ.get('NNR_DETERMINISTIC', '1') != '0'      # reproducible forms of the small reductions (category tables, proxy nodes)
+
+
 def fusion_rows_bwd(cat0, sub0, cat1, sub1, cd, sd, dout_view, lddo, dcat_table, dsub_table, p, seed_cat, seed_sub):
     n0, n1 = cat0.numel(), (cat1.numel() if cat1 is not None else 0)
+    if DETERMINISTIC and cd <= 128 and sd <= 128:
+        L.check(L.lib().nnr_fusion_rows_bwd_det(_p(cat0), _p(sub0), n0, _p(cat1), _p(sub1), n1, cd, sd, dcat_table.shape[0], dsub_table.shape[0],
+                                                _p(dout_view), lddo, _p(dcat_table), _p(dsub_table), C.c_float(p), C.c_uint32(seed_cat & 0xFFFFFFFF),
+                                                C.c_uint32(seed_sub & 0xFFFFFFFF), _s()), 'nnr_fusion_rows_bwd_det')
+        return
     L.check(L.lib().nnr_fusion_rows_bwd(_p(cat0), _p(sub0), n0, _p(cat1), _p(sub1), n1, cd, sd, _p(dout_view), lddo, _p(dcat_table), _p(dsub_table),
                                         C.c_float(p), C.c_uint32(seed_cat & 0xFFFFFFFF), C.c_uint32(seed_sub & 0xFFFFFFFF), _s()), 'nnr_fusion_rows_bwd')
 
@@ -988,6 +1016,44 @@ def _embed_scatter(dout, idx, dtable, p, seed, dyn, n, dim):
         return
     L.check(L.lib().nnr_embed_scatter(_p(dout), _p(idx), C.c_long(n), dim, _p(dtable), C.c_float(p), C.c_uint32(seed & 0xFFFFFFFF), _s()),
             'nnr_embed_scatter')
+
+
+SCATTER_SORTED = os.environ.get('NNR_SCATTER_SORTED', '1') != '0'      # embedding-row gradient as a sorted segmented reduction (0: f32-atomic scatter)
+
+
+class TokenSort:
+    """The live rows of a packed token stream sorted by word id (csrc/sort.hip), issued on the LEAF stream behind the planner: it
+    needs nothing but the planned ids, so it runs under the forward pass; the backward's nnr_embed_scatter_sorted waits for `event`."""
+
+    def __init__(self, tok, total, vocab):
+        dev, cap = tok.device, tok.numel()
+        self.cap, self.vocab, self.total = cap, int(vocab), total
+        i32 = dict(device=dev, dtype=torch.int32)
+        buf = torch.empty(4 * cap, **i32)                        # keys_tmp | rows_tmp | keys_sorted | rows_sorted
+        self.keys, self.rows = buf[2 * cap:3 * cap], buf[3 * cap:]
+        nb = int(L.lib().nnr_token_sort_workspace_bytes(C.c_long(cap), self.vocab))
+        temp = torch.empty(max(nb, 256), device=dev, dtype=torch.uint8)
+        self.partial = torch.empty(int(L.lib().nnr_embed_scatter_sorted_workspace_floats(C.c_long(cap))), device=dev, dtype=torch.float32)
+        key = (dev.type, dev.index)
+        if key not in _LEAF:
+            _LEAF[key] = new_stream(dev)
+        leaf = _LEAF[key]
+        leaf.wait_stream(torch.cuda.current_stream(dev))          # behind the planner that wrote `tok` / `total`
+        with torch.cuda.stream(leaf):
+            L.check(L.lib().nnr_token_sort(_p(tok), C.c_long(cap), _p(total), self.vocab, _p(buf[:cap]), _p(buf[cap:2 * cap]), _p(self.keys), _p(self.rows),
+                                           _p(temp), C.c_size_t(temp.numel()), _s()), 'nnr_token_sort')
+            self.event = torch.cuda.Event()
+            self.event.record()
+        self._keep = (buf, temp)
+
+
+def embed_scatter_sorted(dout, ts, dtable, p, seed):
+    """dtable[w] += sum of mask * dout[row] over the rows of word w in list order (reproducible; see TokenSort)."""
+    dim = dtable.shape[1]
+    torch.cuda.current_stream(dout.device).wait_event(ts.event)
+    with _hbm_span('embed_scatter', 2 * 4.0 * dim + 8.0, ts.cap, dyn=ts.total, tag='sorted cap%d' % ts.cap):
+        L.check(L.lib().nnr_embed_scatter_sorted(_p(dout), _p(ts.keys), _p(ts.rows), C.c_long(ts.cap), ts.vocab, dim, _p(dtable), C.c_float(p),
+                                                 C.c_uint32(seed & 0xFFFFFFFF), _p(ts.partial), _s()), 'nnr_embed_scatter_sorted')
 
 
 def fill_zero(t):

@@ -36,6 +36,16 @@ def _pair(cfg, seed, train=True):
     return model, ref
 
 
+def _rel_l2(name, g, rg, total_norm):
+    """Per-tensor bound (round-3 verdict): the max-abs bar above is relative to max(tensor norm, 5 % of the TOTAL norm), so for a small
+    tensor it admits a systematic error of a few per cent of that tensor.  Every gradient tensor that carries signal (norm > 1e-4 of
+    the total) must also agree with the oracle to 1e-3 in relative L2."""
+    n = float(rg.norm())
+    if n > 1e-4 * total_norm:
+        rel = float((g - rg).norm()) / n
+        assert rel <= 1e-3, 'grad %s: relative L2 error %.3e (norm %.3e of total %.3e)' % (name, rel, n, total_norm)
+
+
 def _check_step(model, ref, cfg, batch, lr_steps=1, inject_masks=False):
     from nnr_amd import ops
     from nnr_amd.trainer import Trainer
@@ -79,6 +89,7 @@ def _check_step(model, ref, cfg, batch, lr_steps=1, inject_masks=False):
         worst = max(worst, d / scale)
         assert d <= 1e-4 * scale, 'grad %s: %.3e vs scale %.3e' % (k, d, scale)
         assert abs(float(g.norm()) - float(rg.norm())) <= 1e-4 * scale, 'grad norm ' + k
+        _rel_l2(k, g, rg, rnorm)
     # one Adam step: elements with a well-resolved gradient move identically; the rest move by -+lr each (the first Adam step
     # is lr * sign(g) and the sign of a gradient at the fp32 noise floor is noise): at most 2 * lr apart
     lr = float(cfg.lr)
@@ -109,27 +120,29 @@ def test_cne_sue_batch64_vocab60000_DROPOUT_ON_matches_oracle():
     print('CNE+SUE batch 64, dropout 0.2 ON: logits max|diff| %.2e, worst gradient deviation %.2e of its scale' % (err, worst))
 
 
-def test_cne_sue_batch64_REPLAYED_step_dropout_on_matches_oracle():
-    """The step bench.py times is a native REPLAY of the recorded launch sequence (nnr_amd/tape.py).  Three steps bring the trainer
-    to that state (call by call, call by call, record); the oracle is then synchronised to the product's parameters and the FOURTH
-    step -- replayed from the tape on a new batch, with that step's seeds -- is compared: logits, loss, every gradient, total norm."""
+def _replayed_step_check(cfg, bs, seed, rng_seed):
+    """Three steps bring the trainer to the replaying state (call by call, call by call, record); the oracle is then synchronised to
+    the product's parameters AND its Adam state is rebuilt from the product's moments, and the FOURTH step -- replayed from the tape on
+    a new batch, with that step's seeds -- is compared: logits, loss, every gradient (max-abs and per-tensor relative L2), the total
+    norm, and the parameters after that step's clip + Adam."""
     import hip_masks
     from nnr_amd import ops
     from nnr_amd.trainer import Trainer
     from oracle import nnr_oracle as O
-    cfg = make_config(['--news_encoder=CNE', '--user_encoder=SUE', '--dataset=200k', '--batch_size=64'],
-                      corpus_sizes=dict(vocabulary_size=60000), tie_order='stable')
-    model, ref = _pair(cfg, seed=5)
+    model, ref = _pair(cfg, seed=seed)
     trainer = Trainer(model, cfg)
     corpus = SynthCorpus(SynthSpec(vocabulary_size=cfg.vocabulary_size))
-    rng = np.random.default_rng(105)
+    rng = np.random.default_rng(rng_seed)
     ops.lstm_sync_timeouts(reset=True)
     for want in ('native', 'native', 'record'):
-        trainer.train_step(to_torch(corpus.batch(64, rng), 'cuda'))
+        trainer.train_step(to_torch(corpus.batch(bs, rng), 'cuda'))
         assert trainer.last_path == want
     torch.cuda.synchronize()
+    assert not trainer.tape_violations
     ref.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()})
-    batch = corpus.batch(64, rng)
+    before = {k: p.detach().cpu().clone() for k, p in model.named_parameters()}
+    m_before, v_before = trainer.m.detach().cpu().clone(), trainer.v.detach().cpu().clone()
+    batch = corpus.batch(bs, rng)
     dev_batch = to_torch(batch, 'cuda')
     hip_masks.inject(model, ref, dict(zip(BATCH_FIELDS, dev_batch)))
     logits, loss = trainer.train_step(dev_batch)
@@ -152,8 +165,78 @@ def test_cne_sue_batch64_REPLAYED_step_dropout_on_matches_oracle():
         d = float((g - rg).abs().max())
         worst = max(worst, d / scale)
         assert d <= 1e-4 * scale, 'grad %s: %.3e vs scale %.3e' % (k, d, scale)
-    print('CNE+SUE batch 64, dropout ON, REPLAYED step: logits max|diff| %.2e, worst gradient deviation %.2e, tape %s' %
-          (err, worst, trainer.tapes[next(iter(trainer.tapes))].info()))
+        _rel_l2(k, g, rg, rnorm)
+    # the Adam step of the replay (step 4: bias corrections of t = 4) from the ORACLE's gradient and the product's own moments
+    lr, b1, b2, eps, t = float(cfg.lr), 0.9, 0.999, 1e-8, 4
+    clip = min(1.0, float(cfg.gradient_clip_norm) / (rnorm + 1e-6))
+    offs = dict(zip((id(q) for q in trainer.flat.params), trainer.flat.offsets))
+    for k, p in model.named_parameters():
+        o, n = offs[id(p)], p.numel()
+        g = rp[k].grad.double().reshape(-1) * clip
+        m = b1 * m_before[o:o + n].double() + (1 - b1) * g
+        v = b2 * v_before[o:o + n].double() + (1 - b2) * g * g
+        want = before[k].double().reshape(-1) - lr * (m / (1 - b1 ** t)) / ((v / (1 - b2 ** t)).sqrt() + eps)
+        d = (p.detach().cpu().double().reshape(-1) - want).abs()
+        resolved = rp[k].grad.abs().reshape(-1) > 0.05 * max(float(rp[k].grad.abs().max()), 1e-30)
+        assert float(d[resolved].max()) <= 5e-5 if bool(resolved.any()) else True, 'param (resolved) ' + k
+        assert float(d.max()) <= 2 * lr * 1.01 + 5e-5, 'param ' + k
+    return err, worst, trainer.tapes[next(iter(trainer.tapes))].info()
+
+
+def test_cne_sue_batch64_REPLAYED_step_dropout_on_matches_oracle():
+    """The step bench.py times is a native REPLAY of the recorded launch sequence (nnr_amd/tape.py)."""
+    cfg = make_config(['--news_encoder=CNE', '--user_encoder=SUE', '--dataset=200k', '--batch_size=64'],
+                      corpus_sizes=dict(vocabulary_size=60000), tie_order='stable')
+    err, worst, info = _replayed_step_check(cfg, 64, 5, 105)
+    print('CNE+SUE batch 64, dropout ON, REPLAYED step: logits max|diff| %.2e, worst gradient deviation %.2e, tape %s' % (err, worst, info))
+
+
+def test_cne_sue_config4_shard_batch8_vocab60000_REPLAYED_dropout_on_matches_oracle():
+    """BASELINE.json configs[3]'s per-GPU shard at REAL size (round-3 verdict: it had only run at V = 800 / 900): `--batch_size=64
+    --world_size=8` => 8 impressions per GPU (trainer.py:218), V = 60 000, dropout 0.2 ON, through native -> record -> replay: the
+    chain-bound regime (quad recurrence tiles for every long sequence, skinny GEMMs, ~95 dependent launches)."""
+    cfg = make_config(['--news_encoder=CNE', '--user_encoder=SUE', '--dataset=200k', '--batch_size=64', '--world_size=8'],
+                      corpus_sizes=dict(vocabulary_size=60000), tie_order='stable')
+    assert cfg.batch_size // cfg.world_size == 8 and abs(cfg.dropout_rate - 0.2) < 1e-12
+    err, worst, info = _replayed_step_check(cfg, 8, 7, 107)
+    print('CNE+SUE config-4 shard (batch 8, V 60 000), dropout ON, REPLAYED step: logits max|diff| %.2e, worst gradient deviation %.2e, tape %s' % (err, worst, info))
+
+
+def test_two_identical_steps_give_bit_identical_gradients():
+    """The reference's runs are seeded and deterministic (config.py:125-130: seeds + cudnn.deterministic).  Round 4: split-K weight
+    gradients go through slabs + a fixed-order reduction, the embedding-row gradient is a sorted segmented reduction, the column
+    sums / small-table / proxy-node gradients add in a fixed order -- so the SAME step (same batch, same seeds, lr 0) run twice at
+    the headline size, all four HIP streams active, gives BIT-IDENTICAL logits, loss, gradients and gradient norm; and a third time
+    as a recorded / replayed step."""
+    from nnr_amd import ops
+    from nnr_amd.trainer import Trainer
+    cfg = make_config(['--news_encoder=CNE', '--user_encoder=SUE', '--dataset=200k', '--batch_size=64'],
+                      corpus_sizes=dict(vocabulary_size=60000), tie_order='stable')
+    model, _ = _pair(cfg, seed=8)
+    trainer = Trainer(model, cfg)
+    trainer.lr = 0.0                                     # the parameters stay put: every step sees the same weights
+    batch = SynthCorpus(SynthSpec(vocabulary_size=cfg.vocabulary_size)).batch(64, np.random.default_rng(108))
+    runs = []
+    for i in range(5):
+        model.news_encoder._calls = model.user_encoder._calls = 0          # the same dropout seeds every time
+        logits, loss = trainer.train_step(to_torch(batch, 'cuda'))
+        torch.cuda.synchronize()
+        runs.append((trainer.last_path, logits.clone(), loss.clone(), trainer.flat.grad.clone(), trainer.sumsq.clone()))
+    assert [r[0] for r in runs] == ['native', 'native', 'record', 'replay', 'replay'], [r[0] for r in runs]
+    assert ops.lstm_sync_timeouts() == 0
+    base = runs[0]
+    for path, logits, loss, grad, ss in runs[1:]:
+        assert torch.equal(logits, base[1]) and torch.equal(loss, base[2]), path
+        if not torch.equal(grad, base[3]):
+            bad = []
+            offs = dict(zip((id(q) for q in trainer.flat.params), trainer.flat.offsets))
+            for k, p in model.named_parameters():
+                o = offs[id(p)]
+                a, b = grad[o:o + p.numel()], base[3][o:o + p.numel()]
+                if not torch.equal(a, b):
+                    bad.append('%s (%d of %d elements, max |diff| %.2e)' % (k, int((a != b).sum()), p.numel(), float((a - b).abs().max())))
+            raise AssertionError('gradients are not reproducible (%s step): %s' % (path, '; '.join(bad)))
+        assert torch.equal(ss, base[4]), path
 
 
 def test_cne_sue_batch64_inference_with_pad_dedup_matches_oracle():

@@ -90,6 +90,12 @@ def test_model_matches_reference_golden(tag):
                 exp, act = case.expect_grad(k, p.grad)
                 scale = max(1e-3, float(case.expect('gradnorm/' + k)), 0.05 * total)
                 assert float(np.abs(act - exp).max()) <= 5e-5 * scale, 'grad ' + k
+                # per-tensor relative L2 (round-3 verdict: the bar above is relative to 5 % of the TOTAL norm, loose for small tensors):
+                # every tensor that carries signal agrees with the reference's own gradient to 1e-3 (full arrays: the tiny-dim fixtures)
+                nk = float(case.expect('gradnorm/' + k))
+                if exp.size == p.numel() and nk > 1e-4 * total:
+                    rel = float(np.linalg.norm((act - exp).astype(np.float64))) / nk
+                    assert rel <= 1e-3, 'grad %s: relative L2 error %.3e' % (k, rel)
                 gn = float(p.grad.double().norm())
                 assert abs(gn - float(case.expect('gradnorm/' + k))) <= 5e-5 * scale, 'gradnorm ' + k
             assert abs(trainer.grad_total_norm() - total) <= 2e-5 * max(1.0, total)

@@ -915,6 +915,50 @@ def test_gemm_fused_bias_gradient():
     close(db, 0.25 + dy[:used].double().sum(0), tol=5e-5, what='fused db')
 
 
+@pytest.mark.parametrize('V,E,cap,live,p', [(500, 300, 3000, 3000, 0.0), (60000, 300, 20000, 15111, 0.2), (37, 300, 4100, 4000, 0.2), (900, 64, 1000, 7, 0.5),
+                                             (5000, 320, 9000, 9000, 0.1), (50, 300, 640, 0, 0.2)])
+def test_sorted_segmented_embedding_gradient_is_exact_and_reproducible(V, E, cap, live, p):
+    """csrc/sort.hip: token rows sorted by word id (stable radix sort, pad key for rows beyond the live count) + segmented reduction
+    = the f32-atomic scatter's result (same dropout mask) = the fp64 reference, and BIT-IDENTICAL from run to run; ids are heavily
+    skewed (one word owns a third of the rows: a segment of hundreds of 32-row chunks), some ids invalid (negative: skipped)."""
+    from nnr_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(V + cap)
+    ids = torch.randint(0, V, (cap,), generator=g).int()
+    hot = torch.rand(cap, generator=g)
+    ids[hot < 0.33] = 3 % V                                  # one very long segment
+    ids[(hot > 0.33) & (hot < 0.45)] = (V - 1)               # ... and the largest id (next to the pad key)
+    ids[::97] = -1                                           # invalid ids are skipped by both forms
+    dout = rnd(cap, E, seed=cap)
+    total = torch.tensor([live], dtype=torch.int32, device=d)
+    idd, dd = ids.to(d), dout.to(d)
+    ref = torch.zeros(V, E, device=d)
+    ops.embed_scatter(dd, idd, ref, p, 77, dyn=total)
+    outs = []
+    for rep in range(2):
+        ts = ops.TokenSort(idd, total, V)
+        keys = ts.keys.cpu().long()
+        rows = ts.rows.cpu().long()
+        torch.cuda.synchronize()
+        valid = (torch.arange(cap) < live) & (ids >= 0)
+        nv = int(valid.sum())
+        assert bool((keys[:nv] < V).all()) and bool((keys[nv:] == V).all()) and bool((keys[1:] >= keys[:-1]).all())
+        assert torch.equal(keys[:nv], ids.long()[rows[:nv]]) and sorted(rows.tolist()) == list(range(cap))
+        same = keys[1:nv] == keys[:nv - 1]
+        assert bool((rows[1:nv][same] > rows[:nv - 1][same]).all())          # stable: ascending row order inside a word's segment
+        o = torch.zeros(V, E, device=d)
+        ops.embed_scatter_sorted(dd, ts, o, p, 77)
+        outs.append(o)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    close(outs[0], ref, tol=2e-5, what='sorted vs atomic scatter')
+    keep = (ops.dropout(torch.ones(cap, E, device=d), p, 77) != 0).double().cpu() / (1.0 - p) if p > 0 else torch.ones(cap, E, dtype=torch.float64)
+    want = torch.zeros(V, E, dtype=torch.float64)
+    sel = (torch.arange(cap) < live) & (ids >= 0)
+    want.index_add_(0, ids[sel].long(), (dout.double() * keep)[sel])
+    close(outs[0], want, tol=2e-6, what='sorted vs fp64')
+
+
 TN_PIPE_TILES = [20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 32]
 TN_NO_GATHER = [26, 28, 29]          # gen-2 loop: gathered B rows only with the 256-float pitch (tile 27)
 
@@ -951,6 +995,43 @@ def test_gemm_pipelined_tn_tiles(tile, M, N, K, split):
     b_ = B2[:, 8:].double()[bidx[:used].long().clamp_min(0)] * (bidx[:used] >= 0).double()[:, None]
     close(o, a_.t() @ b_, tol=5e-5, what='TN pipe gather dyn')
     close(cs, a_.sum(dim=0), tol=5e-5, what='TN pipe column sums')
+
+
+@pytest.mark.parametrize('tile', [2, 6, 20, 26, 27, 30, 32])
+@pytest.mark.parametrize('M,N,K,split', [(400, 400, 7000, 40), (200, 400, 333, 9), (832, 200, 5000, 13), (1664, 300, 9000, 16), (36, 20, 50, 3), (132, 84, 16, 5)])
+def test_split_k_slabs_reduce_in_fixed_order(tile, M, N, K, split):
+    """nnr_gemm_args.slab: every slice of a split-K weight-gradient launch stores its partial result, a second launch adds the live
+    slices in slice order (csrc/gemm.hip: splitk_reduce_kernel) -- same value as the f32-atomic epilogue up to rounding order, and
+    BIT-IDENTICAL from run to run (the atomic form is not), including the fused column sums, a device-side reduction length (fewer
+    live slices than the host sized for, down to none) and gathered rows."""
+    from nnr_amd import ops
+    d = dev()
+    gather = tile in (20, 27, 32) and N <= 256
+    A, Bm = rnd(K, M + 64, seed=6).to(d), rnd(K, N + 8, seed=7).to(d)
+    bidx = torch.randint(0, K, (K,), generator=torch.Generator().manual_seed(8)).int()
+    bidx[::7] = -1
+    base = rnd(M, N, seed=5).to(d)
+    for used in (K, max(1, K // 3), 1, 0):
+        dyn = torch.tensor([used], dtype=torch.int32, device=d)
+        res = {}
+        for mode in ('slab', 'slab', 'atomic'):
+            ops.TN_SLAB = mode == 'slab'
+            try:
+                o, cs = base.clone(), torch.full((M,), 0.5, device=d)
+                ops.gemm(A[:, 64:], Bm[:, 8:], o, M=M, N=N, K=K, lda=M + 64, ldb=N + 8, ldc=N, trans_a=True, trans_b=True, split_k=split, atomic=True,
+                         b_idx=bidx.to(d) if gather else None, dyn=dyn, dyn_dim=2, colsum_out=cs, tile=tile)
+            finally:
+                ops.TN_SLAB = True
+            res.setdefault(mode, []).append((o, cs))
+        torch.cuda.synchronize()
+        (o1, c1), (o2, c2) = res['slab']
+        assert torch.equal(o1, o2) and torch.equal(c1, c2), 'slab mode is not reproducible (tile %d, used %d)' % (tile, used)
+        a_ = A[:used, 64:].double().cpu()
+        b_ = Bm[:, 8:].double().cpu()
+        b_ = (b_[bidx[:used].long().clamp_min(0)] * (bidx[:used] >= 0).double()[:, None]) if gather else b_[:used]
+        close(o1, base.double().cpu() + a_.t() @ b_, tol=5e-5, what='slab TN tile %d used %d' % (tile, used))
+        close(c1, 0.5 + a_.sum(dim=0), tol=5e-5, what='slab column sums')
+        close(res['atomic'][0][0], o1, tol=2e-5, what='atomic vs slab')
 
 
 def test_transpose_batch_and_weight_transpose_cache():
