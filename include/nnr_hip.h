@@ -350,6 +350,16 @@ int nnr_dp_init(const void* uid128, int rank, int world, nnr_dp_ctx** ctx);     
 int nnr_dp_allreduce(nnr_dp_ctx* ctx, float* flat, size_t n, hipStream_t stream);
 int nnr_dp_broadcast(nnr_dp_ctx* ctx, float* flat, size_t n, int root, hipStream_t stream);
 int nnr_dp_destroy(nnr_dp_ctx* ctx);
+/* Touched-row exchange of the word-embedding table's gradient (the table is 70 % of the all-reduced bytes, and only
+ * the rows of words in the step's batch are non-zero; trainer.py:297 reduces all of it).  nnr_rows_touch: flags[tok[i]] = 1 for the live
+ * packed rows of a token stream (flags: V floats, zeroed by the caller at the start of the step and summed over the ranks before
+ * nnr_rows_compact); nnr_rows_compact: pos[w] = index of row w among the touched rows (flags[w] > 0) or -1, *count = their number;
+ * nnr_rows_pack / nnr_rows_unpack: packed[pos[w], :] <-> dense[w, :] for the touched rows.  The dense gradient after unpacking equals
+ * what the full all-reduce produces (untouched rows are zero on every rank), so clip + Adam stay dense and unchanged. */
+int nnr_rows_touch(const int* tok, long cap, const int* n_dev, int V, float* flags, hipStream_t stream);
+int nnr_rows_compact(const float* flags, int V, int* pos, int* count, hipStream_t stream);
+int nnr_rows_pack(const float* dense, const int* pos, int V, int E, float* packed, hipStream_t stream);
+int nnr_rows_unpack(const float* packed, const int* pos, int V, int E, float* dense, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------ fused small launches (csrc/fuse.hip)
  * feature_fusion (newsEncoders.py:50-54) for the union of the candidate call (rows [0, n0), ids cat0 / sub0) and the history call

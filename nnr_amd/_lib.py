@@ -65,6 +65,7 @@ SYMBOLS = [
     'nnr_tape_event_wait', 'nnr_tape_segment', 'nnr_tape_patch', 'nnr_tape_finalize', 'nnr_tape_info', 'nnr_tape_replay', 'nnr_tape_timings', 'nnr_tape_timeline',
     'nnr_tape_last_error',
     'nnr_token_sort_workspace_bytes', 'nnr_token_sort', 'nnr_embed_scatter_sorted_workspace_floats', 'nnr_embed_scatter_sorted', 'nnr_fusion_rows_bwd_det',
+    'nnr_rows_touch', 'nnr_rows_compact', 'nnr_rows_pack', 'nnr_rows_unpack',
 ]
 
 

@@ -88,3 +88,84 @@ extern "C" int nnr_dp_destroy(nnr_dp_ctx* ctx) {
   delete ctx;
   return ok ? NNR_OK : NNR_ERR_LAUNCH;
 }
+
+// ------------------------------------------------------------------------------------------------ touched-row exchange of the table gradient
+// 72 of the 102 MB all-reduced per step are the word-embedding table's gradient (V x 300 fp32), of which only the rows of words that
+// occur in the step's batch are non-zero (trainer.py:297 reduces all of it).  The ranks agree on the UNION of
+// their touched rows (a V-float flag vector, summed over the ranks: 240 KB), pack those rows of their gradient into [U, E], all-reduce
+// the packed buffer and write the sums back; every other row is zero on every rank, so the dense gradient -- and the unchanged dense
+// clip + Adam that follows -- is bit-for-bit what the full all-reduce would have produced.
+namespace {
+__global__ void rows_touch_kernel(const int* __restrict__ tok, long cap, const int* __restrict__ n_dev, int V, float* __restrict__ flags) {
+  const long n = n_dev ? (cap < (long)*n_dev ? cap : (long)*n_dev) : cap;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int t = tok[i];
+    if (t >= 0 && t < V) flags[t] = 1.f;                          // (every writer stores the same value)
+  }
+}
+// pos[w] = number of touched rows below w if row w is touched, else -1; *count = touched rows.  One workgroup: V is a vocabulary.
+__global__ __launch_bounds__(1024) void rows_compact_kernel(const float* __restrict__ flags, int V, int* __restrict__ pos, int* __restrict__ count) {
+  __shared__ int part[1024];
+  const int tid = threadIdx.x;
+  const int per = (V + 1023) / 1024, lo = tid * per, hi = lo + per < V ? lo + per : V;
+  int c = 0;
+  for (int w = lo; w < hi; ++w) c += flags[w] > 0.f;
+  part[tid] = c;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {                             // inclusive scan (Hillis-Steele; integers: exact)
+    const int v = tid >= o ? part[tid - o] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int base = part[tid] - c;
+  for (int w = lo; w < hi; ++w) {
+    const bool t = flags[w] > 0.f;
+    pos[w] = t ? base : -1;
+    base += t;
+  }
+  if (tid == 1023) *count = part[1023];
+}
+// dir 0: packed[pos[w], :] = dense[w, :];  dir 1: dense[w, :] = packed[pos[w], :]   (touched rows only; one wave per row, float lanes)
+__global__ __launch_bounds__(256) void rows_move_kernel(float* __restrict__ dense, float* __restrict__ packed, const int* __restrict__ pos, int V, int E,
+                                                        int dir) {
+  const int lane = threadIdx.x & 63;
+  for (long w = blockIdx.x * 4L + (threadIdx.x >> 6); w < V; w += gridDim.x * 4L) {
+    const int p = pos[w];
+    if (p < 0) continue;
+    float* d = dense + w * E;
+    float* q = packed + (long)p * E;
+    for (int c = lane; c < E; c += 64) {
+      if (dir == 0) q[c] = d[c];
+      else d[c] = q[c];
+    }
+  }
+}
+}  // namespace
+
+extern "C" int nnr_rows_touch(const int* tok, long cap, const int* n_dev, int V, float* flags, hipStream_t stream) {
+  if (!tok || !flags || cap < 0 || V <= 0) return NNR_ERR_ARG;
+  if (cap == 0) return NNR_OK;
+  const long b = (cap + 255) / 256;
+  hipLaunchKernelGGL(rows_touch_kernel, dim3((int)(b > 1024 ? 1024 : b)), dim3(256), 0, stream, tok, cap, n_dev, V, flags);
+  NNR_CHECK_LAUNCH();
+  return NNR_OK;
+}
+extern "C" int nnr_rows_compact(const float* flags, int V, int* pos, int* count, hipStream_t stream) {
+  if (!flags || !pos || !count || V <= 0) return NNR_ERR_ARG;
+  hipLaunchKernelGGL(rows_compact_kernel, dim3(1), dim3(1024), 0, stream, flags, V, pos, count);
+  NNR_CHECK_LAUNCH();
+  return NNR_OK;
+}
+extern "C" int nnr_rows_pack(const float* dense, const int* pos, int V, int E, float* packed, hipStream_t stream) {
+  if (!dense || !pos || !packed || V <= 0 || E <= 0) return NNR_ERR_ARG;
+  hipLaunchKernelGGL(rows_move_kernel, dim3(V / 4 + 1 > 2048 ? 2048 : V / 4 + 1), dim3(256), 0, stream, const_cast<float*>(dense), packed, pos, V, E, 0);
+  NNR_CHECK_LAUNCH();
+  return NNR_OK;
+}
+extern "C" int nnr_rows_unpack(const float* packed, const int* pos, int V, int E, float* dense, hipStream_t stream) {
+  if (!dense || !pos || !packed || V <= 0 || E <= 0) return NNR_ERR_ARG;
+  hipLaunchKernelGGL(rows_move_kernel, dim3(V / 4 + 1 > 2048 ? 2048 : V / 4 + 1), dim3(256), 0, stream, dense, const_cast<float*>(packed), pos, V, E, 1);
+  NNR_CHECK_LAUNCH();
+  return NNR_OK;
+}

@@ -117,54 +117,68 @@ __global__ __launch_bounds__(256) void embed_scatter_sorted_kernel(const float* 
 
 __global__ __launch_bounds__(256) void embed_scatter_sorted_fix_kernel(const unsigned* __restrict__ keys, long cap, unsigned V, int dim,
                                                                        float* __restrict__ dtable, const float* __restrict__ partial) {
+  // A workgroup looks after four consecutive chunks; for every multi-chunk segment that STARTS in one of them (at most two per chunk:
+  // its first run and its last run) all four waves add the partial rows of the following chunks -- wave w takes chunks w, w + 4, ...
+  // of the run, 8 rows in flight -- and the four sums are added in wave order: a frequent word's segment is hundreds of chunks long
+  // (the top word of a Zipf vocabulary owns a seventh of the tokens), and one wave walking it alone was the kernel's long pole.
+  __shared__ float red[4][SS_PITCH];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const long c = blockIdx.x * 4L + wv;
-  const long p0 = c * SS_CH;
-  if (p0 >= cap) return;
-  const long p1 = min(cap, p0 + SS_CH);
   const long nchunks = (cap + SS_CH - 1) / SS_CH;
-  const unsigned k0 = keys[p0];
-  if (k0 >= V) return;
-  const unsigned prevK = p0 > 0 ? keys[p0 - 1] : 0xFFFFFFFFu;
-  const unsigned kl = keys[p1 - 1];
-  const unsigned nextK = p1 < cap ? keys[p1] : 0xFFFFFFFFu;
-  for (int cand = 0; cand < 2; ++cand) {
-    // cand 0: the chunk's first run, if the segment STARTS here and runs on into the next chunk; cand 1: its last run, likewise
-    const unsigned key = cand == 0 ? k0 : kl;
-    const bool own = cand == 0 ? (prevK != k0 && kl == k0 && nextK == k0) : (kl != k0 && kl < V && nextK == kl);
-    if (!own) continue;                                           // (wave-uniform)
-    float acc[SS_MAXJ];
-    const float* src = partial + (c * 2 + cand) * (long)SS_PITCH;
+  for (int ci = 0; ci < 4; ++ci) {
+    const long c = blockIdx.x * 4L + ci;
+    const long p0 = c * SS_CH;
+    if (p0 >= cap) break;                                          // (uniform over the workgroup, like every branch below)
+    const long p1 = min(cap, p0 + SS_CH);
+    const unsigned k0 = keys[p0];
+    if (k0 >= V) break;                                            // sorted: nothing but pad rows from here on
+    const unsigned prevK = p0 > 0 ? keys[p0 - 1] : 0xFFFFFFFFu;
+    const unsigned kl = keys[p1 - 1];
+    const unsigned nextK = p1 < cap ? keys[p1] : 0xFFFFFFFFu;
+    for (int cand = 0; cand < 2; ++cand) {
+      // cand 0: the chunk's first run, if the segment STARTS here and runs on into the next chunk; cand 1: its last run, likewise
+      const unsigned key = cand == 0 ? k0 : kl;
+      const bool own = cand == 0 ? (prevK != k0 && kl == k0 && nextK == k0) : (kl != k0 && kl < V && nextK == kl);
+      if (!own) continue;
+      float acc[SS_MAXJ];
 #pragma unroll
-    for (int j = 0; j < SS_MAXJ; ++j) acc[j] = src[lane + 64 * j];
-    long cc = c + 1;
-    while (true) {
-      const bool cont = (cc + lane < nchunks) && keys[(cc + lane) * SS_CH] == key;
-      const unsigned long long m = __ballot(cont);
-      const int nc = (m == ~0ull) ? 64 : __builtin_ctzll(~m);     // chunks cc .. cc + nc - 1 begin with this word: their slot 0 is its partial
-      for (int q = 0; q < nc; q += 8) {
-        float v[8][SS_MAXJ];
+      for (int j = 0; j < SS_MAXJ; ++j) acc[j] = 0.f;
+      long cc = c + 1;
+      while (true) {
+        const bool cont = (cc + lane < nchunks) && keys[(cc + lane) * SS_CH] == key;
+        const unsigned long long m = __ballot(cont);
+        const int nc = (m == ~0ull) ? 64 : __builtin_ctzll(~m);   // chunks cc .. cc + nc - 1 begin with this word: their slot 0 is its partial
+        for (int q = wv; q < nc; q += 32) {                        // this wave: chunks q, q + 4, ..., q + 28 of the window, in order
+          float v[8][SS_MAXJ];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const float* s = partial + ((cc + min(q + u, nc - 1)) * 2) * (long)SS_PITCH;
+          for (int u = 0; u < 8; ++u) {
+            const float* sp = partial + ((cc + min(q + 4 * u, nc - 1)) * 2) * (long)SS_PITCH;
 #pragma unroll
-          for (int j = 0; j < SS_MAXJ; ++j) v[u][j] = s[lane + 64 * j];
-        }
+            for (int j = 0; j < SS_MAXJ; ++j) v[u][j] = sp[lane + 64 * j];
+          }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          if (q + u < nc) {
+          for (int u = 0; u < 8; ++u) {
+            if (q + 4 * u < nc) {
 #pragma unroll
-            for (int j = 0; j < SS_MAXJ; ++j) acc[j] += v[u][j];
+              for (int j = 0; j < SS_MAXJ; ++j) acc[j] += v[u][j];
+            }
           }
         }
+        cc += nc;
+        if (nc < 64) break;
       }
-      cc += nc;
-      if (nc < 64) break;
-    }
 #pragma unroll
-    for (int j = 0; j < SS_MAXJ; ++j) {
-      const int col = lane + 64 * j;
-      if (col < dim) atomicAdd(&dtable[(long)key * dim + col], acc[j]);
+      for (int j = 0; j < SS_MAXJ; ++j) red[wv][lane + 64 * j] = acc[j];
+      __syncthreads();
+      if (wv == 0) {
+        const float* src = partial + (c * 2 + cand) * (long)SS_PITCH;      // the run's own part in its first chunk
+#pragma unroll
+        for (int j = 0; j < SS_MAXJ; ++j) {
+          const int col = lane + 64 * j;
+          const float t = (((src[col] + red[0][col]) + red[1][col]) + red[2][col]) + red[3][col];
+          if (col < dim) atomicAdd(&dtable[(long)key * dim + col], t);
+        }
+      }
+      __syncthreads();
     }
   }
 }

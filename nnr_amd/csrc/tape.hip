@@ -49,6 +49,7 @@ const Entry REGISTRY[] = {
   R(nnr_layernorm_fwd), R(nnr_layernorm_bwd), R(nnr_sumsq), R(nnr_clip_adam), R(nnr_dp_allreduce), R(nnr_dp_broadcast),
   R(nnr_fill_zero), R(nnr_copy_bytes), R(nnr_fill_column_u8), R(nnr_fusion_rows_fwd), R(nnr_fusion_rows_bwd), R(nnr_click_loss), R(nnr_rank_metrics),
   R(nnr_token_sort), R(nnr_embed_scatter_sorted), R(nnr_fusion_rows_bwd_det),
+  R(nnr_rows_touch), R(nnr_rows_compact), R(nnr_rows_pack), R(nnr_rows_unpack),
 };
 #undef R
 constexpr int NREG = (int)(sizeof(REGISTRY) / sizeof(REGISTRY[0]));

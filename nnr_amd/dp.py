@@ -178,6 +178,12 @@ class GradientExchange:
             pos = max(pos, b)
         if pos < total:
             self.late_spans.append((pos, total))
+        # touched-row exchange of the table bucket (opt-in, NNR_DP_TOUCHED_ROWS=1): see table_rows_exchange()
+        self.touched = os.environ.get('NNR_DP_TOUCHED_ROWS') == '1' and self.table_span is not None and table_param is not None and table_param.dim() == 2
+        self.table_shape = tuple(table_param.shape) if table_param is not None else None
+        self._flags = self._pos = self._count = self._packed = None
+        self._noted = []              # events behind the nnr_rows_touch launches of this step (one per token stream)
+        self.last_touched = None      # (rows exchanged, rows of the table) of the last step that used the touched-row exchange
         self._pending = None
         self._pending_table = None
         self._table_events = []
@@ -192,7 +198,14 @@ class GradientExchange:
     def describe(self):
         es = self.early_span
         ts = self.table_span
-        return {'buckets': ([{'name': 'early (user encoder)', 'floats': es[1] - es[0]}] if es else []) +
+        extra = {}
+        if self.touched:
+            extra['table_bucket'] = 'touched rows only (NNR_DP_TOUCHED_ROWS=1): flags [V] + packed [U, E] instead of [V, E]'
+            if self.last_touched is not None:
+                U, V = self.last_touched
+                E = self.table_shape[1]
+                extra['touched_rows_last_step'] = {'rows': U, 'of': V, 'bytes': 4 * (V + U * E), 'dense_bytes': 4 * V * E}
+        return {**extra, 'buckets': ([{'name': 'early (user encoder)', 'floats': es[1] - es[0]}] if es else []) +
                            ([{'name': 'table (word embedding)', 'floats': ts[1] - ts[0]}] if ts else []) +
                            [{'name': 'late', 'floats': sum(b - a for a, b in self.late_spans)}],
                 'binding': 'C-ABI nnr_dp_allreduce (RCCL, recorded in the launch tape)' if native_active(self.grad.is_cuda) else 'torch.distributed all_reduce',
@@ -235,15 +248,104 @@ class GradientExchange:
             self.events['early_issued'].record()
         self._pending = self._reduce(self.grad[a:b], True)
 
+    # ------------------------------------------------------------------------------------------------ touched rows of the table
+    def _touch_buffers(self):
+        if self._flags is None:
+            V, E = self.table_shape
+            dev = self.grad.device
+            self._flags = torch.zeros(V, device=dev, dtype=torch.float32)
+            self._pos = torch.empty(V, device=dev, dtype=torch.int32)
+            self._count = torch.zeros(1, device=dev, dtype=torch.int32)
+            self._packed = torch.empty(V * E, device=dev, dtype=torch.float32)
+        if self.grad.is_cuda:
+            from . import ops
+            ops.tape_keep(self._flags, self._pos, self._count, self._packed)      # long-lived buffers a recording tape may point at
+        return self._flags
+
+    def begin_step(self):
+        """Start of an optimizer step (before the forward pass): clear the touched-row flags."""
+        if not (self.touched and self.active()):
+            return
+        flags = self._touch_buffers()
+        self._noted = []
+        if flags.is_cuda:
+            from . import ops
+            ops.fill_zero(flags)
+        else:
+            flags.zero_()
+
+    def note_tokens(self, tok, total=None):
+        """The word ids of one token stream of this step (device int32 `tok`, live count `total` on the device or None): mark their
+        table rows as touched.  Called by the news encoder right after it planned the stream (forward pass)."""
+        if not (self.touched and self.active()):
+            return
+        flags = self._touch_buffers()
+        V = self.table_shape[0]
+        if flags.is_cuda:
+            from . import _lib as L, ops
+            L.check(L.lib().nnr_rows_touch(ops._p(tok), C.c_long(tok.numel()), ops._p(total), V, ops._p(flags), ops._s()), 'nnr_rows_touch')
+            ev = torch.cuda.Event()
+            ev.record()
+            self._noted.append(ev)
+        else:
+            ids = tok.reshape(-1)[:int(total.reshape(-1)[0])] if total is not None else tok.reshape(-1)
+            ids = ids[(ids >= 0) & (ids < V)].long()
+            flags[ids] = 1.0
+            self._noted.append(None)
+
+    def table_rows_exchange(self):
+        """The table bucket as a TOUCHED-ROW exchange (trainer.py:297 all-reduces all V rows): the ranks sum
+        their flag vectors (V floats), every rank derives the same packed order of the union, packs those rows of its table gradient,
+        all-reduces [U, E] instead of [V, E] and writes the sums back.  Rows outside the union are zero on every rank, so the dense
+        gradient -- and the dense clip + Adam after it -- is what the full all-reduce gives.  Needs the host once (U sizes the
+        collective): runs on the helper stream behind the last embedding-row scatter, as a host callback of a recorded step."""
+        V, E = self.table_shape
+        a, _ = self.table_span
+        flags, pos, count, packed = self._flags, self._pos, self._count, self._packed
+        dense = self.grad[a:a + V * E]
+        if flags.is_cuda:
+            from . import _lib as L, ops
+            cur = torch.cuda.current_stream(flags.device)
+            for ev in self._noted:
+                cur.wait_event(ev)
+            self._reduce(flags, False)
+            L.check(L.lib().nnr_rows_compact(ops._p(flags), V, ops._p(pos), ops._p(count), ops._s()), 'nnr_rows_compact')
+            U = int(count.item())                                    # (synchronises THIS stream: the helper stream)
+            if U > 0:
+                L.check(L.lib().nnr_rows_pack(ops._p(dense), ops._p(pos), V, E, ops._p(packed), ops._s()), 'nnr_rows_pack')
+                self._reduce(packed[:U * E], False)
+                L.check(L.lib().nnr_rows_unpack(ops._p(packed), ops._p(pos), V, E, ops._p(dense), ops._s()), 'nnr_rows_unpack')
+        else:
+            dist.all_reduce(flags, op=dist.ReduceOp.SUM)
+            rows = torch.nonzero(flags > 0).reshape(-1)
+            U = int(rows.numel())
+            if U > 0:
+                d2 = dense.view(V, E)
+                buf = d2.index_select(0, rows).contiguous()
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+                d2.index_copy_(0, rows, buf)
+        self._noted = []
+        self.last_touched = (U, V)
+        return U
+
     def table_scatter_done(self, expected):
         """One of the `expected` embedding-row scatter GEMMs of this backward pass is ordered on the CURRENT stream (they run on
         different HIP streams).  When the last one has reported, the table bucket is handed to the exchange on a helper stream that
         waits for all of them -- no stream of the backward pass waits for another one here."""
-        if self.table_span is None or not self.active() or not self.grad.is_cuda:
+        if self.table_span is None or not self.active():
             return
-        if self._native():
+        if not self.grad.is_cuda:
+            # host tensors (gloo tests of the exchange logic): no streams to overlap with; only the touched-row form does anything here
+            if self.touched and self._noted and self._pending_table is None:
+                self._table_events.append(None)
+                if len(self._table_events) >= expected:
+                    self.table_rows_exchange()
+                    self._pending_table = (None, None)
+                    self._table_events = []
+            return
+        if self._native() and not self.touched:
             return self._table_scatter_done(expected)
-        from .tape import host_call
+        from .tape import host_call              # (the touched-row exchange needs the host: the union's row count sizes the collective)
         host_call(lambda: self._table_scatter_done(expected))
 
     def _table_scatter_done(self, expected):
@@ -263,7 +365,11 @@ class GradientExchange:
             if self.events is not None:
                 self.events['table_issued'] = torch.cuda.Event(enable_timing=True)
                 self.events['table_issued'].record()
-            self._pending_table = (self._reduce(self.grad[a:b], True), self._helper)
+            if self.touched and self._noted:
+                self.table_rows_exchange()
+                self._pending_table = (None, self._helper)
+            else:
+                self._pending_table = (self._reduce(self.grad[a:b], True), self._helper)
         self._table_events = []
 
     def finish(self):
@@ -317,7 +423,7 @@ class GradientExchange:
                 cur.wait_stream(p)
             else:
                 p.wait()                                       # NCCL: the current stream waits; gloo: the host waits
-        if pend_t is not None:
+        if pend_t is not None and pend_t[1] is not None:
             cur.wait_stream(pend_t[1])
         if self.events is not None and self.grad.is_cuda:
             self.events['finished'] = torch.cuda.Event(enable_timing=True)

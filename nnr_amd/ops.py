@@ -326,6 +326,8 @@ def split_for(m, n, k, tile_m=64, tile_n=80, target_blocks=2048, kmin=256):
     """split-K factor for the token-reduction (weight-gradient) GEMMs: enough blocks to fill 256 CUs x ~3.  (Cutting short
     reductions finer, kmin 64, measured no better.)"""
     tiles = max(1, ((m + tile_m - 1) // tile_m) * ((n + tile_n - 1) // tile_n))
+    if k <= 640:
+        return 1      # a few hundred reduction rows (the per-candidate projections: 320 rows at batch 64): one slice -- no slab, no second launch
     return int(max(1, min((k + kmin - 1) // kmin, (target_blocks + tiles - 1) // tiles)))
 
 

@@ -124,6 +124,7 @@ class Trainer:
             ue.__dict__['_grads_ready_hook'] = self.exchange.early_ready
         if ne is not None:
             ne.__dict__['_table_scatter_hook'] = self.exchange.table_scatter_done      # (CNE calls it after each embedding-row scatter GEMM)
+            ne.__dict__['_tokens_hook'] = self.exchange.note_tokens                     # (... and with each planned token stream: touched-row exchange)
 
     def train_step(self, batch):
         """One optimizer step on `batch` (21 device tensors, Model.forward order).  Returns (logits, loss) as device
@@ -134,6 +135,7 @@ class Trainer:
             if native_step.supported(model):
                 return self._native_train_step(batch, native_step)
         self.last_path = 'autograd'
+        self.exchange.begin_step()
         self.flat.zero_grad()
         logits = model(*batch)
         loss = negative_log_softmax(logits)
@@ -166,6 +168,7 @@ class Trainer:
             torch.cuda.current_stream(self.flat.grad.device).wait_event(ev)
 
     def _body(self, batch, native_step):
+        self.exchange.begin_step()
         self._zero_grad_aside()
         logits, loss = native_step.forward_backward(self, batch)
         scale = self.exchange.finish()

@@ -89,6 +89,7 @@ def build(seed):
 
 
 def backward_only(tr, batch):
+    tr.exchange.begin_step()
     tr.flat.zero_grad()
     loss = negative_log_softmax(tr.model(*[t.clone() for t in batch]))
     loss.backward()
@@ -245,6 +246,7 @@ if rank == 0:
     print(json.dumps({'world': world, 'backend': args.backend, 'rccl_ranks': rccl_ranks, 'devices': torch.cuda.device_count(),
                       'binding': (trainer if args.only_epoch else tr).exchange.describe()['binding'], 'buckets': [b['name'] for b in (trainer if args.only_epoch else tr).exchange.describe()['buckets']],
                       'grad_rel_err_vs_mean_of_shard_gradients': err_prod, 'grad_err_vs_oracle_mean_of_shard_gradients': err_oracle,
+                      'touched_rows': (trainer if args.only_epoch else tr0).exchange.describe().get('touched_rows_last_step'),
                       'worst_gradient': worst_name, 'recurrence_exchange_timeouts': tmo, 'parameters_identical_across_ranks': params_same, 'epoch': epoch, 'ok': bool(ok)}))
 dist.barrier()
 dist.destroy_process_group()

@@ -20,8 +20,10 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, tag, out_dir):
+def _worker(rank, world, port, tag, out_dir, touched=False):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    if touched:
+        os.environ['NNR_DP_TOUCHED_ROWS'] = '1'
     import sys
     sys.path[:0] = [os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))]
     from nnr_amd import dp
@@ -41,25 +43,44 @@ def _worker(rank, world, port, tag, out_dir):
     dp.broadcast_parameters(flat.flat)
     from nnr_amd.trainer import _Own
     ue = model.user_encoder
-    ex = dp.GradientExchange(flat, early_modules=[_Own(ue, [m for name, m in ue.named_children() if name != 'news_encoder'])])
-    assert ex.early_span is not None and ex.active()
+    ex = dp.GradientExchange(flat, early_modules=[_Own(ue, [m for name, m in ue.named_children() if name != 'news_encoder'])],
+                             table_param=model.news_encoder.word_embedding.weight)
+    assert ex.early_span is not None and ex.table_span is not None and ex.active() and ex.touched == touched
     batch = dp.shard_batch(case.batch(), rank, world)
+    ex.begin_step()
     flat.zero_grad()
+    if touched:
+        # what the HIP news encoder reports for each planned token stream (here: every id of the shard's four id tensors -- a superset
+        # of the live tokens, which is all the exchange needs: a row outside the union must be zero on every rank)
+        from nnr_amd.synth import BATCH_FIELDS
+        named = dict(zip(BATCH_FIELDS, batch))
+        for k in ('news_title_text', 'news_content_text', 'user_title_text', 'user_content_text'):
+            ex.note_tokens(named[k].reshape(-1).to(torch.int32))
     loss = O.negative_log_softmax(model(*batch))
     loss.backward()
     ex.early_ready()                                   # (the HIP path calls this from the user encoder's backward function)
+    ex.table_scatter_done(1)                           # (... and this behind the last embedding-row scatter of the backward pass)
     scale = ex.finish()
     dp.barrier()
+    if touched:
+        U, V = ex.last_touched
+        assert 0 < U < V and ex.describe()['touched_rows_last_step']['bytes'] < ex.describe()['touched_rows_last_step']['dense_bytes']
+        a, b = ex.table_span
+        rows = flat.grad[a:a + V * case.config.word_embedding_dim].view(V, -1)
+        assert int((rows.abs().sum(dim=1) > 0).sum()) <= U      # nothing outside the union carries a gradient
     if rank == 0:
         np.save(os.path.join(out_dir, 'grad.npy'), (flat.grad * scale).numpy())
         np.save(os.path.join(out_dir, 'param.npy'), flat.flat.numpy())
     torch.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize('tag', ['tiny_CNE_SUE_stable'])
-def test_two_rank_gradient_equals_full_batch(tag, tmp_path):
+@pytest.mark.parametrize('tag,touched', [('tiny_CNE_SUE_stable', False), ('tiny_CNE_SUE_stable', True)])
+def test_two_rank_gradient_equals_full_batch(tag, touched, tmp_path):
+    """touched=True: the word-embedding table's bucket goes out as a TOUCHED-ROW exchange (dp.GradientExchange.table_rows_exchange,
+    NNR_DP_TOUCHED_ROWS=1: flag vectors summed over the ranks, the union's rows packed, all-reduced and written back) -- the dense
+    gradient every rank ends up with is the same full-batch mean, so the dense clip + Adam after it is unchanged."""
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), tag, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), tag, str(tmp_path), touched), nprocs=world, join=True)
     from nnr_amd.trainer import FlatParams
     from oracle import nnr_oracle as O
     case = GoldenCase(tag)

@@ -20,8 +20,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _launch(world, backend, port, native=None, extra=()):
-    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'NNR_DP_NATIVE')}
+def _launch(world, backend, port, native=None, extra=(), env_extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'NNR_DP_NATIVE', 'NNR_DP_TOUCHED_ROWS')}
+    env.update(env_extra or {})
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')           # dmabuf IPC: RCCL's intra-node transport needs it on this image
     if native is not None:
         env['NNR_DP_NATIVE'] = '1' if native else '0'           # (None: the product's default -- the C-ABI binding on an "nccl" job)
@@ -68,6 +69,18 @@ def _check(out, world):
 def test_two_ranks_of_the_product_path_share_one_gpu_through_gloo():
     out = _launch(2, 'gloo', 29571)
     _check(out, 2)
+
+
+def test_two_ranks_touched_row_exchange_of_the_table_gradient():
+    """NNR_DP_TOUCHED_ROWS=1 (dp.GradientExchange.table_rows_exchange): the ranks sum their touched-row flags, pack the
+    union's rows of the word-embedding table's gradient, all-reduce [U, E] instead of [V, E] and write the sums back.  Same oracle legs
+    as above -- the exchanged gradient is the mean of the oracle's per-shard gradients, differently initialised ranks are bit-identical
+    after two optimizer steps (dense clip + Adam unchanged) -- plus the bytes the exchange moved."""
+    out = _launch(2, 'gloo', 29575, extra=('--skip_epoch',), env_extra={'NNR_DP_TOUCHED_ROWS': '1'})
+    assert out['ok'] and out['world'] == 2 and out['parameters_identical_across_ranks']
+    assert out['grad_err_vs_oracle_mean_of_shard_gradients'] <= 1e-4 and out['grad_rel_err_vs_mean_of_shard_gradients'] <= 2e-5
+    t = out['touched_rows']
+    assert t is not None and 0 < t['rows'] <= t['of'] == 3000 and t['bytes'] == 4 * (3000 + t['rows'] * 300) and t['dense_bytes'] == 4 * 3000 * 300
 
 
 @pytest.mark.parametrize('binding', ['torch', 'native'])

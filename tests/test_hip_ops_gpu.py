@@ -809,8 +809,8 @@ def test_sumsq_is_accurate_and_deterministic(n):
 
 def test_slot_spread_column_sums():
     """Long reductions into a short vector (bias gradients, dw2 of the additive attention) go through the per-stream slot
-    workspace (nnr_slot_workspace_floats): same sums as the direct form, and the workspace is left zeroed -- the second call,
-    on the same stream and on a side stream with its own workspace, must be exact too."""
+    workspace (nnr_slot_workspace_floats): same sums as the direct form; the second call, on the same stream and on a side stream
+    with its own workspace, must be exact too."""
     from nnr_amd import ops
     d = dev()
     f32 = dict(device=d, dtype=torch.float32)
@@ -838,8 +838,26 @@ def test_slot_spread_column_sums():
         torch.cuda.current_stream().wait_stream(stream)
         close(dw2.reshape(-1), (k + 1) * ref_dw2, what='tanh score bwd dw2 (slots), call %d' % k)
         close(t, ref_dpre, what='tanh score bwd dpre')
+    # round 4: every workgroup stores to its own slot row and the rows are added in a fixed order: bit-identical from run to run,
+    # for small inputs too (one to a few workgroups), with a device-side row count, and on a dirty workspace (nothing relies on zeros)
     for ws in ops._SLOT_WS.values():
-        assert float(ws.abs().max()) == 0.0
+        ws.fill_(float('nan'))
+    for rows, live in ((20000, 19001), (300, 300), (7, 5), (4000, 0)):
+        dyn = torch.tensor([live], dtype=torch.int32, device=d)
+        outs = []
+        for rep in range(2):
+            o = torch.zeros(400, **f32)
+            ops.bias_grad(xd[:rows], o, dyn=dyn)
+            t2 = th[:rows].to(d)
+            g2 = torch.zeros(1, 200, **f32)
+            plan = type('P', (), {'total': dyn, 'cap': rows})()
+            ops.tanh_score_bwd(t2, ds[:rows].to(d), w2.to(d), g2, plan, 200)
+            outs.append((o, g2, t2))
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        close(outs[0][0], x[:live].double().sum(0), what='colsum %d of %d rows' % (live, rows))
+        close(outs[0][1].reshape(-1), (ds.double()[:live, None] * th.double()[:live]).sum(0), what='dw2 %d of %d rows' % (live, rows))
+        close(outs[0][2][:live], ref_dpre[:live], what='dpre %d of %d rows' % (live, rows))
 
 
 # ------------------------------------------------------------------------------------------------ MFMA attention core
