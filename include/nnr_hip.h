@@ -90,6 +90,12 @@ typedef struct nnr_gemm_args {
   float* slab;
   long slab_floats;
   int slab_mode;            /* filled by the library */
+  /* fused cross-selective gate backward (newsEncoders.py:128-131: Ht = H * G, G = sigmoid(pre)) in the epilogue of the GEMM that
+   * completes dHt:  x = alpha * acc + pre_add[m][n];  aux_out[m][n] = x * resid * mul * (1 - mul)  (= d pre, resid = H, mul = G);
+   * C[m][n] = x * mul  (= dH).  Needs the float4 epilogue (aligned operands, N % 4 == 0), no bias / activation / dropout. */
+  const float* pre_add;     /* [M, ldpre]: added to the product before anything else (also without gate_bwd) */
+  int ldpre;
+  int gate_bwd;
 } nnr_gemm_args;
 
 int nnr_gemm_f32(const nnr_gemm_args* args, hipStream_t stream);

@@ -20,7 +20,7 @@ class GemmArgs(C.Structure):
                 ('ldmul', ci), ('resid', vp), ('ldres', ci), ('accumulate', ci), ('atomic', ci), ('c_idx', vp),
                 ('split_k', ci), ('rowdot_w', vp), ('rowdot_out', vp), ('batch', ci), ('strideA', cl), ('strideB', cl),
                 ('strideC', cl), ('stride_aux', cl), ('stride_res', cl), ('k_chunk', ci), ('colsum_out', vp), ('tile', ci), ('drop_thresh', cu32),
-                ('drop_scale', cf), ('vec_epi', ci), ('sched', ci), ('slab', vp), ('slab_floats', cl), ('slab_mode', ci)]
+                ('drop_scale', cf), ('vec_epi', ci), ('sched', ci), ('slab', vp), ('slab_floats', cl), ('slab_mode', ci), ('pre_add', vp), ('ldpre', ci), ('gate_bwd', ci)]
 
 
 class LstmProblem(C.Structure):

@@ -62,16 +62,17 @@ __global__ __launch_bounds__(256) void fusion_rows_bwd_kernel(const int* __restr
   }
 }
 
-// Reproducible form (round 4; config.py:125-130): one workgroup per TABLE ROW t.  Its four waves scan the id list in 64-row chunks
-// (wave w takes chunks w, w + 4, ...: one coalesced id load, a ballot, then the matching rows in ascending order), lane = column; the four
-// partial sums are added in wave order and the table row gets ONE f32 atomic per element (a second launch -- the other encoder call
+// Reproducible form (round 4; config.py:125-130): one workgroup per TABLE ROW t.  Its sixteen waves scan the id list in 64-row chunks
+// (wave w takes chunks w, w + 16, ...: one coalesced id load, a ballot, then the matching rows in ascending order, eight in flight), lane =
+// column; the sixteen partial sums are added in wave order and the table row gets ONE f32 atomic per element (a second launch -- the other encoder call
 // of the plugin API -- may add into the same gradient: two addends into a zeroed buffer commute).  No run merging, no arrival order.
-__global__ __launch_bounds__(256) void fusion_rows_bwd_det_kernel(const int* __restrict__ cat0, const int* __restrict__ sub0, int n0,
-                                                                  const int* __restrict__ cat1, const int* __restrict__ sub1, int n, int cd,
-                                                                  int sd, int ncat, const float* __restrict__ dout, int lddo,
-                                                                  float* __restrict__ dctab, float* __restrict__ dstab, uint32_t seed_cat,
-                                                                  uint32_t seed_sub, uint32_t thr, float scale) {
-  __shared__ float part[4][128];
+constexpr int FRD_WAVES = 16;
+__global__ __launch_bounds__(FRD_WAVES * 64) void fusion_rows_bwd_det_kernel(const int* __restrict__ cat0, const int* __restrict__ sub0, int n0,
+                                                                             const int* __restrict__ cat1, const int* __restrict__ sub1, int n, int cd,
+                                                                             int sd, int ncat, const float* __restrict__ dout, int lddo,
+                                                                             float* __restrict__ dctab, float* __restrict__ dstab, uint32_t seed_cat,
+                                                                             uint32_t seed_sub, uint32_t thr, float scale) {
+  __shared__ float part[FRD_WAVES][128];
   const bool is_cat = (int)blockIdx.x < ncat;
   const int t = is_cat ? blockIdx.x : blockIdx.x - ncat;
   const int dim = is_cat ? cd : sd, col0 = is_cat ? 0 : cd;
@@ -80,26 +81,35 @@ __global__ __launch_bounds__(256) void fusion_rows_bwd_det_kernel(const int* __r
   float* dtab = is_cat ? dctab : dstab;
   const uint32_t seed = is_cat ? seed_cat : seed_sub;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c0 = min(lane, dim - 1), c1 = min(lane + 64, dim - 1);      // (clamped: the loads below are unconditional)
   float acc0 = 0.f, acc1 = 0.f;                       // columns lane and lane + 64 (dim <= 128, checked by the launcher)
-  for (int base = w * 64; base < n; base += 256) {
+  for (int base = w * 64; base < n; base += FRD_WAVES * 64) {
     const int row = base + lane;
     int id = -1;
     if (row < n) id = row < n0 ? i0[row] : i1[row - n0];
     unsigned long long m = __ballot(id == t);
     while (m) {                                         // eight matching rows in flight, added in ascending row order
+      long rr[8];
+      float wgt[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {                     // (wave-uniform arithmetic: which rows, and whether the slot is used at all)
+        wgt[q] = m ? 1.f : 0.f;
+        rr[q] = m ? base + __builtin_ctzll(m) : base;
+        m &= m - 1;
+      }
       float v0[8], v1[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        v0[q] = v1[q] = 0.f;
-        if (m) {                                        // (wave-uniform)
-          const long r = base + __builtin_ctzll(m);
-          m &= m - 1;
-          if (lane < dim) v0[q] = dout[r * lddo + col0 + lane] * (nnr_keep(seed, (uint64_t)(r * dim + lane), thr) ? scale : 0.f);
-          if (lane + 64 < dim) v1[q] = dout[r * lddo + col0 + lane + 64] * (nnr_keep(seed, (uint64_t)(r * dim + lane + 64), thr) ? scale : 0.f);
-        }
+      for (int q = 0; q < 8; ++q) {                     // all sixteen loads are issued before the first one is used
+        v0[q] = dout[rr[q] * lddo + col0 + c0];
+        v1[q] = dout[rr[q] * lddo + col0 + c1];
       }
 #pragma unroll
-      for (int q = 0; q < 8; ++q) { acc0 += v0[q]; acc1 += v1[q]; }
+      for (int q = 0; q < 8; ++q) {
+        const float k0 = (lane < dim && nnr_keep(seed, (uint64_t)(rr[q] * dim + lane), thr)) ? scale * wgt[q] : 0.f;
+        const float k1 = (lane + 64 < dim && nnr_keep(seed, (uint64_t)(rr[q] * dim + lane + 64), thr)) ? scale * wgt[q] : 0.f;
+        acc0 += v0[q] * k0;
+        acc1 += v1[q] * k1;
+      }
     }
   }
   part[w][lane] = acc0;
@@ -107,7 +117,9 @@ __global__ __launch_bounds__(256) void fusion_rows_bwd_det_kernel(const int* __r
   __syncthreads();
   if (w == 0) {
     for (int c = lane; c < dim; c += 64) {
-      const float v = ((part[0][c] + part[1][c]) + part[2][c]) + part[3][c];
+      float v = 0.f;
+#pragma unroll
+      for (int q = 0; q < FRD_WAVES; ++q) v += part[q][c];
       if (v != 0.f) atomicAdd(&dtab[(long)t * dim + c], v);
     }
   }
@@ -219,7 +231,7 @@ extern "C" int nnr_fusion_rows_bwd_det(const int* cat0, const int* sub0, int n0,
   const int n = n0 + n1;
   if (n == 0 || ncat + nsub == 0) return NNR_OK;
   const float sc = p > 0.f ? 1.f / (1.f - p) : 1.f;
-  hipLaunchKernelGGL(fusion_rows_bwd_det_kernel, dim3(ncat + nsub), dim3(256), 0, stream, cat0, sub0, n0, cat1, sub1, n, cd, sd, ncat, dout, lddo,
+  hipLaunchKernelGGL(fusion_rows_bwd_det_kernel, dim3(ncat + nsub), dim3(FRD_WAVES * 64), 0, stream, cat0, sub0, n0, cat1, sub1, n, cd, sd, ncat, dout, lddo,
                      dcat_table, dsub_table, seed_cat, seed_sub, nnr_drop_thresh(p), sc);
   NNR_CHECK_LAUNCH();
   return NNR_OK;

@@ -92,6 +92,15 @@ __device__ __forceinline__ void gemm_epilogue(const nnr_gemm_args& g, f32x4 (&ac
         const int col = n0 + 4 * c4;
         if (row >= M || col >= N) continue;
         f32x4 x = *reinterpret_cast<const f32x4*>(&stage[lr * E_LD + 4 * c4]) * g.alpha;
+        if (g.pre_add) x += *reinterpret_cast<const f32x4*>(g.pre_add + (long)row * g.ldpre + col);
+        if (g.gate_bwd) {
+          // d(Ht = H * G): this GEMM completes dHt = x; dH = x * G and d pre = x * H * G * (1 - G) leave from the same registers
+          const f32x4 gv = *reinterpret_cast<const f32x4*>(mulp + (long)row * g.ldmul + col);
+          const f32x4 hv = *reinterpret_cast<const f32x4*>(res + (long)row * g.ldres + col);
+          *reinterpret_cast<f32x4*>(aux + (long)row * g.ldaux + col) = x * hv * gv * (1.f - gv);
+          *reinterpret_cast<f32x4*>(C + (long)row * g.ldc + col) = x * gv;
+          continue;
+        }
         if (g.accumulate == 2) x += *reinterpret_cast<const f32x4*>(C + (long)row * g.ldc + col);
         if (g.bias) x += *reinterpret_cast<const f32x4*>(g.bias + col);
         if (g.rowvec) x += *reinterpret_cast<const f32x4*>(g.rowvec + (long)(g.rowvec_map ? g.rowvec_map[row] : row) * g.ldrv + col);
@@ -1601,9 +1610,13 @@ static int dispatch_tile(int tile, const nnr_gemm_args& g, hipStream_t stream) {
     case 29: if (!tn_pipe_ok(g) || g.b_idx) return NNR_ERR_ARG; return launch_tn_pipe2<4, 5, 3, 2>(g, stream);    // gen-2 TN 256 x 80
     case 30: if (!tn_pipe_ok(g)) return NNR_ERR_ARG; return launch_tn_pipe2<2, 10, 3, 2>(g, stream);              // gen-2 TN 128 x 160 (N = 300 in two column blocks)
     case 31: if (!pipe_ok(g) || g.a_idx) return NNR_ERR_ARG; return launch_pipe2<2, 4, 3, 2>(g, stream);          // gen-2 NT 128 x 64, 3 x 24 KB stages, 2 workgroups / CU
+    case 33: if (!pipe_ok(g)) return NNR_ERR_ARG; return launch_pipe<2, 13, 16, 3, 2>(g, stream);   // NT 128 x 208, BK 16, 3 x 21 KB stages, 2 workgroups / CU (N = 1664 = 8 x 208)
+    case 34: if (!pipe_ok(g) || g.a_idx) return NNR_ERR_ARG; return launch_pipe2<2, 13, 3, 1>(g, stream);          // gen-2 NT 128 x 208, 3 x 43 KB stages, 1 workgroup / CU
+    case 36: if (!pipe_ok(g)) return NNR_ERR_ARG; return launch_pipe<4, 5, 16, 3, 3>(g, stream);    // NT 256 x 80, BK 16, 3 x 21 KB stages, 3 workgroups / CU
     case 32: if (!tn_pipe_ok(g)) return NNR_ERR_ARG; return launch_tn_pipe2<1, 13, 3, 2>(g, stream);              // gen-2 TN 64 x 208, 3 x 20 KB stages: row tiles of 64 fit M = 200 / 400 / 832
                                                                                                                   // (256 / 448 / 832 rows of MFMA work instead of 256 / 512 / 896)
     case 7:
+      if (g.pre_add || g.gate_bwd) return NNR_ERR_ARG;
       if (g.trans_a || g.a_idx || g.b_idx || g.c_idx || g.dyn_dev || g.split_k > 1 || g.k_chunk > 0 || g.rowdot_w || g.colsum_out || g.atomic ||
           (g.drop_target != 0 && g.drop_target != 3)) return NNR_ERR_ARG;
       return launch_skinny(g, stream);
@@ -1632,6 +1645,11 @@ extern "C" int nnr_gemm_f32(const nnr_gemm_args* a, hipStream_t stream) {
                  ok(g.rowvec, g.ldrv) && ok(g.aux_out, g.ldaux) && ok(g.mul, g.ldmul) && ok(g.resid, g.ldres) && strides &&
                  (g.drop_target != 3 || (g.drop_cols & 3) == 0)) ? 1 : 0;
   }
+  if (g.pre_add || g.gate_bwd) {
+    auto al = [](const void* p, int ld) { return p != nullptr && (((uintptr_t)p) & 15) == 0 && (ld & 3) == 0; };
+    if (!g.vec_epi || g.split_k > 1 || g.k_chunk > 0 || g.batch > 1 || (g.pre_add && !al(g.pre_add, g.ldpre))) return NNR_ERR_ARG;
+    if (g.gate_bwd && (!g.C || !g.aux_out || !g.mul || !g.resid || g.bias || g.rowvec || g.act || g.drop_target || g.accumulate || g.rowdot_w)) return NNR_ERR_ARG;
+  }
   // reproducible split-K: the slices store into the caller's slab, a second launch adds them in slice order (splitk_reduce_kernel)
   float* slab_C = nullptr;
   float* slab_cs = nullptr;
@@ -1651,7 +1669,7 @@ extern "C" int nnr_gemm_f32(const nnr_gemm_args* a, hipStream_t stream) {
     const long wg128 = (long)((g.M + 127) / 128) * ((g.N + 79) / 80) * (g.k_chunk > 0 ? (g.K + g.k_chunk - 1) / g.k_chunk : (g.split_k > 1 ? g.split_k : (g.batch > 1 ? g.batch : 1)));
     const long wg64 = (long)((g.M + 63) / 64) * ((g.N + 79) / 80) * (g.split_k > 1 ? g.split_k : (g.batch > 1 ? g.batch : 1));
     const bool plain = !g.trans_a && !g.a_idx && !g.b_idx && !g.c_idx && !g.dyn_dev && g.split_k <= 1 && g.k_chunk <= 0 && !g.rowdot_w &&
-                       !g.colsum_out && !g.atomic && (g.drop_target == 0 || g.drop_target == 3);
+                       !g.colsum_out && !g.atomic && (g.drop_target == 0 || g.drop_target == 3) && !g.pre_add && !g.gate_bwd;
     static const bool use_t9 = [] { const char* e = getenv("NNR_NT9"); return !(e && atoi(e) == 0); }();   // A/B
     static const bool use_pipe = [] { const char* e = getenv("NNR_GEMM_PIPE"); return !(e && atoi(e) == 0); }();   // A/B switch
     if (g.rowdot_w) tile = 3;

@@ -808,14 +808,20 @@ __global__ __launch_bounds__((UB > 4 ? 16 : 4) * 64) void lstm_bwd_kernel(LstmAr
 // lane layout (row = 4*(lane>>4)+e, unit = lane&15), so it adds the four words to its own partial sums in registers at
 // the start of the next step: no LDS staging, no extra barrier, and the round trip hides under the own-tile MFMAs.
 // W_hh fragments are resident: the own tile's K range in registers, the partner tile's half in registers, half in LDS.
-template <int UB, int hv>
+// BAL (round 4): the 13 output tiles of a step (nb own + npb partner tiles per half) cannot be dealt evenly to four SIMDs as whole
+// tiles -- waves w and w + 4 share a SIMD, and with waves 0..5 carrying two tiles each, wave 6 one and wave 7 none, two SIMDs did
+// 4 tiles of MFMA work per step (448 instructions), the others 3 and 2: 6.0 of the step's 9.7 us.  Now the LAST own tile is split
+// four ways along the reduction: waves 0-3 keep (own w, partner w), waves 4-7 take one whole tile each (the remaining own / partner
+// tiles, fragments in registers) plus a QUARTER of the split tile; the four quarter sums meet in LDS and the tile's owner wave adds
+// them in order at the start of the next step (where it needs them).  Every SIMD then issues 3.25 tiles = 364 MFMAs per step.
+template <int UB, int hv, bool BAL>
 __device__ __forceinline__ void lstm_bwd_pair_body(const LstmArgs& a, const LstmProblem& P, const int d, const int tile, const int s0,
                                                    float* dg, f32x4 (*wl)[64]) {
   constexpr int HP = UB * 16, NP = UB * 64, KGB = NP / 16, UB0 = (UB + 1) / 2, NW = 8;
   constexpr int ub_lo = hv ? UB0 : 0, nb = hv ? UB - UB0 : UB0;          // own unit blocks
   constexpr int npb = UB - nb, pb_lo = hv ? 0 : UB0;                     // the partner's unit blocks
   constexpr int KO = nb * 4, k_lo = ub_lo * 4;                           // own K range (16-column groups of p-ordered gate columns)
-  constexpr int KR = KO / 2, KL = KO - KR;                               // partner-tile fragments in registers / in LDS
+  constexpr int KR = BAL ? 8 : KO / 2, KL = KO - KR;                               // partner-tile fragments in registers / in LDS
   constexpr int DLD = nb * 64 + 16;                                      // row stride = 4 (mod 16) 16-byte chunks (swizzle)
   static_assert((DLD / 4) % 16 == 4, "dgates tile stride must keep the ds_read_b128 swizzle conflict-free");
   const int H = a.H;
@@ -872,9 +878,16 @@ __device__ __forceinline__ void lstm_bwd_pair_body(const LstmArgs& a, const Lstm
   unsigned long long* tbuf = reinterpret_cast<unsigned long long*>(diag + SYNC_PAD);
   const bool stamp = (a.dbg & 32) && blockIdx.x == 0 && tid == 0;
 #define STAMP(slot) do { if (stamp && step < 128) tbuf[step * 16 + (slot)] = wall_clock64(); } while (0)
-  const bool own = w < nb;                               // this wave owns unit block ub_lo + w (gate gradients + own output tile)
-  const bool par = w < npb;                              // ... and computes the partner's output tile pb_lo + w
-  if (!own && !par) {                                    // nothing to do: keep the barrier count
+  const bool own = w < nb;                               // this wave owns unit block ub_lo + w (gate gradients; legacy: + its output tile)
+  constexpr int SPL = nb - 1;                            // BAL: the own tile that is split four ways; wave SPL is its owner
+  constexpr int KQ4 = KO / 4;                            // k-groups per quarter
+  static_assert(!BAL || (KO % 4 == 0 && nb >= 6 && npb >= 6 && nb <= 7 && npb <= 7 && KQ4 <= KR), "balanced split is laid out for 13 unit blocks");
+  const bool hi = BAL && w >= 4;                         // BAL, waves 4-7: one whole tile (registers) + quarter w - 4 of the split tile
+  const bool t1_own = BAL ? (w < 4 || w < SPL) : own;    // the tile whose fragments sit in `wo` is an own tile (result stays in dhr)
+  const int t1_tile = (BAL && w >= SPL) ? 4 + (w - SPL) : w;      // ... its index among the own / the partner's tiles
+  const bool t1_on = BAL ? true : own;
+  const bool par = BAL ? (w < 4) : (w < npb);            // (wp / wl fragments) the partner's output tile pb_lo + w
+  if (!BAL && !own && !par) {                            // nothing to do: keep the barrier count
     for (int step = 0; step < tmax; ++step) { __syncthreads(); __syncthreads(); }
     return;
   }
@@ -891,8 +904,9 @@ __device__ __forceinline__ void lstm_bwd_pair_body(const LstmArgs& a, const Lstm
   f32x4 wo[KO], wp[KR];
   {
     const f32x4* wb = reinterpret_cast<const f32x4*>(P.wfrag) + (long)d * UB * KGB * 64 + lane;
+    const int t1_blk = (t1_own ? ub_lo : pb_lo) + t1_tile;       // unit block (n-tile of W_hh^T) of the whole tile kept in `wo`
 #pragma unroll
-    for (int k = 0; k < KO; ++k) wo[k] = own ? wb[((long)ub * KGB + k_lo + k) * 64] : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < KO; ++k) wo[k] = t1_on ? wb[((long)t1_blk * KGB + k_lo + k) * 64] : f32x4{0.f, 0.f, 0.f, 0.f};
     const int pb = pb_lo + (par ? w : 0);
 #pragma unroll
     for (int k = 0; k < KR; ++k) wp[k] = par ? wb[((long)pb * KGB + k_lo + k) * 64] : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -900,7 +914,13 @@ __device__ __forceinline__ void lstm_bwd_pair_body(const LstmArgs& a, const Lstm
 #pragma unroll
       for (int k = 0; k < KL; ++k) wl[w * KL + k][lane] = wb[((long)pb * KGB + k_lo + KR + k) * 64];
     }
+    if (hi) {                                                // quarter w - 4 of the split own tile: KQ4 fragments, in wp's registers
+#pragma unroll
+      for (int k = 0; k < KR; ++k)
+        if (k < KQ4) wp[k] = wb[((long)(ub_lo + SPL) * KGB + k_lo + (w - 4) * KQ4 + k) * 64];
+    }
   }
+  f32x4 (*qs)[64] = wl + 4 * KL;                             // BAL: the four quarter sums of the split tile (rows of wl nobody else uses)
   float dhr[4] = {0.f, 0.f, 0.f, 0.f}, dcr[4] = {0.f, 0.f, 0.f, 0.f};
   // software-pipelined inputs of the gate-gradient phase (loaded under the MFMA phase of the previous step)
   f32x4 in_g[4];
@@ -935,6 +955,15 @@ __device__ __forceinline__ void lstm_bwd_pair_body(const LstmArgs& a, const Lstm
     // ---- (1) gate gradients of the own unit block
     STAMP(4);
     if (own) {
+      if (BAL && w == SPL && step > 0) {
+        // this wave's own output tile of the previous step was computed in four K-quarters by waves 4-7: add them in order
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = qs[q][lane];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dhr[e] = q ? dhr[e] + v[e] : v[e];
+        }
+      }
       // the partner's contribution to dh of these units (its own-K partial sums of the previous step)
       if (step > 0) {
         const unsigned long long* src = xtheirs + ((step + 1) & 1) * XT + (w * 4) * 64 + lane;
@@ -988,8 +1017,9 @@ __device__ __forceinline__ void lstm_bwd_pair_body(const LstmArgs& a, const Lstm
       for (int e = 0; e < 4; ++e) st_tag(dst + e * 64, acc[e], a.epoch + (unsigned)(step + 1), same_xcd);
       STAMP(8);
     }
-    // ---- (3) the own output tile over the own K range (stays in registers: same lane needs it next step)
-    if (own) {
+    // ---- (3) the whole tile whose fragments are resident in registers: an own tile stays in registers (the same lane needs it next
+    //      step), a partner tile (BAL, waves >= SPL) is sent like the ones above
+    if (t1_on) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int k = 0; k < KO; ++k) {
@@ -997,9 +1027,28 @@ __device__ __forceinline__ void lstm_bwd_pair_body(const LstmArgs& a, const Lstm
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], wo[k][i], acc, 0, 0, 0);
       }
+      if (t1_own) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) dhr[e] = acc[e];
+        for (int e = 0; e < 4; ++e) dhr[e] = acc[e];
+      } else {
+        unsigned long long* dst = xmine + (step & 1) * XT + (t1_tile * 4) * 64 + lane;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) st_tag(dst + e * 64, acc[e], a.epoch + (unsigned)(step + 1), same_xcd);
+      }
       if (stamp && step < 128) tbuf[step * 16 + 9] = wall_clock64() + (unsigned long long)(dhr[0] == 123.456f);
+    }
+    // ---- (4) BAL, waves 4-7: quarter w - 4 of the split own tile
+    if (hi) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < KR; ++k) {
+        if (k < KQ4) {
+          const f32x4 af = *reinterpret_cast<const f32x4*>(&dg[r * DLD + ((w - 4) * KQ4 + k) * 16 + 4 * (kk ^ swz16(r))]);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], wp[k][i], acc, 0, 0, 0);
+        }
+      }
+      qs[w - 4][lane] = acc;
     }
     __syncthreads();
   }
@@ -1156,7 +1205,7 @@ __device__ __forceinline__ void lstm_bwd_quad_body(const LstmArgs& a, const Lstm
   }
 }
 
-template <int UB>
+template <int UB, bool BAL>
 __global__ __launch_bounds__(512) void lstm_bwd_pair_kernel(LstmArgs a) {
   constexpr int UB0 = (UB + 1) / 2;
   __shared__ __attribute__((aligned(16))) float dg[16 * (UB0 * 64 + 16)];
@@ -1170,8 +1219,8 @@ __global__ __launch_bounds__(512) void lstm_bwd_pair_kernel(LstmArgs a) {
     return;
   }
   const int s0 = 4 * nq + 16 * (id.tile - nq);
-  if (pair_half(blockIdx.x)) lstm_bwd_pair_body<UB, 1>(a, P, id.d, id.tile, s0, dg, wl);
-  else lstm_bwd_pair_body<UB, 0>(a, P, id.d, id.tile, s0, dg, wl);
+  if (pair_half(blockIdx.x)) lstm_bwd_pair_body<UB, 1, BAL>(a, P, id.d, id.tile, s0, dg, wl);
+  else lstm_bwd_pair_body<UB, 0, BAL>(a, P, id.d, id.tile, s0, dg, wl);
 }
 
 // ------------------------------------------------------------------------------------------------ weight (un)packing
@@ -1283,8 +1332,15 @@ template <int UB>
 int launch_pair(const LstmArgs& a, bool backward, int max_tiles, hipStream_t s) {
   const int tiles = max_tiles + (a.quad_T > 0 ? MAXQ : 0);             // quad tiles take the first ids; whatever is not needed exits
   dim3 grid(((tiles + 7) / 8) * 16 * 2 * a.nprob), block(512);         // groups of 8 tiles x 2 halves, see pair_id()
-  if (backward) hipLaunchKernelGGL((lstm_bwd_pair_kernel<UB>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((lstm_fwd_pair_kernel<UB>), grid, block, 0, s, a);
+  static const bool bal = [] { const char* e = getenv("NNR_LSTM_BWD_BAL"); return !(e && atoi(e) == 0); }();      // A/B: 0 = the legacy whole-tile split
+  if (backward) {
+    if constexpr (UB == 13) {
+      if (bal) hipLaunchKernelGGL((lstm_bwd_pair_kernel<UB, true>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((lstm_bwd_pair_kernel<UB, false>), grid, block, 0, s, a);
+    } else {
+      hipLaunchKernelGGL((lstm_bwd_pair_kernel<UB, false>), grid, block, 0, s, a);
+    }
+  } else hipLaunchKernelGGL((lstm_fwd_pair_kernel<UB>), grid, block, 0, s, a);
   NNR_CHECK_LAUNCH();
   return NNR_OK;
 }

@@ -77,25 +77,25 @@ __global__ __launch_bounds__(256) void embed_scatter_sorted_kernel(const float* 
     }
   };
   bool done = false;
+  const int dlast = dim - 1;
   for (int i0 = 0; i0 < cnt && !done; i0 += 4) {
+    // four rows in flight: every load is issued UNCONDITIONALLY before any of them is used (a branch per row cuts the block, and the
+    // wait for row u's loads then sits in front of row u + 1's: one row in flight -- 32 dependent round trips per wave, 85 us for the
+    // 88 k-row content stream); pad entries read row 0 / a clamped column and are discarded below
     float v[4][SS_MAXJ];
     unsigned kk[4];
+    int rr[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int i = i0 + u;                                       // (< 64: lanes >= cnt hold the pad key)
-      const unsigned k = __shfl(myk, i, 64);
-      const int r = __shfl(myr, i, 64);
-      kk[u] = k;
+      const int i = i0 + u;                                       // (< 64: lanes >= cnt hold the pad key and row 0)
+      kk[u] = __shfl(myk, i, 64);
+      rr[u] = __shfl(myr, i, 64);
+    }
 #pragma unroll
-      for (int j = 0; j < SS_MAXJ; ++j) {
-        const int col = lane + 64 * j;
-        float x = 0.f;
-        if (k < V && col < dim) {
-          x = dout[(long)r * dim + col];
-          if (thr) x = nnr_keep(seed, (uint64_t)r * dim + col, thr) ? x * scale : 0.f;
-        }
-        v[u][j] = x;
-      }
+    for (int u = 0; u < 4; ++u) {
+      const float* src = dout + (long)rr[u] * dim;
+#pragma unroll
+      for (int j = 0; j < SS_MAXJ; ++j) v[u][j] = src[min(lane + 64 * j, dlast)];
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -109,7 +109,12 @@ __global__ __launch_bounds__(256) void embed_scatter_sorted_kernel(const float* 
         for (int j = 0; j < SS_MAXJ; ++j) acc[j] = 0.f;
       }
 #pragma unroll
-      for (int j = 0; j < SS_MAXJ; ++j) acc[j] += v[u][j];
+      for (int j = 0; j < SS_MAXJ; ++j) {
+        const int col = lane + 64 * j;
+        float x = col < dim ? v[u][j] : 0.f;
+        if (thr) x = nnr_keep(seed, (uint64_t)rr[u] * dim + col, thr) ? x * scale : 0.f;
+        acc[j] += x;
+      }
     }
   }
   flush(nextK == run_key);                                        // (a chunk that ran into pad rows has nextK = pad: closed)

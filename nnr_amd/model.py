@@ -94,6 +94,8 @@ class Model(nn.Module):
             raise Exception(config.user_encoder + ' is not on the MI355X hot path (in scope: SUE, MHSA, ATT; SURVEY.md section 8a)')
         self.model_name = config.news_encoder + '-' + config.user_encoder
         self.news_embedding_dim = self.news_encoder.news_embedding_dim
+        self.dropout = nn.Dropout(p=config.dropout_rate)                    # (model.py:77: part of the attribute surface; only the
+                                                                              #  out-of-scope mlp / FIM click predictors call it)
         self.use_user_embedding = False
         if config.click_predictor != 'dot_product':
             raise Exception('click_predictor=%s is out of scope (dot_product only, model.py:126-127)' % config.click_predictor)

@@ -138,6 +138,7 @@ _LSTM_FWD_SPLIT = os.environ.get('NNR_LSTM_FWD_SPLIT', '0') == '1'      # A/B: t
 _POST_INLINE = os.environ.get('NNR_POST_INLINE', '0') == '1'      # A/B: the content stream's tail GEMMs on one HIP stream
 _DX_SPLIT = os.environ.get('NNR_DX_SPLIT', '1') == '1'      # embedding-row gradient as plain GEMM + scatter kernel (11.46 vs 11.51 ms fused)
 _BWD_SPLIT = os.environ.get('NNR_LSTM_BWD_SPLIT', '1') == '1'      # batch 8: 4.68 (split) vs 4.93 ms; batch 64: no difference
+_GATE_FUSED = os.environ.get('NNR_GATE_FUSED', '1') != '0'      # A/B: the gate's backward inside the epilogue of the GEMM that completes dHt
 _CNE_UNION = os.environ.get('NNR_CNE_UNION', '1') != '0'      # A/B switch: candidate + history call as one packed token stream
 
 
@@ -502,13 +503,18 @@ def _cne_bwd_pre(mod, sv, drep, par=False, leaf=None):
                      dout=drep[:, col0:], lddo=D, dout2=st['dself_x'], lddo2=H2, dx=st['dHt'], lddx=H2, dx_accumulate=True, dscore=ds)
         th = st['th']
         ops.tanh_score_bwd(th, ds, sa.affine2.weight, grad_of(sa.affine2.weight), plan, A)    # th := dpre
-        ops.gemm(th, ops.wt(sa.affine1.weight), st['dHt'], M=cap, N=H2, K=A, lda=A, ldb=A, ldc=H2, accumulate=True,      # NT on W1^T
-                 dyn=plan.total, dyn_dim=1)
-        leaf(lambda: ops.linear_bwd_weight(th, st['Ht'], grad_of(sa.affine1.weight), dyn=plan.total, db=grad_of(sa.affine1.bias)), th, st['Ht'])
-        # gate: Ht = hout * G
         st['dH'] = torch.empty((cap, H2), **f32)
-        dpre = torch.empty((cap, H2), **f32)             # (not Ht's buffer: the deferred weight-gradient GEMM above still reads it)
-        ops.gate_bwd(st['dHt'], st['hout'], st['G'], st['dH'], dpre, plan, H2)
+        dpre = torch.empty((cap, H2), **f32)             # (not Ht's buffer: the deferred weight-gradient GEMM below still reads it)
+        if _GATE_FUSED:
+            # the GEMM that completes dHt (+= d tanh-projection . W1) applies the gate's backward in its epilogue: Ht = hout * G ->
+            # dH = dHt * G, d pre = dHt * hout * G * (1 - G) -- one launch and one pass over dHt less on the dependent chain (round 4)
+            ops.gemm(th, ops.wt(sa.affine1.weight), st['dH'], M=cap, N=H2, K=A, lda=A, ldb=A, ldc=H2, dyn=plan.total, dyn_dim=1,
+                     pre_add=st['dHt'], ldpre=H2, gate_bwd=True, mul=st['G'], ldmul=H2, resid=st['hout'], ldres=H2, aux_out=dpre, ldaux=H2)
+        else:
+            ops.gemm(th, ops.wt(sa.affine1.weight), st['dHt'], M=cap, N=H2, K=A, lda=A, ldb=A, ldc=H2, accumulate=True,      # NT on W1^T
+                     dyn=plan.total, dyn_dim=1)
+            ops.gate_bwd(st['dHt'], st['hout'], st['G'], st['dH'], dpre, plan, H2)               # gate: Ht = hout * G
+        leaf(lambda: ops.linear_bwd_weight(th, st['Ht'], grad_of(sa.affine1.weight), dyn=plan.total, db=grad_of(sa.affine1.bias)), th, st['Ht'])
         ops.gemm(dpre, ops.wt(st['Hlin'].weight), st['dH'], M=cap, N=H2, K=H2, lda=H2, ldb=H2, ldc=H2, accumulate=True,   # NT on W_H^T
                  dyn=plan.total, dyn_dim=1)
         leaf(lambda: ops.linear_bwd_weight(dpre, st['hout'], grad_of(st['Hlin'].weight), dyn=plan.total), dpre, st['hout'])

@@ -187,6 +187,8 @@ def leaf_deferred(dev, rows, fn, *tensors):
     _DEFER['calls'] += 1
     with torch.cuda.stream(leaf):
         fn()
+    if _DEFER.get('manual'):
+        return                           # the native step (nnr_amd.step) joins the leaf stream itself when its backward sequence ends
     if not _DEFER['queued']:
         _DEFER['queued'] = True
         try:                             # end-of-pass callbacks run on the stream that surrounded the caller's backward()
@@ -334,7 +336,8 @@ def split_for(m, n, k, tile_m=64, tile_n=80, target_blocks=2048, kmin=256):
 def gemm(A, B, C_=None, *, M, N, K, lda, ldb, ldc=0, trans_a=False, trans_b=False, dyn=None, dyn_dim=0, a_idx=None, b_idx=None,
          drop=None, alpha=1.0, bias=None, rowvec=None, ldrv=0, rowvec_map=None, act=0, aux_out=None, ldaux=0, mul=None, ldmul=0,
          resid=None, ldres=0, accumulate=False, atomic=False, c_idx=None, split_k=1, rowdot_w=None, rowdot_out=None, batch=1,
-         strideA=0, strideB=0, strideC=0, stride_aux=0, stride_res=0, tile=0, colsum_out=None, k_chunk=0, flop_scale=1.0, slab=None):
+         strideA=0, strideB=0, strideC=0, stride_aux=0, stride_res=0, tile=0, colsum_out=None, k_chunk=0, flop_scale=1.0, slab=None,
+         pre_add=None, ldpre=0, gate_bwd=False):
     # flop_scale: algorithmic / padded work of this launch (the LSTM gate columns are padded 800 -> 832 per direction; the live
     # profile counts the true 8H columns, not the padded 2*NP)
     # ctypes zero-initialises the struct: only the fields a call actually uses are written (a field store costs ~0.2 us of host
@@ -385,6 +388,10 @@ def gemm(A, B, C_=None, *, M, N, K, lda, ldb, ldc=0, trans_a=False, trans_b=Fals
         g.colsum_out = colsum_out.data_ptr()
     if k_chunk:
         g.k_chunk = int(k_chunk)
+    if pre_add is not None:
+        g.pre_add, g.ldpre = pre_add.data_ptr(), ldpre
+    if gate_bwd:
+        g.gate_bwd = 1
     if slab is None and TN_SLAB and trans_a and trans_b and split_k > 1 and not k_chunk and c_idx is None and (N & 3) == 0 and C_ is not None:
         slab = _slab_ws(A.device, int(split_k) * (M * N + M))      # reproducible split-K: partial results to a slab + fixed-order reduction
     if slab is not None:
@@ -444,7 +451,7 @@ def gemm(A, B, C_=None, *, M, N, K, lda, ldb, ldc=0, trans_a=False, trans_b=Fals
         if dyn is not None:
             d = int(vals[dyn.data_ptr()]) if vals is not None else int(dyn.item())
             m, k = (min(M, d), K) if dyn_dim == 1 else (M, min(K, d))
-        outs = (1 if C_ is not None else 0) + (1 if accumulate else 0) + (1 if aux_out is not None else 0) + (1 if mul is not None else 0) + (1 if resid is not None else 0)
+        outs = (1 if C_ is not None else 0) + (1 if accumulate else 0) + (1 if aux_out is not None else 0) + (1 if mul is not None else 0) + (1 if resid is not None else 0) + (1 if pre_add is not None else 0)
         return 4.0 * max(1, batch) * (m * k + N * k + m * N * outs)
     flops.bytes_fn = op_bytes
     if trans_a and trans_b and split_k > 1:

@@ -6,17 +6,37 @@ Same kernels, same order, same HIP streams and the same dropout seeds as `loss.b
 news_encoders / user_encoders / model (tests/test_hip_tape_gpu.py compares the two); what is gone is the framework in between:
 autograd's bookkeeping, its gradient-accumulation / fill / cat kernels, and every host-side tensor op that is not a call into
 libnnr_hip.so.  That makes the step RECORDABLE: nnr_amd.tape captures the calls of one such step and replays them natively."""
+import os
+
 import torch
 
 from . import ops
 from .news_encoders import cne_forward_many, cne_backward_many, _CNE_UNION
 
+_MHSA_NATIVE = os.environ.get('NNR_MHSA_NATIVE', '1') != '0'      # A/B: MHSA+MHSA through autograd (round 3) instead of the native step
+
+
+def kind(model):
+    """Which native step covers `model`: 'cne_sue' (the headline pair, BASELINE.json configs[2..4]; device-side tie order), 'mhsa'
+    (configs[1]: MHSA news + MHSA user encoder), or None (autograd path)."""
+    from . import news_encoders as NE, user_encoders as UE
+    if model.click_predictor != 'dot_product' or not model.training:
+        return None
+    if type(model.news_encoder) is NE.CNE and type(model.user_encoder) is UE.SUE and model.news_encoder.tie_order == 'stable' and NE._CNE_UNION:
+        return 'cne_sue'
+    if type(model.news_encoder) is NE.MHSA and type(model.user_encoder) is UE.MHSA and _MHSA_NATIVE:
+        return 'mhsa'
+    return None
+
 
 def supported(model):
-    """The native step covers the headline pair (BASELINE.json: CNE + SUE, dot-product click predictor), device-side tie order."""
-    from . import news_encoders as NE, user_encoders as UE
-    return (type(model.news_encoder) is NE.CNE and type(model.user_encoder) is UE.SUE and model.click_predictor == 'dot_product'
-            and model.news_encoder.tie_order == 'stable' and NE._CNE_UNION and model.training)
+    return kind(model) is not None
+
+
+def news_calls_per_step(model):
+    """Encoder calls (= per-call dropout seeds drawn) of one step: the CNE step plans candidates + history as ONE call, the MHSA step
+    makes the reference's two calls (model.py:123-125)."""
+    return 2 if kind(model) == 'mhsa' else 1
 
 
 _ID_INPUTS = (1, 2, 3, 6, 13, 14, 15, 18)       # category / subCategory / title / content ids of the history and the candidate call
@@ -31,10 +51,125 @@ def recordable(batch):
             and batch[11].dim() == 2 and batch[11].element_size() == 1 and batch[12].dtype == torch.int64)
 
 
+class _Ctx:
+    """Stands in for autograd's ctx: the encoders' building blocks (nnr_amd.functional, layers._AttentionFn) are autograd Functions whose
+    static forward / backward only set and read attributes on it."""
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+
+def _fwd(fn, *args):
+    ctx = _Ctx()
+    return fn.forward(ctx, *args), (fn, ctx)
+
+
+def _bwd(node, *grads):
+    fn, ctx = node
+    return fn.backward(ctx, *grads)
+
+
+def _mhsa_news_forward(ne, title_text, title_mask, category, subCategory):
+    """newsEncoders.py:187-200 (nnr_amd.news_encoders.MHSA.forward) as a plain call sequence; returns ([B, N, D], nodes)."""
+    from . import functional as Fn
+    from .layers import _AttentionFn
+    B, N = title_text.shape[:2]
+    n, Lx = B * N, ne.max_sentence_length
+    p = ne.dropout_rate if ne.training else 0.0
+    seed = ne._next_seed()
+    mask = title_mask.view(n, Lx)
+    w, n1 = _fwd(Fn.EmbedDropFn, ne.word_embedding.weight, title_text, p, seed + 1)
+    qkv, n2 = _fwd(Fn.QKVFn, w, ne.multiheadAttention)
+    c, n3 = _fwd(Fn.MhsaCoreFn, qkv, mask, n, Lx, ne.head_num, ne.head_dim, p, seed + 2)
+    rep, n4 = _fwd(_AttentionFn, c.view(n, Lx, ne.feature_dim), ne.attention, mask)
+    out, n5 = _fwd(Fn.FuseFn, rep, ne, category, subCategory, p, seed)
+    return out.view(B, N, ne.news_embedding_dim), (n1, n2, n3, n4, n5, (n, Lx))
+
+
+def _mhsa_news_backward(ne, nodes, dout):
+    n1, n2, n3, n4, n5, (n, Lx) = nodes
+    drep = _bwd(n5, dout.reshape(n, -1))[0]
+    dc = _bwd(n4, drep)[0]
+    dqkv = _bwd(n3, dc.reshape(n * Lx, -1))[0]
+    dw = _bwd(n2, dqkv)[0]
+    _bwd(n1, dw)
+
+
+def forward_backward_mhsa(trainer, batch):
+    """BASELINE.json configs[1] (MHSA + MHSA) without an autograd graph: the same building blocks, seeds, HIP streams and order as
+    Model.forward + loss.backward() (candidate call on the side stream beside the history call; weight gradients on the leaf stream),
+    every device-side operation a C-ABI call -- so the step is recordable (nnr_amd.tape) like the CNE+SUE one."""
+    from . import functional as Fn
+    from .layers import _AttentionFn
+    from .news_encoders import _side_stream
+    model = trainer.model
+    ne, ue = model.news_encoder, model.user_encoder
+    (user_ID, user_category, user_subCategory, user_title_text, user_title_mask, user_title_entity, user_content_text, user_content_mask,
+     user_content_entity, user_history_mask, user_history_graph, user_history_category_mask, user_history_category_indices, news_category,
+     news_subCategory, news_title_text, news_title_mask, news_title_entity, news_content_text, news_content_mask, news_content_entity) = batch
+    dev = news_title_text.device
+    f32 = dict(device=dev, dtype=torch.float32)
+    with torch.no_grad():
+        ops.wt_prefetch(dev)
+        ops.STEP_ROWS[0] = user_title_text.shape[0] * user_title_text.shape[1] * user_title_text.shape[2]
+        ops._DEFER['manual'] = True                      # ops.leaf_deferred: no autograd end-of-pass callback here; joined below
+        try:
+            side, main = _side_stream(dev), torch.cuda.current_stream(dev)
+            two = ops.SIDE_CALL and ops.STEP_ROWS[0] >= ops.LEAF_MIN_ROWS and not ops.ONE_STREAM[0]
+            if two:                                       # the candidate call on a side stream beside the history call (model.py:123-125)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    rep_c, nodes_c = _mhsa_news_forward(ne, news_title_text, news_title_mask, news_category, news_subCategory)
+            else:
+                rep_c, nodes_c = _mhsa_news_forward(ne, news_title_text, news_title_mask, news_category, news_subCategory)
+            rep_h, nodes_h = _mhsa_news_forward(ne, user_title_text, user_title_mask, user_category, user_subCategory)
+            if two:
+                main.wait_stream(side)
+            B, N, D = rep_c.shape
+            Hn = rep_h.shape[1]
+            # user encoder (userEncoders.py:164-173)
+            qkv, u1 = _fwd(Fn.QKVFn, rep_h.reshape(B * Hn, D), ue.multiheadAttention)
+            h, u2 = _fwd(Fn.MhsaCoreFn, qkv, user_history_mask.contiguous(), B, Hn, ue.head_num, ue.head_dim)
+            h, u3 = _fwd(Fn.LinearFn, h, ue.affine.weight, ue.affine.bias, ops.ACT_RELU, 0.5 if ue.training else 0.0, ue._next_seed())
+            user, u4 = _fwd(_AttentionFn, h.view(B, Hn, D), ue.attention, None)
+            user_rep, u5 = _fwd(Fn.ExpandFn, user, N)
+            # click predictor + loss + their backward in one launch (model.py:126-127, trainer.py:64-66)
+            logits = torch.empty((B, N), **f32)
+            loss = torch.empty((), **f32)
+            duser = torch.empty((B, N, D), **f32)
+            dcand = torch.empty((B, N, D), **f32)
+            trainer.wait_grad_zeroed()
+            ops.click_loss(user_rep, rep_c.contiguous(), B, N, D, logits, loss, None, duser, dcand, torch.empty(B, **f32))
+            # backward: user encoder, then the two encoder calls (the candidates' on the side stream again)
+            du = _bwd(u5, duser)[0]
+            dh = _bwd(u4, du)[0]
+            dh = _bwd(u3, dh.reshape(B * Hn, D))[0]
+            dqkv = _bwd(u2, dh)[0]
+            dhist = _bwd(u1, dqkv)[0]
+            hook = ue.__dict__.get('_grads_ready_hook')
+            if hook is not None:
+                hook()
+            if two:
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    _mhsa_news_backward(ne, nodes_c, dcand)
+                _mhsa_news_backward(ne, nodes_h, dhist.reshape(B, Hn, D))
+                main.wait_stream(side)
+            else:
+                _mhsa_news_backward(ne, nodes_c, dcand)
+                _mhsa_news_backward(ne, nodes_h, dhist.reshape(B, Hn, D))
+        finally:
+            ops._DEFER['manual'] = False
+        ops.join_extra_streams()
+    return logits, loss
+
+
 def forward_backward(trainer, batch):
     """Forward + loss + backward of one batch (21 device tensors, Model.forward order) into the trainer's flat gradient buffer.
     Returns (logits [B, N], loss []) -- fresh tensors of this call."""
     model = trainer.model
+    if kind(model) == 'mhsa':
+        return forward_backward_mhsa(trainer, batch)
     ne, ue = model.news_encoder, model.user_encoder
     (user_ID, user_category, user_subCategory, user_title_text, user_title_mask, user_title_entity, user_content_text, user_content_mask,
      user_content_entity, user_history_mask, user_history_graph, user_history_category_mask, user_history_category_indices, news_category,

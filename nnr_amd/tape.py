@@ -32,6 +32,7 @@ _VALUE_ARGS = {('nnr_clip_adam', 13): 'adam_step'}            # (entry point, ar
 _HANDLE_ARGS = {'nnr_dp_allreduce', 'nnr_dp_broadcast'}       # their FIRST pointer is an opaque host handle (the communicator), not device memory
 
 
+NEWS_SEED_STRIDE = 104729      # NewsEncoder._next_seed: the per-call seed advances by this much (news_encoders.py)
 TAG_ALL = [False]
 
 
@@ -217,6 +218,8 @@ class Tape:
             d = (v - self.seeds[name]) & 0xFFFFFFFF
             if d < 64:
                 return VALUE_KINDS[name], d
+            if name == 'news_seed' and 0 <= d - NEWS_SEED_STRIDE < 64:
+                return VALUE_KINDS[name], d      # the SECOND news-encoder call of the step (MHSA step: candidates, then history)
         raise TapeError('a uint32 argument (%d) that is not derived from this step\'s dropout seeds reached a recorded call' % v)
 
     def _add_call(self, name, args):

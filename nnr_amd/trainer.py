@@ -190,7 +190,7 @@ class Trainer:
         # scalars baked into the recorded arguments + the HIP stream the step is issued on (the tape replays on the recorded streams:
         # a caller that switches its current stream gets a fresh tape, not launches that are unordered with its own work)
         hyper = (self.lr, self.weight_decay, self.gradient_clip_norm, dp.world_size(), float(self.model.news_encoder.dropout_rate),
-                 float(self.model.user_encoder.dropout_rate), torch.cuda.current_stream(self.flat.grad.device).cuda_stream)
+                 float(getattr(self.model.user_encoder, 'dropout_rate', 0.0)), torch.cuda.current_stream(self.flat.grad.device).cuda_stream)
         if tape is not None and tape.hyper != hyper:
             # something that is baked into the recording changed (learning rate, clip, weight decay, dropout rate, world size, the
             # caller's current stream): drop the tape and record a fresh one on the next step
@@ -200,7 +200,7 @@ class Trainer:
         eager_profile = _prof._on                       # eager HIP-event spans requested (bench's isolated leg, tools): no tape
         if tape is not None and self.replay and not eager_profile and not ops.ONE_STREAM[0] and tape.matches(batch):
             values = self._next_seeds()
-            self.model.news_encoder._calls += 1         # the replayed calls consume the same per-call seeds the eager ones would
+            self.model.news_encoder._calls += native_step.news_calls_per_step(self.model)      # the replayed calls consume the same per-call seeds the eager ones would
             self.model.user_encoder._calls += 1
             self.step_count += 1
             values['adam_step'] = self.step_count

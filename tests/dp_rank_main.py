@@ -96,7 +96,8 @@ def backward_only(tr, batch):
     ops.join_extra_streams()
 
 
-err_prod = err_oracle = 0.0
+err_prod = err_oracle = err_touched = 0.0
+touched_stats = None
 worst_name, params_same, rccl_ranks = '', True, None
 if not args.only_epoch:
     cpu_model = build(0)
@@ -132,6 +133,21 @@ if not args.only_epoch:
         e = float(np.abs(g - w).max()) / max(1e-3, 0.05 * total, float(np.linalg.norm(w)))
         if e > err_oracle:
             err_oracle, worst_name = e, k
+
+    # the same exchange with the table bucket as a TOUCHED-ROW exchange (NNR_DP_TOUCHED_ROWS=1: flags summed over the ranks, the union's
+    # rows packed, all-reduced, written back): the dense gradient every rank ends up with must be the same mean
+    touched_stats, err_touched = None, 0.0
+    os.environ['NNR_DP_TOUCHED_ROWS'] = '1'
+    try:
+        tr1 = Trainer(build(0).to(dev).train(), cfg)
+        assert tr1.exchange.touched
+        backward_only(tr1, shard)
+        scale1 = tr1.exchange.finish()
+        torch.cuda.synchronize()
+        err_touched = float((tr1.flat.grad * scale1 - want_prod).abs().max()) / max(1e-12, float(want_prod.abs().max()))
+        touched_stats = tr1.exchange.describe().get('touched_rows_last_step')
+    finally:
+        del os.environ['NNR_DP_TOUCHED_ROWS']
 
     tr = Trainer(build(100 + rank).to(dev).train(), cfg)         # different initial parameters per rank: the constructor's broadcast fixes that
     for _ in range(2):
@@ -241,12 +257,12 @@ if not args.skip_epoch:
     epoch['ok'] = epoch['ok'] and epoch['parameters_identical_across_ranks']
 
 tmo = ops.lstm_sync_timeouts()
-ok = err_prod <= 2e-5 and err_oracle <= 1e-4 and params_same and (epoch is None or epoch['ok']) and tmo == 0
+ok = err_prod <= 2e-5 and err_touched <= 2e-5 and err_oracle <= 1e-4 and params_same and (epoch is None or epoch['ok']) and tmo == 0
 if rank == 0:
     print(json.dumps({'world': world, 'backend': args.backend, 'rccl_ranks': rccl_ranks, 'devices': torch.cuda.device_count(),
                       'binding': (trainer if args.only_epoch else tr).exchange.describe()['binding'], 'buckets': [b['name'] for b in (trainer if args.only_epoch else tr).exchange.describe()['buckets']],
                       'grad_rel_err_vs_mean_of_shard_gradients': err_prod, 'grad_err_vs_oracle_mean_of_shard_gradients': err_oracle,
-                      'touched_rows': (trainer if args.only_epoch else tr0).exchange.describe().get('touched_rows_last_step'),
+                      'touched_rows': touched_stats, 'grad_rel_err_touched_row_exchange': err_touched,
                       'worst_gradient': worst_name, 'recurrence_exchange_timeouts': tmo, 'parameters_identical_across_ranks': params_same, 'epoch': epoch, 'ok': bool(ok)}))
 dist.barrier()
 dist.destroy_process_group()

@@ -61,6 +61,10 @@ def _check(out, world):
     assert out['grad_err_vs_oracle_mean_of_shard_gradients'] <= 1e-4          # the oracle leg (per-shard mean, as under the reference's DDP)
     assert out['grad_rel_err_vs_mean_of_shard_gradients'] <= 2e-5
     assert out['parameters_identical_across_ranks']
+    # the same gradient through the TOUCHED-ROW exchange of the table bucket (NNR_DP_TOUCHED_ROWS=1; dp.GradientExchange.table_rows_exchange)
+    t = out['touched_rows']
+    assert out['grad_rel_err_touched_row_exchange'] <= 2e-5
+    assert t is not None and 0 < t['rows'] <= t['of'] == 3000 and t['bytes'] == 4 * (3000 + t['rows'] * 300) and t['dense_bytes'] == 4 * 3000 * 300
     ep = out['epoch']
     assert ep['negative_samples_identical_across_ranks'] and ep['sampler_covers_every_behaviour'] and ep['parameters_identical_across_ranks']
     assert ep['worst_loss_diff_vs_oracle'] <= 5e-5 and ep['steps_per_rank'] == 10
@@ -69,18 +73,6 @@ def _check(out, world):
 def test_two_ranks_of_the_product_path_share_one_gpu_through_gloo():
     out = _launch(2, 'gloo', 29571)
     _check(out, 2)
-
-
-def test_two_ranks_touched_row_exchange_of_the_table_gradient():
-    """NNR_DP_TOUCHED_ROWS=1 (dp.GradientExchange.table_rows_exchange): the ranks sum their touched-row flags, pack the
-    union's rows of the word-embedding table's gradient, all-reduce [U, E] instead of [V, E] and write the sums back.  Same oracle legs
-    as above -- the exchanged gradient is the mean of the oracle's per-shard gradients, differently initialised ranks are bit-identical
-    after two optimizer steps (dense clip + Adam unchanged) -- plus the bytes the exchange moved."""
-    out = _launch(2, 'gloo', 29575, extra=('--skip_epoch',), env_extra={'NNR_DP_TOUCHED_ROWS': '1'})
-    assert out['ok'] and out['world'] == 2 and out['parameters_identical_across_ranks']
-    assert out['grad_err_vs_oracle_mean_of_shard_gradients'] <= 1e-4 and out['grad_rel_err_vs_mean_of_shard_gradients'] <= 2e-5
-    t = out['touched_rows']
-    assert t is not None and 0 < t['rows'] <= t['of'] == 3000 and t['bytes'] == 4 * (3000 + t['rows'] * 300) and t['dense_bytes'] == 4 * 3000 * 300
 
 
 @pytest.mark.parametrize('binding', ['torch', 'native'])
