@@ -51,7 +51,7 @@ if args.backend == 'gloo':
 host = dist.new_group(backend='gloo') if args.backend == 'nccl' else None      # host-side exchange of the oracle's results
 dev = torch.device('cuda', torch.cuda.current_device())
 O.BiLSTM.backend = 'aten'
-torch.set_num_threads(max(1, (os.cpu_count() or 8) // world))
+torch.set_num_threads(max(1, min(16, (os.cpu_count() or 8) // world)))      # (more threads are SLOWER on the oracle's mid-size ops)
 
 
 def gather_mean(arrays):
