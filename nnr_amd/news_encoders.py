@@ -138,6 +138,8 @@ _LSTM_FWD_SPLIT = os.environ.get('NNR_LSTM_FWD_SPLIT', '0') == '1'      # A/B: t
 _POST_INLINE = os.environ.get('NNR_POST_INLINE', '0') == '1'      # A/B: the content stream's tail GEMMs on one HIP stream
 _DX_SPLIT = os.environ.get('NNR_DX_SPLIT', '1') == '1'      # embedding-row gradient as plain GEMM + scatter kernel (11.46 vs 11.51 ms fused)
 _BWD_SPLIT = os.environ.get('NNR_LSTM_BWD_SPLIT', '1') == '1'      # batch 8: 4.68 (split) vs 4.93 ms; batch 64: no difference
+_PROJ_TILE = int(os.environ.get('NNR_PROJ_TILE', '0'))       # A/B (round 4): tile of the LSTM input projection (N = 1664 = 8 x 208), 0 = automatic (15)
+_GATE_TILE = int(os.environ.get('NNR_GATE_TILE', '0'))       # ... of the gate / attention / their data-gradient GEMMs over the token rows (N = 400 / 200)
 _GATE_FUSED = os.environ.get('NNR_GATE_FUSED', '1') != '0'      # A/B: the gate's backward inside the epilogue of the GEMM that completes dHt
 _CNE_UNION = os.environ.get('NNR_CNE_UNION', '1') != '0'      # A/B switch: candidate + history call as one packed token stream
 
@@ -302,7 +304,7 @@ def _cne_fwd_pre(mod, title_text, title_mask, content_text, content_mask, catego
             # ceiling): the sort needs only the planned ids and runs on the leaf stream under the forward pass
             st['tsort'] = ops.TokenSort(plan.tok, plan.total, emb.shape[0])
         ops.gemm(st['xd'], w.w_ihp, st['gates'], M=cap, N=2 * w.NP, K=E, lda=E, ldb=E, ldc=2 * w.NP, dyn=plan.total, dyn_dim=1, bias=w.b_p,
-                 flop_scale=4.0 * H / w.NP)
+                 flop_scale=4.0 * H / w.NP, tile=_PROJ_TILE)
         st['cell'] = torch.empty((cap, 2 * w.HP), **f32)
         st['hout'] = torch.empty((cap, H2), **f32)
         st['cn'] = torch.empty((n, H2), **f32)
@@ -367,11 +369,11 @@ def _cne_fwd_post(mod, sv, par=False):
         st['Ht'] = torch.empty((cap, H2), **f32)
         ops.gemm(st['hout'], st['Hlin'].weight, st['Ht'], M=cap, N=H2, K=H2, lda=H2, ldb=H2, ldc=H2, dyn=plan.total, dyn_dim=1,
                  rowvec=st['mproj'], ldrv=H2, rowvec_map=plan.row_seq, act=ops.ACT_SIGMOID, aux_out=st['G'], ldaux=H2,
-                 mul=st['hout'], ldmul=H2)
+                 mul=st['hout'], ldmul=H2, tile=_GATE_TILE)
         st['th'] = torch.empty((cap, A), **f32)
         sa = st['satt']
         ops.gemm(st['Ht'], sa.affine1.weight, st['th'], M=cap, N=A, K=H2, lda=H2, ldb=H2, ldc=A, dyn=plan.total, dyn_dim=1,
-                 bias=sa.affine1.bias, act=ops.ACT_TANH)
+                 bias=sa.affine1.bias, act=ops.ACT_TANH, tile=_GATE_TILE)
         st['alpha_s'] = torch.empty(cap, **f32)
         st['selfv'] = torch.empty((n, H2), **f32)
         if A <= 256 and A % 4 == 0:
@@ -509,14 +511,15 @@ def _cne_bwd_pre(mod, sv, drep, par=False, leaf=None):
             # the GEMM that completes dHt (+= d tanh-projection . W1) applies the gate's backward in its epilogue: Ht = hout * G ->
             # dH = dHt * G, d pre = dHt * hout * G * (1 - G) -- one launch and one pass over dHt less on the dependent chain (round 4)
             ops.gemm(th, ops.wt(sa.affine1.weight), st['dH'], M=cap, N=H2, K=A, lda=A, ldb=A, ldc=H2, dyn=plan.total, dyn_dim=1,
-                     pre_add=st['dHt'], ldpre=H2, gate_bwd=True, mul=st['G'], ldmul=H2, resid=st['hout'], ldres=H2, aux_out=dpre, ldaux=H2)
+                     pre_add=st['dHt'], ldpre=H2, gate_bwd=True, mul=st['G'], ldmul=H2, resid=st['hout'], ldres=H2, aux_out=dpre, ldaux=H2,
+                     tile=_GATE_TILE)
         else:
             ops.gemm(th, ops.wt(sa.affine1.weight), st['dHt'], M=cap, N=H2, K=A, lda=A, ldb=A, ldc=H2, accumulate=True,      # NT on W1^T
                      dyn=plan.total, dyn_dim=1)
             ops.gate_bwd(st['dHt'], st['hout'], st['G'], st['dH'], dpre, plan, H2)               # gate: Ht = hout * G
         leaf(lambda: ops.linear_bwd_weight(th, st['Ht'], grad_of(sa.affine1.weight), dyn=plan.total, db=grad_of(sa.affine1.bias)), th, st['Ht'])
         ops.gemm(dpre, ops.wt(st['Hlin'].weight), st['dH'], M=cap, N=H2, K=H2, lda=H2, ldb=H2, ldc=H2, accumulate=True,   # NT on W_H^T
-                 dyn=plan.total, dyn_dim=1)
+                 dyn=plan.total, dyn_dim=1, tile=_GATE_TILE)
         leaf(lambda: ops.linear_bwd_weight(dpre, st['hout'], grad_of(st['Hlin'].weight), dyn=plan.total), dpre, st['hout'])
         dP = torch.empty((n, H2), **f32)                  # d mproj[rank]
         ops.packed_seq_sum(dpre, H2, plan, dP)
