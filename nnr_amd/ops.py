@@ -126,10 +126,14 @@ def join_extra_streams(dev=None):
 
 
 class leaf_scope:
-    """with leaf_scope(device) as leaf:  leaf(fn, *input_tensors)  ...   -- joined on exit."""
+    """with leaf_scope(device) as leaf:  leaf(fn, *input_tensors)  ...   -- joined on exit.
+    defer_join: do NOT make the caller's stream wait for the leaf stream on exit; the leaf work (weight gradients nothing downstream
+    reads) is joined by the step's final join_extra_streams(), and the input tensors are held until then.  (Round 4: the user
+    encoder's backward ended with the main stream waiting ~150 us for its last weight-gradient GEMMs before the news encoder's
+    backward could start -- a dependency only the data-parallel early bucket needs.)"""
 
-    def __init__(self, dev, enable=True):
-        self.dev, self.enable = dev, enable
+    def __init__(self, dev, enable=True, defer_join=False):
+        self.dev, self.enable, self.defer_join = dev, enable, defer_join
 
     def __enter__(self):
         self.keep = []
@@ -156,7 +160,9 @@ class leaf_scope:
             torch.cuda.current_stream(self.dev).wait_stream(self.leaf)
 
     def __exit__(self, *a):
-        if self.enable:
+        if self.enable and self.defer_join and a[0] is None:
+            _DEFER['keep'].extend(self.keep)      # held until join_extra_streams(): the leaf stream may still be reading them
+        elif self.enable:
             self.main.wait_stream(self.leaf)
         self.keep = []                   # (dropped on the host after the join was ENQUEUED: later main-stream work is ordered behind it)
 

@@ -176,6 +176,17 @@ def forward_backward(trainer, batch):
      news_subCategory, news_title_text, news_title_mask, news_title_entity, news_content_text, news_content_mask, news_content_entity) = batch
     dev = news_title_text.device
     f32 = dict(device=dev, dtype=torch.float32)
+    ops._DEFER['step_joins'] = True                   # this function ends with join_extra_streams(): leaf work may stay un-joined until then
+    try:
+        return _forward_backward_cne_sue(trainer, model, ne, ue, batch, dev, f32)
+    finally:
+        ops._DEFER['step_joins'] = False
+
+
+def _forward_backward_cne_sue(trainer, model, ne, ue, batch, dev, f32):
+    (user_ID, user_category, user_subCategory, user_title_text, user_title_mask, user_title_entity, user_content_text, user_content_mask,
+     user_content_entity, user_history_mask, user_history_graph, user_history_category_mask, user_history_category_indices, news_category,
+     news_subCategory, news_title_text, news_title_mask, news_title_entity, news_content_text, news_content_mask, news_content_entity) = batch
     with torch.no_grad():
         ops.wt_prefetch(dev)                          # W^T copies the backward pass multiplies by, on the leaf stream
         cand = (news_title_text, news_title_mask, news_content_text, news_content_mask, news_category, news_subCategory)

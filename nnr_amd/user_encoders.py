@@ -56,6 +56,7 @@ class _SUEFunction(torch.autograd.Function):
         return dhist, dcand, None, None, None, None
 
 
+_SUE_JOIN = os.environ.get('NNR_SUE_JOIN', '0') == '1'      # A/B: 1 = the round-3 form (main stream waits for this encoder's weight-gradient GEMMs)
 _GCN_FUSED = os.environ.get('NNR_GCN_FUSED', '1') != '0'      # A/B: dedicated per-user aggregate kernel vs the batched tile GEMM
 
 
@@ -212,13 +213,18 @@ def sue_backward(mod, sv, dout, dhist_out=None, dcand_accum=None):
     cand2 = sv['cand'].view(B * N, D)
     dout = dout.view(B * N, D)
     ia = mod.interClusterAttention
-    with ops.leaf_scope(dev) as leaf:
+    hook = mod.__dict__.get('_grads_ready_hook')
+    # a data-parallel trainer starts reducing this encoder's gradients right after this function (early bucket): then they must be
+    # ordered on the current stream when it returns.  Otherwise nobody needs them before the optimizer: the leaf stream is joined at
+    # the end of the backward pass, and the news encoder's backward starts without waiting for the last weight-gradient GEMMs
+    exchange = getattr(hook, '__self__', None)
+    need_now = _SUE_JOIN or (exchange is not None and exchange.active()) or not ops._DEFER.get('step_joins')      # (only the native step ends with its own join)
+    with ops.leaf_scope(dev, defer_join=not need_now) as leaf:
         res = _sue_backward_body(mod, sv, dout, leaf, B, Hn, D, N, Kc, G, Cn, A, p, seed, dev, f32, cand2, ia, dhist_out, dcand_accum)
-    # every parameter gradient of this encoder is now ordered on the current stream (the leaf stream was joined on exit):
+    # (joined form) every parameter gradient of this encoder is now ordered on the current stream:
     # a data-parallel trainer starts reducing them while the news encoder's backward is still to come (dp.GradientExchange).
     # (Measured and rejected: issuing this encoder's weight-gradient GEMMs only after its data-gradient chain, so that they
     # overlap the news encoder's backward prologue instead of slowing the 4 352-row chain: 13.05 vs 12.84 ms/step.)
-    hook = mod.__dict__.get('_grads_ready_hook')
     if hook is not None:
         hook()
     return res
