@@ -1572,7 +1572,7 @@ static bool tile_shape(int tile, int* bm, int* bn, int* bk, int* occ, int* kind)
   static const T tab[] = {{1, 256, 80, 16, 1, 0}, {2, 64, 80, 16, 1, 0}, {3, 128, 208, 16, 1, 0}, {4, 128, 80, 16, 1, 0}, {5, 128, 80, 32, 1, 0}, {6, 64, 80, 64, 1, 0},
                           {20, 128, 80, 16, 3, 1}, {21, 128, 80, 16, 3, 1}, {22, 64, 80, 16, 4, 1}, {23, 256, 80, 16, 2, 1}, {24, 128, 208, 16, 2, 1},
                           {25, 128, 128, 16, 2, 1}, {26, 128, 80, 16, 3, 1}, {27, 128, 208, 16, 2, 1}, {28, 128, 80, 16, 2, 1}, {29, 256, 80, 16, 2, 1},
-                          {30, 128, 160, 16, 2, 1}, {32, 64, 208, 16, 2, 1}};
+                          {30, 128, 160, 16, 2, 1}, {32, 64, 208, 16, 2, 1}, {37, 256, 160, 16, 1, 1}, {38, 128, 160, 16, 1, 1}, {39, 64, 160, 16, 3, 1}};
   for (const T& t : tab)
     if (t.tile == tile) { *bm = t.bm; *bn = t.bn; *bk = t.bk; *occ = t.occ; *kind = t.kind; return true; }
   return false;
@@ -1613,6 +1613,9 @@ static int dispatch_tile(int tile, const nnr_gemm_args& g, hipStream_t stream) {
     case 33: if (!pipe_ok(g)) return NNR_ERR_ARG; return launch_pipe<2, 13, 16, 3, 2>(g, stream);   // NT 128 x 208, BK 16, 3 x 21 KB stages, 2 workgroups / CU (N = 1664 = 8 x 208)
     case 34: if (!pipe_ok(g) || g.a_idx) return NNR_ERR_ARG; return launch_pipe2<2, 13, 3, 1>(g, stream);          // gen-2 NT 128 x 208, 3 x 43 KB stages, 1 workgroup / CU
     case 36: if (!pipe_ok(g)) return NNR_ERR_ARG; return launch_pipe<4, 5, 16, 3, 3>(g, stream);    // NT 256 x 80, BK 16, 3 x 21 KB stages, 3 workgroups / CU
+    case 37: if (!tn_pipe_ok(g)) return NNR_ERR_ARG; return launch_tn_pipe2<4, 10, 3, 1>(g, stream);              // gen-2 TN 256 x 160, 3 x 32 KB stages, 1 workgroup / CU
+    case 38: if (!tn_pipe_ok(g)) return NNR_ERR_ARG; return launch_tn_pipe2<2, 10, 4, 1>(g, stream);              // gen-2 TN 128 x 160, 4 stages, 1 workgroup / CU
+    case 39: if (!tn_pipe_ok(g)) return NNR_ERR_ARG; return launch_tn_pipe2<1, 10, 3, 3>(g, stream);              // gen-2 TN 64 x 160, 3 x 20 KB stages, 3 workgroups / CU
     case 32: if (!tn_pipe_ok(g)) return NNR_ERR_ARG; return launch_tn_pipe2<1, 13, 3, 2>(g, stream);              // gen-2 TN 64 x 208, 3 x 20 KB stages: row tiles of 64 fit M = 200 / 400 / 832
                                                                                                                   // (256 / 448 / 832 rows of MFMA work instead of 256 / 512 / 896)
     case 7:

@@ -56,7 +56,10 @@ class _SUEFunction(torch.autograd.Function):
         return dhist, dcand, None, None, None, None
 
 
-_SUE_JOIN = os.environ.get('NNR_SUE_JOIN', '0') == '1'      # A/B: 1 = the round-3 form (main stream waits for this encoder's weight-gradient GEMMs)
+_SUE_JOIN = os.environ.get('NNR_SUE_JOIN', '1') == '1'      # 1 (default) = the main stream waits for this encoder's weight-gradient GEMMs when its backward
+                                                             # returns; 0 = they are joined at the end of the step (round 4: measured neutral, 10.61-10.64 vs
+                                                             # 10.60-10.68 ms -- the ~150 us the main stream no longer waits are paid back by the news encoder's
+                                                             # first backward kernels sharing the chip with those GEMMs)
 _GCN_FUSED = os.environ.get('NNR_GCN_FUSED', '1') != '0'      # A/B: dedicated per-user aggregate kernel vs the batched tile GEMM
 
 

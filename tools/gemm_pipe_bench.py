@@ -42,8 +42,8 @@ def tn_main():
             pass
         fns = {}
         for t in tiles:
-            bm = {2: 64, 4: 128, 20: 128, 21: 128, 22: 64, 23: 256, 24: 128, 25: 128, 26: 128, 27: 128, 28: 128, 29: 256}[t]
-            bn = {24: 208, 25: 128, 27: 208}.get(t, 80)
+            bm = {2: 64, 4: 128, 20: 128, 21: 128, 22: 64, 23: 256, 24: 128, 25: 128, 26: 128, 27: 128, 28: 128, 29: 256, 30: 128, 32: 64, 37: 256, 38: 128, 39: 64}[t]
+            bn = {24: 208, 25: 128, 27: 208, 30: 160, 32: 208, 37: 160, 38: 160, 39: 160}.get(t, 80)
             if gather and t in (26, 28, 29):
                 continue
             for target in (512, 1024, 2048):
