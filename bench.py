@@ -262,6 +262,8 @@ def timed_run(a, trainer, fresh, steps, warmup, prof, dp, torch, dev, world, ins
         # live HIP-event spans on every `roofline_every`-th step of the timed region (replayed steps: recorded natively by the tape
         # around the same launches, on the launch streams)
         prof.enable(every=a.roofline_every, eager=not taped)
+        for tape in trainer.tapes.values():          # (their HIP events exist before the window opens: no hipEventCreate inside it)
+            tape.prepare_timing(len(range(0, steps, max(1, a.roofline_every))))
     from nnr_amd import _lib
     calls0 = _lib.CALLS[0]
     t0 = time.perf_counter()

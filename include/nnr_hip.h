@@ -416,6 +416,8 @@ int nnr_tape_event_wait(nnr_tape* t, hipStream_t s, uint64_t key);
 int nnr_tape_segment(nnr_tape* t);
 int nnr_tape_patch(nnr_tape* t, size_t arena_byte_off, int kind, int width, int64_t addend);
 int nnr_tape_finalize(nnr_tape* t);
+/* Create the HIP events of timing sets [0, nsets) ahead of a timed window of replays (host-side only, no launch). */
+int nnr_tape_prepare_timing(nnr_tape* t, int nsets);
 int nnr_tape_info(const nnr_tape* t, int* calls, int* ops, int* segments, int* streams, size_t* arena_bytes);
 int nnr_tape_replay(nnr_tape* t, int segment, const uint64_t* values, int nvalues, const uint64_t* inputs, int ninputs, int timing_set);
 int nnr_tape_timings(nnr_tape* t, int set, float* ms, int n);

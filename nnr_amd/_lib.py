@@ -62,7 +62,7 @@ SYMBOLS = [
     'nnr_dp_unique_id', 'nnr_dp_init', 'nnr_dp_allreduce', 'nnr_dp_broadcast', 'nnr_dp_destroy',
     'nnr_fill_zero', 'nnr_copy_bytes', 'nnr_fill_column_u8', 'nnr_adam_skipped_steps', 'nnr_fusion_rows_fwd', 'nnr_fusion_rows_bwd', 'nnr_click_loss',
     'nnr_tape_create', 'nnr_tape_destroy', 'nnr_tape_fn_id', 'nnr_tape_fn_nargs', 'nnr_tape_call', 'nnr_tape_wait_stream', 'nnr_tape_event_record',
-    'nnr_tape_event_wait', 'nnr_tape_segment', 'nnr_tape_patch', 'nnr_tape_finalize', 'nnr_tape_info', 'nnr_tape_replay', 'nnr_tape_timings', 'nnr_tape_timeline',
+    'nnr_tape_event_wait', 'nnr_tape_segment', 'nnr_tape_patch', 'nnr_tape_finalize', 'nnr_tape_info', 'nnr_tape_replay', 'nnr_tape_prepare_timing', 'nnr_tape_timings', 'nnr_tape_timeline',
     'nnr_tape_last_error',
     'nnr_token_sort_workspace_bytes', 'nnr_token_sort', 'nnr_embed_scatter_sorted_workspace_floats', 'nnr_embed_scatter_sorted', 'nnr_fusion_rows_bwd_det',
     'nnr_rows_touch', 'nnr_rows_compact', 'nnr_rows_pack', 'nnr_rows_unpack',

@@ -257,6 +257,31 @@ extern "C" int nnr_tape_replay(nnr_tape* t, int segment, const uint64_t* values,
   return NNR_OK;
 }
 
+// Create the HIP events of timing sets [0, nsets) now (host-side only): a caller that is about to time a window of replays does this
+// BEFORE the window, so that the first instrumented replay does not spend a millisecond of host time in hipEventCreate while the GPU
+// it has just synchronised with sits idle.
+extern "C" int nnr_tape_prepare_timing(nnr_tape* t, int nsets) {
+  if (!t || !t->final || nsets < 0) return NNR_ERR_ARG;
+  if (nsets > MAX_TIMING_SETS) nsets = MAX_TIMING_SETS;
+  if (t->ntagged <= 0) return NNR_OK;
+  if ((int)t->tset.size() < nsets) t->tset.resize(nsets);
+  for (int s = 0; s < nsets; ++s) {
+    if (!t->tset[s].empty()) continue;
+    std::vector<hipEvent_t> fresh;
+    fresh.reserve(2 * (size_t)t->ntagged);
+    for (int i = 0; i < 2 * t->ntagged; ++i) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) {
+        for (hipEvent_t d : fresh) (void)hipEventDestroy(d);
+        return NNR_ERR_LAUNCH;
+      }
+      fresh.push_back(e);
+    }
+    t->tset[s] = std::move(fresh);
+  }
+  return NNR_OK;
+}
+
 // ms[tag] = duration of the tagged call in timing set `set` (synchronises with those events).  Returns the number written.
 extern "C" int nnr_tape_timings(nnr_tape* t, int set, float* ms, int n) {
   if (!t || set < 0 || set >= (int)t->tset.size() || t->tset[set].empty()) return NNR_ERR_ARG;

@@ -344,6 +344,10 @@ class Tape:
                 with torch.cuda.stream(stream):          # the very stream object that was current when the callback was recorded
                     fn()
 
+    def prepare_timing(self, nsets):
+        """Create the events of the next `nsets` timing replays now (bench.py: before the timed window starts)."""
+        L.check(self.lib.nnr_tape_prepare_timing(self.h, min(64, self._nsets + int(nsets))), 'nnr_tape_prepare_timing')
+
     def timings(self):
         """Per timing replay so far: [(family, flops_fn, ms)] of its tagged calls (synchronises)."""
         out = []
