@@ -253,7 +253,13 @@ def measure_exchange(trainer, torch, dev, world, a):
 def timed_run(a, trainer, fresh, steps, warmup, prof, dp, torch, dev, world, instrument):
     """W untimed + K timed steps bracketed by barrier + synchronize; returns the MAX over ranks of the elapsed seconds."""
     for i in range(warmup):
+        # the last warm-up step is a TIMING replay whose spans are thrown away: the first one of a process pays the HIP runtime's lazy
+        # set-up of timed events (5-12 ms on a fresh box: 16.1 ms for the window's first step vs 11.1 in later processes, tools/r4_first_run.sh)
+        trainer.timing = bool(instrument and i == warmup - 1 and trainer.tapes)
         trainer.train_step(fresh(i))
+    trainer.timing = False
+    if instrument:
+        trainer.collect_timings()                    # (discarded: prof.enable() below starts from empty records)
     dp.barrier()
     torch.cuda.synchronize()
     from nnr_amd import step as native_step
@@ -266,15 +272,22 @@ def timed_run(a, trainer, fresh, steps, warmup, prof, dp, torch, dev, world, ins
             tape.prepare_timing(len(range(0, steps, max(1, a.roofline_every))))
     from nnr_amd import _lib
     calls0 = _lib.CALLS[0]
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if os.environ.get('NNR_BENCH_STEP_MARKS') == '1' else None
+    if marks:
+        marks[0].record()
     t0 = time.perf_counter()
     for i in range(steps):
         if instrument:
             trainer.timing = prof.begin_step(i) and taped
         trainer.train_step(fresh(warmup + i))
+        if marks:
+            marks[i + 1].record()
     dp.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     trainer.timing = False
+    if marks:         # diagnostic: where inside the window the time went (one event per step on the main stream; stderr only)
+        print('step marks (ms): ' + ' '.join('%.2f' % marks[i].elapsed_time(marks[i + 1]) for i in range(steps)), file=sys.stderr)
     if instrument:
         trainer.collect_timings()
         prof.disable()
