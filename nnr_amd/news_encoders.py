@@ -135,6 +135,8 @@ def cne_forward(mod, title_text, title_mask, content_text, content_mask, categor
 _SIDE = {}
 ops.STREAM_CACHES.append(_SIDE)
 _LSTM_FWD_SPLIT = os.environ.get('NNR_LSTM_FWD_SPLIT', '0') == '1'      # A/B: title recurrence launched on the title stream
+_PROJ_ORDER = os.environ.get('NNR_PROJ_ORDER', '0') == '1'      # A/B (round 4, with NNR_LSTM_FWD_SPLIT=1): the content projection waits for the title projection, so the
+                                                                # title recurrence runs UNDER the content projection instead of inside the shared recurrence launch
 _POST_INLINE = os.environ.get('NNR_POST_INLINE', '0') == '1'      # A/B: the content stream's tail GEMMs on one HIP stream
 _DX_SPLIT = os.environ.get('NNR_DX_SPLIT', '1') == '1'      # embedding-row gradient as plain GEMM + scatter kernel (11.46 vs 11.51 ms fused)
 _BWD_SPLIT = os.environ.get('NNR_LSTM_BWD_SPLIT', '1') == '1'      # batch 8: 4.68 (split) vs 4.93 ms; batch 64: no difference
@@ -275,6 +277,7 @@ def _cne_fwd_pre(mod, title_text, title_mask, content_text, content_mask, catego
     emb = mod.word_embedding.weight
 
     streams = [None, None]
+    proj_done = {}
 
     def prepare(slot, name, ids, mask, Lx, lstm, Hlin, Mlin, satt, catt):
         parts = list(zip(ids, mask)) if union else [(ids, mask)]
@@ -303,8 +306,13 @@ def _cne_fwd_pre(mod, title_text, title_mask, content_text, content_mask, catego
             # the backward's embedding-row gradient is a segmented reduction over the rows sorted by word id (reproducible, no atomic
             # ceiling): the sort needs only the planned ids and runs on the leaf stream under the forward pass
             st['tsort'] = ops.TokenSort(plan.tok, plan.total, emb.shape[0])
+        if _PROJ_ORDER and par and name == 'content' and 'ev' in proj_done:
+            torch.cuda.current_stream(dev).wait_event(proj_done['ev'])      # A/B: content projection BEHIND the title projection (see _PROJ_ORDER)
         ops.gemm(st['xd'], w.w_ihp, st['gates'], M=cap, N=2 * w.NP, K=E, lda=E, ldb=E, ldc=2 * w.NP, dyn=plan.total, dyn_dim=1, bias=w.b_p,
                  flop_scale=4.0 * H / w.NP, tile=_PROJ_TILE)
+        if _PROJ_ORDER and par and name == 'title':
+            proj_done['ev'] = torch.cuda.Event()
+            proj_done['ev'].record()
         st['cell'] = torch.empty((cap, 2 * w.HP), **f32)
         st['hout'] = torch.empty((cap, H2), **f32)
         st['cn'] = torch.empty((n, H2), **f32)
