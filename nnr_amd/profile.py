@@ -3,6 +3,8 @@ launch (the kernels run on torch's current stream, so torch.cuda.Event sees them
 launch (true dims, not the padded tile dims; data-dependent token counts are read back from device memory after the
 timed region).  Families map 1:1 to kernel symbols, so the rocprofv3 --kernel-trace --stats averages under profiles/
 can be compared directly."""
+import os
+
 import torch
 
 _on = False
@@ -19,7 +21,7 @@ KERNEL_OF = {
     'gemm_nt_pipe2_128x80': 'gemm_nt_pipe2_kernel<2, 5, 3, 2>', 'gemm_nt_pipe2_128x64': 'gemm_nt_pipe2_kernel<2, 4, 3, 2>',
     'gemm_tn_pipe2_128x80': 'gemm_tn_pipe2_kernel<2, 5, 3, 3>', 'gemm_tn_pipe2_128x208': 'gemm_tn_pipe2_kernel<2, 13, 3, 2>', 'gemm_tn_pipe2_128x160': 'gemm_tn_pipe2_kernel<2, 10, 3, 2>', 'gemm_tn_pipe2_64x208': 'gemm_tn_pipe2_kernel<1, 13, 3, 2>',
     'gemm_tn_pipe128x80': 'gemm_tn_pipe_kernel<2, 5, 3, 3, 0>', 'gemm_tn_pipe128x208': 'gemm_tn_pipe_kernel<2, 13, 3, 2, 0>',
-    'gemm_nn_128x80': 'gemm_kernel<2, 5, false, true, 16>', 'gemm_tn_128x80': 'gemm_kernel<2, 5, true, true, 16>', 'lstm_fwd': 'lstm_fwd_pair_kernel<13>', 'lstm_bwd': 'lstm_bwd_pair_kernel<13>',
+    'gemm_nn_128x80': 'gemm_kernel<2, 5, false, true, 16>', 'gemm_tn_128x80': 'gemm_kernel<2, 5, true, true, 16>', 'lstm_fwd': 'lstm_fwd_pair_kernel<13>', 'lstm_bwd': 'lstm_bwd_pair_kernel<13, true>' if os.environ.get('NNR_LSTM_BWD_BAL', '1') != '0' else 'lstm_bwd_pair_kernel<13, false>',
 }
 
 

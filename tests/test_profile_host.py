@@ -31,7 +31,7 @@ def records(monkeypatch):
     M, N, K = 1664, 200, 22000                                   # a weight-gradient launch: K = live token rows
     tn = _fn(2.0 * M * N * K, op_bytes=(K * (M + N) + M * N) * 4.0, tn_dims=(M, N, 1))
     nt = _fn(9.0e9, op_bytes=5.0e7)
-    profile.TAPE_RECORDS.extend([('gemm_tn_pipe2_128x208', tn, 0.5), ('gemm_nt_pipe2_128x80', nt, 0.3), ('gemm_tn_pipe2_128x208', tn, 0.7),
+    profile.TAPE_RECORDS.extend([('gemm_tn_pipe2_64x208', tn, 0.5), ('gemm_nt_pipe2_128x80', nt, 0.3), ('gemm_tn_pipe2_64x208', tn, 0.7),
                                  ('lstm_bwd', _fn(3.4e10), 0.2)])
     profile._PMC.clear()
     yield dict(M=M, N=N, K=K, tn_flops=2.0 * M * N * K)
@@ -43,18 +43,18 @@ def records(monkeypatch):
 def test_roofline_arithmetic_and_dominant_family(records):
     r = profile.roofline(PEAK, sampled_steps=1, ms_per_step=2.0)
     f = records['tn_flops']
-    assert r['family'] == 'gemm_tn_pipe2_128x208' and r['kernel'] == 'gemm_tn_pipe2_kernel<2, 13, 3, 2>'      # most instrumented time
+    assert r['family'] == 'gemm_tn_pipe2_64x208' and r['kernel'] == 'gemm_tn_pipe2_kernel<1, 13, 3, 2>'      # most instrumented time
     assert r['launches'] == 2 and r['avg_launch_us'] == 600.0 and r['bound'] == 'mfma' and r['peak'] == PEAK
     ach = 2 * f / 1.2e-3 / 1e12
     assert r['achieved'] == round(ach, 3) and r['frac'] == round(ach / PEAK, 4)
     assert r['share_of_instrumented_time'] == round(1.2 / 1.7, 3)
-    assert list(r['families']) == ['gemm_tn_pipe2_128x208', 'gemm_nt_pipe2_128x80', 'lstm_bwd']                # by time, descending
+    assert list(r['families']) == ['gemm_tn_pipe2_64x208', 'gemm_nt_pipe2_128x80', 'lstm_bwd']                # by time, descending
     assert r['families']['gemm_nt_pipe2_128x80'] == {'ms': 0.3, 'tflops': 30.0, 'launches': 1}
     total = 2 * f + 9.0e9 + 3.4e10
     assert r['step'] == {'gflop': round(total / 1e9, 1), 'tflops': round(total / 2.0e-3 / 1e12, 2), 'frac': round(total / 2.0e-3 / 1e12 / PEAK, 4)}
     assert r['algorithmic_bytes_per_launch'] == round((records['K'] * (records['M'] + records['N']) + records['M'] * records['N']) * 4.0)
     # operand bytes of the token reduction alone (what the counter traffic of a weight-gradient family is compared with)
-    tn = profile.tn_operand_bytes()['gemm_tn_pipe2_128x208']
+    tn = profile.tn_operand_bytes()['gemm_tn_pipe2_64x208']
     assert tn['launches'] == 2 and tn['bytes'] == pytest.approx(2 * records['K'] * (records['M'] + records['N']) * 4.0)
 
 
@@ -62,7 +62,7 @@ def test_counter_traffic_is_quoted_only_for_the_build_it_was_collected_on(record
     d = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
     have = d['build_id']
     per_launch = {k['kernel']: k['hbm_bytes_per_launch'] for k in d['kernels']}
-    want = per_launch['gemm_tn_pipe2_kernel<2, 13, 3, 2>']
+    want = per_launch['gemm_tn_pipe2_kernel<1, 13, 3, 2>']
     # another build: neither the sources' nor the binary's hash matches
     monkeypatch.setattr(_lib, 'build_id', lambda: {'src_sha256': 'x' * 16, 'lib_sha256': 'y' * 16})
     r = profile.roofline(PEAK, sampled_steps=1, ms_per_step=2.0)
@@ -77,7 +77,7 @@ def test_counter_traffic_is_quoted_only_for_the_build_it_was_collected_on(record
         assert r['traffic_over_algorithmic'] == round(want / r['algorithmic_bytes_per_launch'], 2)
         w = profile.weight_gradient_traffic()
         op = records['K'] * (records['M'] + records['N']) * 4.0
-        assert w['gemm_tn_pipe2_128x208'] == {'operand_mb_per_launch': round(op / 1e6, 1), 'counter_mb_per_launch': round(want / 1e6, 1),
+        assert w['gemm_tn_pipe2_64x208'] == {'operand_mb_per_launch': round(op / 1e6, 1), 'counter_mb_per_launch': round(want / 1e6, 1),
                                               'ratio': round(want / op, 2)}
         assert w['all'] == {'ratio': round(want / op, 2)}
 
@@ -89,7 +89,7 @@ def test_committed_counter_file_is_well_formed():
     for k in d['kernels']:
         assert k['launches'] > 0 and k['hbm_bytes_per_launch'] == pytest.approx(k['fetch_bytes_per_launch'] + k['write_bytes_per_launch'], abs=2)
     names = {k['kernel'] for k in d['kernels']}
-    assert {'gemm_tn_pipe2_kernel<2, 13, 3, 2>', 'gemm_nt_pipe2_kernel<2, 5, 3, 2>', 'lstm_bwd_pair_kernel<13>'} <= names
+    assert {'gemm_tn_pipe2_kernel<1, 13, 3, 2>', 'gemm_nt_pipe2_kernel<2, 5, 3, 2>', 'lstm_bwd_pair_kernel<13, true>'} <= names
 
 
 def test_hbm_families_get_their_own_roofline_and_stay_out_of_the_mfma_one(records, monkeypatch):
@@ -101,8 +101,9 @@ def test_hbm_families_get_their_own_roofline_and_stay_out_of_the_mfma_one(record
         return f
     profile.TAPE_RECORDS.extend([('embed_gather', hb(2.0e8), 0.05), ('embed_gather', hb(0.5e8), 0.02), ('clip_adam', hb(7.17e8), 5.0),
                                  ('sue_intra_bwd', hb(1.0e8), 0.1)])
+    monkeypatch.setattr(_lib, 'build_id', lambda: {'src_sha256': 'x' * 16, 'lib_sha256': 'y' * 16})       # a build the committed counters are not of
     r = profile.roofline(PEAK, sampled_steps=1, ms_per_step=2.0)
-    assert r['family'] == 'gemm_tn_pipe2_128x208' and list(r['families']) == ['gemm_tn_pipe2_128x208', 'gemm_nt_pipe2_128x80', 'lstm_bwd']
+    assert r['family'] == 'gemm_tn_pipe2_64x208' and list(r['families']) == ['gemm_tn_pipe2_64x208', 'gemm_nt_pipe2_128x80', 'lstm_bwd']
     assert r['share_of_instrumented_time'] == round(1.2 / 1.7, 3)
     h = r['hbm']
     assert list(h) == ['clip_adam', 'sue_intra_bwd', 'embed_gather']
