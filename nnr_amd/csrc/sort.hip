@@ -24,6 +24,7 @@ namespace {
 
 constexpr int SS_CH = 32;        // sorted rows per wave
 constexpr int SS_MAXJ = 5;       // columns per lane: dim <= 320
+constexpr int SS_FL = 8;         // rows in flight per wave in the segmented reduction
 constexpr int SS_PITCH = 64 * SS_MAXJ;
 
 __global__ __launch_bounds__(256) void token_sort_keys_kernel(const int* __restrict__ tok, long cap, const int* __restrict__ n_dev, unsigned V,
@@ -78,27 +79,27 @@ __global__ __launch_bounds__(256) void embed_scatter_sorted_kernel(const float* 
   };
   bool done = false;
   const int dlast = dim - 1;
-  for (int i0 = 0; i0 < cnt && !done; i0 += 4) {
-    // four rows in flight: every load is issued UNCONDITIONALLY before any of them is used (a branch per row cuts the block, and the
+  for (int i0 = 0; i0 < cnt && !done; i0 += SS_FL) {
+    // SS_FL (8; round 4 first had 4: half as many dependent round trips per chunk now) rows in flight: every load is issued UNCONDITIONALLY before any of them is used (a branch per row cuts the block, and the
     // wait for row u's loads then sits in front of row u + 1's: one row in flight -- 32 dependent round trips per wave, 85 us for the
     // 88 k-row content stream); pad entries read row 0 / a clamped column and are discarded below
-    float v[4][SS_MAXJ];
-    unsigned kk[4];
-    int rr[4];
+    float v[SS_FL][SS_MAXJ];
+    unsigned kk[SS_FL];
+    int rr[SS_FL];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < SS_FL; ++u) {
       const int i = i0 + u;                                       // (< 64: lanes >= cnt hold the pad key and row 0)
       kk[u] = __shfl(myk, i, 64);
       rr[u] = __shfl(myr, i, 64);
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < SS_FL; ++u) {
       const float* src = dout + (long)rr[u] * dim;
 #pragma unroll
       for (int j = 0; j < SS_MAXJ; ++j) v[u][j] = src[min(lane + 64 * j, dlast)];
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < SS_FL; ++u) {
       if (done) break;
       if (kk[u] >= V) { done = true; break; }
       if (kk[u] != run_key) {

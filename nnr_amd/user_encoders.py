@@ -61,6 +61,19 @@ _SUE_JOIN = os.environ.get('NNR_SUE_JOIN', '1') == '1'      # 1 (default) = the 
                                                              # 10.60-10.68 ms -- the ~150 us the main stream no longer waits are paid back by the news encoder's
                                                              # first backward kernels sharing the chip with those GEMMs)
 _GCN_FUSED = os.environ.get('NNR_GCN_FUSED', '1') != '0'      # A/B: dedicated per-user aggregate kernel vs the batched tile GEMM
+_SUE_SIDE = os.environ.get('NNR_SUE_SIDE', '1') != '0'        # round 4: the candidate-side projections (inputs: the candidates only) and the candidate gradient's
+                                                              # accumulations (read by nobody before the news encoder's backward) leave SUE's dependent chain for a side stream
+_SIDE = {}
+ops.STREAM_CACHES.append(_SIDE)
+
+
+def _sue_side(dev):
+    if not _SUE_SIDE or ops.ONE_STREAM[0]:
+        return None
+    key = (dev.type, dev.index)
+    if key not in _SIDE:
+        _SIDE[key] = ops.new_stream(dev, critical=True)
+    return _SIDE[key]
 
 
 def gcn_forward(gcn, x0, graph, seed0, training):
@@ -169,6 +182,26 @@ def sue_forward(mod, hist, cand, graph, cmask, cidx):
     sv = dict(B=B, Hn=Hn, D=D, N=N, Kc=Kc, G=G, Cn=Cn, A=A, p=p, seed=seed, hist=hist, cand=cand, cidx=cidx, cmask=cmask,
               graph=graph)
     x0 = torch.empty((B, G, D), **f32)
+    # ---- the candidate-side projections need nothing but `cand`: three small launches (q of the intra-cluster attention, q and v of the
+    # inter-cluster attention; 15-30 us each, latency-bound) that sat on the dependent chain behind the GCN run beside it instead
+    cand2 = cand.view(B * N, D)
+    ia = mod.interClusterAttention
+    qc = torch.empty((B * N, A), **f32)
+    qv = torch.empty((B * N, A), **f32)
+    v = torch.empty((B * N, D), **f32)
+
+    def cand_side():
+        ops.linear_fwd(cand2, mod.intraCluster_Q.weight, mod.intraCluster_Q.bias, out=qc)                # [B*N, A]
+        ops.linear_fwd(cand2, ia.Q.weight, ia.Q.bias, out=qv)                                            # [B*N, A]
+        ops.gemm(qv, ia.K.weight, v, M=B * N, N=D, K=A, lda=A, ldb=D, ldc=D, trans_b=True)
+    side = _sue_side(dev)
+    side_ev = None
+    if side is not None:
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            cand_side()
+            side_ev = torch.cuda.Event()
+            side_ev.record()
     # (+ the in-place `user_history_category_mask[:, -1] = 1` of userEncoders.py:73 in the same launch)
     fix = cmask if (cmask.is_cuda and cmask.dim() == 2 and cmask.is_contiguous() and tuple(cmask.shape) == (B, Kc + 1)) else None
     if fix is None:
@@ -183,9 +216,11 @@ def sue_forward(mod, hist, cand, graph, cmask, cidx):
     gfeat = torch.empty((B, Hn, D), **f32)
     ops.sue_slice_fwd(x, x0, gfeat, B, Hn, G, D)
     # ---- intra-cluster attention
-    cand2 = cand.view(B * N, D)
     kf = ops.linear_fwd(gfeat.view(B * Hn, D), mod.intraCluster_K.weight)                                # [B*Hn, A]
-    qc = ops.linear_fwd(cand2, mod.intraCluster_Q.weight, mod.intraCluster_Q.bias)                       # [B*N, A]
+    if side is None:
+        cand_side()
+    else:
+        torch.cuda.current_stream(dev).wait_event(side_ev)
     alpha_i = torch.empty((B, N, Hn), **f32)
     feat = torch.empty((B * N * Cn, D), **f32)
     ops.sue_intra_fwd(kf, qc, gfeat, cidx, B, N, Hn, Cn, A, D, alpha_i, feat)
@@ -195,10 +230,6 @@ def sue_forward(mod, hist, cand, graph, cmask, cidx):
     ops.gemm(feat, mod.clusterFeatureAffine.weight, f2, M=B * N * Cn, N=D, K=D, lda=D, ldb=D, ldc=D, bias=mod.clusterFeatureAffine.bias,
              act=ops.ACT_RELU, aux_out=rc, ldaux=D, resid=feat, ldres=D, drop=(3, p, seed + 2, D))
     # ---- inter-cluster attention (layers.py:196-203) in GEMV form
-    ia = mod.interClusterAttention
-    qv = ops.linear_fwd(cand2, ia.Q.weight, ia.Q.bias)                                                   # [B*N, A]
-    v = torch.empty((B * N, D), **f32)
-    ops.gemm(qv, ia.K.weight, v, M=B * N, N=D, K=A, lda=A, ldb=D, ldc=D, trans_b=True)
     alpha_o = torch.empty(B * N * Cn, **f32)
     out = torch.empty((B * N, D), **f32)
     ops.pool_fwd(x=f2, ldx=D, D=D, n=B * N, Lx=Cn, mask=cmask, mask_div=N, v=v, ldv=D, scale=1.0 / math.sqrt(A), alpha=alpha_o, out=out,
@@ -240,13 +271,25 @@ def _sue_backward_body(mod, sv, dout, leaf, B, Hn, D, N, Kc, G, Cn, A, p, seed, 
     ops.pool_bwd(x=sv['f2'], ldx=D, D=D, n=B * N, Lx=Cn, mask=sv['cmask'], mask_div=N, v=sv['v'], ldv=D, scale=1.0 / math.sqrt(A),
                  alpha=sv['alpha_o'], dout=dout, lddo=D, dx=df2, lddx=D, dv=dv, lddv=D)
     dqv = torch.empty((B * N, A), **f32)
-    ops.gemm(dv, ia.K.weight, dqv, M=B * N, N=A, K=D, lda=D, ldb=D, ldc=A)
-    leaf(lambda: (ops.linear_bwd_weight(sv['qv'], dv, grad_of(ia.K.weight)),
-                  ops.linear_bwd_weight(dqv, cand2, grad_of(ia.Q.weight), db=grad_of(ia.Q.bias))), dv, dqv)
-    if dcand_accum is not None:                      # the step without autograd: straight into the union gradient buffer's candidate rows
-        dcand = ops.linear_bwd_data(dqv, ia.Q.weight, out=dcand_accum, accumulate=True)
-    else:
-        dcand = ops.linear_bwd_data(dqv, ia.Q.weight)                                                    # [B*N, D]
+    # the step without autograd: the candidate gradient goes straight into the union gradient buffer's candidate rows
+    dcand = dcand_accum if dcand_accum is not None else torch.empty((B * N, D), **f32)
+    main = torch.cuda.current_stream(dev)
+    side = _sue_side(dev)
+
+    def on_side(fn):
+        # nobody reads the candidate gradient (or d q_v) before the news encoder's backward: off the chain, joined when this function returns
+        if side is None:
+            return fn()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            return fn()
+
+    def inter_q():
+        ops.gemm(dv, ia.K.weight, dqv, M=B * N, N=A, K=D, lda=D, ldb=D, ldc=A)
+        leaf(lambda: (ops.linear_bwd_weight(sv['qv'], dv, grad_of(ia.K.weight)),
+                      ops.linear_bwd_weight(dqv, cand2, grad_of(ia.Q.weight), db=grad_of(ia.Q.bias))), dv, dqv)
+        ops.linear_bwd_data(dqv, ia.Q.weight, out=dcand, accumulate=dcand_accum is not None)             # [B*N, D]
+    on_side(inter_q)
     # ---- cluster affine
     dS = torch.empty((B * N * Cn, D), **f32)
     dfeat = torch.empty((B * N * Cn, D), **f32)
@@ -263,7 +306,7 @@ def _sue_backward_body(mod, sv, dout, leaf, B, Hn, D, N, Kc, G, Cn, A, p, seed, 
     dqc = torch.empty((B * N, A), **f32)
     ops.sue_intra_bwd(sv['kf'], sv['qc'], sv['gfeat'], sv['cidx'], sv['alpha_i'], dfeat, B, N, Hn, Cn, A, D, dg, dkf, dqc)
     ops.linear_bwd_data(dkf, mod.intraCluster_K.weight, out=dg.view(B * Hn, D), accumulate=True)
-    ops.linear_bwd_data(dqc, mod.intraCluster_Q.weight, out=dcand, accumulate=True)
+    on_side(lambda: ops.linear_bwd_data(dqc, mod.intraCluster_Q.weight, out=dcand, accumulate=True))
     leaf(lambda: (ops.linear_bwd_weight(dkf, sv['gfeat'].view(B * Hn, D), grad_of(mod.intraCluster_K.weight)),
                   ops.linear_bwd_weight(dqc, cand2, grad_of(mod.intraCluster_Q.weight), db=grad_of(mod.intraCluster_Q.bias))), dkf, dqc)
     # ---- GCN (+ outer residual)
@@ -272,6 +315,8 @@ def _sue_backward_body(mod, sv, dout, leaf, B, Hn, D, N, Kc, G, Cn, A, p, seed, 
     dy = gcn_backward(mod.gcn, sv['gcn'], dpad, sv['graph'], leaf)
     dhist = torch.empty((B, Hn, D), **f32) if dhist_out is None else dhist_out
     ops.sue_x0_bwd(dy, dhist, grad_of(mod.proxy_node_embedding), B, Hn, Kc, D, p, seed + 1, dx0_add=dpad)      # d(gcn(X0) + X0)
+    if side is not None:
+        main.wait_stream(side)                        # the candidate gradient is complete
     return dhist, dcand.view(B, N, D)
 
 

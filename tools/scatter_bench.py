@@ -12,7 +12,8 @@ d = torch.device('cuda')
 V, E = 60000, 300
 spec = SynthSpec(vocabulary_size=V)
 corpus = SynthCorpus(spec)
-b = corpus.batch(64, np.random.default_rng(100))
+BS = int(sys.argv[sys.argv.index('--batch_size') + 1]) if '--batch_size' in sys.argv else 64
+b = corpus.batch(BS, np.random.default_rng(100))
 
 
 def timed(fn, n=20):
