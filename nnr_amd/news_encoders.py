@@ -137,6 +137,7 @@ ops.STREAM_CACHES.append(_SIDE)
 _LSTM_FWD_SPLIT = os.environ.get('NNR_LSTM_FWD_SPLIT', '0') == '1'      # A/B: title recurrence launched on the title stream
 _PROJ_ORDER = os.environ.get('NNR_PROJ_ORDER', '0') == '1'      # A/B (round 4, with NNR_LSTM_FWD_SPLIT=1): the content projection waits for the title projection, so the
                                                                 # title recurrence runs UNDER the content projection instead of inside the shared recurrence launch
+_DWHH_FIRST = os.environ.get('NNR_DWHH_FIRST', '0') == '1'      # A/B (round 4): this stream's dW_hh GEMM in front of the embedding-row gradient GEMM + scatter instead of behind them
 _POST_INLINE = os.environ.get('NNR_POST_INLINE', '0') == '1'      # A/B: the content stream's tail GEMMs on one HIP stream
 _DX_SPLIT = os.environ.get('NNR_DX_SPLIT', '1') == '1'      # embedding-row gradient as plain GEMM + scatter kernel (11.46 vs 11.51 ms fused)
 _BWD_SPLIT = os.environ.get('NNR_LSTM_BWD_SPLIT', '1') == '1'      # batch 8: 4.68 (split) vs 4.93 ms; batch 64: no difference
@@ -638,9 +639,12 @@ def _cne_bwd_post(mod, sv, st, leaf=None):
             dw_ih(); dw_hh(0); dw_hh(1)
         else:
             leaf(lambda: (dw_ih(), dw_hh(1)), dw_ihp, db_p, dw_hhp)
+            if _DWHH_FIRST:
+                dw_hh(0)
             dx_scatter()
             table_hook()
-            dw_hh(0)
+            if not _DWHH_FIRST:
+                dw_hh(0)
             leaf.sync()
     ops.lstm_unpack_grads(dw_ihp, db_p, dw_hhp, H, E, [grad_of(q) for q in st['lstm'].param_list()], zero_src=True)
     if leaf is None and not _TITLE_DX_FIRST:
