@@ -212,7 +212,10 @@ __device__ __forceinline__ void softmax_T(f32x16 (&p)[NB][NB], const MhsaArgs& a
 }
 
 // C^T[x][y] (NB x NB blocks of 32x32) = sum_k X[x][k] Y[y][k], X and Y staged [LP][SD], k < dh (dh even)
-template <int NB>
+// DH > 0: the head dimension is a compile-time constant (20 in every BASELINE config): the k loop unrolls, all of a product's LDS reads are
+// issued ahead of its dependent MFMA chain instead of one (read, wait ~100 clk, MFMA 64 clk) round per step -- with two waves per SIMD
+// that chain, not the matrix pipe (0.23 busy) or HBM, was what a head's ~14 us were made of (round 4)
+template <int NB, int DH = 0>
 __device__ __forceinline__ void rows_dot(const float* X, const float* Y, int dh, int SD, int lane, f32x16 (&c)[NB][NB]) {
   const int l31 = lane & 31, half = lane >> 5;
 #pragma unroll
@@ -220,10 +223,21 @@ __device__ __forceinline__ void rows_dot(const float* X, const float* Y, int dh,
 #pragma unroll
     for (int yb = 0; yb < NB; ++yb) {
       f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      for (int ks = 0; ks < dh; ks += 2) {
-        const float a = X[(xb * 32 + l31) * SD + ks + half];
-        const float b = Y[(yb * 32 + l31) * SD + ks + half];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      if (DH > 0) {
+        float av[DH / 2 > 0 ? DH / 2 : 1], bv[DH / 2 > 0 ? DH / 2 : 1];
+#pragma unroll
+        for (int k2 = 0; k2 < DH / 2; ++k2) {
+          av[k2] = X[(xb * 32 + l31) * SD + 2 * k2 + half];
+          bv[k2] = Y[(yb * 32 + l31) * SD + 2 * k2 + half];
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < DH / 2; ++k2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[k2], bv[k2], acc, 0, 0, 0);
+      } else {
+        for (int ks = 0; ks < dh; ks += 2) {
+          const float a = X[(xb * 32 + l31) * SD + ks + half];
+          const float b = Y[(yb * 32 + l31) * SD + ks + half];
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
       }
       c[xb][yb] = acc;
     }
@@ -237,12 +251,14 @@ __device__ __forceinline__ void acc_as_b(const float* X, const f32x16 (&P)[NB][N
   for (int ib = 0; ib < NB; ++ib) {
     f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int jb = 0; jb < NB; ++jb)
+    for (int jb = 0; jb < NB; ++jb) {
+      float av[16];
 #pragma unroll
-      for (int s = 0; s < 16; ++s) {
-        const float a = (l31 < dh) ? X[(jb * 32 + acc_row(s, half)) * SD + l31] : 0.f;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, P[jb][ib][s], acc, 0, 0, 0);
-      }
+      for (int s = 0; s < 16; ++s) av[s] = X[(jb * 32 + acc_row(s, half)) * SD + l31];      // reads first, then the chain.  (Lanes l31 >= dh read up to 11
+                                                                                          // floats past the row -- inside the workgroup's tiles -- and only feed output ROWS >= dh, which nobody stores)
+#pragma unroll
+      for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], P[jb][ib][s], acc, 0, 0, 0);
+    }
     o[ib] = acc;
   }
 }
@@ -264,14 +280,16 @@ __device__ __forceinline__ void store_T(float* dst, int ld, const f32x16 (&o)[NB
   }
 }
 
-template <int NB>
-__global__ __launch_bounds__(256) void mhsa_fwd_kernel(MhsaArgs a, int coop) {
+template <int NB, int DH, bool FULL = false>
+__global__ __launch_bounds__(256) void mhsa_fwd_kernel(MhsaArgs a_in, int coop) {
   constexpr int LP = 32 * NB;
+  MhsaArgs a = a_in;
+  if (FULL) a.Lq = LP;
   extern __shared__ float smem[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, half = lane >> 5;
   const int nw = blockDim.x >> 6;
   const int pair = blockIdx.x * nw + wv;
-  const int dh = a.dh, SD = dh | 1, HD = a.heads * dh, ld = 3 * HD;
+  const int dh = DH > 0 ? DH : a.dh, SD = dh | 1, HD = a.heads * dh, ld = 3 * HD;      // (DH > 0: every / dh, % dh and * SD below folds)
   const int wstride = 3 * LP * SD;
   float* Qs = smem + wv * wstride;
   float* Ks = Qs + LP * SD;
@@ -300,7 +318,7 @@ __global__ __launch_bounds__(256) void mhsa_fwd_kernel(MhsaArgs a, int coop) {
     __builtin_amdgcn_s_waitcnt(0xc07f);    // lgkmcnt(0): this wave's own LDS writes (no cross-wave sharing)
   }
   f32x16 p[NB][NB];                        // p[jb][ib] = S^T block: rows keys, cols queries
-  rows_dot<NB>(Ks, Qs, dh, SD, lane, p);
+  rows_dot<NB, DH>(Ks, Qs, dh, SD, lane, p);
   softmax_T<NB>(p, a, key_bits(a, smp, lane), half);
   if (a.prob) {
     float* pp = a.prob + (long)pair * (NB * NB * 1024);
@@ -333,13 +351,13 @@ __global__ __launch_bounds__(256) void mhsa_fwd_kernel(MhsaArgs a, int coop) {
   }
 }
 
-template <int NB>
+template <int NB, int DH>
 __global__ __launch_bounds__(256) void mhsa_bwd_kernel(MhsaArgs a, int coop) {
   constexpr int LP = 32 * NB, ST = LP + 1;
   extern __shared__ float smem[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l31 = lane & 31, half = lane >> 5;
   const int pair = blockIdx.x * (blockDim.x >> 6) + wv;
-  const int dh = a.dh, SD = dh | 1, HD = a.heads * dh, ld = 3 * HD;
+  const int dh = DH > 0 ? DH : a.dh, SD = dh | 1, HD = a.heads * dh, ld = 3 * HD;      // (DH > 0: every / dh, % dh and * SD below folds)
   const int wstride = 4 * LP * SD + LP * ST;
   float* Qs = smem + wv * wstride;
   float* Ks = Qs + LP * SD;
@@ -384,7 +402,7 @@ __global__ __launch_bounds__(256) void mhsa_bwd_kernel(MhsaArgs a, int coop) {
   } else {
     // recompute P^T from Q, K: one more 32 x 32 x dh product + softmax instead of 4 KB of HBM traffic each way per head
     __builtin_amdgcn_s_waitcnt(0xc07f);
-    rows_dot<NB>(Ks, Qs, dh, SD, lane, p);
+    rows_dot<NB, DH>(Ks, Qs, dh, SD, lane, p);
     softmax_T<NB>(p, a, live, half);
   }
   // P^T -> LDS tile (rows keys j, cols queries i) for dV = P^T dO
@@ -401,10 +419,16 @@ __global__ __launch_bounds__(256) void mhsa_bwd_kernel(MhsaArgs a, int coop) {
 #pragma unroll
     for (int xb = 0; xb < NB; ++xb) {
       f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      for (int i = 0; i < LP; i += 2) {
-        const float av = T[(xb * 32 + l31) * ST + i + half];
-        const float bv = (l31 < dh) ? Y[(i + half) * SD + l31] : 0.f;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+#pragma unroll
+      for (int i0 = 0; i0 < LP; i0 += 32) {
+        float av[16], bv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          av[u] = T[(xb * 32 + l31) * ST + i0 + 2 * u + half];
+          bv[u] = (l31 < dh) ? Y[(i0 + 2 * u + half) * SD + l31] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
       }
       // acc: rows x (keys), cols d
       if (l31 < dh) {
@@ -417,7 +441,7 @@ __global__ __launch_bounds__(256) void mhsa_bwd_kernel(MhsaArgs a, int coop) {
     }
   };
   // dP^T = V dO^T first: afterwards the V tile is free and takes dV (coop path: results leave through LDS as row segments)
-  rows_dot<NB>(Vs, Gs, dh, SD, lane, dp);
+  rows_dot<NB, DH>(Vs, Gs, dh, SD, lane, dp);
   if (coop) t_times(Gs, Vs, SD);           // dV (LDS ops of one wave execute in order: the reads of V above are done)
   else t_times(Gs, dbase + 2 * HD, ld);
   // dS^T = P^T * (dP^T - delta_i) * scale
@@ -466,6 +490,149 @@ __global__ __launch_bounds__(256) void mhsa_bwd_kernel(MhsaArgs a, int coop) {
   }
 }
 
+
+// ---- persistent backward (round 4): NB = 1, 4-head groups, P recomputed.  A workgroup walks `gp` consecutive 4-head groups; the
+// global loads of group g + 1 (Q, K, V, dO row segments + the key-mask byte: 13 registers of float4 per lane) are issued BEFORE the
+// products of group g and land in LDS after them, and the results of group g leave LDS through registers so that their global stores
+// are issued after the next group's tiles are in place -- per group a wave no longer sits through a load latency, a workgroup launch
+// and a store drain with only one other wave on its SIMD to cover for it (the one-group kernel: 8 us per head for ~4 us of work).
+template <int NMAT, int DM>
+__device__ __forceinline__ void load4v(float4 (&r)[NMAT][3], const float* const (&src)[NMAT], const int (&ld)[NMAT], int Lq, int dh, int tid,
+                                       const MhsaArgs& a, long e0) {
+  const int n4 = 32 * dh;                  // <= 768: one batch of three float4 per thread and matrix
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    const int idx = u * 256 + tid, q = idx / dh, c4 = idx - q * dh;
+    const bool live = idx < n4 && q < Lq;
+#pragma unroll
+    for (int m = 0; m < NMAT; ++m)
+      r[m][u] = live ? *(const float4*)(src[m] + (long)q * ld[m] + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (DM >= 0 && a.thr && live) {
+      bool k[4];
+      nnr_keep4(a.seed, (uint64_t)(e0 + (long)q * ld[DM >= 0 ? DM : 0] + 4 * c4), a.thr, k);
+      float4& v = r[DM >= 0 ? DM : 0][u];
+      v.x = k[0] ? v.x * a.dscale : 0.f; v.y = k[1] ? v.y * a.dscale : 0.f;
+      v.z = k[2] ? v.z * a.dscale : 0.f; v.w = k[3] ? v.w * a.dscale : 0.f;
+    }
+  }
+}
+template <int NMAT>
+__device__ __forceinline__ void put4v(float* smem, int wstride, const float4 (&r)[NMAT][3], int dh, int SD, int tid) {
+  const int n4 = 32 * dh;
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    const int idx = u * 256 + tid, q = idx / dh, c = 4 * (idx - q * dh), w = c / dh, d = c - w * dh;
+    if (idx < n4) {
+#pragma unroll
+      for (int m = 0; m < NMAT; ++m) {
+        float* t = smem + w * wstride + m * 32 * SD + q * SD + d;
+        t[0] = r[m][u].x; t[1] = r[m][u].y; t[2] = r[m][u].z; t[3] = r[m][u].w;
+      }
+    }
+  }
+}
+
+template <int DH, bool FULL>
+__global__ __launch_bounds__(256, 2) void mhsa_bwd_persist_kernel(MhsaArgs a_in, int gp) {
+  constexpr int NB = 1, LP = 32, ST = LP + 1;
+  MhsaArgs a = a_in;
+  if (FULL) a.Lq = LP;                       // every `< Lq` predicate of the tiles (~70 per group) folds: titles are padded to 32 tokens in every config
+  extern __shared__ float smem[];
+  const int tid0 = threadIdx.x, lane0 = tid0 & 63, wv = tid0 >> 6;
+  const int dh = DH > 0 ? DH : a.dh, SD = dh | 1, HD = a.heads * dh, ld = 3 * HD;      // (DH > 0: every / dh, % dh and * SD below folds)
+  const int wstride = 4 * LP * SD + LP * ST;
+  float* Qs = smem + wv * wstride;
+  float* Ks = Qs + LP * SD;
+  float* Vs = Ks + LP * SD;
+  float* Gs = Vs + LP * SD;                // dO
+  float* T = Gs + LP * SD;                 // [LP][ST] transpose tile
+  const int ngroups = a.n * a.heads / 4;
+  const int g_lo = blockIdx.x * gp, g_hi = min(ngroups, g_lo + gp);
+  if (g_lo >= g_hi) return;
+  float4 r[4][3];
+  int mb = 0;                              // the key-mask byte of this lane's key position, loaded with the group's tiles
+  auto issue = [&](int g) __attribute__((always_inline)) {
+    const int pair0 = g * 4, smp0 = pair0 / a.heads, head0 = pair0 - smp0 * a.heads;
+    const float* base0 = a.qkv + (long)smp0 * a.Lq * ld + head0 * dh;
+    const long e0 = (long)smp0 * a.Lq * HD + head0 * dh;
+    const float* const src[4] = {base0, base0 + HD, base0 + 2 * HD, a.dout + e0};
+    const int lds[4] = {ld, ld, ld, HD};
+    mb = (a.mask && lane0 < a.Lq) ? (int)a.mask[(long)smp0 * a.Lq + lane0] : (a.mask ? 0 : 1);
+    load4v<4, 3>(r, src, lds, a.Lq, dh, tid0, a, e0);
+  };
+  issue(g_lo);
+  put4v<4>(smem, wstride, r, dh, SD, tid0);
+#pragma nounroll
+  for (int g = g_lo; g < g_hi; ++g) {
+    // the lane id goes through an opaque move once per group: every LDS address below depends on it, so the compiler cannot hoist the
+    // ~100 loop-invariant per-lane offsets of the transposes out of the group loop (it did, and spilled 26-59 of them)
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int pair0 = g * 4, smp0 = pair0 / a.heads, head0 = pair0 - smp0 * a.heads;
+    const unsigned long long live = a.mask ? __ballot(mb != 0) : ~0ull;
+    __syncthreads();                                            // this group's tiles are in LDS
+    f32x16 p[NB][NB], dp[NB][NB];
+    rows_dot<NB, DH>(Ks, Qs, dh, SD, lane, p);
+    softmax_T<NB>(p, a, live, half);
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) T[acc_row(reg, half) * ST + l31] = p[0][0][reg];
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    auto t_times = [&](const float* Y, float* dst, int dld) __attribute__((always_inline)) {
+      f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      float av[16], bv[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        av[u] = T[l31 * ST + 2 * u + half];
+        bv[u] = Y[(2 * u + half) * SD + l31];                   // (lanes l31 >= dh: junk columns, not stored)
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+      if (l31 < dh) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int j = acc_row(reg, half);
+          if (j < a.Lq) dst[(long)j * dld + l31] = acc[reg];
+        }
+      }
+    };
+    rows_dot<NB, DH>(Vs, Gs, dh, SD, lane, dp);
+    t_times(Gs, Vs, SD);                                        // dV into the V tile
+    {
+      float delta = 0.f;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) delta += p[0][0][reg] * dp[0][0][reg];
+      delta += __shfl_xor(delta, 32, 64);
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int j = acc_row(reg, half);
+        const bool dead = j < a.Lq && !((live >> j) & 1);
+        dp[0][0][reg] = dead ? 0.f : p[0][0][reg] * (dp[0][0][reg] - delta) * a.scale;
+      }
+    }
+    // the next group's loads go out HERE: P is dead, the remaining products (dQ, dK: half of the group's MFMA work) and the result
+    // stores cover their latency, and the 52 registers they land in do not overlap the scores / dP phase (issued at the top of the
+    // group they cost 26-59 spilled VGPRs at two waves per SIMD)
+    if (g + 1 < g_hi) issue(g + 1);
+    f32x16 dq[NB];
+    acc_as_b<NB>(Ks, dp, dh, SD, lane, dq);
+    tile_T<NB>(Gs, SD, dq, dh, lane);                           // dQ into the dO tile
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) T[acc_row(reg, half) * ST + l31] = dp[0][0][reg];
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    t_times(Qs, Ks, SD);                                        // dK into the K tile
+    __syncthreads();
+    // results leave through LDS as row segments; then the NEXT group's tiles (already in registers) go in
+    float* d0 = a.dqkv + (long)smp0 * a.Lq * ld + head0 * dh;
+    unstage4v<LP>(smem + 3 * LP * SD, wstride, d0, ld, a.Lq, dh, SD, tid);            // dQ
+    unstage4v<LP>(smem + 1 * LP * SD, wstride, d0 + HD, ld, a.Lq, dh, SD, tid);       // dK
+    unstage4v<LP>(smem + 2 * LP * SD, wstride, d0 + 2 * HD, ld, a.Lq, dh, SD, tid);   // dV
+    __syncthreads();                                            // every wave has read the result tiles
+    if (g + 1 < g_hi) put4v<4>(smem, wstride, r, dh, SD, tid);
+  }
+}
+
 }  // namespace
 
 extern "C" int nnr_mhsa_fwd(const float* qkv, const uint8_t* mask, int n, int Lq, int heads, int dh, float scale, float* out,
@@ -477,10 +644,13 @@ extern "C" int nnr_mhsa_fwd(const float* qkv, const uint8_t* mask, int n, int Lq
   const int NB = Lq > 32 ? 2 : 1, LP = 32 * NB, SD = dh | 1;
   const int waves = 4;
   const int coop = (heads % 4 == 0 && dh % 4 == 0) ? 1 : 0;        // a workgroup's 4 waves then are 4 adjacent heads of one sample
-  const size_t shm = (size_t)waves * 3 * LP * SD * sizeof(float);
+  const size_t shm = ((size_t)waves * 3 * LP * SD + 16) * sizeof(float);      // + 16: operand reads of lanes >= dh run up to 11 floats past the last row
   const int blocks = (n * heads + waves - 1) / waves;
-  if (NB == 1) hipLaunchKernelGGL((mhsa_fwd_kernel<1>), dim3(blocks), dim3(64 * waves), shm, stream, a, coop);
-  else hipLaunchKernelGGL((mhsa_fwd_kernel<2>), dim3(blocks), dim3(64 * waves), shm, stream, a, coop);
+  if (NB == 1 && dh == 20 && Lq == 32) hipLaunchKernelGGL((mhsa_fwd_kernel<1, 20, true>), dim3(blocks), dim3(64 * waves), shm, stream, a, coop);
+  else if (NB == 1 && dh == 20) hipLaunchKernelGGL((mhsa_fwd_kernel<1, 20>), dim3(blocks), dim3(64 * waves), shm, stream, a, coop);
+  else if (NB == 1) hipLaunchKernelGGL((mhsa_fwd_kernel<1, 0>), dim3(blocks), dim3(64 * waves), shm, stream, a, coop);
+  else if (dh == 20) hipLaunchKernelGGL((mhsa_fwd_kernel<2, 20>), dim3(blocks), dim3(64 * waves), shm, stream, a, coop);
+  else hipLaunchKernelGGL((mhsa_fwd_kernel<2, 0>), dim3(blocks), dim3(64 * waves), shm, stream, a, coop);
   NNR_CHECK_LAUNCH();
   return NNR_OK;
 }
@@ -494,10 +664,25 @@ extern "C" int nnr_mhsa_bwd(const float* qkv, const uint8_t* mask, const float* 
   const int NB = Lq > 32 ? 2 : 1, LP = 32 * NB, SD = dh | 1;
   const int waves = NB == 1 ? 4 : 1;
   const int coop = (waves == 4 && heads % 4 == 0 && dh % 4 == 0) ? 1 : 0;
-  const size_t shm = (size_t)waves * (4 * LP * SD + LP * (LP + 1)) * sizeof(float);
+  const size_t shm = ((size_t)waves * (4 * LP * SD + LP * (LP + 1)) + 16) * sizeof(float);
   const int blocks = (n * heads + waves - 1) / waves;
-  if (NB == 1) hipLaunchKernelGGL((mhsa_bwd_kernel<1>), dim3(blocks), dim3(64 * waves), shm, stream, a, coop);
-  else hipLaunchKernelGGL((mhsa_bwd_kernel<2>), dim3(blocks), dim3(64 * waves), shm, stream, a, coop);
+  static const int persist = [] { const char* e = getenv("NNR_MHSA_PERSIST"); return e ? atoi(e) : 1; }();      // A/B: 0 = one 4-head group per workgroup
+  if (persist && coop && !prob && 32 * dh <= 768) {
+    // one workgroup per sample's heads (heads / 4 groups), or fewer groups when that leaves the chip short of workgroups
+    const int ngroups = n * heads / 4;
+    int gp = heads / 4;
+    while (gp > 1 && (ngroups + gp - 1) / gp < 1024) --gp;
+    const dim3 grid((ngroups + gp - 1) / gp);
+    if (dh == 20 && Lq == 32) hipLaunchKernelGGL((mhsa_bwd_persist_kernel<20, true>), grid, dim3(256), shm, stream, a, gp);
+    else if (dh == 20) hipLaunchKernelGGL((mhsa_bwd_persist_kernel<20, false>), grid, dim3(256), shm, stream, a, gp);
+    else hipLaunchKernelGGL((mhsa_bwd_persist_kernel<0, false>), grid, dim3(256), shm, stream, a, gp);
+    NNR_CHECK_LAUNCH();
+    return NNR_OK;
+  }
+  if (NB == 1 && dh == 20) hipLaunchKernelGGL((mhsa_bwd_kernel<1, 20>), dim3(blocks), dim3(64 * waves), shm, stream, a, coop);
+  else if (NB == 1) hipLaunchKernelGGL((mhsa_bwd_kernel<1, 0>), dim3(blocks), dim3(64 * waves), shm, stream, a, coop);
+  else if (dh == 20) hipLaunchKernelGGL((mhsa_bwd_kernel<2, 20>), dim3(blocks), dim3(64 * waves), shm, stream, a, coop);
+  else hipLaunchKernelGGL((mhsa_bwd_kernel<2, 0>), dim3(blocks), dim3(64 * waves), shm, stream, a, coop);
   NNR_CHECK_LAUNCH();
   return NNR_OK;
 }
