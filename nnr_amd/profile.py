@@ -170,10 +170,14 @@ def mfma_busy(kernel_prefix):
     have, now = d.get('build_id') or {}, _lib.build_id()
     if not (have.get('src_sha256') == now['src_sha256'] or (have.get('lib_sha256') and have.get('lib_sha256') == now['lib_sha256'])):
         return None
-    for k in d.get('kernels', []):
-        if k['kernel'].startswith(kernel_prefix):
-            return k
-    return None
+    hits = [k for k in d.get('kernels', []) if k['kernel'].startswith(kernel_prefix)]
+    if not hits:
+        return None
+    # several instantiations of a family (the news encoder's and the user encoder's attention core): cycles-weighted over all launches
+    busy = sum(k['mfma_busy_cycles_per_launch'] * k['launches'] for k in hits)
+    active = sum(k['gui_active_per_launch'] * k['launches'] for k in hits)
+    return {'kernel': ' + '.join(k['kernel'] for k in hits), 'launches': sum(k['launches'] for k in hits),
+            'mfma_busy': round(busy / (active / 8.0 * 1024.0), 4) if active else None}
 
 
 def mhsa_roofline(peak_tflops):
@@ -182,7 +186,7 @@ def mhsa_roofline(peak_tflops):
     bytes against the HBM peak (the kernel is HBM-bound: 32 x 32 x 20 attention matrices), and the matrix-pipe busy counter."""
     fam = summary()
     out = {}
-    for k, kern in (('mhsa_fwd', 'mhsa_fwd_kernel'), ('mhsa_bwd', 'mhsa_bwd_kernel')):
+    for k, kern in (('mhsa_fwd', 'mhsa_fwd'), ('mhsa_bwd', 'mhsa_bwd')):      # (prefixes: mhsa_bwd_kernel<..> and mhsa_bwd_persist_kernel<..>)
         v = fam.get(k)
         if not v or v['ms'] <= 0:
             continue
@@ -190,7 +194,7 @@ def mhsa_roofline(peak_tflops):
         nbytes = sum((_bytes_of(fn) or 0.0) for f, fn, _ in _all_records() if f == k)
         gbs = nbytes / (v['ms'] * 1e-3) / 1e9
         busy = mfma_busy(kern)
-        out[k] = {'kernel': kern, 'launches': v['launches'], 'avg_launch_us': round(1000 * v['ms'] / v['launches'], 2),
+        out[k] = {'kernel': kern + '*_kernel' if busy is None else busy['kernel'], 'launches': v['launches'], 'avg_launch_us': round(1000 * v['ms'] / v['launches'], 2),
                   'mfma_tflops': round(tf, 2), 'mfma_utilisation': round(tf / peak_tflops, 4),
                   'hbm_gb_s': round(gbs, 1), 'hbm_frac': round(gbs / PEAK_HBM_GBS, 4),
                   'mfma_busy_counter': None if busy is None else busy.get('mfma_busy'),
