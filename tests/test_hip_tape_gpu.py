@@ -191,6 +191,27 @@ def test_other_shapes_and_modes_fall_back():
     assert tr2.last_path == 'autograd' and not tr2.tapes
 
 
+def test_tape_footprint_budget_keeps_the_step_call_by_call(monkeypatch):
+    """A tape pins every buffer of its step; the tapes of a trainer stay under NNR_TAPE_MAX_GB (default: a quarter of the device's memory).
+    A recording that would exceed it is discarded with a warning and the shape stays on the call-by-call native step -- same results."""
+    from nnr_amd.trainer import Trainer
+    cfg = make_config(['--news_encoder=CNE', '--user_encoder=SUE'], corpus_sizes=dict(vocabulary_size=900), tie_order='stable', batch_size=4)
+    corpus = SynthCorpus(SynthSpec(vocabulary_size=900, news_pool=500, seed=6))
+    batches = [to_torch(corpus.batch(4, np.random.default_rng(11 + i)), 'cuda') for i in range(5)]
+    m_a, _ = _models(cfg, seed=5)
+    m_b, _ = _models(cfg, seed=5)
+    tr_a = Trainer(m_a, cfg)
+    ref = [tr_a.train_step(b)[0].clone() for b in batches]
+    assert tr_a.last_path == 'replay' and len(tr_a.tapes) == 1 and 0 < tr_a.tapes[next(iter(tr_a.tapes))].info()['buffers_held_gb'] < 8
+    monkeypatch.setenv('NNR_TAPE_MAX_GB', '0.001')
+    tr_b = Trainer(m_b, cfg)
+    with pytest.warns(UserWarning, match='NNR_TAPE_MAX_GB'):
+        out = [tr_b.train_step(b)[0].clone() for b in batches]
+    assert tr_b.last_path == 'native' and not tr_b.tapes and len(tr_b.unrecordable) == 1
+    for a, b in zip(ref, out):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize('batch_size', [3, 64])
 def test_mhsa_pair_native_step_equals_autograd_and_replays_against_oracle(batch_size):
     """BASELINE.json configs[1] (MHSA + MHSA; newsEncoders.py:187-200, userEncoders.py:164-173): (1) the native step (nnr_amd.step.
