@@ -32,6 +32,7 @@ def _tape_budget_gb(dev):
         return 64.0
 
 
+_SKIP_POLL = int(os.environ.get('NNR_SKIP_POLL', '512'))
 _WARM_STEPS = 2          # eager steps before a tape is recorded (first-use allocations: workspaces, W^T copies, packed weights)
 
 
@@ -109,6 +110,7 @@ class Trainer:
         self.native = _NATIVE_STEP if native is None else bool(native)
         self.replay = (_REPLAY and (dp.world_size() == 1 or _REPLAY_DP)) if replay is None else bool(replay)
         self.tapes = {}              # batch-shape key -> nnr_amd.tape.Tape
+        self._skipped_seen = None    # the library's skipped-step count (process-wide) when this trainer first polled / started
         self.unrecordable = set()    # batch-shape keys whose recording was discarded (tape.violations): they stay call by call
         self.tape_violations = []    # diagnostics: the violations of the last discarded recording
         self.native_steps = {}       # batch-shape key -> eager native steps run so far
@@ -138,7 +140,23 @@ class Trainer:
 
     def train_step(self, batch):
         """One optimizer step on `batch` (21 device tensors, Model.forward order).  Returns (logits, loss) as device
-        tensors -- no host synchronisation (the reference's float(loss) sync at trainer.py:115 is the caller's choice)."""
+        tensors -- no host synchronisation (the reference's float(loss) sync at trainer.py:115 is the caller's choice), except that
+        every NNR_SKIP_POLL-th step (default 512, 0 = never) reads the library's count of optimizer steps dropped for a non-finite
+        gradient norm and warns when it moved: a recurrence exchange time-out poisons its tile with NaN, nnr_clip_adam then leaves the
+        parameters untouched, and a loop that never polls skipped_steps() would train on silently (round-3 verdict)."""
+        if self._skipped_seen is None and batch[15].is_cuda:
+            self._skipped_seen = self.skipped_steps()          # baseline (the counter is process-wide); one sync at the first step
+        out = self._train_step(batch)
+        if _SKIP_POLL and self.step_count % _SKIP_POLL == 0 and batch[15].is_cuda:
+            n = self.skipped_steps()
+            if n > self._skipped_seen:
+                import warnings
+                warnings.warn('nnr_amd: %d optimizer step(s) skipped so far because the gradient norm was not finite (recurrence exchange time-outs: %d)'
+                              % (n, ops.lstm_sync_timeouts()))
+                self._skipped_seen = n
+        return out
+
+    def _train_step(self, batch):
         model = self.model
         if self.native and batch[15].is_cuda and model.training:
             from . import step as native_step

@@ -191,6 +191,31 @@ def test_other_shapes_and_modes_fall_back():
     assert tr2.last_path == 'autograd' and not tr2.tapes
 
 
+def test_trainer_warns_when_optimizer_steps_are_skipped(monkeypatch):
+    """nnr_clip_adam leaves the parameters untouched when the gradient norm is not finite (a recurrence exchange time-out poisons its
+    tile with NaN); the trainer reads the library's skipped-step count every NNR_SKIP_POLL-th step and warns when it moved."""
+    from nnr_amd import trainer as T
+    monkeypatch.setattr(T, '_SKIP_POLL', 2)
+    cfg = make_config(['--news_encoder=CNE', '--user_encoder=SUE'], corpus_sizes=dict(vocabulary_size=900), tie_order='stable', batch_size=4)
+    corpus = SynthCorpus(SynthSpec(vocabulary_size=900, news_pool=500, seed=6))
+    batches = [to_torch(corpus.batch(4, np.random.default_rng(21 + i)), 'cuda') for i in range(4)]
+    model, _ = _models(cfg, seed=5)
+    tr = T.Trainer(model, cfg)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        tr.train_step(batches[0])
+        tr.train_step(batches[1])                        # step 2 is polled: nothing skipped, no warning
+    before = tr.skipped_steps()
+    with torch.no_grad():
+        model.news_encoder.title_lstm.param_list()[0].view(-1)[0] = float('nan')          # (not behind a ReLU: fmaxf(NaN, 0) = 0 swallows it)
+    tr.train_step(batches[2])                            # step 3: NaN gradient norm -> skipped, not polled
+    with pytest.warns(UserWarning, match='optimizer step'):
+        tr.train_step(batches[3])                        # step 4: polled
+    assert tr.skipped_steps() >= before + 2
+    tr.skipped_steps(reset=True)
+
+
 def test_tape_footprint_budget_keeps_the_step_call_by_call(monkeypatch):
     """A tape pins every buffer of its step; the tapes of a trainer stay under NNR_TAPE_MAX_GB (default: a quarter of the device's memory).
     A recording that would exceed it is discarded with a warning and the shape stays on the call-by-call native step -- same results."""
