@@ -1402,10 +1402,12 @@ static bool tn_pipe_ok(const nnr_gemm_args& g) {
 // tile and its four waves split the K range (wave w takes the 16-wide k-groups w, w+4, ...): 4x shorter chains, 4x more
 // workgroups, MFMA fragments loaded straight from global memory (no LDS staging, no barrier inside the loop), one LDS
 // reduction of the four partial tiles, then the same element-wise epilogue as the tiled kernel.
-template <bool TB>
-__global__ __launch_bounds__(256) void skinny_gemm_kernel(nnr_gemm_args g) {
+// NW waves split K (round 4: 8 / 16 waves for the few-tile, long-K launches of the dependent chain -- a wave's K share is a chain of
+// global-load round trips, 14 of them at K = 900 with 4 waves and one group in flight: 20-28 us for 0.9 GFLOP; and TWO groups in flight)
+template <bool TB, int NW>
+__global__ __launch_bounds__(64 * NW) void skinny_gemm_kernel(nnr_gemm_args g) {
   constexpr int TN = 5, BN = 16 * TN, E_LD = BN + 4;
-  __shared__ float red[4][16 * E_LD];
+  __shared__ float red[NW][16 * E_LD];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, kk = lane >> 4;
   const int nbn = (g.N + BN - 1) / BN;
   const int bm = blockIdx.x / nbn, bn = blockIdx.x - bm * nbn;
@@ -1458,21 +1460,26 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(nnr_gemm_args g) {
   f32x4 acc[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x4 af, bf[TN];
+  constexpr int KS = 16 * NW;                              // K covered by one round of the workgroup's waves
+  f32x4 af, bf[TN], a1 = {0.f, 0.f, 0.f, 0.f}, b1[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) b1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   int k0 = w * 16;
   if (k0 < K) load_frags(k0, af, bf);
-  for (; k0 < K; k0 += 64) {
+  if (k0 + KS < K) load_frags(k0 + KS, a1, b1);
+  for (; k0 < K; k0 += KS) {
     f32x4 an = {0.f, 0.f, 0.f, 0.f}, bn_[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) bn_[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (k0 + 64 < K) load_frags(k0 + 64, an, bn_);          // next group in flight under this group's MFMAs
+    if (k0 + 2 * KS < K) load_frags(k0 + 2 * KS, an, bn_);   // two groups in flight under this group's MFMAs
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j][i], acc[j], 0, 0, 0);
-    af = an;
+    af = a1;
+    a1 = an;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) bf[j] = bn_[j];
+    for (int j = 0; j < TN; ++j) { bf[j] = b1[j]; b1[j] = bn_[j]; }
   }
 #pragma unroll
   for (int j = 0; j < TN; ++j)
@@ -1480,11 +1487,14 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(nnr_gemm_args g) {
     for (int reg = 0; reg < 4; ++reg) red[w][(kk * 4 + reg) * E_LD + 16 * j + r] = acc[j][reg];
   __syncthreads();
   const float* mulp = g.mul;
-  for (int idx = tid; idx < 16 * BN; idx += 256) {
+  for (int idx = tid; idx < 16 * BN; idx += 64 * NW) {
     const int lr = idx / BN, c = idx - lr * BN;
     const int row = m0 + lr, col = n0 + c;
     if (row >= M || col >= N) continue;
-    float x = (red[0][lr * E_LD + c] + red[1][lr * E_LD + c] + red[2][lr * E_LD + c] + red[3][lr * E_LD + c]) * g.alpha;
+    float x = 0.f;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) x += red[q][lr * E_LD + c];          // fixed order
+    x *= g.alpha;
     if (g.accumulate == 2) x += C[(long)row * g.ldc + col];      // running sum BEFORE bias / activation
     if (g.bias) x += g.bias[col];
     if (g.rowvec) x += g.rowvec[(long)(g.rowvec_map ? g.rowvec_map[row] : row) * g.ldrv + col];
@@ -1505,9 +1515,17 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(nnr_gemm_args g) {
 }
 
 int launch_skinny(const nnr_gemm_args& g, hipStream_t s) {
-  dim3 grid(((g.M + 15) / 16) * ((g.N + 79) / 80), 1, g.batch > 1 ? g.batch : 1), block(256);
-  if (g.trans_b) hipLaunchKernelGGL((skinny_gemm_kernel<true>), grid, block, 0, s, g);
-  else hipLaunchKernelGGL((skinny_gemm_kernel<false>), grid, block, 0, s, g);
+  const int tiles = ((g.M + 15) / 16) * ((g.N + 79) / 80) * (g.batch > 1 ? g.batch : 1);
+  dim3 grid(((g.M + 15) / 16) * ((g.N + 79) / 80), 1, g.batch > 1 ? g.batch : 1);
+  static const int force = [] { const char* e = getenv("NNR_SKINNY_WAVES"); return e ? atoi(e) : 0; }();      // A/B: 4 = the round 1-3 kernel everywhere
+  int nw = 4;
+  if (tiles <= 640 && g.K >= 384) nw = 8;              // every workgroup resident at once (43 KB of LDS): 8 waves.  (16 waves for the handful-of-tiles
+                                                       // launches measured no better than 8 -- batch 8: 26.2 vs 23.6 us per launch incl. dispatch gaps, 28.7 with 4)
+  if (force == 4 || force == 8 || force == 16) nw = force;
+#define NNR_SKINNY(TBV, NWV) hipLaunchKernelGGL((skinny_gemm_kernel<TBV, NWV>), grid, dim3(64 * NWV), 0, s, g)
+  if (g.trans_b) { if (nw == 16) NNR_SKINNY(true, 16); else if (nw == 8) NNR_SKINNY(true, 8); else NNR_SKINNY(true, 4); }
+  else { if (nw == 16) NNR_SKINNY(false, 16); else if (nw == 8) NNR_SKINNY(false, 8); else NNR_SKINNY(false, 4); }
+#undef NNR_SKINNY
   NNR_CHECK_LAUNCH();
   return NNR_OK;
 }
