@@ -56,10 +56,10 @@ class _SUEFunction(torch.autograd.Function):
         return dhist, dcand, None, None, None, None
 
 
-_SUE_JOIN = os.environ.get('NNR_SUE_JOIN', '1') == '1'      # 1 (default) = the main stream waits for this encoder's weight-gradient GEMMs when its backward
-                                                             # returns; 0 = they are joined at the end of the step (round 4: measured neutral, 10.61-10.64 vs
-                                                             # 10.60-10.68 ms -- the ~150 us the main stream no longer waits are paid back by the news encoder's
-                                                             # first backward kernels sharing the chip with those GEMMs)
+_SUE_JOIN = os.environ.get('NNR_SUE_JOIN', '0') == '1'      # 0 (default) = this encoder's weight-gradient GEMMs (leaf stream) are joined at the end of the step; 1 = the main
+                                                             # stream waits for them when this encoder's backward returns (what a data-parallel early bucket needs: forced there).
+                                                             # Round 4, same box: batch 8 3.20-3.21 vs 3.33-3.40 ms (the main stream sat idle for ~200 us behind four 65 us GEMMs),
+                                                             # batch 16 4.35-4.40 vs 4.42-4.44, batch 64 10.43-10.49 vs 10.47-10.55 (an earlier A/B at batch 64 alone read neutral)
 _GCN_FUSED = os.environ.get('NNR_GCN_FUSED', '1') != '0'      # A/B: dedicated per-user aggregate kernel vs the batched tile GEMM
 _SUE_SIDE = os.environ.get('NNR_SUE_SIDE', '1') != '0'        # round 4: the candidate-side projections (inputs: the candidates only) and the candidate gradient's
                                                               # accumulations (read by nobody before the news encoder's backward) leave SUE's dependent chain for a side stream
