@@ -138,6 +138,7 @@ _LSTM_FWD_SPLIT = os.environ.get('NNR_LSTM_FWD_SPLIT', '0') == '1'      # A/B: t
 _PROJ_ORDER = os.environ.get('NNR_PROJ_ORDER', '0') == '1'      # A/B (round 4, with NNR_LSTM_FWD_SPLIT=1): the content projection waits for the title projection, so the
                                                                 # title recurrence runs UNDER the content projection instead of inside the shared recurrence launch
 _DWHH_FIRST = os.environ.get('NNR_DWHH_FIRST', '0') == '1'      # A/B (round 4): this stream's dW_hh GEMM in front of the embedding-row gradient GEMM + scatter instead of behind them
+_LEAF2_ROWS = int(os.environ.get('NNR_LEAF2_ROWS', '65536'))
 _POST_INLINE = os.environ.get('NNR_POST_INLINE', '0') == '1'      # A/B: the content stream's tail GEMMs on one HIP stream
 _DX_SPLIT = os.environ.get('NNR_DX_SPLIT', '1') == '1'      # embedding-row gradient as plain GEMM + scatter kernel (11.46 vs 11.51 ms fused)
 _BWD_SPLIT = os.environ.get('NNR_LSTM_BWD_SPLIT', '1') == '1'      # batch 8: 4.68 (split) vs 4.93 ms; batch 64: no difference
@@ -476,7 +477,7 @@ def _cne_bwd_rest(mod, pairs, H, dev, leaf):
 
 def _cne_bwd_pre(mod, sv, drep, par=False, leaf=None):
     if leaf is None:
-        leaf = lambda fn, *tensors: fn()
+        leaf = lambda fn, *tensors, **kw: fn()
     t_, c_ = sv['streams']
     n, p, seed = sv['n'], sv['p'], sv['seed']
     H, E, A = mod.hidden_dim, mod.word_embedding_dim, mod.attention_dim
@@ -491,6 +492,12 @@ def _cne_bwd_pre(mod, sv, drep, par=False, leaf=None):
     leaf(lambda: ops.fusion_rows_bwd(*sv['cats'], sv['cd'], sv['sd'], drep[:, 2 * H2:], D, grad_of(mod.category_embedding.weight),
                                      grad_of(mod.subCategory_embedding.weight), p, seed + _SITE['cat'], seed + _SITE['sub']), drep)
 
+    # the title stream's weight-gradient GEMMs on a SECOND leaf stream when the step is small and latency-bound (content stream <= 64 k token
+    # rows = per-GPU batch 8: the leaf stream was the last to finish, 3.27-3.31 -> 3.23-3.24 ms); at batch 16 neutral, at batch 64 -- where the
+    # leaf work is throughput-bound -- 0.1 ms SLOWER (10.72-10.77 vs 10.61-10.65), hence the bound
+    def alt_leaf(st):
+        return st['name'] == 'title' and c_['plan'].cap <= _LEAF2_ROWS
+
     # ---- cross attention pools: dHt (overwrite), dv -> K / Q params and the gradient of the OTHER stream's self vector
     def cross_bwd(st, other, col0):
         plan, ca, cap = st['plan'], st['catt'], st['plan'].cap
@@ -501,7 +508,7 @@ def _cne_bwd_pre(mod, sv, drep, par=False, leaf=None):
         dqv = torch.empty((n, A), **f32)
         ops.gemm(dv, ca.K.weight, dqv, M=n, N=A, K=H2, lda=H2, ldb=H2, ldc=A)                 # dqv = dv . K^T
         leaf(lambda: (ops.linear_bwd_weight(st['qv'], dv, grad_of(ca.K.weight)),             # dK[A,H2] += qv^T dv
-                      ops.linear_bwd_weight(dqv, other['selfv'], grad_of(ca.Q.weight), db=grad_of(ca.Q.bias))), dv, dqv)      # (bias gradient fused: column sums of dqv)
+                      ops.linear_bwd_weight(dqv, other['selfv'], grad_of(ca.Q.weight), db=grad_of(ca.Q.bias))), dv, dqv, alt=alt_leaf(st))      # (bias gradient fused: column sums of dqv)
         other['dself_x'] = ops.linear_bwd_data(dqv, ca.Q.weight)                              # grad of other.selfv via the query
 
     _two_chains(dev, par, lambda: cross_bwd(t_, c_, 0), lambda: cross_bwd(c_, t_, H2))
@@ -526,15 +533,15 @@ def _cne_bwd_pre(mod, sv, drep, par=False, leaf=None):
             ops.gemm(th, ops.wt(sa.affine1.weight), st['dHt'], M=cap, N=H2, K=A, lda=A, ldb=A, ldc=H2, accumulate=True,      # NT on W1^T
                      dyn=plan.total, dyn_dim=1)
             ops.gate_bwd(st['dHt'], st['hout'], st['G'], st['dH'], dpre, plan, H2)               # gate: Ht = hout * G
-        leaf(lambda: ops.linear_bwd_weight(th, st['Ht'], grad_of(sa.affine1.weight), dyn=plan.total, db=grad_of(sa.affine1.bias)), th, st['Ht'])
+        leaf(lambda: ops.linear_bwd_weight(th, st['Ht'], grad_of(sa.affine1.weight), dyn=plan.total, db=grad_of(sa.affine1.bias)), th, st['Ht'], alt=alt_leaf(st))
         ops.gemm(dpre, ops.wt(st['Hlin'].weight), st['dH'], M=cap, N=H2, K=H2, lda=H2, ldb=H2, ldc=H2, accumulate=True,   # NT on W_H^T
                  dyn=plan.total, dyn_dim=1, tile=_GATE_TILE)
-        leaf(lambda: ops.linear_bwd_weight(dpre, st['hout'], grad_of(st['Hlin'].weight), dyn=plan.total), dpre, st['hout'])
+        leaf(lambda: ops.linear_bwd_weight(dpre, st['hout'], grad_of(st['Hlin'].weight), dyn=plan.total), dpre, st['hout'], alt=alt_leaf(st))
         dP = torch.empty((n, H2), **f32)                  # d mproj[rank]
         ops.packed_seq_sum(dpre, H2, plan, dP)
         pm, opm = st['pm'], other['pm']                   # union of two calls: mproj[s] = M(cn_other[pm[s]])  (pm^-1 = other's pm)
         leaf(lambda: ops.linear_bwd_weight(dP, other['cn'], grad_of(st['Mlin'].weight), db=grad_of(st['Mlin'].bias),
-                                           **({} if pm is None else {'b_idx': pm})), dP)
+                                           **({} if pm is None else {'b_idx': pm})), dP, alt=alt_leaf(st))
         if opm is not None and _CN_SPLIT:
             other['dcn'] = ops.embed_gather(ops.linear_bwd_data(dP, st['Mlin'].weight), opm, 0.0, 0)            # [n, H2], rank-indexed
         else:

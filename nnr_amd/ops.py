@@ -112,6 +112,9 @@ STREAM_PRIO = int(os.environ.get('NNR_PRIO', '0'))
 
 
 STREAM_CACHES.append(_LEAF)
+_LEAF_ALT = {}
+STREAM_CACHES.append(_LEAF_ALT)
+LEAF2 = os.environ.get('NNR_LEAF2', '1') != '0'      # a second leaf stream for the title token stream's weight-gradient GEMMs (A/B)
 
 
 def join_extra_streams(dev=None):
@@ -142,28 +145,44 @@ class leaf_scope:
             if key not in _LEAF:
                 _LEAF[key] = new_stream(self.dev)
             self.leaf = _LEAF[key]
+            self.leaf2 = None
             self.main = torch.cuda.current_stream(self.dev)
         return self
 
-    def __call__(self, fn, *tensors):
+    def __call__(self, fn, *tensors, alt=False):
+        """alt: the SECOND leaf stream (LEAF2, round 4): leaf work of the title token stream, so that it does not queue behind the
+        content stream's on small, latency-bound steps."""
         if not self.enable:
             fn()
             return
-        self.leaf.wait_stream(torch.cuda.current_stream(self.dev))     # the producer of the inputs (may be a side stream)
+        st = self.leaf
+        if alt and LEAF2 and not ONE_STREAM[0]:
+            if self.leaf2 is None:
+                key = (self.dev.type, self.dev.index)
+                if key not in _LEAF_ALT:
+                    _LEAF_ALT[key] = new_stream(self.dev)
+                self.leaf2 = _LEAF_ALT[key]
+            st = self.leaf2
+        st.wait_stream(torch.cuda.current_stream(self.dev))     # the producer of the inputs (may be a side stream)
         self.keep.extend(tensors)
-        with torch.cuda.stream(self.leaf):
+        with torch.cuda.stream(st):
             fn()
 
     def sync(self):
         """Make the CURRENT stream wait for the leaf work issued so far (for a consumer in the middle of the scope)."""
         if self.enable:
-            torch.cuda.current_stream(self.dev).wait_stream(self.leaf)
+            cur = torch.cuda.current_stream(self.dev)
+            cur.wait_stream(self.leaf)
+            if self.leaf2 is not None:
+                cur.wait_stream(self.leaf2)
 
     def __exit__(self, *a):
         if self.enable and self.defer_join and a[0] is None:
             _DEFER['keep'].extend(self.keep)      # held until join_extra_streams(): the leaf stream may still be reading them
         elif self.enable:
             self.main.wait_stream(self.leaf)
+            if self.leaf2 is not None:
+                self.main.wait_stream(self.leaf2)
         self.keep = []                   # (dropped on the host after the join was ENQUEUED: later main-stream work is ordered behind it)
 
 
