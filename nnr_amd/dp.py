@@ -103,7 +103,35 @@ def _native_exchange():
         import warnings
         warnings.warn('nnr_amd.dp: ' + _native_state['why'])
         return None
-    _native = NativeExchange(rank, world_size())
+    # the communicator is exercised once before anything depends on it -- ncclCommInitRank + an 8-float all-reduce whose result every rank
+    # can check -- and the ranks agree on the outcome over the torch group: a binding that came up on some ranks only, or sums wrongly,
+    # is dropped by ALL of them in favour of torch.distributed's all_reduce (>= 2 RCCL ranks have never run where this build ran)
+    nx, ok, why = None, 1, ''
+    try:
+        nx = NativeExchange(rank, world_size())
+        if world_size() > 1:
+            probe_t = torch.ones(8, device='cuda', dtype=torch.float32)
+            nx.allreduce(probe_t)
+            torch.cuda.synchronize()
+            ok = 1 if float(probe_t[0]) == float(world_size()) and float(probe_t[7]) == float(world_size()) else 0
+            why = '' if ok else 'probe all-reduce returned %r on rank %d' % (float(probe_t[0]), rank)
+    except Exception as e:                # noqa: BLE001  (any failure of the optional binding means: use the fallback)
+        ok, why = 0, '%s: %s' % (type(e).__name__, e)
+    if world_size() > 1:
+        flag = torch.tensor([ok], device='cuda' if dist.get_backend() == 'nccl' else 'cpu', dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = int(flag.item())
+    if not ok:
+        if nx is not None:
+            try:
+                nx.close()
+            except Exception:             # noqa: BLE001
+                pass
+        _native_state['why'] = 'the C-ABI RCCL binding did not come up on every rank (%s): torch.distributed binding' % (why or 'another rank failed')
+        import warnings
+        warnings.warn('nnr_amd.dp: ' + _native_state['why'])
+        return None
+    _native = nx
     return _native
 
 
