@@ -67,5 +67,12 @@ out.append('Live vs rocprofv3 duration of the dominant family: the bench line\'s
            'launch\'s workgroups queue for CUs held by the other streams\' kernels (%.1f us between first wave and last wave in the rocprofv3 trace of the same command vs %.0f us between the events; with '
            'one stream %.1f us in the trace).  `roofline.frac` uses the event figure (the pessimistic one); `roofline.isolated` is the one-stream figure.' % (
                float(dom[0]['AverageNs']) / 1e3, r['avg_launch_us'], float(one[0]['AverageNs']) / 1e3))
+for b, n in (('b64', 'batch 64'), ('b8', 'per-GPU batch 8')):
+    f = os.path.join(P, 'r04f_soak_long_%s.json' % b)
+    if os.path.exists(f):
+        d = json.load(open(f))
+        ms = [v for k, v in d.items() if k.startswith('ms_per_step')][0]
+        out.append('\nLong soak at %s (`%s`): %d replayed steps, %.3f ms/step including the loss read-backs, %d recurrence exchange time-outs, %d skipped optimizer steps, parameters finite %s.'
+                   % (n, os.path.basename(f), d['steps'], ms, d['recurrence_exchange_timeouts'], d['adam_steps_skipped'], d['parameters_finite']))
 open(os.path.join(P, 'r04_summary.md'), 'w').write('\n'.join(out) + '\n')
 print('\n'.join(out)[:2600])
