@@ -344,6 +344,10 @@ int nnr_clip_adam(float* p, const float* g, float* m, float* v, long n, const fl
  * exchange).  The reference would go visibly NaN there (trainer.py:118-120); here the step is dropped and COUNTED -- poll this every few
  * hundred steps (synchronous device read); reset != 0 clears the counter. */
 int nnr_adam_skipped_steps(unsigned* host_out, int reset);
+/* The same count WITHOUT a synchronisation: nnr_clip_adam's kernel mirrors it into pinned, device-mapped host memory, so the value covers
+ * every optimizer step that has completed on the device.  Cheap enough to read after every step (Trainer.train_step does; with an event
+ * wait every NNR_SKIP_POLL-th step that bounds how far the host runs ahead, a skipped step is reported within 2 x NNR_SKIP_POLL steps). */
+int nnr_adam_skipped_peek(unsigned* host_out);
 
 /* ------------------------------------------------------------------------------------------------ data parallelism (RCCL over xGMI)
  * Replaces DistributedDataParallel's gradient all-reduce / parameter broadcast (trainer.py:212-219,297): one communicator per

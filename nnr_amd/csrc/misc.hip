@@ -768,6 +768,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   }
 }
 __device__ unsigned g_adam_skipped;          // optimizer steps skipped because the gradient norm was not finite (nnr_adam_skipped_steps)
+__device__ unsigned* g_adam_skipped_mirror;  // host-pinned, device-mapped copy of the count: read by nnr_adam_skipped_peek WITHOUT a synchronisation
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             long n, const float* __restrict__ sumsq, float grad_scale, float clip, float lr, float b1, float b2,
                             float eps, float wd, float bc1, float bc2_sqrt) {
@@ -776,7 +777,11 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   // reach the parameters or the moments: the step is skipped as a whole (torch's clip_grad_norm_ + Adam would write NaN into
   // all three, permanently)
   if (!isfinite(*sumsq)) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_adam_skipped, 1u);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      const unsigned c = atomicAdd(&g_adam_skipped, 1u) + 1u;
+      unsigned* mirror = g_adam_skipped_mirror;
+      if (mirror) __hip_atomic_store(mirror, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     return;
   }
   float coef = grad_scale;
@@ -1123,8 +1128,27 @@ extern "C" int nnr_sumsq(const float* g, long n, float* out_zeroed, hipStream_t 
   return NNR_OK;
 }
 
+// The mirror of g_adam_skipped in pinned host memory (one word per process, never freed): set up by the first nnr_clip_adam /
+// nnr_adam_skipped_peek call of the process.
+static unsigned* g_skip_mirror_host = nullptr;
+static int skip_mirror_init() {
+  static int state = 0;                      // 0 = not tried, 1 = ready, -1 = unavailable (peek then reports NNR_ERR_LAUNCH, the sync read still works)
+  if (state != 0) return state;
+  unsigned* host = nullptr;
+  unsigned* dev = nullptr;
+  if (hipHostMalloc(reinterpret_cast<void**>(&host), 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); state = -1; return state; }
+  *host = 0;
+  if (hipHostGetDevicePointer(reinterpret_cast<void**>(&dev), host, 0) != hipSuccess ||
+      hipMemcpyToSymbol(HIP_SYMBOL(g_adam_skipped_mirror), &dev, sizeof(dev)) != hipSuccess) {
+    (void)hipGetLastError(); (void)hipHostFree(host); state = -1; return state;
+  }
+  g_skip_mirror_host = host;
+  state = 1;
+  return state;
+}
 extern "C" int nnr_clip_adam(float* p, const float* g, float* m, float* v, long n, const float* sumsq, float grad_scale, float clip,
                              float lr, float beta1, float beta2, float eps, float weight_decay, int step, hipStream_t stream) {
+  skip_mirror_init();
   const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
   const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
   EW_LAUNCH(adam_kernel, n, p, g, m, v, n, sumsq, grad_scale, clip, lr, beta1, beta2, eps, weight_decay, bc1, bc2s);
@@ -1134,6 +1158,16 @@ extern "C" int nnr_adam_skipped_steps(unsigned* host_out, int reset) {
   unsigned v = 0;
   if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_adam_skipped), sizeof(v)) != hipSuccess) return NNR_ERR_LAUNCH;
   if (host_out) *host_out = v;
-  if (reset) { const unsigned z = 0; if (hipMemcpyToSymbol(HIP_SYMBOL(g_adam_skipped), &z, sizeof(z)) != hipSuccess) return NNR_ERR_LAUNCH; }
+  if (reset) {
+    const unsigned z = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_adam_skipped), &z, sizeof(z)) != hipSuccess) return NNR_ERR_LAUNCH;
+    if (g_skip_mirror_host) __atomic_store_n(g_skip_mirror_host, 0u, __ATOMIC_RELAXED);
+  }
+  return NNR_OK;
+}
+extern "C" int nnr_adam_skipped_peek(unsigned* host_out) {
+  // NO synchronisation: the count as of the last nnr_clip_adam launch that has COMPLETED and skipped (the kernel stores it to pinned host memory)
+  if (skip_mirror_init() != 1) return NNR_ERR_LAUNCH;
+  if (host_out) *host_out = __atomic_load_n(g_skip_mirror_host, __ATOMIC_RELAXED);
   return NNR_OK;
 }

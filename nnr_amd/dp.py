@@ -37,16 +37,14 @@ class NativeExchange:
     (any backend) when world > 1.  Default when the job's backend is "nccl" and world > 1 (see _native_wanted); NNR_DP_NATIVE=0 keeps
     `torch.distributed`'s all_reduce ("nccl" = the same RCCL)."""
 
-    def __init__(self, rank, world):
+    def __init__(self, rank, world, uid=None):
+        """uid: the 128-byte communicator id every rank already holds (see exchange_unique_id); None = make / fetch it here."""
         from . import _lib as L
         self.L, self.rank, self.world = L, rank, world
-        uid = (C.c_ubyte * 128)()
-        if rank == 0:
-            L.check(L.lib().nnr_dp_unique_id(uid), 'nnr_dp_unique_id')
-        if world > 1:
-            box = [bytes(uid)]
-            dist.broadcast_object_list(box, src=0)
-            uid = (C.c_ubyte * 128).from_buffer_copy(box[0])
+        if uid is None:
+            uid = exchange_unique_id(rank, world)
+            if uid is None:
+                raise RuntimeError('nnr_dp_unique_id failed on rank 0')
         self.ctx = C.c_void_p()
         L.check(L.lib().nnr_dp_init(uid, rank, world, C.byref(self.ctx)), 'nnr_dp_init')
 
@@ -65,8 +63,75 @@ class NativeExchange:
             self.ctx = C.c_void_p()
 
 
+def exchange_unique_id(rank, world):
+    """Rank 0 makes the RCCL unique id, every rank receives it over the torch.distributed group.  Rank 0 ALWAYS reaches the
+    broadcast (an empty id on failure), so a rank-0 failure is seen by every rank as `None` instead of leaving the others blocked
+    in the broadcast (round-4 advisor)."""
+    from . import _lib as L
+    raw = b''
+    if rank == 0:
+        uid = (C.c_ubyte * 128)()
+        try:
+            if L.lib().nnr_dp_unique_id(uid) == 0:
+                raw = bytes(uid)
+        except Exception:                 # noqa: BLE001
+            raw = b''
+    if world > 1:
+        box = [raw]
+        dist.broadcast_object_list(box, src=0)
+        raw = box[0]
+    if len(raw) != 128:
+        return None
+    return (C.c_ubyte * 128).from_buffer_copy(raw)
+
+
 _native = None
 _native_state = {'decided': False, 'why': ''}
+_PROBE_TIMEOUT_S = float(os.environ.get('NNR_DP_PROBE_TIMEOUT', '90'))
+
+
+def _agree(ok):
+    """MIN of `ok` over the ranks of the torch.distributed group."""
+    if world_size() > 1:
+        flag = torch.tensor([int(ok)], device='cuda' if dist.get_backend() == 'nccl' else 'cpu', dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = int(flag.item())
+    return int(ok)
+
+
+def _probe_native(rank, world, uid, timeout_s):
+    """ncclCommInitRank + an 8-float all-reduce on a WATCHDOG thread: both block without a time-out of their own, and a rank that
+    never arrives (it failed elsewhere, or RCCL stalls beside torch's communicator) would otherwise hang every other rank before
+    they reach the agreement.  After `timeout_s` the caller gives the binding up (the thread, a daemon blocked inside RCCL with the
+    GIL released, is abandoned; the process goes on with torch.distributed's all_reduce).  Returns (NativeExchange | None, ok, why)."""
+    import threading
+    res = {'nx': None, 'ok': 0, 'why': 'timed out after %.0f s inside ncclCommInitRank / the probe all-reduce' % timeout_s}
+    dev_index = torch.cuda.current_device()
+
+    def run():
+        try:
+            torch.cuda.set_device(dev_index)             # (the current device is per thread)
+            nx = NativeExchange(rank, world, uid)
+            res['nx'] = nx
+            ok, why = 1, ''
+            if world > 1:
+                st = torch.cuda.Stream(device=dev_index)
+                with torch.cuda.stream(st):
+                    probe_t = torch.ones(8, device='cuda', dtype=torch.float32)
+                    nx.allreduce(probe_t)
+                st.synchronize()
+                ok = 1 if float(probe_t[0]) == float(world) and float(probe_t[7]) == float(world) else 0
+                why = '' if ok else 'probe all-reduce returned %r on rank %d' % (float(probe_t[0]), rank)
+            res['ok'], res['why'] = ok, why
+        except Exception as e:            # noqa: BLE001  (any failure of the optional binding means: use the fallback)
+            res['ok'], res['why'] = 0, '%s: %s' % (type(e).__name__, e)
+
+    th = threading.Thread(target=run, name='nnr-dp-probe', daemon=True)
+    th.start()
+    th.join(timeout_s)
+    if th.is_alive():
+        return None, 0, res['why']
+    return res['nx'], res['ok'], res['why']
 
 
 def _native_wanted():
@@ -92,35 +157,30 @@ def _native_exchange():
     _native_state['decided'] = True
     from . import _lib as L
     rank = dist.get_rank() if dist.is_initialized() else 0
-    probe = (C.c_ubyte * 128)()
-    ok = 1 if L.lib().nnr_dp_unique_id(probe) == 0 else 0
-    if world_size() > 1:
-        flag = torch.tensor([ok], device='cuda' if dist.get_backend() == 'nccl' else 'cpu', dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        ok = int(flag.item())
+    try:
+        scratch = (C.c_ubyte * 128)()
+        ok = 1 if L.lib().nnr_dp_unique_id(scratch) == 0 else 0      # resolves RCCL (dlsym); the id itself is discarded
+    except Exception:                     # noqa: BLE001
+        ok = 0
+    ok = _agree(ok)
     if not ok:
         _native_state['why'] = 'RCCL could not be resolved by libnnr_hip.so on every rank: torch.distributed binding'
         import warnings
         warnings.warn('nnr_amd.dp: ' + _native_state['why'])
         return None
-    # the communicator is exercised once before anything depends on it -- ncclCommInitRank + an 8-float all-reduce whose result every rank
-    # can check -- and the ranks agree on the outcome over the torch group: a binding that came up on some ranks only, or sums wrongly,
-    # is dropped by ALL of them in favour of torch.distributed's all_reduce (>= 2 RCCL ranks have never run where this build ran)
-    nx, ok, why = None, 1, ''
-    try:
-        nx = NativeExchange(rank, world_size())
-        if world_size() > 1:
-            probe_t = torch.ones(8, device='cuda', dtype=torch.float32)
-            nx.allreduce(probe_t)
-            torch.cuda.synchronize()
-            ok = 1 if float(probe_t[0]) == float(world_size()) and float(probe_t[7]) == float(world_size()) else 0
-            why = '' if ok else 'probe all-reduce returned %r on rank %d' % (float(probe_t[0]), rank)
-    except Exception as e:                # noqa: BLE001  (any failure of the optional binding means: use the fallback)
-        ok, why = 0, '%s: %s' % (type(e).__name__, e)
-    if world_size() > 1:
-        flag = torch.tensor([ok], device='cuda' if dist.get_backend() == 'nccl' else 'cpu', dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        ok = int(flag.item())
+    # step 1: the communicator id (rank 0 always reaches the broadcast); agreed before anyone enters the blocking init
+    uid = exchange_unique_id(rank, world_size())
+    if not _agree(uid is not None):
+        _native_state['why'] = 'nnr_dp_unique_id failed: torch.distributed binding'
+        import warnings
+        warnings.warn('nnr_amd.dp: ' + _native_state['why'])
+        return None
+    # step 2: the communicator is exercised once before anything depends on it -- ncclCommInitRank + an 8-float all-reduce whose result
+    # every rank can check, on a watchdog thread with a time-out -- and the ranks agree on the outcome over the torch group: a binding that
+    # came up on some ranks only, stalls, or sums wrongly is dropped by ALL of them in favour of torch.distributed's all_reduce
+    # (>= 2 RCCL ranks have never run where this build ran)
+    nx, ok, why = _probe_native(rank, world_size(), uid, _PROBE_TIMEOUT_S)
+    ok = _agree(ok)
     if not ok:
         if nx is not None:
             try:
@@ -158,6 +218,9 @@ def allreduce_gradients(flat_grads):
         else:
             dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM)
     return 1.0 / w
+
+
+TOUCHED_MAX_BATCH = int(os.environ.get('NNR_DP_TOUCHED_MAX_BATCH', '16'))
 
 
 class GradientExchange:
@@ -206,8 +269,14 @@ class GradientExchange:
             pos = max(pos, b)
         if pos < total:
             self.late_spans.append((pos, total))
-        # touched-row exchange of the table bucket (opt-in, NNR_DP_TOUCHED_ROWS=1): see table_rows_exchange()
-        self.touched = os.environ.get('NNR_DP_TOUCHED_ROWS') == '1' and self.table_span is not None and table_param is not None and table_param.dim() == 2
+        # touched-row exchange of the table bucket (table_rows_exchange): decided BY RULE per step (begin_step) -- on when the per-GPU
+        # batch is <= TOUCHED_MAX_BATCH (16) and world > 1: there a step touches a few thousand of the V table rows (per-GPU batch 8 x 8
+        # ranks: ~18 of 72 MB) and is short enough (3 ms) for the dense 72 MB all-reduce to show; at larger per-GPU batches the dense
+        # bucket hides behind the backward tail and the union grows.  NNR_DP_TOUCHED_ROWS=1 / 0 forces it on / off.
+        e = os.environ.get('NNR_DP_TOUCHED_ROWS')
+        self.touched_capable = self.table_span is not None and table_param is not None and table_param.dim() == 2
+        self.touched_mode = 'auto' if e is None else ('on' if e == '1' else 'off')
+        self.touched = self.touched_capable and self.touched_mode == 'on'
         self.table_shape = tuple(table_param.shape) if table_param is not None else None
         self._flags = self._pos = self._count = self._packed = None
         self._noted = []              # events behind the nnr_rows_touch launches of this step (one per token stream)
@@ -226,13 +295,15 @@ class GradientExchange:
     def describe(self):
         es = self.early_span
         ts = self.table_span
-        extra = {}
+        extra = {'table_bucket_rule': 'touched rows when per-GPU batch <= %d and world > 1 (NNR_DP_TOUCHED_ROWS: %s)' % (TOUCHED_MAX_BATCH, self.touched_mode)}
         if self.touched:
-            extra['table_bucket'] = 'touched rows only (NNR_DP_TOUCHED_ROWS=1): flags [V] + packed [U, E] instead of [V, E]'
+            extra['table_bucket'] = 'touched rows only: flags [V] + packed [U, E] instead of [V, E]'
             if self.last_touched is not None:
                 U, V = self.last_touched
                 E = self.table_shape[1]
                 extra['touched_rows_last_step'] = {'rows': U, 'of': V, 'bytes': 4 * (V + U * E), 'dense_bytes': 4 * V * E}
+        elif ts is not None:
+            extra['table_bucket'] = 'dense [V, E] all-reduce'
         return {**extra, 'buckets': ([{'name': 'early (user encoder)', 'floats': es[1] - es[0]}] if es else []) +
                            ([{'name': 'table (word embedding)', 'floats': ts[1] - ts[0]}] if ts else []) +
                            [{'name': 'late', 'floats': sum(b - a for a, b in self.late_spans)}],
@@ -290,8 +361,11 @@ class GradientExchange:
             ops.tape_keep(self._flags, self._pos, self._count, self._packed)      # long-lived buffers a recording tape may point at
         return self._flags
 
-    def begin_step(self):
-        """Start of an optimizer step (before the forward pass): clear the touched-row flags."""
+    def begin_step(self, per_gpu_batch=None):
+        """Start of an optimizer step (before the forward pass): decide the form of the table bucket for THIS step (rule above; a
+        launch tape is per batch shape, so the decision is part of what it records) and clear the touched-row flags."""
+        if self.touched_mode == 'auto' and per_gpu_batch is not None:
+            self.touched = bool(self.touched_capable and per_gpu_batch <= TOUCHED_MAX_BATCH and world_size() > 1)
         if not (self.touched and self.active()):
             return
         flags = self._touch_buffers()
@@ -393,7 +467,11 @@ class GradientExchange:
             if self.events is not None:
                 self.events['table_issued'] = torch.cuda.Event(enable_timing=True)
                 self.events['table_issued'].record()
-            if self.touched and self._noted:
+            if self.touched:
+                # (NOT `and self._noted`: on a REPLAYED step note_tokens' Python never runs -- nnr_rows_touch and the flag fill are part
+                # of the tape --, and the exchange used to degrade silently to the dense all-reduce there; round-4 advisor.  Only CNE
+                # calls this hook, and it notes every token stream it scatters.  The events in _noted are an extra ordering edge of
+                # the eager step; the scatter events above already order this stream behind the forward pass that marked the rows.)
                 self.table_rows_exchange()
                 self._pending_table = (None, self._helper)
             else:

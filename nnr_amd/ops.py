@@ -128,6 +128,19 @@ def join_extra_streams(dev=None):
     _DEFER['queued'] = False             # (also the recovery path if a backward pass died before its end-of-pass callback ran)
 
 
+def join_leaf_streams(dev=None):
+    """Make the current stream wait for the leaf streams only (weight-gradient launches issued so far), leaving the side / title
+    streams alone.  The tensors those launches read stay held until the step's final join_extra_streams()."""
+    if dev is None:
+        dev = torch.device('cuda', torch.cuda.current_device())
+    cur = torch.cuda.current_stream(dev)
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    for table in (_LEAF, _LEAF_ALT):
+        st = table.get(key)
+        if st is not None and st is not cur:
+            cur.wait_stream(st)
+
+
 class leaf_scope:
     """with leaf_scope(device) as leaf:  leaf(fn, *input_tensors)  ...   -- joined on exit.
     defer_join: do NOT make the caller's stream wait for the leaf stream on exit; the leaf work (weight gradients nothing downstream

@@ -148,6 +148,12 @@ def forward_backward_mhsa(trainer, batch):
             dhist = _bwd(u1, dqkv)[0]
             hook = ue.__dict__.get('_grads_ready_hook')
             if hook is not None:
+                # The user encoder's weight gradients were issued on the leaf stream (ops.leaf_deferred under _DEFER['manual']) and are
+                # joined only at the end of the step.  The early bucket's all-reduce is ordered behind THIS stream only, so under data
+                # parallelism this stream first waits for the leaf streams (round-4 advisor, high: otherwise the collective could read
+                # -- and the leaf GEMMs / slab reductions later add into -- a half-written bucket).  sue_backward does the same (need_now).
+                if trainer.exchange.active():
+                    ops.join_leaf_streams(dev)
                 hook()
             if two:
                 side.wait_stream(main)

@@ -32,7 +32,7 @@ def _tape_budget_gb(dev):
         return 64.0
 
 
-_SKIP_POLL = int(os.environ.get('NNR_SKIP_POLL', '512'))
+_SKIP_POLL = int(os.environ.get('NNR_SKIP_POLL', '8'))
 _WARM_STEPS = 2          # eager steps before a tape is recorded (first-use allocations: workspaces, W^T copies, packed weights)
 
 
@@ -111,6 +111,8 @@ class Trainer:
         self.replay = (_REPLAY and (dp.world_size() == 1 or _REPLAY_DP)) if replay is None else bool(replay)
         self.tapes = {}              # batch-shape key -> nnr_amd.tape.Tape
         self._skipped_seen = None    # the library's skipped-step count (process-wide) when this trainer first polled / started
+        self._skip_event = None      # HIP event behind the step NNR_SKIP_POLL steps back (train_step)
+        self.skip_warnings = []      # (step_count at which it was noticed, library count) per warning
         self.unrecordable = set()    # batch-shape keys whose recording was discarded (tape.violations): they stay call by call
         self.tape_violations = []    # diagnostics: the violations of the last discarded recording
         self.native_steps = {}       # batch-shape key -> eager native steps run so far
@@ -140,20 +142,31 @@ class Trainer:
 
     def train_step(self, batch):
         """One optimizer step on `batch` (21 device tensors, Model.forward order).  Returns (logits, loss) as device
-        tensors -- no host synchronisation (the reference's float(loss) sync at trainer.py:115 is the caller's choice), except that
-        every NNR_SKIP_POLL-th step (default 512, 0 = never) reads the library's count of optimizer steps dropped for a non-finite
-        gradient norm and warns when it moved: a recurrence exchange time-out poisons its tile with NaN, nnr_clip_adam then leaves the
-        parameters untouched, and a loop that never polls skipped_steps() would train on silently (round-3 verdict)."""
-        if self._skipped_seen is None and batch[15].is_cuda:
+        tensors -- no host synchronisation (the reference's float(loss) sync at trainer.py:115 is the caller's choice).
+
+        Skipped optimizer steps (a recurrence exchange time-out poisons its tile with NaN, nnr_clip_adam then leaves the parameters
+        untouched) are reported within 2 x NNR_SKIP_POLL steps (default 8 -> 16; 0 = never): the clip+Adam kernel mirrors the
+        library's skipped-step count into pinned host memory, which is read after EVERY step without a synchronisation
+        (nnr_adam_skipped_peek); every NNR_SKIP_POLL-th step the host additionally waits for the event recorded NNR_SKIP_POLL
+        steps earlier (normally long complete), which bounds how far the host runs ahead of the device and so how stale the mirror
+        can be.  (Round 4 polled a synchronous device read every 512 steps: up to 511 silently skipped steps.)"""
+        gpu = batch[15].is_cuda
+        if self._skipped_seen is None and gpu:
             self._skipped_seen = self.skipped_steps()          # baseline (the counter is process-wide); one sync at the first step
         out = self._train_step(batch)
-        if _SKIP_POLL and self.step_count % _SKIP_POLL == 0 and batch[15].is_cuda:
-            n = self.skipped_steps()
-            if n > self._skipped_seen:
+        if _SKIP_POLL and gpu:
+            if self.step_count % _SKIP_POLL == 0:
+                prev, self._skip_event = self._skip_event, torch.cuda.Event()
+                self._skip_event.record()
+                if prev is not None:
+                    prev.synchronize()                         # the step NNR_SKIP_POLL steps back is complete: its count is in the mirror
+            n = self.skipped_peek()
+            if n is not None and n > self._skipped_seen:
                 import warnings
-                warnings.warn('nnr_amd: %d optimizer step(s) skipped so far because the gradient norm was not finite (recurrence exchange time-outs: %d)'
-                              % (n, ops.lstm_sync_timeouts()))
+                warnings.warn('nnr_amd: %d optimizer step(s) skipped so far because the gradient norm was not finite (recurrence exchange time-outs: %d); '
+                              'noticed at step %d' % (n, ops.lstm_sync_timeouts(), self.step_count))
                 self._skipped_seen = n
+                self.skip_warnings.append((self.step_count, n))
         return out
 
     def _train_step(self, batch):
@@ -163,7 +176,7 @@ class Trainer:
             if native_step.supported(model):
                 return self._native_train_step(batch, native_step)
         self.last_path = 'autograd'
-        self.exchange.begin_step()
+        self.exchange.begin_step(int(batch[0].shape[0]))
         self.flat.zero_grad()
         logits = model(*batch)
         loss = negative_log_softmax(logits)
@@ -196,7 +209,7 @@ class Trainer:
             torch.cuda.current_stream(self.flat.grad.device).wait_event(ev)
 
     def _body(self, batch, native_step):
-        self.exchange.begin_step()
+        self.exchange.begin_step(int(batch[0].shape[0]))
         self._zero_grad_aside()
         logits, loss = native_step.forward_backward(self, batch)
         scale = self.exchange.finish()
@@ -330,6 +343,16 @@ class Trainer:
         from . import _lib as L
         v = C.c_uint()
         L.check(L.lib().nnr_adam_skipped_steps(C.byref(v), int(reset)), 'nnr_adam_skipped_steps')
+        return int(v.value)
+
+    def skipped_peek(self):
+        """The skipped-step count as of the last COMPLETED optimizer step -- no synchronisation (pinned host mirror written by the
+        clip+Adam kernel); None when the mirror could not be set up (then only skipped_steps() works)."""
+        import ctypes as C
+        from . import _lib as L
+        v = C.c_uint()
+        if L.lib().nnr_adam_skipped_peek(C.byref(v)) != 0:
+            return None
         return int(v.value)
 
     def grad_total_norm(self, grad_scale=1.0):

@@ -18,7 +18,11 @@ Checks (rank 0 prints one JSON line; exit code 1 on failure):
      semantics of trainer.py:252-258 -- every rank draws the SAME negative samples (identical numpy seed, MIND_dataset.py:27-47),
      DistributedSampler.set_epoch(e) order (dp.sampler_indices), per-rank batch = batch_size // world, last partial batch kept --
      DeviceCorpus.train_batch -> Trainer.train_step on every rank, against the oracle stepping with the mean of the ranks' oracle
-     gradients: per-step loss of every rank and the final parameters."""
+     gradients: per-step loss of every rank and the final parameters;
+  D. MHSA+MHSA (BASELINE configs[1]) through the NATIVE step at a per-rank batch where the user encoder's weight-gradient GEMMs run on
+     the leaf stream (B * 50 * 32 >= ops.LEAF_MIN_ROWS): the exchanged gradient == the mean of the ranks' exchange-free shard
+     gradients, bit-identical on every rank, and the early bucket's all-reduce is ordered behind the leaf stream (round-4 advisor,
+     high: it was issued behind the main stream only)."""
 import argparse
 import json
 import os
@@ -41,6 +45,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--backend', default='gloo', choices=['gloo', 'nccl'])
 ap.add_argument('--skip_epoch', action='store_true')
 ap.add_argument('--only_epoch', action='store_true', help='diagnostics: part C only')
+ap.add_argument('--skip_mhsa', action='store_true', help='skip part D (MHSA+MHSA native step)')
 ap.add_argument('--trace2', action='store_true', help='diagnostics: device-side per-step checksums of the parameter buckets, compared at the end (no extra host sync)')
 ap.add_argument('--trace', action='store_true', help='diagnostics: per step, which bucket of the parameters differs between the ranks')
 args = ap.parse_args()
@@ -159,6 +164,49 @@ if not args.only_epoch:
         rccl_ranks = dist.get_world_size()
         assert dist.get_backend() == 'nccl'
 
+# --------------------------------------------------------------------------------------------- D: MHSA+MHSA native step, leaf-deferred weight gradients
+mhsa = None
+if not args.skip_mhsa and not args.only_epoch:
+    from nnr_amd import step as native_step
+    Bm = 32 * world                                              # per-rank 32: 32 * 50 * 32 = 51 200 token rows >= ops.LEAF_MIN_ROWS -> deferral on
+    mcfg = make_config(['--news_encoder=MHSA', '--user_encoder=MHSA', '--dataset=200k', '--batch_size=%d' % Bm, '--world_size=%d' % world],
+                       corpus_sizes=dict(vocabulary_size=3000), dropout_rate=0.2)
+    mfull = to_torch(SynthCorpus(SynthSpec(vocabulary_size=3000, news_pool=1500)).batch(Bm, np.random.default_rng(11)), dev)
+    mshard = dp.shard_batch(mfull, rank, world)
+
+    def mbuild():
+        torch.manual_seed(0)
+        m = Model(mcfg)
+        m.initialize()
+        return m.to(dev).train()
+
+    def native_grad(tr):
+        assert native_step.kind(tr.model) == 'mhsa'
+        tr.exchange.begin_step()
+        tr._zero_grad_aside()
+        before = ops._DEFER['calls']
+        native_step.forward_backward(tr, [t.clone() for t in mshard])
+        return tr.exchange.finish(), ops._DEFER['calls'] - before
+
+    t_no = Trainer(mbuild(), mcfg)
+    t_no.exchange.active = lambda: False
+    native_grad(t_no)
+    want = t_no.flat.grad.clone()
+    dist.all_reduce(want)
+    want /= world
+    worst, deferred = 0.0, 0
+    same = True
+    for rep in range(3):                                         # (the race was timing-dependent: a few repetitions)
+        t_ex = Trainer(mbuild(), mcfg)
+        assert t_ex.exchange.active() and t_ex.exchange.early_span is not None
+        sc, deferred = native_grad(t_ex)
+        got = t_ex.flat.grad * sc
+        torch.cuda.synchronize()
+        worst = max(worst, float((got - want).abs().max()) / max(1e-12, float(want.abs().max())))
+        same &= all_equal(t_ex.flat.grad.cpu().numpy())
+    mhsa = {'per_rank_batch': Bm // world, 'leaf_deferred_launches': deferred, 'grad_rel_err_vs_mean_of_shard_gradients': worst,
+            'gradients_identical_across_ranks': bool(same), 'ok': bool(worst <= 2e-5 and same and deferred > 0)}
+
 # --------------------------------------------------------------------------------------------- C: two epochs over a tiny corpus
 epoch = None
 if not args.skip_epoch:
@@ -257,13 +305,13 @@ if not args.skip_epoch:
     epoch['ok'] = epoch['ok'] and epoch['parameters_identical_across_ranks']
 
 tmo = ops.lstm_sync_timeouts()
-ok = err_prod <= 2e-5 and err_touched <= 2e-5 and err_oracle <= 1e-4 and params_same and (epoch is None or epoch['ok']) and tmo == 0
+ok = err_prod <= 2e-5 and err_touched <= 2e-5 and err_oracle <= 1e-4 and params_same and (epoch is None or epoch['ok']) and (mhsa is None or mhsa['ok']) and tmo == 0
 if rank == 0:
     print(json.dumps({'world': world, 'backend': args.backend, 'rccl_ranks': rccl_ranks, 'devices': torch.cuda.device_count(),
                       'binding': (trainer if args.only_epoch else tr).exchange.describe()['binding'], 'buckets': [b['name'] for b in (trainer if args.only_epoch else tr).exchange.describe()['buckets']],
                       'grad_rel_err_vs_mean_of_shard_gradients': err_prod, 'grad_err_vs_oracle_mean_of_shard_gradients': err_oracle,
                       'touched_rows': touched_stats, 'grad_rel_err_touched_row_exchange': err_touched,
-                      'worst_gradient': worst_name, 'recurrence_exchange_timeouts': tmo, 'parameters_identical_across_ranks': params_same, 'epoch': epoch, 'ok': bool(ok)}))
+                      'worst_gradient': worst_name, 'recurrence_exchange_timeouts': tmo, 'parameters_identical_across_ranks': params_same, 'mhsa_native': mhsa, 'epoch': epoch, 'ok': bool(ok)}))
 dist.barrier()
 dist.destroy_process_group()
 sys.exit(0 if ok else 1)

@@ -22,8 +22,11 @@ def _free_port():
 
 def _worker(rank, world, port, tag, out_dir, touched=False):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
-    if touched:
+    os.environ.pop('NNR_DP_TOUCHED_ROWS', None)
+    if touched is True:
         os.environ['NNR_DP_TOUCHED_ROWS'] = '1'
+    elif touched is False:
+        os.environ['NNR_DP_TOUCHED_ROWS'] = '0'
     import sys
     sys.path[:0] = [os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))]
     from nnr_amd import dp
@@ -45,9 +48,17 @@ def _worker(rank, world, port, tag, out_dir, touched=False):
     ue = model.user_encoder
     ex = dp.GradientExchange(flat, early_modules=[_Own(ue, [m for name, m in ue.named_children() if name != 'news_encoder'])],
                              table_param=model.news_encoder.word_embedding.weight)
-    assert ex.early_span is not None and ex.table_span is not None and ex.active() and ex.touched == touched
+    assert ex.early_span is not None and ex.table_span is not None and ex.active() and ex.touched == (touched is True)
     batch = dp.shard_batch(case.batch(), rank, world)
-    ex.begin_step()
+    if touched == 'auto':
+        # the RULE (no environment variable): touched rows when the per-GPU batch is <= 16 and world > 1, the dense bucket above that
+        assert ex.touched_mode == 'auto'
+        ex.begin_step(per_gpu_batch=64)
+        assert not ex.touched
+        ex.begin_step(per_gpu_batch=int(batch[0].shape[0]))
+        assert ex.touched and 'per-GPU batch <= 16' in ex.describe()['table_bucket_rule']
+    else:
+        ex.begin_step()
     flat.zero_grad()
     if touched:
         # what the HIP news encoder reports for each planned token stream (here: every id of the shard's four id tensors -- a superset
@@ -74,7 +85,7 @@ def _worker(rank, world, port, tag, out_dir, touched=False):
     torch.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize('tag,touched', [('tiny_CNE_SUE_stable', False), ('tiny_CNE_SUE_stable', True)])
+@pytest.mark.parametrize('tag,touched', [('tiny_CNE_SUE_stable', False), ('tiny_CNE_SUE_stable', True), ('tiny_CNE_SUE_stable', 'auto')])
 def test_two_rank_gradient_equals_full_batch(tag, touched, tmp_path):
     """touched=True: the word-embedding table's bucket goes out as a TOUCHED-ROW exchange (dp.GradientExchange.table_rows_exchange,
     NNR_DP_TOUCHED_ROWS=1: flag vectors summed over the ranks, the union's rows packed, all-reduced and written back) -- the dense

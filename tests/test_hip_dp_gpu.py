@@ -65,6 +65,8 @@ def _check(out, world):
     t = out['touched_rows']
     assert out['grad_rel_err_touched_row_exchange'] <= 2e-5
     assert t is not None and 0 < t['rows'] <= t['of'] == 3000 and t['bytes'] == 4 * (3000 + t['rows'] * 300) and t['dense_bytes'] == 4 * 3000 * 300
+    mh = out['mhsa_native']          # part D: MHSA+MHSA native step, user-encoder weight gradients on the leaf stream, early bucket behind them
+    assert mh['ok'] and mh['leaf_deferred_launches'] > 0 and mh['gradients_identical_across_ranks'] and mh['grad_rel_err_vs_mean_of_shard_gradients'] <= 2e-5
     ep = out['epoch']
     assert ep['negative_samples_identical_across_ranks'] and ep['sampler_covers_every_behaviour'] and ep['parameters_identical_across_ranks']
     assert ep['worst_loss_diff_vs_oracle'] <= 5e-5 and ep['steps_per_rank'] == 10
