@@ -68,7 +68,14 @@ def parse(argv=None):
     ap.add_argument('--no_isolated', action='store_true', help='skip the two serialised extra steps behind `roofline.isolated`')
     ap.add_argument('--sustained_seconds', type=float, default=3.0, help='after the K timed steps, keep stepping for this long (same '
                     'workload, no instrumentation) and report it as the `sustained` object: clocks under a multi-second load; 0 = skip')
+    ap.add_argument('--no_secondary', action='store_true', help='N = 1: skip the short secondary legs over the other BASELINE.json configs '
+                    '(`secondary`: mhsa_mhsa_b64, cne_sue_shard_b8, cne_sue_large_shard_b16_v130000)')
+    ap.add_argument('--secondary_steps', type=int, default=10)
+    ap.add_argument('--secondary_warmup', type=int, default=5, help='two call-by-call steps + the recording + one replay + the discarded timing '
+                    'replay: the timed steps of a secondary leg are all native replays, like the headline window')
     ap.add_argument('--cpu_baseline_batch', type=int, default=8)
+    ap.add_argument('--cpu_baseline_headline_steps', type=int, default=1, help='extra CPU-baseline steps at the HEADLINE batch (own thread probe), '
+                    'reported beside the bounded batch-8 sample; 0 = skip')
     ap.add_argument('--cpu_baseline_steps', type=int, default=2)
     ap.add_argument('--plumbing_check', action='store_true', help='CPU only (gloo): run the launcher + the product\'s flat-buffer / '
                     'exchange plumbing (trainer.FlatParams, nnr_amd.dp) on a stand-in module and print one JSON line; no HIP call')
@@ -115,7 +122,7 @@ def launch_ranks(a):
     return subprocess.call(cmd, env=env)
 
 
-def cpu_baseline(cfg, spec, batch_size, steps):
+def cpu_baseline(cfg, spec, batch_size, steps, headline_batch=0, headline_steps=1):
     """Time the CPU oracle (oracle/nnr_oracle.py, pinned against the reference by tests/golden) on this box's host cores.
     The Bi-LSTM runs through ATen's own packed-sequence LSTM -- the code path the reference's nn.LSTM takes on the host
     (newsEncoders.py:119-127) -- not through the oracle's explicit time loop (2.8x slower, kept as the parity checker)."""
@@ -154,10 +161,33 @@ def cpu_baseline(cfg, spec, batch_size, steps):
         O.train_step(model, opt, b, cfg.gradient_clip_norm)
         dt += time.perf_counter() - t0
         done += 1
-    return dict(value=round(done * batch_size / dt, 4), unit='impressions/s', cores=best, kind='port',
-                sample='%d optimizer steps of the same workload at batch %d (%.1f s of CPU work), oracle with ATen packed-sequence LSTM '
-                       '(= the reference\'s nn.LSTM host path), torch %s, %d of %d cores (probe s/step: %s)' %
-                       (done, batch_size, dt, torch.__version__, best, ncpu, {k: round(v, 2) for k, v in probe.items()}))
+    res = dict(value=round(done * batch_size / dt, 4), unit='impressions/s', cores=best, kind='port',
+               sample='%d optimizer steps of the same workload at batch %d (%.1f s of CPU work), oracle with ATen packed-sequence LSTM '
+                      '(= the reference\'s nn.LSTM host path), torch %s, %d of %d cores (probe s/step: %s)' %
+                      (done, batch_size, dt, torch.__version__, best, ncpu, {k: round(v, 2) for k, v in probe.items()}))
+    if headline_batch and headline_batch != batch_size and headline_steps > 0:
+        # the same oracle at the HEADLINE batch with its own thread probe (round-4 verdict: do more host cores help the reference
+        # there?): one step per candidate thread count {8, 32} (the batch-8 sample above warmed the process up); the best probe step counts as the first of `headline_steps` timed steps
+        hb, hprobe = None, {}
+        for c in sorted({min(ncpu, c) for c in (8, 32)}):
+            torch.set_num_threads(c)
+            t0 = time.perf_counter()
+            O.train_step(model, opt, to_torch(corpus.batch(headline_batch, rng)), cfg.gradient_clip_norm)
+            hprobe[c] = time.perf_counter() - t0
+            if hb is None or hprobe[c] < hprobe[hb]:
+                hb = c
+        torch.set_num_threads(hb)
+        hdt = hprobe[hb]                          # (a batch-64 oracle step is ~20 s: the best probe step is the first timed step)
+        for _ in range(headline_steps - 1):
+            b = to_torch(corpus.batch(headline_batch, rng))
+            t0 = time.perf_counter()
+            O.train_step(model, opt, b, cfg.gradient_clip_norm)
+            hdt += time.perf_counter() - t0
+        res['headline_batch'] = dict(batch=headline_batch, value=round(headline_steps * headline_batch / hdt, 4), unit='impressions/s', cores=hb,
+                                     steps=headline_steps, seconds=round(hdt, 2), probe_s_per_step={k: round(v, 2) for k, v in hprobe.items()})
+        res['sample'] += '; + %d step(s) at the headline batch %d on %d cores: %.2f impressions/s (probe s/step: %s)' % (
+            headline_steps, headline_batch, hb, res['headline_batch']['value'], res['headline_batch']['probe_s_per_step'])
+    return res
 
 
 def plumbing_check(a):
@@ -245,6 +275,18 @@ def measure_exchange(trainer, torch, dev, world, a):
         out['bus_gb_s_overall'] = round(tot * 2 * (world - 1) / world / (tms * 1e-3) / 1e9, 1) if tms > 0 else None
         out['frac_of_xgmi_peak'] = round(out['bus_gb_s_overall'] / (7 * 153), 3) if out['bus_gb_s_overall'] else None
         out['exposed_ms'] = ex.exposed_ms()
+        # the table bucket in BOTH forms (round-4 verdict, item 6c): dense [V, E] vs touched rows (flags [V] + packed [U, E]); which one
+        # the steps above used is decided by rule (per-GPU batch <= 16 and world > 1, dp.GradientExchange.begin_step)
+        if ex.table_span is not None and ex.table_shape is not None:
+            V, E = ex.table_shape
+            tb = {'rule': ex.describe().get('table_bucket_rule'), 'used': 'touched rows' if ex.touched else 'dense', 'dense_bytes': 4 * V * E}
+            if ex.last_touched is not None:
+                U = ex.last_touched[0]
+                tb.update(touched_rows_last_step=U, touched_bytes=4 * (V + U * E))
+            else:
+                tb.update(touched_rows_last_step=None, touched_bytes=None,
+                          note='the touched-row form did not run in this job (per-GPU batch above the rule\'s threshold); NNR_DP_TOUCHED_ROWS=1 forces it')
+            out['table_bucket'] = tb
         return out
     except Exception as e:                      # a measurement of its own: never take the headline line down with it
         return {'error': repr(e)}
@@ -295,6 +337,72 @@ def timed_run(a, trainer, fresh, steps, warmup, prof, dp, torch, dev, world, ins
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     return float(tmax), (_lib.CALLS[0] - calls0) / max(1, steps)
+
+
+SECONDARY_LEGS = (
+    # name, encoder pair, dataset, global batch / world of the BASELINE config, per-GPU batch, vocabulary
+    ('mhsa_mhsa_b64', 'MHSA', 'MHSA', '200k', 64, 1, 64, 60000),                       # BASELINE.json configs[1]
+    ('cne_sue_shard_b8', 'CNE', 'SUE', '200k', 64, 8, 8, 60000),                       # configs[3]: one GPU's shard of batch 64 over 8 GPUs
+    ('cne_sue_large_shard_b16_v130000', 'CNE', 'SUE', 'large', 128, 8, 16, 130000),    # configs[4]: MIND-large, batch 128 over 8 GPUs
+)
+
+
+def secondary_legs(a, prof, dp, torch, dev, rank_seed=0):
+    """N = 1: every other BASELINE.json config the GPU can run alone, each as a short driver-run leg on a FRESH model + trainer
+    (round-4 verdict, item 3): K = --secondary_steps native replays after --secondary_warmup steps, a fresh batch from the device-
+    resident corpus inside every step, the same barrier + synchronize bracket as the headline window.  Per leg: ms_per_step, value
+    (impressions/s of that per-GPU shard), step.frac (algorithmic GEMM + recurrence FLOPs of a step / step time / fp32 MFMA peak) and
+    the dominant kernel family; the MHSA leg adds `roofline_mhsa` (north_star's MFMA figure of the QK^T / PV contraction).  The
+    configs of BASELINE.json that need 8 GPUs appear as the PER-GPU SHARD they put on one MI355X (`shard_of`)."""
+    import argparse
+    import gc
+    import numpy as np
+    from nnr_amd.config import make_config
+    from nnr_amd.corpus import from_synth
+    from nnr_amd.model import Model
+    from nnr_amd.synth import SynthSpec, SynthCorpus
+    from nnr_amd.trainer import Trainer
+    out = {}
+    for name, ne, ue, dataset, gbatch, gworld, per_gpu, V in SECONDARY_LEGS:
+        t_leg = time.perf_counter()
+        try:
+            cfg = make_config(['--news_encoder=' + ne, '--user_encoder=' + ue, '--dataset=' + dataset, '--batch_size=%d' % gbatch,
+                               '--world_size=%d' % gworld], corpus_sizes=dict(vocabulary_size=V))
+            spec = SynthSpec(vocabulary_size=V)
+            torch.manual_seed(cfg.seed)
+            table = torch.randn(V, cfg.word_embedding_dim) * 0.3
+            table[0] = 0
+            model = Model(cfg, table)
+            model.initialize()
+            trainer = Trainer(model.to(dev).train(), cfg)
+            rng = np.random.default_rng(200 + rank_seed)
+            steps, warm = a.secondary_steps, a.secondary_warmup
+            dc = from_synth(SynthCorpus(spec), 2048, rng, dev, graph='build')
+            order = [torch.from_numpy(rng.permutation(2048)[:per_gpu].astype(np.int32)).to(dev) for _ in range(steps + warm)]
+            a2 = argparse.Namespace(**vars(a))
+            a2.roofline_every = max(1, steps // 2)
+            dt, calls = timed_run(a2, trainer, lambda i: dc.train_batch(order[i % len(order)]), steps, warm, prof, dp, torch, dev, 1, True)
+            sampled = len(range(0, steps, a2.roofline_every))
+            roof = prof.roofline(PEAK_F32_TFLOPS, sampled_steps=sampled, ms_per_step=1000 * dt / steps) or {}
+            leg = {'config': '%s+%s, --dataset=%s, dropout %.2f, V %d' % (ne, ue, dataset, cfg.dropout_rate, V),
+                   'shard_of': None if gworld == 1 else {'global_batch': gbatch, 'gpus': gworld},
+                   'per_gpu_batch': per_gpu, 'steps': steps, 'warmup': warm, 'ms_per_step': round(1000 * dt / steps, 3),
+                   'value': round(steps * per_gpu / dt, 2), 'unit': 'impressions/s (this GPU\'s shard)',
+                   'step': roof.get('step'), 'abi_calls_per_step': round(calls, 1), 'launch_path': launch_path(trainer)['path'],
+                   'dominant': {k: roof.get(k) for k in ('kernel', 'family', 'achieved', 'frac', 'avg_launch_us', 'launches', 'share_of_instrumented_time')} if roof else None}
+            if ne == 'MHSA':
+                leg['roofline_mhsa'] = prof.mhsa_roofline(PEAK_F32_TFLOPS)
+            for t in list(trainer.tapes.values()):
+                t.close()
+            trainer.tapes.clear()
+            del trainer, model, dc, order
+        except Exception as e:                  # a secondary measurement never takes the headline line down with it
+            leg = {'error': repr(e)}
+        gc.collect()
+        torch.cuda.empty_cache()
+        leg['leg_seconds'] = round(time.perf_counter() - t_leg, 1)
+        out[name] = leg
+    return out
 
 
 def main():
@@ -420,6 +528,10 @@ def main():
             other = {'scaling': 'strong' if weak else 'weak', 'global_batch': og_, 'per_gpu_batch': op_, 'value': round(a.steps * og_ / odt, 2),
                      'unit': 'impressions/s', 'ms_per_step': round(1000 * odt / a.steps, 3), 'abi_calls_per_step': round(ocalls, 1)}
 
+    secondary = None
+    if world == 1 and not a.no_secondary and headline:
+        secondary = secondary_legs(a, prof, dp, torch, dev)
+
     exchange_timeouts = ops.lstm_sync_timeouts()      # persistent device counter over EVERY pair-kernel launch of this process
     tmo = torch.tensor([exchange_timeouts], device=dev, dtype=torch.int64)
     if world > 1:
@@ -455,8 +567,11 @@ def main():
             out['exchange'] = exchange
         if other is not None:
             out['weak_scaling' if other['scaling'] == 'weak' else 'strong_scaling'] = other
+        if secondary is not None:
+            out['secondary'] = secondary
         if not a.no_cpu_baseline and world == 1:
-            out['cpu_baseline'] = cpu_baseline(cfg, spec, a.cpu_baseline_batch, a.cpu_baseline_steps)
+            out['cpu_baseline'] = cpu_baseline(cfg, spec, a.cpu_baseline_batch, a.cpu_baseline_steps,
+                                               headline_batch=per_gpu if a.cpu_baseline_headline_steps > 0 else 0, headline_steps=a.cpu_baseline_headline_steps)
         print(json.dumps(out))
         sys.stdout.flush()
     if world > 1:

@@ -170,6 +170,10 @@ class _GCNFunction(torch.autograd.Function):
         return dx, None, None
 
 
+CAPTURE = [None]      # diagnostics / parity tests: set CAPTURE[0] = [] and every sue_forward appends its saved state (ReLU outputs of the GCN
+                      # layers in sv['gcn']['rs'], of the cluster affine in sv['rc']); a replayed step rewrites the SAME buffers
+
+
 def sue_forward(mod, hist, cand, graph, cmask, cidx):
     B, Hn, D = hist.shape
     N = cand.shape[1]
@@ -235,6 +239,8 @@ def sue_forward(mod, hist, cand, graph, cmask, cidx):
     ops.pool_fwd(x=f2, ldx=D, D=D, n=B * N, Lx=Cn, mask=cmask, mask_div=N, v=v, ldv=D, scale=1.0 / math.sqrt(A), alpha=alpha_o, out=out,
                  ldo=D)
     sv.update(gfeat=gfeat, kf=kf, qc=qc, alpha_i=alpha_i, feat=feat, rc=rc, f2=f2, qv=qv, v=v, alpha_o=alpha_o)
+    if CAPTURE[0] is not None:
+        CAPTURE[0].append(sv)
     return out.view(B, N, D), sv
 
 

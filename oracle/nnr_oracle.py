@@ -65,6 +65,27 @@ def forced_dropout(x, p, training, keep=None):
     return x * (keep.to(x.dtype).reshape(x.shape) * (1.0 / (1.0 - p)))
 
 
+RELU_PROBE = None       # parity tests only: {'z': {}, 'u': {}, 'force': {site: bool mask} | None}, see probed_relu
+
+
+def probed_relu(z, site, u=None):
+    """torch.relu(z) -- plus, when a parity test set RELU_PROBE, a record of the pre-activation `z` (and of the affine layer's input
+    `u`) of this user-encoder ReLU site, and optionally the ReLU's active set FORCED to a given mask (y = z * mask, derivative = mask).
+    tests/test_hip_headline_gpu.py uses it to PROVE that a gradient deviation above the bar is a pre-activation that is zero to fp32
+    rounding and landed on the other side of the kink in the HIP path: the oracle is re-run with the product's active set and must then
+    agree at the strict bar.  Sites: 'gcn0'..'gcn{L-1}' (layers.py:285-292), 'affine' (userEncoders.py:91)."""
+    pr = RELU_PROBE
+    if pr is None:
+        return torch.relu(z)
+    pr['z'][site] = z.detach()
+    if u is not None:
+        pr['u'][site] = u.detach()
+    force = (pr.get('force') or {}).get(site)
+    if force is None:
+        return torch.relu(z)
+    return z * force.to(z.dtype).reshape(z.shape)
+
+
 def masked_softmax(scores, mask, dim):
     """softmax after masked_fill(mask==0, -1e9)  (layers.py:143,171,199)."""
     if mask is not None:
@@ -438,10 +459,11 @@ class GCNLayer(nn.Module):
         nn.init.zeros_(self.W.bias)
 
     def forward(self, x, graph):  # layers.py:285-292
-        y = self.W(torch.einsum('bij,bjd->bid', graph, x))
+        u = torch.einsum('bij,bjd->bid', graph, x)
+        y = self.W(u)
         if self.layer_norm:
             y = self.layer_normalization(y)
-        y = torch.relu(y)
+        y = probed_relu(y, getattr(self, '_site', 'gcn'), u)
         return y + x if self.residual else y
 
 
@@ -461,6 +483,7 @@ class GCN(nn.Module):
 
     def forward(self, x, graph):
         for i, layer in enumerate(self.gcn_layers):
+            layer._site = 'gcn%d' % i
             x = layer(x, graph)
             if i + 1 < len(self.gcn_layers):
                 x = forced_dropout(x, self.p, self.training, None if self.forced_keep is None else self.forced_keep.get(i))
@@ -519,7 +542,7 @@ class SUE(UserEncoder):
         denom = torch.einsum('bnj,bjc->bnc', e, member)               # per-cluster sums
         alpha = e / torch.gather(denom, 2, pick)
         feat = torch.einsum('bnj,bjc,bjd->bncd', alpha, member, g)    # empty clusters -> 0
-        feat = forced_dropout(torch.relu(self.clusterFeatureAffine(feat)) + feat, self.p, self.training, fk.get('affine'))
+        feat = forced_dropout(probed_relu(self.clusterFeatureAffine(feat), 'affine', feat) + feat, self.p, self.training, fk.get('affine'))
         C = self.cluster_num
         out = self.interClusterAttention(feat.reshape(B * N, C, D), cand.reshape(B * N, D),
                                          cmask.unsqueeze(1).expand(-1, N, -1).reshape(B * N, C))

@@ -82,3 +82,40 @@ def test_gradient_exchange_buckets_cover_the_flat_buffer_exactly_once():
     flat.grad.fill_(2.0)
     ex.early_ready()
     assert ex.finish() == 1.0 and float(flat.grad.min()) == 2.0
+
+
+def test_secondary_legs_name_every_other_baseline_config():
+    """`bench.py --gpus 1` reports every other BASELINE.json config it can run on one GPU under `secondary` (round-4 verdict, item 3).
+    CPU side of that contract: the leg table matches BASELINE.json's configs (encoder pair, dataset, global batch / GPU count ->
+    per-GPU shard, trainer.py:218), the reference's per-dataset overrides apply (config.py:85-94), and the plumbing line says which
+    keys a GPU run adds.  (The legs themselves need the MI355X; profiles/r05_bench.json is a driver-shaped run.)"""
+    sys.path.insert(0, ROOT)
+    import bench
+    from nnr_amd.config import make_config
+    base = json.load(open(os.path.join(ROOT, 'BASELINE.json')))['configs']
+    legs = {l[0]: l for l in bench.SECONDARY_LEGS}
+    assert list(legs) == ['mhsa_mhsa_b64', 'cne_sue_shard_b8', 'cne_sue_large_shard_b16_v130000']
+    # configs[1]: MHSA+MHSA, 200k, one GPU
+    assert 'MHSA' in base[1] and legs['mhsa_mhsa_b64'][1:4] == ('MHSA', 'MHSA', '200k') and legs['mhsa_mhsa_b64'][4:7] == (64, 1, 64)
+    # configs[3]: CNE+SUE, 200k, batch 64 over 8 GPUs -> 8 per GPU
+    assert 'batch_size=64, 8' in base[3] and legs['cne_sue_shard_b8'][4:7] == (64, 8, 8)
+    # configs[4]: CNE+SUE, large, batch 128 over 8 GPUs -> 16 per GPU, large vocabulary
+    assert 'batch_size=128, 8' in base[4] and legs['cne_sue_large_shard_b16_v130000'][3:8] == ('large', 128, 8, 16, 130000)
+    for name, ne, ue, dataset, gbatch, gworld, per_gpu, V in bench.SECONDARY_LEGS:
+        cfg = make_config(['--news_encoder=' + ne, '--user_encoder=' + ue, '--dataset=' + dataset, '--batch_size=%d' % gbatch,
+                           '--world_size=%d' % gworld], corpus_sizes=dict(vocabulary_size=V))
+        assert cfg.batch_size // cfg.world_size == per_gpu and cfg.vocabulary_size == V
+        assert abs(cfg.dropout_rate - (0.1 if dataset == 'large' else 0.2)) < 1e-12 and cfg.gcn_layer_num == 4
+    a = bench.parse([])
+    assert not a.no_secondary and a.secondary_steps == 10 and a.secondary_warmup >= 5      # >= 5: the timed steps are all native replays
+    committed = os.path.join(ROOT, 'profiles', 'r05_bench.json')
+    if os.path.exists(committed):                      # the shape of a real GPU line (committed with the round's profiles)
+        line = json.load(open(committed))
+        sec = line['secondary']
+        assert set(sec) == set(legs)
+        for name, leg in sec.items():
+            assert 'error' not in leg, (name, leg)
+            assert leg['ms_per_step'] > 0 and leg['value'] > 0 and 0 < leg['step']['frac'] < 1 and leg['per_gpu_batch'] == legs[name][6]
+        m = sec['mhsa_mhsa_b64']['roofline_mhsa']
+        assert m['mhsa_fwd']['mfma_tflops'] > 0 and m['mhsa_bwd']['mfma_tflops'] > 0
+        assert line['cpu_baseline']['headline_batch']['batch'] == 64
