@@ -73,6 +73,7 @@ def parse(argv=None):
     ap.add_argument('--secondary_steps', type=int, default=10)
     ap.add_argument('--secondary_warmup', type=int, default=5, help='two call-by-call steps + the recording + one replay + the discarded timing '
                     'replay: the timed steps of a secondary leg are all native replays, like the headline window')
+    ap.add_argument('--cpu_baseline_headline_threads', default='32', help='comma-separated intra-op thread counts probed at the headline batch')
     ap.add_argument('--cpu_baseline_batch', type=int, default=8)
     ap.add_argument('--cpu_baseline_headline_steps', type=int, default=1, help='extra CPU-baseline steps at the HEADLINE batch (own thread probe), '
                     'reported beside the bounded batch-8 sample; 0 = skip')
@@ -122,7 +123,7 @@ def launch_ranks(a):
     return subprocess.call(cmd, env=env)
 
 
-def cpu_baseline(cfg, spec, batch_size, steps, headline_batch=0, headline_steps=1):
+def cpu_baseline(cfg, spec, batch_size, steps, headline_batch=0, headline_steps=1, headline_threads='32'):
     """Time the CPU oracle (oracle/nnr_oracle.py, pinned against the reference by tests/golden) on this box's host cores.
     The Bi-LSTM runs through ATen's own packed-sequence LSTM -- the code path the reference's nn.LSTM takes on the host
     (newsEncoders.py:119-127) -- not through the oracle's explicit time loop (2.8x slower, kept as the parity checker)."""
@@ -167,9 +168,9 @@ def cpu_baseline(cfg, spec, batch_size, steps, headline_batch=0, headline_steps=
                       (done, batch_size, dt, torch.__version__, best, ncpu, {k: round(v, 2) for k, v in probe.items()}))
     if headline_batch and headline_batch != batch_size and headline_steps > 0:
         # the same oracle at the HEADLINE batch with its own thread probe (round-4 verdict: do more host cores help the reference
-        # there?): one step per candidate thread count {8, 32} (the batch-8 sample above warmed the process up); the best probe step counts as the first of `headline_steps` timed steps
+        # there?): one step per candidate thread count (--cpu_baseline_headline_threads, default 32 only: a batch-64 oracle step is 29 s on 32 and 41 s on 8 threads of the 256-core host, profiles/r05a_bench.json; the batch-8 sample above warmed the process up); the best probe step counts as the first of `headline_steps` timed steps
         hb, hprobe = None, {}
-        for c in sorted({min(ncpu, c) for c in (8, 32)}):
+        for c in sorted({min(ncpu, int(c)) for c in str(headline_threads).split(',')}):
             torch.set_num_threads(c)
             t0 = time.perf_counter()
             O.train_step(model, opt, to_torch(corpus.batch(headline_batch, rng)), cfg.gradient_clip_norm)
@@ -571,7 +572,8 @@ def main():
             out['secondary'] = secondary
         if not a.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(cfg, spec, a.cpu_baseline_batch, a.cpu_baseline_steps,
-                                               headline_batch=per_gpu if a.cpu_baseline_headline_steps > 0 else 0, headline_steps=a.cpu_baseline_headline_steps)
+                                               headline_batch=per_gpu if a.cpu_baseline_headline_steps > 0 else 0, headline_steps=a.cpu_baseline_headline_steps,
+                                               headline_threads=a.cpu_baseline_headline_threads)
         print(json.dumps(out))
         sys.stdout.flush()
     if world > 1:

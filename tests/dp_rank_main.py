@@ -198,13 +198,16 @@ if not args.skip_mhsa and not args.only_epoch:
     same = True
     for rep in range(3):                                         # (the race was timing-dependent: a few repetitions)
         t_ex = Trainer(mbuild(), mcfg)
-        assert t_ex.exchange.active() and t_ex.exchange.early_span is not None
+        assert t_ex.exchange.active()
+        # (in today's flat layout the MHSA user encoder's parameters are NOT contiguous -- the fused W_Q|W_K|W_V groups of both encoders go
+        # first --, so early_span is None and everything is reduced by finish() behind the step's final join; the leaf-stream join in front
+        # of the hook is what keeps the step correct if a layout change ever makes the early bucket exist: reported below)
         sc, deferred = native_grad(t_ex)
         got = t_ex.flat.grad * sc
         torch.cuda.synchronize()
         worst = max(worst, float((got - want).abs().max()) / max(1e-12, float(want.abs().max())))
         same &= all_equal(t_ex.flat.grad.cpu().numpy())
-    mhsa = {'per_rank_batch': Bm // world, 'leaf_deferred_launches': deferred, 'grad_rel_err_vs_mean_of_shard_gradients': worst,
+    mhsa = {'per_rank_batch': Bm // world, 'early_bucket': t_ex.exchange.early_span is not None, 'leaf_deferred_launches': deferred, 'grad_rel_err_vs_mean_of_shard_gradients': worst,
             'gradients_identical_across_ranks': bool(same), 'ok': bool(worst <= 2e-5 and same and deferred > 0)}
 
 # --------------------------------------------------------------------------------------------- C: two epochs over a tiny corpus
