@@ -187,6 +187,12 @@ typedef struct nnr_pool_args {
   /* forward only, instead of `score`: score[row] = <th[row, :A], w2>  (the w2 . tanh(.) of layers.py:168 computed in the pool's
    * own pass over the tokens; A <= 256, A % 4 == 0, th rows laid out like x) */
   const float* th; int ldth; int A; const float* w2;
+  /* backward only (round 5): the token gradient of a SECOND pool over the same x, folded into this call's ONE write of dx:
+   *   dx[row] = alpha[row] * (dout + dout2)  +  alpha_b[row] * dout_b[out index]  +  scale_b * dscore_b[row] * v_b[out index]
+   * CNE pools every token stream twice (self attention, layers.py:167-175, and cross attention, layers.py:196-203, newsEncoders.py:
+   * 132-137): the cross pool's backward (which must run first: its dv feeds the OTHER stream's self vector) is called with dx = NULL
+   * and only writes dscore / dv; the self pool's backward then writes dH~ once instead of write + read-modify-write.  All NULL / 0: off. */
+  const float* alpha_b; const float* dout_b; int lddo_b; const float* dscore_b; const float* v_b; int ldv_b; float scale_b;
 } nnr_pool_args;
 int nnr_attn_pool_fwd(const nnr_pool_args* a, hipStream_t stream);
 int nnr_attn_pool_bwd(const nnr_pool_args* a, hipStream_t stream);

@@ -48,7 +48,8 @@ class PoolArgs(C.Structure):
                 ('order', vp), ('mask', vp), ('mask_div', ci), ('score', vp), ('v', vp), ('ldv', ci), ('scale', cf),
                 ('alpha', vp), ('out', vp), ('ldo', ci), ('add_in', vp), ('ldadd', ci), ('dout', vp), ('lddo', ci),
                 ('dout2', vp), ('lddo2', ci), ('dx', vp), ('lddx', ci), ('dx_accumulate', ci), ('dscore', vp), ('dv', vp),
-                ('lddv', ci), ('th', vp), ('ldth', ci), ('A', ci), ('w2', vp)]
+                ('lddv', ci), ('th', vp), ('ldth', ci), ('A', ci), ('w2', vp),
+                ('alpha_b', vp), ('dout_b', vp), ('lddo_b', ci), ('dscore_b', vp), ('v_b', vp), ('ldv_b', ci), ('scale_b', cf)]
 
 
 # every symbol include/nnr_hip.h declares (tests check the .so exports all of them)

@@ -31,6 +31,8 @@ struct PoolArgs {
   float* dscore;
   float* dv; int lddv;
   const float* th; int ldth; int A; const float* w2;      // score = <th[row, :A], w2> computed here (forward)
+  // backward: a second pool's token gradient folded into the one write of dx (see nnr_pool_args)
+  const float* alpha_b; const float* dout_b; int lddo_b; const float* dscore_b; const float* v_b; int ldv_b; float scale_b;
 };
 
 __device__ __forceinline__ long item_row(const PoolArgs& a, int s, int t) {
@@ -246,6 +248,26 @@ __global__ __launch_bounds__(256) void pool_kernel(PoolArgs a) {
     f32x4 dvacc[MAXV];
 #pragma unroll
     for (int j = 0; j < MAXV; ++j) dvacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!a.dx && !(dot && a.dv)) return;        // nothing but dscore was wanted
+    // the second pool's terms (alpha_b * dout_b + scale_b * dscore_b * v_b): per-sequence vectors and per-token scalars
+    const bool two = a.alpha_b != nullptr;
+    f32x4 go2[MAXV], q2[MAXV];
+    float al2[MAXT], ds2[MAXT];
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+      const int c = lane + 64 * j;
+      go2[j] = q2[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (two && c < nv) {
+        go2[j] = *reinterpret_cast<const f32x4*>(a.dout_b + (long)oidx * a.lddo_b + 4 * c);
+        q2[j] = *reinterpret_cast<const f32x4*>(a.v_b + (long)oidx * a.ldv_b + 4 * c);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < MAXT; ++k) {
+      const int t = lane + 64 * k;
+      al2[k] = (two && t < len) ? a.alpha_b[item_row(a, s, t)] : 0.f;
+      ds2[k] = (two && t < len) ? a.dscore_b[item_row(a, s, t)] * a.scale_b : 0.f;
+    }
     for (int t0 = w * UR; t0 < len; t0 += NWV * UR) {
       f32x4 xv[UR][MAXV], old[UR][MAXV];
       long rows[UR];
@@ -267,11 +289,15 @@ __global__ __launch_bounds__(256) void pool_kernel(PoolArgs a) {
         if (t >= len) continue;
         const float alt = __shfl(t < 64 ? al[0] : al[1], t & 63, 64);
         const float dst = __shfl(t < 64 ? ds[0] : ds[1], t & 63, 64) * a.scale;
+        const float alt2 = __shfl(t < 64 ? al2[0] : al2[1], t & 63, 64);
+        const float dst2 = __shfl(t < 64 ? ds2[0] : ds2[1], t & 63, 64);
 #pragma unroll
         for (int j = 0; j < MAXV; ++j) {
           const int c = lane + 64 * j;
           if (c < nv) {
-            f32x4 g = alt * go[j] + old[u][j];
+            // (two: in the association the two-pass form used -- (alpha_b dout_b + dscore_b v_b) first, as the stored `old`)
+            const f32x4 prev = two ? (alt2 * go2[j] + dst2 * q2[j]) : old[u][j];
+            f32x4 g = alt * go[j] + prev;
             if (dot) {
               g += dst * q[j];
               dvacc[j] += dst * xv[u][j];
@@ -315,6 +341,7 @@ static PoolArgs to_args(const nnr_pool_args* p) {
   a.dout = p->dout; a.lddo = p->lddo; a.dout2 = p->dout2; a.lddo2 = p->lddo2;
   a.dx = p->dx; a.lddx = p->lddx; a.dx_accumulate = p->dx_accumulate; a.dscore = p->dscore; a.dv = p->dv; a.lddv = p->lddv;
   a.th = p->th; a.ldth = p->ldth; a.A = p->A; a.w2 = p->w2;
+  a.alpha_b = p->alpha_b; a.dout_b = p->dout_b; a.lddo_b = p->lddo_b; a.dscore_b = p->dscore_b; a.v_b = p->v_b; a.ldv_b = p->ldv_b; a.scale_b = p->scale_b;
   return a;
 }
 
@@ -342,5 +369,6 @@ extern "C" int nnr_attn_pool_bwd(const nnr_pool_args* p, hipStream_t stream) {
   int rc = pool_check(p);
   if (rc != NNR_OK) return rc;
   if (!p->dout || !p->alpha) return NNR_ERR_ARG;
+  if (p->alpha_b && (!p->dout_b || !p->dscore_b || !p->v_b || !p->dx || p->dx_accumulate || (p->lddo_b & 3) || (p->ldv_b & 3))) return NNR_ERR_ARG;
   return pool_launch<true>(p, stream);
 }

@@ -139,6 +139,7 @@ _PROJ_ORDER = os.environ.get('NNR_PROJ_ORDER', '0') == '1'      # A/B (round 4, 
                                                                 # title recurrence runs UNDER the content projection instead of inside the shared recurrence launch
 _DWHH_FIRST = os.environ.get('NNR_DWHH_FIRST', '0') == '1'      # A/B (round 4): this stream's dW_hh GEMM in front of the embedding-row gradient GEMM + scatter instead of behind them
 _LEAF2_ROWS = int(os.environ.get('NNR_LEAF2_ROWS', '65536'))
+_POOL_FUSED = os.environ.get('NNR_POOL_FUSED', '1') != '0'      # A/B (round 5): the two pools' token gradient in ONE write of dHt (see _cne_bwd_pre)
 _POST_INLINE = os.environ.get('NNR_POST_INLINE', '0') == '1'      # A/B: the content stream's tail GEMMs on one HIP stream
 _DX_SPLIT = os.environ.get('NNR_DX_SPLIT', '1') == '1'      # embedding-row gradient as plain GEMM + scatter kernel (11.46 vs 11.51 ms fused)
 _BWD_SPLIT = os.environ.get('NNR_LSTM_BWD_SPLIT', '1') == '1'      # batch 8: 4.68 (split) vs 4.93 ms; batch 64: no difference
@@ -498,13 +499,21 @@ def _cne_bwd_pre(mod, sv, drep, par=False, leaf=None):
     def alt_leaf(st):
         return st['name'] == 'title' and c_['plan'].cap <= _LEAF2_ROWS
 
-    # ---- cross attention pools: dHt (overwrite), dv -> K / Q params and the gradient of the OTHER stream's self vector
+    # ---- cross attention pools: dv -> K / Q params and the gradient of the OTHER stream's self vector.  Round 5 (_POOL_FUSED): this pass no
+    # longer writes dHt -- it leaves its per-token d score (ds_c) behind, and the self pool's backward below writes
+    # dHt = alpha_s d self + alpha_c d cross + scale ds_c v in ONE store (before: store here, read-modify-write there: 5 passes over
+    # [tokens, 400] for the two pools instead of 3; the cross pool must still run first, its dv feeds the other stream's self vector)
     def cross_bwd(st, other, col0):
         plan, ca, cap = st['plan'], st['catt'], st['plan'].cap
-        st['dHt'] = torch.empty((cap, H2), **f32)
         dv = torch.empty((n, H2), **f32)
-        ops.pool_bwd(x=st['Ht'], ldx=H2, D=H2, n=n, Lx=st['L'], plan=plan, v=st['v'], ldv=H2, scale=1.0 / math.sqrt(A),
-                     alpha=st['alpha_c'], dout=drep[:, col0:], lddo=D, dx=st['dHt'], lddx=H2, dv=dv, lddv=H2)
+        if _POOL_FUSED:
+            st['ds_c'] = torch.empty(cap, **f32)
+            ops.pool_bwd(x=st['Ht'], ldx=H2, D=H2, n=n, Lx=st['L'], plan=plan, v=st['v'], ldv=H2, scale=1.0 / math.sqrt(A),
+                         alpha=st['alpha_c'], dout=drep[:, col0:], lddo=D, dscore=st['ds_c'], dv=dv, lddv=H2)
+        else:
+            st['dHt'] = torch.empty((cap, H2), **f32)
+            ops.pool_bwd(x=st['Ht'], ldx=H2, D=H2, n=n, Lx=st['L'], plan=plan, v=st['v'], ldv=H2, scale=1.0 / math.sqrt(A),
+                         alpha=st['alpha_c'], dout=drep[:, col0:], lddo=D, dx=st['dHt'], lddx=H2, dv=dv, lddv=H2)
         dqv = torch.empty((n, A), **f32)
         ops.gemm(dv, ca.K.weight, dqv, M=n, N=A, K=H2, lda=H2, ldb=H2, ldc=A)                 # dqv = dv . K^T
         leaf(lambda: (ops.linear_bwd_weight(st['qv'], dv, grad_of(ca.K.weight)),             # dK[A,H2] += qv^T dv
@@ -517,8 +526,15 @@ def _cne_bwd_pre(mod, sv, drep, par=False, leaf=None):
     def self_gate_bwd(st, other, col0):
         plan, sa, cap = st['plan'], st['satt'], st['plan'].cap
         ds = torch.empty(cap, **f32)
-        ops.pool_bwd(x=st['Ht'], ldx=H2, D=H2, n=n, Lx=st['L'], plan=plan, score=None, alpha=st['alpha_s'],
-                     dout=drep[:, col0:], lddo=D, dout2=st['dself_x'], lddo2=H2, dx=st['dHt'], lddx=H2, dx_accumulate=True, dscore=ds)
+        if _POOL_FUSED:
+            st['dHt'] = torch.empty((cap, H2), **f32)
+            ops.pool_bwd(x=st['Ht'], ldx=H2, D=H2, n=n, Lx=st['L'], plan=plan, score=None, alpha=st['alpha_s'],
+                         dout=drep[:, col0:], lddo=D, dout2=st['dself_x'], lddo2=H2, dx=st['dHt'], lddx=H2, dscore=ds,
+                         alpha_b=st['alpha_c'], dout_b=drep[:, col0:], lddo_b=D, dscore_b=st['ds_c'], v_b=st['v'], ldv_b=H2, scale_b=1.0 / math.sqrt(A))
+            st['ds_c'] = None
+        else:
+            ops.pool_bwd(x=st['Ht'], ldx=H2, D=H2, n=n, Lx=st['L'], plan=plan, score=None, alpha=st['alpha_s'],
+                         dout=drep[:, col0:], lddo=D, dout2=st['dself_x'], lddo2=H2, dx=st['dHt'], lddx=H2, dx_accumulate=True, dscore=ds)
         th = st['th']
         ops.tanh_score_bwd(th, ds, sa.affine2.weight, grad_of(sa.affine2.weight), plan, A)    # th := dpre
         st['dH'] = torch.empty((cap, H2), **f32)

@@ -747,7 +747,7 @@ def lstm_bwd(items, H):
 # ---------------------------------------------------------------------------------------------- pooling
 def _pool_args(x, ldx, D, n, Lx, plan=None, mask=None, mask_div=1, score=None, v=None, ldv=0, scale=1.0, alpha=None, out=None,
                ldo=0, add_in=None, ldadd=0, dout=None, lddo=0, dout2=None, lddo2=0, dx=None, lddx=0, dx_accumulate=False,
-               dscore=None, dv=None, lddv=0, th=None, w2=None):
+               dscore=None, dv=None, lddv=0, th=None, w2=None, alpha_b=None, dout_b=None, lddo_b=0, dscore_b=None, v_b=None, ldv_b=0, scale_b=1.0):
     a = L.PoolArgs()
     a.x, a.ldx, a.D, a.n, a.L = _p(x), ldx, D, n, Lx
     a.packed = int(plan is not None)
@@ -762,6 +762,8 @@ def _pool_args(x, ldx, D, n, Lx, plan=None, mask=None, mask_div=1, score=None, v
     a.dx, a.lddx, a.dx_accumulate, a.dscore, a.dv, a.lddv = _p(dx), lddx, int(dx_accumulate), _p(dscore), _p(dv), lddv
     if th is not None:            # forward: score = <th[row], w2> inside the pool's pass (instead of a separate nnr_rowdot launch)
         a.th, a.ldth, a.A, a.w2 = _p(th), th.stride(0), th.shape[1], _p(w2)
+    if alpha_b is not None:       # backward: a second pool's token gradient folded into this call's one write of dx (csrc/pool.hip)
+        a.alpha_b, a.dout_b, a.lddo_b, a.dscore_b, a.v_b, a.ldv_b, a.scale_b = _p(alpha_b), _p(dout_b), lddo_b, _p(dscore_b), _p(v_b), ldv_b, float(scale_b)
     return a
 
 
@@ -782,7 +784,7 @@ def pool_fwd(**kw):
 
 
 def pool_bwd(**kw):
-    with _pool_span('pool_bwd', kw, 3 if kw.get('dx_accumulate') else 2):
+    with _pool_span('pool_bwd', kw, (3 if kw.get('dx_accumulate') else 2) if kw.get('dx') is not None else 1):
         L.check(L.lib().nnr_attn_pool_bwd(C.byref(_pool_args(**kw)), _s()), 'nnr_attn_pool_bwd')
 
 

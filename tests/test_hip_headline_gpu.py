@@ -348,7 +348,7 @@ def test_relu_kink_proof_rejects_a_real_error_and_accepts_a_forced_flip():
     z = probe['z']['gcn1']
     flat = z.abs().reshape(-1)
     j = int(flat.argmin())
-    hip = _hip_relu_masks(captured[-1], 4, batch[15].shape[1])
+    hip = _hip_relu_masks(captured[-1], 4, batch['news_title_text'].shape[1])
     same = all(bool((hip[s_].view(probe['z'][s_].shape) == (probe['z'][s_] > 0)).all()) for s_ in hip)
     print('kink proof self-test: smallest |z| at gcn1 = %.3e; HIP and oracle active sets identical: %s' % (float(flat[j]), same))
     # (b) a real error: 3 bars on one element of a small bias gradient

@@ -659,6 +659,69 @@ def test_pool_packed_forward_backward(dot):
         close(gs, scr.grad, what='pool dscore')
 
 
+def test_pool_backward_of_two_pools_in_one_write():
+    """CNE pools every token stream twice (additive self attention, layers.py:167-175; candidate cross attention, layers.py:196-203;
+    newsEncoders.py:132-137).  Round 5: the cross pool's backward runs with dx = NULL (it leaves d score and dv), the self pool's backward
+    then writes  dx = alpha_s (dout + dout2) + alpha_c dout_b + scale dscore_c v  in ONE store.  Checked against fp64 autograd of the sum of
+    both pools, and against the two-pass form (store, then read-modify-write) of rounds 1-4."""
+    from nnr_amd import ops
+    d = dev()
+    n, Lx, D = 37, 128, 400
+    lens = _lengths(n, Lx, 5)
+    mask = torch.arange(Lx)[None, :] < lens[:, None]
+    plan = ops.SeqPlan(mask.clone().to(d), None)
+    off, rank = plan.off.cpu().long(), plan.rank.cpu().long()
+    rows = off[:Lx][None, :] + rank[:, None]
+    cap = plan.cap
+    x = rnd(n, Lx, D, seed=1)
+    xp = torch.zeros(cap, D)
+    xp[rows[mask]] = x[mask]
+    v = rnd(n, D, seed=2, scale=0.2)
+    sc = rnd(n, Lx, seed=3)
+    scale = 0.31
+    xr, vr, scr = x.double().requires_grad_(True), v.double().requires_grad_(True), sc.double().requires_grad_(True)
+    out_s, _ = _softmax_pool_ref(xr, scr, mask)
+    out_c, _ = _softmax_pool_ref(xr, scale * torch.einsum('nld,nd->nl', xr, vr), mask)
+    dout, dout2 = rnd(n, D, seed=5), rnd(n, D, seed=6)
+    (out_s * (dout + dout2).double() + out_c * dout.double()).sum().backward()
+    f32 = dict(device=d, dtype=torch.float32)
+    xd, vd = xp.to(d), v.to(d)
+    scp = torch.zeros(cap)
+    scp[rows[mask]] = sc[mask]
+    alpha_s, alpha_c = torch.zeros(cap, **f32), torch.zeros(cap, **f32)
+    out = torch.empty(n, D, **f32)
+    base = dict(x=xd, ldx=D, D=D, n=n, Lx=Lx, plan=plan)
+    ops.pool_fwd(out=out, ldo=D, score=scp.to(d), alpha=alpha_s, **base)
+    ops.pool_fwd(out=out, ldo=D, v=vd, ldv=D, scale=scale, alpha=alpha_c, **base)
+    dd, dd2 = dout.to(d), dout2.to(d)
+    # two passes (rounds 1-4)
+    dx2 = torch.empty(cap, D, **f32)
+    dv2 = torch.empty(n, D, **f32)
+    ds2 = torch.zeros(cap, **f32)
+    ops.pool_bwd(alpha=alpha_c, v=vd, ldv=D, scale=scale, dout=dd, lddo=D, dx=dx2, lddx=D, dv=dv2, lddv=D, **base)
+    ops.pool_bwd(alpha=alpha_s, dout=dd, lddo=D, dout2=dd2, lddo2=D, dx=dx2, lddx=D, dx_accumulate=True, dscore=ds2, **base)
+    # one write (round 5)
+    dx1 = torch.full((cap, D), 7.0, **f32)
+    dv1 = torch.empty(n, D, **f32)
+    ds_c = torch.zeros(cap, **f32)
+    ds1 = torch.zeros(cap, **f32)
+    ops.pool_bwd(alpha=alpha_c, v=vd, ldv=D, scale=scale, dout=dd, lddo=D, dscore=ds_c, dv=dv1, lddv=D, **base)
+    ops.pool_bwd(alpha=alpha_s, dout=dd, lddo=D, dout2=dd2, lddo2=D, dx=dx1, lddx=D, dscore=ds1,
+                 alpha_b=alpha_c, dout_b=dd, lddo_b=D, dscore_b=ds_c, v_b=vd, ldv_b=D, scale_b=scale, **base)
+    got = torch.zeros(n, Lx, D, dtype=torch.float64)
+    got[mask] = dx1.cpu().double()[rows[mask]]
+    close(got, xr.grad, what='two pools, one write: dx')
+    close(dv1, vr.grad, what='two pools: dv')
+    gs = torch.zeros(n, Lx, dtype=torch.float64)
+    gs[mask] = ds1.cpu().double()[rows[mask]]
+    close(gs, scr.grad, what='two pools: dscore (self)')
+    live = rows[mask]
+    assert torch.equal(dv1, dv2) and torch.equal(ds1, ds2)
+    assert float((dx1[live.to(d)] - dx2[live.to(d)]).abs().max()) <= 1e-6 * float(dx2.abs().max())      # same terms, possibly another fma contraction
+    with pytest.raises(Exception):          # incomplete second-pool arguments are refused
+        ops.pool_bwd(alpha=alpha_s, dout=dd, lddo=D, dx=dx1, lddx=D, alpha_b=alpha_c, **base)
+
+
 def test_pool_dense_masked_dot():
     from nnr_amd import ops
     d = dev()
