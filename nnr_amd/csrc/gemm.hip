@@ -848,6 +848,329 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_pipe2_kernel(nnr_gemm_args g
   gemm_epilogue<TM, TN>(g, acc, lds, C, m0, n0, M, N, z);
 }
 
+// ------------------------------------------------------------------------------------------------ third-generation NT loop (round 5)
+// gemm_nt_pipe2_kernel's stage loop made PERSISTENT and CONTINUOUS across tiles.  A workgroup walks tiles b, b + grid, b + 2 grid ...
+// of the XCD-aware order; the LDS-DMA pipeline never drains at a tile boundary -- the first NS - 1 stages of the NEXT tile are issued
+// during the last NS - 1 stages of the current one (into the stage buffers its reads have left), and the epilogue runs out of the
+// accumulator REGISTERS (no LDS staging: a 4 x 4 lane transpose by DPP gives every lane four consecutive columns of one row, so all
+// global traffic of the epilogue is float4), between the last MFMA block of a tile and the first of the next, whose fragments are
+// already in registers.  The short-reduction GEMMs of the step (K = 200-400: 25 / 13 stages of 16 / 32) paid a cold pipeline
+// (DMA round trip) and an LDS-staged epilogue with two barriers per 64 rows on every tile, all workgroups of a CU in lockstep.
+// Same MFMA order as the other NT kernels (results are bit-identical for the same tile); epilogue = the float4 path of
+// gemm_epilogue (vec_epi launches only: the dispatcher sends everything else to the older kernels).
+__device__ __forceinline__ float quad_xor1(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true)); }   // lanes 1,0,3,2
+__device__ __forceinline__ float quad_xor2(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, true)); }   // lanes 2,3,0,1
+// lane i of a quad holds a[0..3]; afterwards it holds element i of lanes 0..3 (4 x 4 transpose inside every quad of lanes)
+__device__ __forceinline__ f32x4 quad_transpose(f32x4 a, int lane) {
+  const bool x = lane & 1, y = lane & 2;
+  const float s0 = quad_xor1(a[0]), s1 = quad_xor1(a[1]), s2 = quad_xor1(a[2]), s3 = quad_xor1(a[3]);
+  const float b0 = x ? s1 : a[0], b1 = x ? a[1] : s0, b2 = x ? s3 : a[2], b3 = x ? a[3] : s2;
+  const float t0 = quad_xor2(b0), t1 = quad_xor2(b1), t2 = quad_xor2(b2), t3 = quad_xor2(b3);
+  return f32x4{y ? t2 : b0, y ? t3 : b1, y ? b2 : t0, y ? b3 : t1};
+}
+
+// Epilogue of one tile straight from the accumulators.  acc[m][n] = rows (w*TM + m)*16 + kk*4 + reg, column n*16 + r of the tile.
+// The element-wise operands a launch reads (PRE: pre_add, CO: the old C of accumulate = 1 / 2, MU: mul, RE: resid, RV: rowvec) are
+// template flags: the loads of a whole row group (TN float4 per operand) are issued together, BEFORE the arithmetic and the stores of the
+// group -- one round trip per 16 rows instead of one per 16 x 16 block.  The kernel picks the instantiation by (uniform) launch flags;
+// combinations outside the list take the all-flags-off instantiation's serial loads (GEN).
+template <int TM, int TN, bool PRE, bool CO, bool MU, bool RE, bool RV, bool GEN>
+__device__ __forceinline__ void gemm_epilogue_reg(const nnr_gemm_args& g, f32x4 (&acc)[TM][TN], float* __restrict__ C, int m0, int n0, int M,
+                                                  int N, int z, int lane, int w) {
+  const int r = lane & 15, kk = lane >> 4;
+  const uint32_t dthr = g.drop_thresh;
+  const float dscale = g.drop_scale;
+  float* __restrict__ aux = g.aux_out;
+  const float* __restrict__ res = g.resid;
+  const float* __restrict__ mulp = g.mul;
+  if (g.batch > 1) {
+    if (aux) aux += (long)z * g.stride_aux;
+    if (res) res += (long)z * g.stride_res;
+  }
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int m = 0; m < TM; ++m) {
+    const int row = m0 + (w * TM + m) * 16 + kk * 4 + (r & 3);
+    const bool rok = row < M;
+    const int rvrow = (g.rowvec && rok) ? (g.rowvec_map ? g.rowvec_map[row] : row) : 0;
+    f32x4 p_pre[PRE ? TN : 1], p_co[CO ? TN : 1], p_mu[MU ? TN : 1], p_re[RE ? TN : 1], p_rv[RV ? TN : 1], p_bi[TN];
+#pragma unroll
+    for (int n = 0; n < TN; ++n) {
+      const int col = n0 + n * 16 + 4 * (r >> 2);
+      const bool ok = rok && col < N;
+      if constexpr (PRE) p_pre[n] = ok ? *reinterpret_cast<const f32x4*>(g.pre_add + (long)row * g.ldpre + col) : zero4;
+      if constexpr (CO) p_co[n] = ok ? *reinterpret_cast<const f32x4*>(C + (long)row * g.ldc + col) : zero4;
+      if constexpr (MU) p_mu[n] = ok ? *reinterpret_cast<const f32x4*>(mulp + (long)row * g.ldmul + col) : zero4;
+      if constexpr (RE) p_re[n] = ok ? *reinterpret_cast<const f32x4*>(res + (long)row * g.ldres + col) : zero4;
+      if constexpr (RV) p_rv[n] = ok ? *reinterpret_cast<const f32x4*>(g.rowvec + (long)rvrow * g.ldrv + col) : zero4;
+      p_bi[n] = (g.bias && col < N) ? *reinterpret_cast<const f32x4*>(g.bias + col) : zero4;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int n = 0; n < TN; ++n) {
+      const int col = n0 + n * 16 + 4 * (r >> 2);
+      const bool ok = rok && col < N;
+      f32x4 v = quad_transpose(acc[m][n], lane) * g.alpha;
+      if (ok) {
+        if constexpr (PRE) v += p_pre[n];
+        else if (GEN && g.pre_add) v += *reinterpret_cast<const f32x4*>(g.pre_add + (long)row * g.ldpre + col);
+        if (g.gate_bwd) {
+          f32x4 gv, hv;
+          if constexpr (MU) gv = p_mu[n]; else gv = *reinterpret_cast<const f32x4*>(mulp + (long)row * g.ldmul + col);
+          if constexpr (RE) hv = p_re[n]; else hv = *reinterpret_cast<const f32x4*>(res + (long)row * g.ldres + col);
+          *reinterpret_cast<f32x4*>(aux + (long)row * g.ldaux + col) = v * hv * gv * (1.f - gv);
+          *reinterpret_cast<f32x4*>(C + (long)row * g.ldc + col) = v * gv;
+        } else {
+          if (g.accumulate == 2) {
+            if constexpr (CO) v += p_co[n]; else v += *reinterpret_cast<const f32x4*>(C + (long)row * g.ldc + col);
+          }
+          v += p_bi[n];
+          if constexpr (RV) v += p_rv[n];
+          else if (GEN && g.rowvec) v += *reinterpret_cast<const f32x4*>(g.rowvec + (long)rvrow * g.ldrv + col);
+          if (g.act == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          } else if (g.act == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fast_tanh(v[e]);
+          } else if (g.act == 3) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fast_sigmoid(v[e]);
+          }
+          if (aux) *reinterpret_cast<f32x4*>(aux + (long)row * g.ldaux + col) = v;
+          if constexpr (MU) v *= p_mu[n];
+          else if (GEN && mulp) v *= *reinterpret_cast<const f32x4*>(mulp + (long)row * g.ldmul + col);
+          if constexpr (RE) v += p_re[n];
+          else if (GEN && res) v += *reinterpret_cast<const f32x4*>(res + (long)row * g.ldres + col);
+          if (g.drop_target == 3) {
+            bool kp[4];
+            nnr_keep4(g.drop_seed, (uint64_t)(row + (long)z * g.M) * g.drop_cols + col, dthr, kp);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = kp[e] ? v[e] * dscale : 0.f;
+          }
+          if (C) {
+            f32x4* cp = reinterpret_cast<f32x4*>(C + (long)row * g.ldc + col);
+            if (g.accumulate == 1) {
+              if constexpr (CO) v += p_co[n]; else v += *cp;
+            }
+            *cp = v;
+          }
+        }
+      }
+      if constexpr (GEN) __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// the instantiation for a launch's operand set (wave-uniform flags)
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue_reg_any(const nnr_gemm_args& g, f32x4 (&acc)[TM][TN], float* __restrict__ C, int m0, int n0, int M,
+                                                      int N, int z, int lane, int w) {
+  const bool pre = g.pre_add != nullptr, co = g.accumulate != 0 && C != nullptr, mu = g.mul != nullptr, re = g.resid != nullptr, rv = g.rowvec != nullptr;
+  if (!pre && !co && !mu && !re && !rv) gemm_epilogue_reg<TM, TN, false, false, false, false, false, false>(g, acc, C, m0, n0, M, N, z, lane, w);      // bias / activation / aux / dropout only
+  else if (!pre && !co && mu && !re && rv) gemm_epilogue_reg<TM, TN, false, false, true, false, true, false>(g, acc, C, m0, n0, M, N, z, lane, w);   // gate forward
+  else if (pre && !co && mu && re && !rv) gemm_epilogue_reg<TM, TN, true, false, true, true, false, false>(g, acc, C, m0, n0, M, N, z, lane, w);     // gate backward inside the dHt GEMM
+  else if (!pre && co && !mu && !re && !rv) gemm_epilogue_reg<TM, TN, false, true, false, false, false, false>(g, acc, C, m0, n0, M, N, z, lane, w); // accumulate into C
+  else if (!pre && !co && !mu && re && !rv) gemm_epilogue_reg<TM, TN, false, false, false, true, false, false>(g, acc, C, m0, n0, M, N, z, lane, w); // residual (GCN-style)
+  else gemm_epilogue_reg<TM, TN, false, false, false, false, false, true>(g, acc, C, m0, n0, M, N, z, lane, w);                                      // anything else: serial loads
+}
+
+template <int TM, int TN, int OCC>
+__global__ __launch_bounds__(256, OCC) void gemm_nt_pipe3_kernel(nnr_gemm_args g) {
+  constexpr int NS = 3;
+  constexpr int BK = 32, BM = 64 * TM, BN = 16 * TN, ROWS = BM + BN;
+  constexpr int KQ = BK / 4, RPI = 64 / KQ, NI = ROWS / RPI, STAGE = ROWS * BK;
+  static_assert(ROWS % RPI == 0, "tile shape");
+  __shared__ __attribute__((aligned(1024))) float lds[NS * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, kk = lane >> 4;
+  int M = g.M;
+  if (g.dyn_dim == 1) M = min(M, *g.dyn_dev);
+  const int N = g.N, K = g.K;
+  const int nbm = (M + BM - 1) / BM, nbn = (N + BN - 1) / BN;
+  const int nblk = nbm * nbn;
+  if ((int)blockIdx.x >= nblk) return;
+  const int z = blockIdx.z;
+  const float* __restrict__ A = g.A;
+  const float* __restrict__ B = g.B;
+  float* __restrict__ C = g.C;
+  if (g.batch > 1) {
+    A += (long)z * g.strideA;
+    B += (long)z * g.strideB;
+    C += (long)z * g.strideC;
+  }
+  constexpr int NIA = BM / RPI, NIB = BN / RPI, NA = NIA / 4, NBMAX = (NIB + 3) / 4;
+  static_assert(NIA % 4 == 0 && NA <= 8 && NBMAX <= 8, "tile shape");
+  const bool nb_hi = (NIB % 4 == 0) || (w < NIB % 4);      // this wave has NBMAX (else NBMAX - 1) B instructions
+  const float* zero = nnr_zero_page;
+  asm volatile("" : "+s"(zero));
+  const unsigned lds_base = (unsigned)(uintptr_t)lds;
+  const int S = (K + BK - 1) / BK;                           // >= NS (dispatcher)
+  const bool ktail = (K % BK) != 0;
+  const int q8 = nblk >> 3, rem8 = nblk & 7;
+  auto tile_of = [&](int b) { const int x = b & 7, slot = b >> 3; return x * q8 + min(x, rem8) + slot; };   // XCD-aware order (gridDim.x % 8 == 0 or == nblk)
+
+  // ---- the tile the DMA issue currently points at
+  unsigned voffA[8], voffB[8];
+  int kchA[NA], kchB[NBMAX];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) voffA[i] = voffB[i] = 0;
+  const float* Abase;
+  const float* Bbase;
+  auto point_at = [&](int v) {
+    const int bm = v / nbn, bn = v - bm * nbn, m0 = bm * BM, n0 = bn * BN;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int tr = (w + 4 * i) * RPI + lane / KQ;
+      const int c = (lane % KQ) ^ swz<BK>(tr & 15);
+      kchA[i] = 4 * c;
+      voffA[i] = (unsigned)(((long)min(tr, M - 1 - m0) * g.lda + 4 * c) * 4);
+    }
+#pragma unroll
+    for (int j = 0; j < NBMAX; ++j) {
+      const int tr = (w + 4 * j) * RPI + lane / KQ;
+      const int c = (lane % KQ) ^ swz<BK>(tr & 15);
+      kchB[j] = 4 * c;
+      voffB[j] = (unsigned)(((long)min(tr, N - 1 - n0) * g.ldb + 4 * c) * 4);
+    }
+    Abase = A + (long)m0 * g.lda;
+    Bbase = B + (long)n0 * g.ldb;
+  };
+  // stage s (0 .. S-1) of the pointed-at tile into stage buffer `buf`
+  auto issue = [&](int s, int buf) {
+    const int k0 = s * BK;
+    const unsigned sb = lds_base + (unsigned)(buf * STAGE * 4) + (unsigned)(w * 1024);
+    if (!(ktail && s == S - 1)) {
+      lds_dma16_block<NA>(Abase + k0, sb, voffA);
+      if (nb_hi) lds_dma16_block<NBMAX>(Bbase + k0, sb + NIA * 1024, voffB);
+      else if constexpr (NBMAX > 1) lds_dma16_block<NBMAX - 1>(Bbase + k0, sb + NIA * 1024, voffB);
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+      lds_dma16((k0 + kchA[i] < K) ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(Abase + k0) + voffA[i]) : zero, sb + i * 4096);
+#pragma unroll
+    for (int j = 0; j < NBMAX; ++j)
+      if (j < NBMAX - 1 || nb_hi)
+        lds_dma16((k0 + kchB[j] < K) ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(Bbase + k0) + voffB[j]) : zero,
+                  sb + NIA * 1024 + j * 4096);
+  };
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int m = 0; m < TM; ++m)
+#pragma unroll
+    for (int n = 0; n < TN; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+  auto rd = [&](int buf, int kg, f32x4 (&a)[TM], f32x4 (&b)[TN]) {
+    const float* As = lds + buf * STAGE;
+    const float* Bs = As + BM * BK;
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+      a[m] = *reinterpret_cast<const f32x4*>(&As[((w * TM + m) * 16 + r) * BK + 4 * ((kg * 4 + kk) ^ swz<BK>(r))]);
+#pragma unroll
+    for (int n = 0; n < TN; ++n)
+      b[n] = *reinterpret_cast<const f32x4*>(&Bs[(n * 16 + r) * BK + 4 * ((kg * 4 + kk) ^ swz<BK>(r))]);
+  };
+  auto mm = [&](const f32x4 (&a)[TM], const f32x4 (&b)[TN]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][i], b[n][i], acc[m][n], 0, 0, 0);
+  };
+#define NNR_LGKM0() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0xC07F); } while (0)
+  // NS = 3: when a wave waits for a stage, that stage is the only one it can have in flight (the next is issued right behind the barrier)
+  // -- plus, at the first stage of a tile, the previous tile's epilogue stores: vmcnt(0) everywhere
+  int b = blockIdx.x;
+  int v = tile_of(b);
+  point_at(v);
+  int buf = 0;                                               // stage buffer of the stage about to be computed; refills go to (buf + 2) % 3
+  issue(0, 0);
+  issue(1, 1);
+  if (nb_hi) wait_vmcnt<NA + NBMAX>(); else wait_vmcnt<NA + NBMAX - 1>();      // stage 0 landed: only this wave's DMAs of stage 1 may stay in flight
+  __builtin_amdgcn_s_barrier();
+  rd(0, 0, fa0, fb0);
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  for (;;) {
+    const int bm_e = v / nbn, bn_e = v - bm_e * nbn, m0_e = bm_e * BM, n0_e = bn_e * BN;      // the tile being computed (epilogue coordinates)
+    const int bnext = b + (int)gridDim.x;
+    const bool has_next = bnext < nblk;
+    int s = 0;
+    for (; s + NS < S; ++s) {                                  // refill = stage s + 2 <= S - 2 of this tile: lean, branch-free
+      rd(buf, 1, fa1, fb1);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(fa0, fb0);
+      NNR_LGKM0();
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      const int nb1 = buf == 2 ? 0 : buf + 1, nb2 = nb1 == 2 ? 0 : nb1 + 1;
+      issue(s + 2, nb2);
+      rd(nb1, 0, fa0, fb0);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(fa1, fb1);
+      NNR_LGKM0();
+      buf = nb1;
+    }
+    for (; s + 1 < S; ++s) {                                   // the last stages: refill = this tile's last stage, then the next tile's stages 0 .. NS - 3
+      rd(buf, 1, fa1, fb1);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(fa0, fb0);
+      NNR_LGKM0();
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      const int nb1 = buf == 2 ? 0 : buf + 1, nb2 = nb1 == 2 ? 0 : nb1 + 1;
+      if (s + 2 < S) issue(s + 2, nb2);
+      else if (has_next) { point_at(tile_of(bnext)); issue(s + 2 - S, nb2); }
+      rd(nb1, 0, fa0, fb0);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(fa1, fb1);
+      NNR_LGKM0();
+      buf = nb1;
+    }
+    // last stage of the tile: its second k-group, the hand-over to the next tile's stage 0 (already in flight), then the epilogue
+    rd(buf, 1, fa1, fb1);
+    __builtin_amdgcn_sched_barrier(0);
+    mm(fa0, fb0);
+    NNR_LGKM0();
+    if (has_next) {
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      const int nb1 = buf == 2 ? 0 : buf + 1, nb2 = nb1 == 2 ? 0 : nb1 + 1;
+      issue(1, nb2);                                            // (S >= NS: stage 1 of the next tile is an ordinary or a k-tail stage of its own)
+      rd(nb1, 0, fa0, fb0);
+      __builtin_amdgcn_sched_barrier(0);
+      buf = nb1;
+    }
+    mm(fa1, fb1);
+    NNR_LGKM0();
+    gemm_epilogue_reg_any<TM, TN>(g, acc, C, m0_e, n0_e, M, N, z, lane, w);
+    if (!has_next) break;
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+      for (int n = 0; n < TN; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    b = bnext;
+    v = tile_of(b);
+  }
+#undef NNR_LGKM0
+}
+
+template <int TM, int TN, int OCC>
+int launch_pipe3(const nnr_gemm_args& g, hipStream_t s) {
+  constexpr int BM = 64 * TM, BN = 16 * TN;
+  const int nbm = (g.M + BM - 1) / BM, nbn = (g.N + BN - 1) / BN, nblk = nbm * nbn;
+  // persistent: one workgroup per resident slot (256 CUs x OCC), a multiple of 8 so that a workgroup's tiles stay in one XCD's range
+  static const int slots_env = [] { const char* e = getenv("NNR_P3_SLOTS"); return e ? atoi(e) : 0; }();
+  const int slots = slots_env > 0 ? slots_env : 256 * OCC;
+  const int grid_x = nblk <= slots ? nblk : slots;
+  dim3 grid(grid_x, 1, g.batch > 1 ? g.batch : 1), block(256);
+  hipLaunchKernelGGL((gemm_nt_pipe3_kernel<TM, TN, OCC>), grid, block, 0, s, g);
+  NNR_CHECK_LAUNCH();
+  return NNR_OK;
+}
+
 template <int TM, int TN, int NS, int OCC>
 int launch_pipe2(const nnr_gemm_args& g, hipStream_t s) {
   constexpr int BM = 64 * TM, BN = 16 * TN;
@@ -874,6 +1197,11 @@ static bool pipe_ok(const nnr_gemm_args& g) {
   return !g.trans_a && !g.trans_b && !g.b_idx && g.split_k <= 1 && g.k_chunk <= 0 && !g.rowdot_w && !g.colsum_out &&
          (g.drop_target == 0 || g.drop_target == 3 || g.drop_target == 4) && (g.K & 3) == 0 && (g.lda & 3) == 0 && (g.ldb & 3) == 0 &&
          al(g.A) && al(g.B) && (g.batch <= 1 || (((g.strideA | g.strideB) & 3) == 0)) && (g.dyn_dim == 0 || g.dyn_dim == 1);
+}
+
+// what the gen-3 kernel accepts: a plain NT launch whose epilogue is the float4 path (g.vec_epi is set by nnr_gemm_f32 before the dispatch)
+static bool pipe3_ok(const nnr_gemm_args& g) {
+  return pipe_ok(g) && !g.a_idx && !g.c_idx && !g.atomic && g.vec_epi && g.drop_target != 4 && g.K >= 96;
 }
 
 // ------------------------------------------------------------------------------------------------ pipelined TN GEMM (LDS-DMA)
@@ -1634,6 +1962,9 @@ static int dispatch_tile(int tile, const nnr_gemm_args& g, hipStream_t stream) {
     case 37: if (!tn_pipe_ok(g)) return NNR_ERR_ARG; return launch_tn_pipe2<4, 10, 3, 1>(g, stream);              // gen-2 TN 256 x 160, 3 x 32 KB stages, 1 workgroup / CU
     case 38: if (!tn_pipe_ok(g)) return NNR_ERR_ARG; return launch_tn_pipe2<2, 10, 4, 1>(g, stream);              // gen-2 TN 128 x 160, 4 stages, 1 workgroup / CU
     case 39: if (!tn_pipe_ok(g)) return NNR_ERR_ARG; return launch_tn_pipe2<1, 10, 3, 3>(g, stream);              // gen-2 TN 64 x 160, 3 x 20 KB stages, 3 workgroups / CU
+    case 40: if (!pipe3_ok(g)) return NNR_ERR_ARG; return launch_pipe3<2, 5, 2>(g, stream);     // gen-3 NT (persistent, continuous DMA pipeline, register epilogue) 128 x 80, 3 x 26 KB stages, 2 workgroups / CU
+    case 41: if (!pipe3_ok(g)) return NNR_ERR_ARG; return launch_pipe3<2, 4, 2>(g, stream);     // gen-3 NT 128 x 64
+    case 42: if (!pipe3_ok(g)) return NNR_ERR_ARG; return launch_pipe3<2, 10, 1>(g, stream);    // gen-3 NT 128 x 160, 3 x 36 KB stages, 1 workgroup / CU
     case 32: if (!tn_pipe_ok(g)) return NNR_ERR_ARG; return launch_tn_pipe2<1, 13, 3, 2>(g, stream);              // gen-2 TN 64 x 208, 3 x 20 KB stages: row tiles of 64 fit M = 200 / 400 / 832
                                                                                                                   // (256 / 448 / 832 rows of MFMA work instead of 256 / 512 / 896)
     case 7:

@@ -470,7 +470,7 @@ def gemm(A, B, C_=None, *, M, N, K, lda, ldb, ldc=0, trans_a=False, trans_b=Fals
         t = 5 if not trans_b else 4
     fam = 'gemm_%s_%s' % ('tn' if trans_a else ('nn' if trans_b else 'nt'),
                           {1: '256x80', 2: '64x80', 3: '128x208', 4: '128x80', 5: '128x80k32', 6: '64x80k64', 7: '16x80skinny', 8: 'pipe128x80k32', 9: 'pipe2_128x80', 13: 'pipe128x80s4',
-                           15: 'pipe128x80', 16: 'pipe128x80s2', 20: 'pipe128x80', 26: 'pipe2_128x80', 27: 'pipe2_128x208', 30: 'pipe2_128x160', 31: 'pipe2_128x64', 32: 'pipe2_64x208', 33: 'pipe128x208', 34: 'pipe2_128x208', 36: 'pipe256x80', 22: 'pipe64x80', 23: 'pipe256x80', 24: 'pipe128x208', 25: 'pipe128x128'}.get(t, 'tile%d' % t))
+                           15: 'pipe128x80', 16: 'pipe128x80s2', 20: 'pipe128x80', 26: 'pipe2_128x80', 27: 'pipe2_128x208', 30: 'pipe2_128x160', 31: 'pipe2_128x64', 32: 'pipe2_64x208', 33: 'pipe128x208', 34: 'pipe2_128x208', 36: 'pipe256x80', 22: 'pipe64x80', 23: 'pipe256x80', 24: 'pipe128x208', 25: 'pipe128x128', 40: 'pipe3_128x80', 41: 'pipe3_128x64', 42: 'pipe3_128x160'}.get(t, 'tile%d' % t))
 
     def flops(vals=None, M=M, N=N, K=K, dyn=dyn, dyn_dim=dyn_dim, batch=batch):
         # vals: {data_ptr of a device-side size: its value at the time of the launch} (replayed launches: the size buffers are

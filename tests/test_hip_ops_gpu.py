@@ -147,6 +147,86 @@ def test_gemm_pipelined_nt_tiles(tile, M, N, K):
         close(ob, ab.double() @ bb.double().transpose(1, 2), what='pipe batched')
 
 
+@pytest.mark.parametrize('tile', [40, 41, 42])
+@pytest.mark.parametrize('M,N,K', [(70000, 400, 400), (33000, 1664, 300), (5000, 200, 200), (4352, 900, 900), (300, 84, 96), (129, 400, 104)])
+def test_gemm_persistent_nt_tiles(tile, M, N, K):
+    """Third-generation NT kernel (csrc/gemm.hip: gemm_nt_pipe3_kernel, round 5): persistent workgroups, the LDS-DMA pipeline continuous
+    across tile boundaries, epilogue from the accumulator registers.  Shapes: several tiles per workgroup (70 000 x 400: 2 735 tiles on
+    512 slots), a k-tail in every stage count class (K = 300 / 400 / 200 / 900 / 104), the minimum of three stages (K = 96), ragged M
+    and N.  Plain results must be BIT-IDENTICAL to the second-generation kernel on the same tile (same MFMA order); every operand set
+    of the register epilogue (bias + activation; gate forward; gate backward; accumulate 1 / 2; residual + dropout-free GCN form; the
+    serial any-combination form) against fp64; dynamic M with untouched rows beyond the live count."""
+    from nnr_amd import ops
+    d = dev()
+    a, b = rnd(M, K, seed=1).to(d), rnd(N, K, seed=2, scale=0.2).to(d)
+    ad, bd = a.cpu().double(), b.cpu().double()
+    full = ad @ bd.t()
+    etol = 2e-5 * max(1.0, math.sqrt(K / 100.0))
+    out = torch.empty(M, N, device=d)
+    ops.gemm(a, b, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, tile=tile)
+    close(out, full, tol=etol, what='pipe3 plain')
+    twin = {40: 9, 41: 31, 42: 11}[tile]
+    ref = torch.empty(M, N, device=d)
+    ops.gemm(a, b, ref, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, tile=twin)
+    assert torch.equal(out, ref), 'pipe3 tile %d differs from the gen-2 kernel on the same tile (max %.3e)' % (tile, float((out - ref).abs().max()))
+    bias, resid, mul, base, pre = (rnd(N, seed=4).to(d), rnd(M, N, seed=5).to(d), rnd(M, N, seed=6).to(d), rnd(M, N, seed=7).to(d), rnd(M, N, seed=8).to(d))
+    R = 7
+    rv, rmap = rnd(R, N, seed=9).to(d), torch.randint(0, R, (M,), generator=torch.Generator().manual_seed(9)).int().to(d)
+    rvd = rv.cpu().double()[rmap.cpu().long()]
+    # bias + tanh (+ aux)
+    aux = torch.empty(M, N, device=d)
+    ops.gemm(a, b, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias, act=ops.ACT_TANH, aux_out=aux, ldaux=N, tile=tile)
+    want = torch.tanh(full + bias.cpu().double())
+    close(out, want, tol=etol, what='pipe3 bias tanh')
+    close(aux, want, tol=etol, what='pipe3 bias tanh aux')
+    # gate forward: sigmoid(x + rowvec[map]) -> aux, * mul -> C   (newsEncoders.py:128-131)
+    ops.gemm(a, b, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, rowvec=rv, ldrv=N, rowvec_map=rmap, act=ops.ACT_SIGMOID, aux_out=aux, ldaux=N, mul=mul, ldmul=N, tile=tile)
+    gate = torch.sigmoid(full + rvd)
+    close(aux, gate, tol=etol, what='pipe3 gate aux')
+    close(out, gate * mul.cpu().double(), tol=etol, what='pipe3 gate out')
+    # gate backward in the epilogue: x = acc + pre_add; aux = x * resid * mul * (1 - mul); C = x * mul
+    gpos = torch.sigmoid(mul)
+    ops.gemm(a, b, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, pre_add=pre, ldpre=N, gate_bwd=True, mul=gpos, ldmul=N, resid=resid, ldres=N, aux_out=aux, ldaux=N, tile=tile)
+    x = full + pre.cpu().double()
+    gp = gpos.cpu().double()
+    close(out, x * gp, tol=etol, what='pipe3 gate_bwd dH')
+    close(aux, x * resid.cpu().double() * gp * (1 - gp), tol=etol, what='pipe3 gate_bwd dpre')
+    # accumulate (1: after the epilogue; 2: before bias / activation)
+    out = base.clone()
+    ops.gemm(a, b, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, accumulate=True, tile=tile)
+    close(out, base.cpu().double() + full, tol=etol, what='pipe3 accumulate')
+    out = base.clone()
+    ops.gemm(a, b, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias, act=ops.ACT_RELU, accumulate=2, tile=tile)
+    close(out, torch.relu(base.cpu().double() + full + bias.cpu().double()), tol=etol, what='pipe3 accumulate 2')
+    # residual form (GCN layer: relu(x + b) -> aux, + resid)
+    ops.gemm(a, b, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias, act=ops.ACT_RELU, aux_out=aux, ldaux=N, resid=resid, ldres=N, tile=tile)
+    close(out, torch.relu(full + bias.cpu().double()) + resid.cpu().double(), tol=etol, what='pipe3 residual')
+    # everything at once (the serial any-combination instantiation)
+    out = base.clone()
+    ops.gemm(a, b, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, alpha=0.5, bias=bias, rowvec=rv, ldrv=N, rowvec_map=rmap, act=ops.ACT_TANH, aux_out=aux, ldaux=N,
+             mul=mul, ldmul=N, resid=resid, ldres=N, accumulate=True, tile=tile)
+    pr = torch.tanh(0.5 * full + bias.cpu().double() + rvd)
+    close(aux, pr, tol=etol, what='pipe3 full aux')
+    close(out, base.cpu().double() + pr * mul.cpu().double() + resid.cpu().double(), tol=etol, what='pipe3 full epilogue')
+    # dynamic M: rows beyond the live count untouched
+    used = max(1, (M * 2) // 3)
+    out = torch.full((M, N), 7.0, device=d)
+    dyn = torch.tensor([used], dtype=torch.int32, device=d)
+    ops.gemm(a, b, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, dyn=dyn, dyn_dim=1, bias=bias, tile=tile)
+    close(out[:used], (full + bias.cpu().double())[:used], tol=etol, what='pipe3 dyn')
+    assert bool((out[used:] == 7.0).all())
+    if M <= 5000:
+        ab, bb = rnd(3, M, K, seed=20).to(d), rnd(3, N, K, seed=21, scale=0.2).to(d)
+        ob = torch.empty(3, M, N, device=d)
+        ops.gemm(ab, bb, ob, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, batch=3, strideA=M * K, strideB=N * K, strideC=M * N, tile=tile)
+        close(ob, ab.cpu().double() @ bb.cpu().double().transpose(1, 2), tol=etol, what='pipe3 batched')
+    # what the kernel does not take is refused, not mis-run: unaligned N, row scatter, short K
+    for bad in (dict(M=64, N=82, K=128), dict(M=64, N=80, K=64)):
+        aa, bb2 = rnd(bad['M'], bad['K'], seed=1).to(d), rnd(bad['N'], bad['K'], seed=2).to(d)
+        with pytest.raises(Exception):
+            ops.gemm(aa, bb2, torch.empty(bad['M'], bad['N'], device=d), lda=bad['K'], ldb=bad['K'], ldc=bad['N'], tile=tile, **bad)
+
+
 def test_gemm_nn_accumulate_and_tn_splitk_dyn():
     from nnr_amd import ops
     dy, w = rnd(300, 225, seed=1), rnd(225, 900, seed=2)
