@@ -340,6 +340,11 @@ int nnr_layernorm_bwd(const float* dv, const float* xhat, const float* rstd, con
 /* *out = sum g^2 (stored), a DETERMINISTIC function of g (fixed-order two-level sum: data-parallel ranks must clip by the same bits);
  * launches of one process must be stream-ordered (one device-global scratch) */
 int nnr_sumsq(const float* g, long n, float* out, hipStream_t stream);
+/* The same over one SPAN of the gradient, chained: *out = sum g^2 + (add_in ? *add_in : 0), fixed order.  `slot` (0..3) selects the scratch
+ * set: launches that may run concurrently (different streams) must use different slots; nnr_sumsq uses slot 0.  Round 5: the norm of the
+ * word-embedding table's gradient (70 % of the floats) is taken on a helper stream as soon as its last scatter is done, beside the LSTM
+ * weight-gradient GEMMs of the step's tail, and only the remaining spans are summed on the optimizer's stream (trainer.py:118). */
+int nnr_sumsq_part(const float* g, long n, float* out, const float* add_in, int slot, hipStream_t stream);
 /* clip_grad_norm_(max_norm = clip) + torch.optim.Adam step on one flat buffer (trainer.py:118-120); grads are scaled by
  * grad_scale first (1/world_size after the RCCL sum all-reduce).  A step whose squared gradient norm is not finite is
  * skipped as a whole (parameters and moments untouched). */
@@ -366,6 +371,10 @@ int nnr_dp_init(const void* uid128, int rank, int world, nnr_dp_ctx** ctx);     
 int nnr_dp_allreduce(nnr_dp_ctx* ctx, float* flat, size_t n, hipStream_t stream);
 int nnr_dp_broadcast(nnr_dp_ctx* ctx, float* flat, size_t n, int root, hipStream_t stream);
 int nnr_dp_destroy(nnr_dp_ctx* ctx);
+/* Diagnostics: a stand-in for RCCL's RESIDENT ring kernels on a box with one GPU -- `workgroups` x 512 threads sweep their slice of buf
+ * [n] `iters` times (read-modify-write through HBM), occupying as many CU slots for the duration.  The co-residency soak of the CU-pair
+ * recurrence (tests/test_hip_dp_gpu.py, tools/replay_soak.py --busy) runs it on a side stream beside every step. */
+int nnr_dp_busy(float* buf, long n, int workgroups, int iters, hipStream_t stream);
 /* Touched-row exchange of the word-embedding table's gradient (the table is 70 % of the all-reduced bytes, and only
  * the rows of words in the step's batch are non-zero; trainer.py:297 reduces all of it).  nnr_rows_touch: flags[tok[i]] = 1 for the live
  * packed rows of a token stream (flags: V floats, zeroed by the caller at the start of the step and summed over the ranks before

@@ -143,6 +143,27 @@ __global__ __launch_bounds__(256) void rows_move_kernel(float* __restrict__ dens
 }
 }  // namespace
 
+// ---- a stand-in for RCCL's resident ring kernels (co-residency soak of the CU-pair recurrence on a 1-GPU box, round-4 verdict item 6a): RCCL's
+// all-reduce keeps a few dozen 512-thread workgroups RESIDENT on as many CUs for the whole collective, copying / reducing through
+// HBM; a one-rank communicator's all-reduce is a plain copy and exercises none of that.  `workgroups` x 512 threads each sweep their
+// slice of `buf` `iters` times (read-modify-write: the traffic shape of a ring step), holding their CU slots for the duration.
+__global__ __launch_bounds__(512) void busy_ring_kernel(float* __restrict__ buf, long per_wg, int iters) {
+  float* p = buf + (long)blockIdx.x * per_wg;
+  const long half = per_wg / 2;
+  for (int it = 0; it < iters; ++it) {
+    for (long i = threadIdx.x; i < half; i += 512) p[half + i] = p[i] * 0.5f + p[half + i] * 0.5f;
+    __syncthreads();
+    for (long i = threadIdx.x; i < half; i += 512) p[i] = p[half + i];
+    __syncthreads();
+  }
+}
+extern "C" int nnr_dp_busy(float* buf, long n, int workgroups, int iters, hipStream_t stream) {
+  if (!buf || workgroups <= 0 || iters <= 0 || n < 2L * workgroups) return NNR_ERR_ARG;
+  hipLaunchKernelGGL(busy_ring_kernel, dim3(workgroups), dim3(512), 0, stream, buf, (n / workgroups) & ~1L, iters);
+  NNR_CHECK_LAUNCH();
+  return NNR_OK;
+}
+
 extern "C" int nnr_rows_touch(const int* tok, long cap, const int* n_dev, int V, float* flags, hipStream_t stream) {
   if (!tok || !flags || cap < 0 || V <= 0) return NNR_ERR_ARG;
   if (cap == 0) return NNR_OK;

@@ -734,9 +734,10 @@ __global__ void logits_bwd_kernel(const float* __restrict__ dlogits, const float
 // and a clip coefficient that differs in the last bit (f32 atomics add the block sums in arrival order) lets the ranks' parameters drift apart
 // (tools/dp_two_rank_check.py).  Block sums go to fixed slots; the last block to arrive adds the slots in a fixed order.
 constexpr int SUMSQ_BLOCKS = 1024;
-__device__ float g_sumsq_part[SUMSQ_BLOCKS];
-__device__ unsigned g_sumsq_arrived;
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ out) {
+constexpr int SUMSQ_SLOTS = 4;               // independent scratch sets: launches on DIFFERENT streams use different slots (nnr_sumsq_part)
+__device__ float g_sumsq_part[SUMSQ_SLOTS][SUMSQ_BLOCKS];
+__device__ unsigned g_sumsq_arrived[SUMSQ_SLOTS];
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ out, const float* __restrict__ add_in, int slot) {
   __shared__ float part[4];
   __shared__ bool last;
   float acc = 0.f;
@@ -750,21 +751,22 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) {
-    g_sumsq_part[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+    g_sumsq_part[slot][blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
     __threadfence();
-    last = atomicAdd(&g_sumsq_arrived, 1u) == gridDim.x - 1;
+    last = atomicAdd(&g_sumsq_arrived[slot], 1u) == gridDim.x - 1;
   }
   __syncthreads();
   if (!last) return;
   __threadfence();
   float t = 0.f;
-  for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) t += __builtin_nontemporal_load(&g_sumsq_part[i]);
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) t += __builtin_nontemporal_load(&g_sumsq_part[slot][i]);
   t = wave_sum(t);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = t;
   __syncthreads();
   if (threadIdx.x == 0) {
-    *out = (part[0] + part[1]) + (part[2] + part[3]);       // (round 3: STORED, not accumulated -- the caller's fill launch in front of every call is gone)
-    g_sumsq_arrived = 0;                                    // ready for the next launch (launches of one process are stream-ordered)
+    const float own = (part[0] + part[1]) + (part[2] + part[3]);
+    *out = add_in ? own + *add_in : own;                    // (round 3: STORED, not accumulated; round 5: + the partial sum of another span, fixed order)
+    g_sumsq_arrived[slot] = 0;                              // ready for the next launch on this slot (launches that share a slot are stream-ordered)
   }
 }
 __device__ unsigned g_adam_skipped;          // optimizer steps skipped because the gradient norm was not finite (nnr_adam_skipped_steps)
@@ -1121,11 +1123,16 @@ extern "C" int nnr_logits_bwd(const float* dlogits, const float* user, const flo
   EW_LAUNCH(logits_bwd_kernel, (long)B * N * D, dlogits, user, cand, (long)B * N, D, duser, dcand, dcand_accumulate);
 }
 
-extern "C" int nnr_sumsq(const float* g, long n, float* out_zeroed, hipStream_t stream) {
+static int sumsq_launch(const float* g, long n, float* out, const float* add_in, int slot, hipStream_t stream) {
+  if (!g || !out || n < 0 || slot < 0 || slot >= SUMSQ_SLOTS || (((uintptr_t)g) & 15)) return NNR_ERR_ARG;
   const long want = (n / 4 + 255) / 256;
-  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)(want < 1 ? 1 : (want > SUMSQ_BLOCKS ? SUMSQ_BLOCKS : want))), dim3(256), 0, stream, g, n, out_zeroed);
+  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)(want < 1 ? 1 : (want > SUMSQ_BLOCKS ? SUMSQ_BLOCKS : want))), dim3(256), 0, stream, g, n, out, add_in, slot);
   NNR_CHECK_LAUNCH();
   return NNR_OK;
+}
+extern "C" int nnr_sumsq(const float* g, long n, float* out_zeroed, hipStream_t stream) { return sumsq_launch(g, n, out_zeroed, nullptr, 0, stream); }
+extern "C" int nnr_sumsq_part(const float* g, long n, float* out, const float* add_in, int slot, hipStream_t stream) {
+  return sumsq_launch(g, n, out, add_in, slot, stream);
 }
 
 // The mirror of g_adam_skipped in pinned host memory (one word per process, never freed): set up by the first nnr_clip_adam /

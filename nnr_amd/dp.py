@@ -286,6 +286,7 @@ class GradientExchange:
         self._table_events = []
         self._comm = None
         self._helper = None
+        self.table_final_cb = None    # trainer hook (world 1): called on the helper stream once the table bucket's gradient is final (split norm)
         self._finish_events = []      # (start, end) HIP events around finish() on the caller's stream (bench.py: exposed exchange time)
         self.events = None            # tests: {'early_issued': Event, ...} recorded on the issuing stream when set to a dict
 
@@ -364,6 +365,7 @@ class GradientExchange:
     def begin_step(self, per_gpu_batch=None):
         """Start of an optimizer step (before the forward pass): decide the form of the table bucket for THIS step (rule above; a
         launch tape is per batch shape, so the decision is part of what it records) and clear the touched-row flags."""
+        self._table_events = []
         if self.touched_mode == 'auto' and per_gpu_batch is not None:
             self.touched = bool(self.touched_capable and per_gpu_batch <= TOUCHED_MAX_BATCH and world_size() > 1)
         if not (self.touched and self.active()):
@@ -434,7 +436,23 @@ class GradientExchange:
         """One of the `expected` embedding-row scatter GEMMs of this backward pass is ordered on the CURRENT stream (they run on
         different HIP streams).  When the last one has reported, the table bucket is handed to the exchange on a helper stream that
         waits for all of them -- no stream of the backward pass waits for another one here."""
-        if self.table_span is None or not self.active():
+        if self.table_span is None:
+            return
+        if not self.active():
+            # one GPU: nothing to exchange, but the table's gradient is FINAL here -- the trainer takes its share of the gradient norm on the
+            # helper stream, beside the weight-gradient GEMMs of the step's tail (nnr_sumsq_part), instead of on the optimizer's serial tail
+            if self.table_final_cb is not None and self.grad.is_cuda:
+                ev = torch.cuda.Event()
+                ev.record()
+                self._table_events.append(ev)
+                if len(self._table_events) >= expected:
+                    if self._helper is None:
+                        self._helper = torch.cuda.Stream(device=self.grad.device)
+                    with torch.cuda.stream(self._helper):
+                        for e in self._table_events:
+                            self._helper.wait_event(e)
+                        self.table_final_cb()
+                    self._table_events = []
             return
         if not self.grad.is_cuda:
             # host tensors (gloo tests of the exchange logic): no streams to overlap with; only the touched-row form does anything here

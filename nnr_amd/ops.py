@@ -674,6 +674,11 @@ def _timeout_counter(dev):
     return t
 
 
+def dp_busy(buf, workgroups, iters):
+    """Diagnostics: `workgroups` resident 512-thread workgroups sweeping `buf` on the CURRENT stream (a stand-in for RCCL's ring kernels)."""
+    L.check(L.lib().nnr_dp_busy(_p(buf), C.c_long(buf.numel()), int(workgroups), int(iters), _s()), 'nnr_dp_busy')
+
+
 def lstm_sync_timeouts(reset=False):
     """Exchange time-outs of the CU-pair recurrence accumulated over EVERY launch since the process started (or since the
     last reset); must be 0.  A time-out poisons the step with NaN (the optimizer then skips it).  Synchronises."""
@@ -950,6 +955,12 @@ def sumsq(g, out):
 
 def _sumsq(g, out):
     L.check(L.lib().nnr_sumsq(_p(g), C.c_long(g.numel()), _p(out), _s()), 'nnr_sumsq')
+
+
+def sumsq_part(g, out, add_in=None, slot=0):
+    """out[0] = sum g^2 (+ add_in[0]) over one span of the flat gradient (fixed-order sum; `slot`: scratch set, one per concurrent stream)."""
+    with _hbm_span('sumsq', 4.0, g.numel()):
+        L.check(L.lib().nnr_sumsq_part(_p(g), C.c_long(g.numel()), _p(out), _p(add_in), int(slot), _s()), 'nnr_sumsq_part')
 
 
 def fusion_rows_fwd(cat_table, sub_table, cat0, sub0, cat1, sub1, out_view, ldo, p, seed_cat, seed_sub):

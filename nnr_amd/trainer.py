@@ -33,6 +33,7 @@ def _tape_budget_gb(dev):
 
 
 _SKIP_POLL = int(os.environ.get('NNR_SKIP_POLL', '8'))
+_SPLIT_NORM = os.environ.get('NNR_SPLIT_NORM', '1') != '0'      # A/B (round 5): the table bucket's share of the gradient norm on the helper stream
 _WARM_STEPS = 2          # eager steps before a tape is recorded (first-use allocations: workspaces, W^T copies, packed weights)
 
 
@@ -124,6 +125,8 @@ class Trainer:
         self.m = torch.zeros_like(self.flat.flat)
         self.v = torch.zeros_like(self.flat.flat)
         self.sumsq = torch.zeros(1, device=self.flat.flat.device, dtype=torch.float32)
+        self.sumsq_table = torch.zeros(1, device=self.flat.flat.device, dtype=torch.float32)      # the table span's share of the norm (split norm)
+        self._table_norm_ev = None
         self.step_count = 0
         self.gradient_clip_norm = float(config.gradient_clip_norm)
         self.lr, self.weight_decay = float(config.lr), float(config.weight_decay)
@@ -134,6 +137,8 @@ class Trainer:
         ne = getattr(model, 'news_encoder', None)
         table = ne.word_embedding.weight if (ne is not None and hasattr(ne, 'word_embedding')) else None
         self.exchange = dp.GradientExchange(self.flat, early_modules=[_Own(ue, own)] if ue is not None else [], table_param=table)
+        if _SPLIT_NORM and self.exchange.table_span is not None and self.flat.grad.is_cuda:
+            self.exchange.table_final_cb = self._table_norm
         if ue is not None:
             ue.__dict__['_grads_ready_hook'] = self.exchange.early_ready
         if ne is not None:
@@ -263,7 +268,7 @@ class Trainer:
         if can_record:
             from .tape import Tape, TapeError
             try:
-                tape = Tape(batch, self._next_seeds(), known=(self.flat.flat, self.flat.grad, self.m, self.v, self.sumsq))
+                tape = Tape(batch, self._next_seeds(), known=(self.flat.flat, self.flat.grad, self.m, self.v, self.sumsq, self.sumsq_table))
             except TapeError:
                 tape = None                             # (this step's two dropout seeds are too close to tell apart: record the next one)
         if tape is None:
@@ -327,9 +332,42 @@ class Trainer:
                     _prof.TAPE_RECORDS.append((family, c, ms))
         self._snaps = {}
 
+    def _table_norm(self):
+        """On the exchange's helper stream, behind the last embedding-row scatter of the backward pass (world 1): the table span's sum of
+        squares (72 of the 102 MB of CNE+SUE's gradient), off the optimizer's serial tail."""
+        a, b = self.exchange.table_span
+        ops.sumsq_part(self.flat.grad[a:b], self.sumsq_table, None, slot=1)
+        self._table_norm_ev = torch.cuda.Event()
+        self._table_norm_ev.record()
+
+    def _grad_sumsq(self):
+        """sum g^2 over the flat gradient into self.sumsq: one pass, or -- when the table span's share was taken early (_table_norm) -- only
+        the other spans, chained in a fixed order (table, then the spans in address order): every rank / every run adds the same partial
+        sums in the same order."""
+        ev, self._table_norm_ev = self._table_norm_ev, None
+        if ev is None:
+            ops.sumsq(self.flat.grad, self.sumsq)
+            return
+        torch.cuda.current_stream(self.flat.grad.device).wait_event(ev)
+        a, b = self.exchange.table_span
+        spans = [(lo, hi) for lo, hi in ((0, a), (b, self.flat.grad.numel())) if hi > lo]
+        prev = self.sumsq_table
+        if not spans:
+            ops.copy_bytes(self.sumsq, prev)
+        for i, (lo, hi) in enumerate(spans):
+            out = self.sumsq if i == len(spans) - 1 else self._sumsq_mid()
+            ops.sumsq_part(self.flat.grad[lo:hi], out, prev, slot=0)
+            prev = out
+
+    def _sumsq_mid(self):
+        if getattr(self, '_sumsq_mid_buf', None) is None:
+            self._sumsq_mid_buf = torch.zeros(1, device=self.flat.grad.device, dtype=torch.float32)
+        ops.tape_keep(self._sumsq_mid_buf)
+        return self._sumsq_mid_buf
+
     def optimizer_step(self, grad_scale=1.0):
         self.step_count += 1
-        ops.sumsq(self.flat.grad, self.sumsq)
+        self._grad_sumsq()
         ops.clip_adam(self.flat.flat, self.flat.grad, self.m, self.v, self.sumsq, grad_scale, self.gradient_clip_norm, self.lr, 0.9, 0.999,
                       1e-8, self.weight_decay, self.step_count)
         PARAM_EPOCH[0] += 1           # parameters changed behind torch's back: invalidate cached weight layouts

@@ -950,6 +950,40 @@ def test_sumsq_is_accurate_and_deterministic(n):
     assert torch.equal(out[0], out[1])
 
 
+def test_sumsq_over_spans_chained_on_two_streams():
+    """Round 5: the gradient norm in spans (nnr_sumsq_part): the word-embedding table's span on a helper stream with its own scratch slot
+    WHILE another span is summed on the main stream, the partial sums chained in a fixed order -- accurate, and the same bits every time."""
+    from nnr_amd import ops
+    d = dev()
+    n = 25_624_708
+    a, b = 18_000_000, 25_624_708
+    g = (torch.randn(n, generator=torch.Generator().manual_seed(5)) * 0.1).to(d)
+    side = torch.cuda.Stream()
+    outs = []
+    for _ in range(3):
+        part = torch.full((1,), 3.0, device=d)
+        mid = torch.full((1,), 5.0, device=d)
+        tot = torch.full((1,), 7.0, device=d)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            ops.sumsq_part(g[:a], part, None, slot=1)              # "table" span, helper stream, scratch slot 1
+        ops.sumsq_part(g[a:a + 4], mid, None, slot=0)              # (a tiny span at the same time on the main stream, slot 0)
+        torch.cuda.current_stream().wait_stream(side)
+        ops.sumsq_part(g[a:b], tot, part, slot=0)                  # rest + table share
+        outs.append((part.clone(), tot.clone()))
+    ref_a = float((g[:a].double() ** 2).sum())
+    ref = float((g.double() ** 2).sum())
+    assert abs(float(outs[0][0]) - ref_a) <= 1e-5 * ref_a and abs(float(outs[0][1]) - ref) <= 1e-5 * ref
+    assert all(torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1]) for o in outs[1:])
+    one = torch.empty(1, device=d)
+    ops.sumsq(g, one)
+    assert abs(float(one) - float(outs[0][1])) <= 2e-6 * ref       # (another partition of the same sum: equal to rounding, not bit-equal)
+    with pytest.raises(Exception):
+        ops.sumsq_part(g[1:9], one, None, slot=0)                  # spans start 16-byte aligned
+    with pytest.raises(Exception):
+        ops.sumsq_part(g[:8], one, None, slot=9)
+
+
 def test_slot_spread_column_sums():
     """Long reductions into a short vector (bias gradients, dw2 of the additive attention) go through the per-stream slot
     workspace (nnr_slot_workspace_floats): same sums as the direct form; the second call, on the same stream and on a side stream
