@@ -124,6 +124,13 @@ int nnr_seq_plan_pair(uint8_t* mask0, const int* ids0, int n0, uint8_t* mask1, c
  * tmp: 4 * n ints of scratch. */
 int nnr_cne_pair_map(const int* order_t, const int* order_c, int n0, int n, int* pm_t, int* pm_c, int* tmp, hipStream_t stream);
 
+/* Packed token rows for the MHSA news encoder (round 5).  cover[i][t] = 1 for t <= the last valid position of title i (all ones for a title
+ * with no valid position: its softmax over -1e9 scores is uniform, every position counts -- newsEncoders.py:187-200, layers.py:142-143,171);
+ * nnr_seq_plan on `cover` packs exactly the rows that can reach the result, and rowmap[i*L + t] = off[t] + rank[i] (t < len[i], else -1)
+ * tells nnr_mhsa_fwd_packed / nnr_mhsa_bwd_packed where position t of title i lives. */
+int nnr_mask_cover(const uint8_t* mask, int n, int L, uint8_t* cover, hipStream_t stream);
+int nnr_seq_rowmap(const int* off, const int* rank, const int* len, int n, int L, int* rowmap, hipStream_t stream);
+
 /* ------------------------------------------------------------------------------------------------ Bi-LSTM
  * Replaces nn.LSTM(bidirectional) on a PackedSequence (newsEncoders.py:66-67, 119-127) and its backward.
  * Gate columns are kept in "p-order": p = (unit/16)*64 + (unit%16)*4 + gate, padded to NP = ceil(H/16)*64 per direction. */
@@ -270,6 +277,13 @@ int nnr_mhsa_fwd(const float* qkv, const uint8_t* mask, int n, int Lq, int heads
                  float drop_p, uint32_t seed, hipStream_t stream);
 int nnr_mhsa_bwd(const float* qkv, const uint8_t* mask, const float* prob, const float* dout, int n, int Lq, int heads, int dh,
                  float scale, float* dqkv, float drop_p, uint32_t seed, hipStream_t stream);
+/* The same over PACKED token rows: qkv / out / dout / dqkv hold only the rows rowmap names (position t of sample i at row rowmap[i*Lq + t],
+ * -1 = no such row: reads as zero, is not stored); `mask` is still the dense [n, Lq] key mask.  Needs heads % 4 == 0, dh % 4 == 0, Lq <= 32
+ * rows per 4-head group as in the dense cooperative path; dropout indices are (packed row) * heads*dh + column. */
+int nnr_mhsa_fwd_packed(const float* qkv, const uint8_t* mask, const int* rowmap, int n, int Lq, int heads, int dh, float scale, float* out,
+                        float drop_p, uint32_t seed, hipStream_t stream);
+int nnr_mhsa_bwd_packed(const float* qkv, const uint8_t* mask, const int* rowmap, const float* dout, int n, int Lq, int heads, int dh, float scale,
+                        float* dqkv, float drop_p, uint32_t seed, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------ SUE (userEncoders.py:68-98) */
 /* cmask_fix (optional): the [B, Kc + 1] cluster mask; its last column is set to 1 in place by the same launch (:73).

@@ -32,7 +32,9 @@ struct MhsaArgs {
   const float* qkv; const uint8_t* mask; int n, Lq, heads, dh; float scale;
   float* out; float* prob; const float* dout; float* dqkv;
   uint32_t seed, thr; float dscale;        // dropout on the attention output (thr == 0: off): out = keep(idx) ? O * dscale : 0
-};                                         // with idx = the flat element index in out / dout [n*Lq, heads*dh]
+                                           // with idx = the flat element index in out / dout [n*Lq, heads*dh]
+  const int* rowmap;                       // round 5, PACKED token rows (NULL: dense): position q of sample s lives at row rowmap[s*Lq + q] of
+};                                         // qkv / out / dout / dqkv, -1 = the row does not exist (a padded position: reads as zero, is not stored)
 
 // stage the [Lq, dh] slice (row stride ld) of one head into LDS as [LP][SD], zero rows >= Lq
 __device__ __forceinline__ void stage(float* dst, const float* src, int ld, int Lq, int dh, int LP, int SD, int lane) {
@@ -99,17 +101,20 @@ __device__ __forceinline__ void stage1v(float* tiles, const float* const (&src)[
 // float4 -- ALL loads of all NMAT matrices are issued before the first LDS write, so a wave pays the HBM latency once
 // instead of once per loop trip -- and scatters them into the per-wave tiles (tile m of wave w at w*wstride + m*LP*SD).
 // DM >= 0: matrix DM is the upstream gradient and gets the dropout mask (e0 = flat index of src[DM][0] in dout).
+// rmap (packed rows): the sample's slice of MhsaArgs::rowmap -- position q is row rmap[q] (src / e0 then are relative to ROW 0 of the buffers)
 template <int NMAT, int LP, int DM = -1>
 __device__ __forceinline__ void stage4v(float* smem, int wstride, const float* const (&src)[NMAT], const int (&ld)[NMAT],
-                                        int Lq, int dh, int SD, int tid, const MhsaArgs* a = nullptr, long e0 = 0) {
+                                        int Lq, int dh, int SD, int tid, const MhsaArgs* a = nullptr, long e0 = 0, const int* rmap = nullptr) {
   const int n4 = LP * dh;                  // float4 per matrix: LP rows x (4 heads * dh / 4)
   constexpr int U = 3;
   for (int b0 = 0; b0 < n4; b0 += 256 * U) {
     float4 r[NMAT][U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int idx = b0 + u * 256 + tid, q = idx / dh, c4 = idx - q * dh;
-      const bool live = idx < n4 && q < Lq;
+      const int idx = b0 + u * 256 + tid, q0 = idx / dh, c4 = idx - q0 * dh;
+      bool live = idx < n4 && q0 < Lq;
+      long q = q0;
+      if (rmap) { q = live ? rmap[q0] : -1; live = q >= 0; }
 #pragma unroll
       for (int m = 0; m < NMAT; ++m)
         r[m][u] = live ? *(const float4*)(src[m] + (long)q * ld[m] + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -138,11 +143,13 @@ __device__ __forceinline__ void stage4v(float* smem, int wstride, const float* c
 // the reverse: per-wave result tiles [LP][SD] (rows = sequence position) -> [Lq] row segments of 4*dh floats, float4 stores
 template <int LP, bool DROP = false>
 __device__ __forceinline__ void unstage4v(const float* tile0, int wstride, float* dst, int ld, int Lq, int dh, int SD, int tid,
-                                          const MhsaArgs* a = nullptr, long e0 = 0) {
+                                          const MhsaArgs* a = nullptr, long e0 = 0, const int* rmap = nullptr) {
   const int n4 = Lq * dh;
   for (int idx = tid; idx < n4; idx += 256) {
-    const int q = idx / dh, c = 4 * (idx - q * dh), w = c / dh, d = c - w * dh;
-    const float* t = tile0 + w * wstride + q * SD + d;
+    const int q0 = idx / dh, c = 4 * (idx - q0 * dh), w = c / dh, d = c - w * dh;
+    const float* t = tile0 + w * wstride + q0 * SD + d;
+    long q = q0;
+    if (rmap) { q = rmap[q0]; if (q < 0) continue; }         // a padded position: no row to store to
     float4 v = make_float4(t[0], t[1], t[2], t[3]);
     if (DROP && a->thr) {
       bool k[4];
@@ -295,11 +302,12 @@ __global__ __launch_bounds__(256) void mhsa_fwd_kernel(MhsaArgs a_in, int coop) 
   float* Ks = Qs + LP * SD;
   float* Vs = Ks + LP * SD;
   const int pair0 = blockIdx.x * 4, smp0 = pair0 / a.heads, head0 = pair0 - smp0 * a.heads;    // coop: the workgroup's 4 heads
+  const int* rmap = a.rowmap ? a.rowmap + (long)smp0 * a.Lq : nullptr;        // (packed rows: coop path only, checked by the entry point)
   if (coop) {
-    const float* base0 = a.qkv + (long)smp0 * a.Lq * ld + head0 * dh;
+    const float* base0 = a.qkv + (rmap ? 0 : (long)smp0 * a.Lq * ld) + head0 * dh;
     const float* const src[3] = {base0, base0 + HD, base0 + 2 * HD};
     const int lds[3] = {ld, ld, ld};
-    stage4v<3, LP>(smem, wstride, src, lds, a.Lq, dh, SD, threadIdx.x);
+    stage4v<3, LP>(smem, wstride, src, lds, a.Lq, dh, SD, threadIdx.x, nullptr, 0, rmap);
     __syncthreads();
   }
   if (pair >= a.n * a.heads) return;       // never taken on the coop path (n * heads is a multiple of 4 there)
@@ -334,8 +342,8 @@ __global__ __launch_bounds__(256) void mhsa_fwd_kernel(MhsaArgs a_in, int coop) 
   if (coop) {                              // O -> this wave's Q tile (free since the score product) -> 320-B row segments
     tile_T<NB>(Qs, SD, o, dh, lane);
     __syncthreads();
-    const long e0 = (long)smp0 * a.Lq * HD + head0 * dh;
-    unstage4v<LP, true>(smem, wstride, a.out + e0, HD, a.Lq, dh, SD, threadIdx.x, &a, e0);
+    const long e0 = (rmap ? 0 : (long)smp0 * a.Lq * HD) + head0 * dh;
+    unstage4v<LP, true>(smem, wstride, a.out + e0, HD, a.Lq, dh, SD, threadIdx.x, &a, e0, rmap);
   } else {
     const long e0 = (long)smp * a.Lq * HD + head * dh;
     if (a.thr) {
@@ -365,11 +373,13 @@ __global__ __launch_bounds__(256) void mhsa_bwd_kernel(MhsaArgs a, int coop) {
   float* Gs = Vs + LP * SD;                // dO
   float* T = Gs + LP * SD;                 // [LP][ST] transpose tile
   const int pair0 = blockIdx.x * 4, smp0 = pair0 / a.heads, head0 = pair0 - smp0 * a.heads;
+  const int* rmap = a.rowmap ? a.rowmap + (long)smp0 * a.Lq : nullptr;
   if (coop) {
-    const float* base0 = a.qkv + (long)smp0 * a.Lq * ld + head0 * dh;
-    const float* const src[4] = {base0, base0 + HD, base0 + 2 * HD, a.dout + (long)smp0 * a.Lq * HD + head0 * dh};
+    const float* base0 = a.qkv + (rmap ? 0 : (long)smp0 * a.Lq * ld) + head0 * dh;
+    const long e0c = (rmap ? 0 : (long)smp0 * a.Lq * HD) + head0 * dh;
+    const float* const src[4] = {base0, base0 + HD, base0 + 2 * HD, a.dout + e0c};
     const int lds[4] = {ld, ld, ld, HD};
-    stage4v<4, LP, 3>(smem, wstride, src, lds, a.Lq, dh, SD, threadIdx.x, &a, (long)smp0 * a.Lq * HD + head0 * dh);
+    stage4v<4, LP, 3>(smem, wstride, src, lds, a.Lq, dh, SD, threadIdx.x, &a, e0c, rmap);
     __syncthreads();
   }
   if (pair >= a.n * a.heads) return;
@@ -481,10 +491,10 @@ __global__ __launch_bounds__(256) void mhsa_bwd_kernel(MhsaArgs a, int coop) {
   if (coop) {
     t_times(Qs, Ks, SD);                   // dK into the K tile (its last reader was the dQ product)
     __syncthreads();
-    float* d0 = a.dqkv + (long)smp0 * a.Lq * ld + head0 * dh;
-    unstage4v<LP>(smem + 3 * LP * SD, wstride, d0, ld, a.Lq, dh, SD, threadIdx.x);            // dQ
-    unstage4v<LP>(smem + 1 * LP * SD, wstride, d0 + HD, ld, a.Lq, dh, SD, threadIdx.x);       // dK
-    unstage4v<LP>(smem + 2 * LP * SD, wstride, d0 + 2 * HD, ld, a.Lq, dh, SD, threadIdx.x);   // dV
+    float* d0 = a.dqkv + (rmap ? 0 : (long)smp0 * a.Lq * ld) + head0 * dh;
+    unstage4v<LP>(smem + 3 * LP * SD, wstride, d0, ld, a.Lq, dh, SD, threadIdx.x, nullptr, 0, rmap);            // dQ
+    unstage4v<LP>(smem + 1 * LP * SD, wstride, d0 + HD, ld, a.Lq, dh, SD, threadIdx.x, nullptr, 0, rmap);       // dK
+    unstage4v<LP>(smem + 2 * LP * SD, wstride, d0 + 2 * HD, ld, a.Lq, dh, SD, threadIdx.x, nullptr, 0, rmap);   // dV
   } else {
     t_times(Qs, dbase + HD, ld);
   }
@@ -498,12 +508,14 @@ __global__ __launch_bounds__(256) void mhsa_bwd_kernel(MhsaArgs a, int coop) {
 // and a store drain with only one other wave on its SIMD to cover for it (the one-group kernel: 8 us per head for ~4 us of work).
 template <int NMAT, int DM>
 __device__ __forceinline__ void load4v(float4 (&r)[NMAT][3], const float* const (&src)[NMAT], const int (&ld)[NMAT], int Lq, int dh, int tid,
-                                       const MhsaArgs& a, long e0) {
+                                       const MhsaArgs& a, long e0, const int* rmap = nullptr) {
   const int n4 = 32 * dh;                  // <= 768: one batch of three float4 per thread and matrix
 #pragma unroll
   for (int u = 0; u < 3; ++u) {
-    const int idx = u * 256 + tid, q = idx / dh, c4 = idx - q * dh;
-    const bool live = idx < n4 && q < Lq;
+    const int idx = u * 256 + tid, q0 = idx / dh, c4 = idx - q0 * dh;
+    bool live = idx < n4 && q0 < Lq;
+    long q = q0;
+    if (rmap) { q = live ? rmap[q0] : -1; live = q >= 0; }
 #pragma unroll
     for (int m = 0; m < NMAT; ++m)
       r[m][u] = live ? *(const float4*)(src[m] + (long)q * ld[m] + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -553,12 +565,13 @@ __global__ __launch_bounds__(256, 2) void mhsa_bwd_persist_kernel(MhsaArgs a_in,
   int mb = 0;                              // the key-mask byte of this lane's key position, loaded with the group's tiles
   auto issue = [&](int g) __attribute__((always_inline)) {
     const int pair0 = g * 4, smp0 = pair0 / a.heads, head0 = pair0 - smp0 * a.heads;
-    const float* base0 = a.qkv + (long)smp0 * a.Lq * ld + head0 * dh;
-    const long e0 = (long)smp0 * a.Lq * HD + head0 * dh;
+    const int* rmap = a.rowmap ? a.rowmap + (long)smp0 * a.Lq : nullptr;
+    const float* base0 = a.qkv + (rmap ? 0 : (long)smp0 * a.Lq * ld) + head0 * dh;
+    const long e0 = (rmap ? 0 : (long)smp0 * a.Lq * HD) + head0 * dh;
     const float* const src[4] = {base0, base0 + HD, base0 + 2 * HD, a.dout + e0};
     const int lds[4] = {ld, ld, ld, HD};
     mb = (a.mask && lane0 < a.Lq) ? (int)a.mask[(long)smp0 * a.Lq + lane0] : (a.mask ? 0 : 1);
-    load4v<4, 3>(r, src, lds, a.Lq, dh, tid0, a, e0);
+    load4v<4, 3>(r, src, lds, a.Lq, dh, tid0, a, e0, rmap);
   };
   issue(g_lo);
   put4v<4>(smem, wstride, r, dh, SD, tid0);
@@ -624,10 +637,11 @@ __global__ __launch_bounds__(256, 2) void mhsa_bwd_persist_kernel(MhsaArgs a_in,
     t_times(Qs, Ks, SD);                                        // dK into the K tile
     __syncthreads();
     // results leave through LDS as row segments; then the NEXT group's tiles (already in registers) go in
-    float* d0 = a.dqkv + (long)smp0 * a.Lq * ld + head0 * dh;
-    unstage4v<LP>(smem + 3 * LP * SD, wstride, d0, ld, a.Lq, dh, SD, tid);            // dQ
-    unstage4v<LP>(smem + 1 * LP * SD, wstride, d0 + HD, ld, a.Lq, dh, SD, tid);       // dK
-    unstage4v<LP>(smem + 2 * LP * SD, wstride, d0 + 2 * HD, ld, a.Lq, dh, SD, tid);   // dV
+    const int* rmap_g = a.rowmap ? a.rowmap + (long)smp0 * a.Lq : nullptr;
+    float* d0 = a.dqkv + (rmap_g ? 0 : (long)smp0 * a.Lq * ld) + head0 * dh;
+    unstage4v<LP>(smem + 3 * LP * SD, wstride, d0, ld, a.Lq, dh, SD, tid, nullptr, 0, rmap_g);            // dQ
+    unstage4v<LP>(smem + 1 * LP * SD, wstride, d0 + HD, ld, a.Lq, dh, SD, tid, nullptr, 0, rmap_g);       // dK
+    unstage4v<LP>(smem + 2 * LP * SD, wstride, d0 + 2 * HD, ld, a.Lq, dh, SD, tid, nullptr, 0, rmap_g);   // dV
     __syncthreads();                                            // every wave has read the result tiles
     if (g + 1 < g_hi) put4v<4>(smem, wstride, r, dh, SD, tid);
   }
@@ -635,15 +649,16 @@ __global__ __launch_bounds__(256, 2) void mhsa_bwd_persist_kernel(MhsaArgs a_in,
 
 }  // namespace
 
-extern "C" int nnr_mhsa_fwd(const float* qkv, const uint8_t* mask, int n, int Lq, int heads, int dh, float scale, float* out,
-                            float* prob, float drop_p, uint32_t seed, hipStream_t stream) {
+static int mhsa_fwd_launch(const float* qkv, const uint8_t* mask, const int* rowmap, int n, int Lq, int heads, int dh, float scale, float* out,
+                           float* prob, float drop_p, uint32_t seed, hipStream_t stream) {
   if (!qkv || !out || n <= 0) return NNR_ERR_ARG;
   if (Lq > 64 || dh > 32 || (dh & 1)) return NNR_ERR_UNSUPPORTED;
   MhsaArgs a{qkv, mask, n, Lq, heads, dh, scale, out, prob, nullptr, nullptr, seed, nnr_drop_thresh(drop_p),
-             drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f};
+             drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, rowmap};
   const int NB = Lq > 32 ? 2 : 1, LP = 32 * NB, SD = dh | 1;
   const int waves = 4;
   const int coop = (heads % 4 == 0 && dh % 4 == 0) ? 1 : 0;        // a workgroup's 4 waves then are 4 adjacent heads of one sample
+  if (rowmap && (!coop || prob)) return NNR_ERR_UNSUPPORTED;       // packed rows: the 4-head cooperative staging only
   const size_t shm = ((size_t)waves * 3 * LP * SD + 16) * sizeof(float);      // + 16: operand reads of lanes >= dh run up to 11 floats past the last row
   const int blocks = (n * heads + waves - 1) / waves;
   if (NB == 1 && dh == 20 && Lq == 32) hipLaunchKernelGGL((mhsa_fwd_kernel<1, 20, true>), dim3(blocks), dim3(64 * waves), shm, stream, a, coop);
@@ -655,15 +670,26 @@ extern "C" int nnr_mhsa_fwd(const float* qkv, const uint8_t* mask, int n, int Lq
   return NNR_OK;
 }
 
-extern "C" int nnr_mhsa_bwd(const float* qkv, const uint8_t* mask, const float* prob, const float* dout, int n, int Lq, int heads, int dh,
-                            float scale, float* dqkv, float drop_p, uint32_t seed, hipStream_t stream) {
+extern "C" int nnr_mhsa_fwd(const float* qkv, const uint8_t* mask, int n, int Lq, int heads, int dh, float scale, float* out,
+                            float* prob, float drop_p, uint32_t seed, hipStream_t stream) {
+  return mhsa_fwd_launch(qkv, mask, nullptr, n, Lq, heads, dh, scale, out, prob, drop_p, seed, stream);
+}
+extern "C" int nnr_mhsa_fwd_packed(const float* qkv, const uint8_t* mask, const int* rowmap, int n, int Lq, int heads, int dh, float scale,
+                                   float* out, float drop_p, uint32_t seed, hipStream_t stream) {
+  if (!rowmap) return NNR_ERR_ARG;
+  return mhsa_fwd_launch(qkv, mask, rowmap, n, Lq, heads, dh, scale, out, nullptr, drop_p, seed, stream);
+}
+
+static int mhsa_bwd_launch(const float* qkv, const uint8_t* mask, const int* rowmap, const float* prob, const float* dout, int n, int Lq, int heads,
+                           int dh, float scale, float* dqkv, float drop_p, uint32_t seed, hipStream_t stream) {
   if (!qkv || !dout || !dqkv || n <= 0) return NNR_ERR_ARG;         // prob == NULL: P is recomputed from Q, K
   if (Lq > 64 || dh > 32 || (dh & 1)) return NNR_ERR_UNSUPPORTED;
   MhsaArgs a{qkv, mask, n, Lq, heads, dh, scale, nullptr, const_cast<float*>(prob), dout, dqkv, seed, nnr_drop_thresh(drop_p),
-             drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f};
+             drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, rowmap};
   const int NB = Lq > 32 ? 2 : 1, LP = 32 * NB, SD = dh | 1;
   const int waves = NB == 1 ? 4 : 1;
   const int coop = (waves == 4 && heads % 4 == 0 && dh % 4 == 0) ? 1 : 0;
+  if (rowmap && (!coop || prob)) return NNR_ERR_UNSUPPORTED;
   const size_t shm = ((size_t)waves * (4 * LP * SD + LP * (LP + 1)) + 16) * sizeof(float);
   const int blocks = (n * heads + waves - 1) / waves;
   static const int persist = [] { const char* e = getenv("NNR_MHSA_PERSIST"); return e ? atoi(e) : 1; }();      // A/B: 0 = one 4-head group per workgroup
@@ -685,4 +711,14 @@ extern "C" int nnr_mhsa_bwd(const float* qkv, const uint8_t* mask, const float* 
   else hipLaunchKernelGGL((mhsa_bwd_kernel<2, 0>), dim3(blocks), dim3(64 * waves), shm, stream, a, coop);
   NNR_CHECK_LAUNCH();
   return NNR_OK;
+}
+
+extern "C" int nnr_mhsa_bwd(const float* qkv, const uint8_t* mask, const float* prob, const float* dout, int n, int Lq, int heads, int dh,
+                            float scale, float* dqkv, float drop_p, uint32_t seed, hipStream_t stream) {
+  return mhsa_bwd_launch(qkv, mask, nullptr, prob, dout, n, Lq, heads, dh, scale, dqkv, drop_p, seed, stream);
+}
+extern "C" int nnr_mhsa_bwd_packed(const float* qkv, const uint8_t* mask, const int* rowmap, const float* dout, int n, int Lq, int heads, int dh,
+                                   float scale, float* dqkv, float drop_p, uint32_t seed, hipStream_t stream) {
+  if (!rowmap) return NNR_ERR_ARG;
+  return mhsa_bwd_launch(qkv, mask, rowmap, nullptr, dout, n, Lq, heads, dh, scale, dqkv, drop_p, seed, stream);
 }

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void pool_kernel(PoolArgs a) {
 #pragma unroll
       for (int k = 0; k < MAXT; ++k) {
         const int t = lane + 64 * k;
-        if (t < len && !a.mask[(long)(s / a.mask_div) * a.L + t]) sc[k] = -1e9f;
+        if (t < len && !a.mask[(long)((a.packed ? oidx : s) / a.mask_div) * a.L + t]) sc[k] = -1e9f;      // (packed: the mask is in the caller's row order)
       }
     }
     // ---- softmax over t < len (every wave computes the same values)
@@ -243,6 +243,9 @@ __global__ __launch_bounds__(256) void pool_kernel(PoolArgs a) {
     for (int k = 0; k < MAXT; ++k) {
       const int t = lane + 64 * k;
       ds[k] = al[k] * (da[k] - dsum);          // d loss / d score_t (masked items have alpha = 0 -> 0)
+      // ... except in a FULLY masked group (every score is the constant -1e9: alpha is uniform, not 0): masked_fill passes no gradient
+      // to the score it replaced (layers.py:171,199)
+      if (a.mask && t < len && !a.mask[(long)((a.packed ? oidx : s) / a.mask_div) * a.L + t]) ds[k] = 0.f;
       if (w == 0 && t < len && a.dscore) a.dscore[item_row(a, s, t)] = ds[k];
     }
     f32x4 dvacc[MAXV];

@@ -210,3 +210,40 @@ extern "C" int nnr_seq_plan_pair(uint8_t* mask0, const int* ids0, int n0, uint8_
   if (!mask1 || n0 <= 0 || n1 <= 0 || (ids0 && !ids1)) return NNR_ERR_ARG;
   return seq_plan_impl(mask0, ids0, n0, mask1, ids1, n0 + n1, L, perm_in, len_out, order, rank, slen, bs, off, row_seq, tok, prev_f, prev_r, stream);
 }
+
+// ---- packed token rows for the MHSA news encoder (round 5; newsEncoders.py:187-200, layers.py:132-148,167-175).  The reference runs its
+// Q/K/V and attention projections over all n * L padded positions; padded positions provably never reach the result (their keys are masked
+// with -1e9, their pooled weight is exactly 0) unless a title is FULLY masked (softmax over 32 x -1e9 is uniform: all 32 positions count).
+//   cover[i][t] = 1 for t <= (last valid position of title i), all ones for a title without any valid position
+// is the set of rows that must exist; nnr_seq_plan on `cover` packs exactly those (for the prefix-shaped masks of the corpus,
+// MIND_corpus.py:316,352: cover == mask), and the ORIGINAL mask still masks keys / pooled positions inside the kernels.
+__global__ void mask_cover_kernel(const uint8_t* __restrict__ mask, int n, int L, uint8_t* __restrict__ cover) {
+  const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= n) return;
+  int last = -1;
+  for (int t = lane; t < L; t += 64) if (mask[(long)i * L + t]) last = max(last, t);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) last = max(last, __shfl_xor(last, o, 64));
+  if (last < 0) last = L - 1;
+  for (int t = lane; t < L; t += 64) cover[(long)i * L + t] = t <= last ? 1 : 0;
+}
+// rowmap[i*L + t] = packed row of position t of sequence i (off[t] + rank[i]) for t < len[i], else -1
+__global__ void seq_rowmap_kernel(const int* __restrict__ off, const int* __restrict__ rank, const int* __restrict__ len, int n, int L,
+                                  int* __restrict__ rowmap) {
+  const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (idx >= (long)n * L) return;
+  const int i = (int)(idx / L), t = (int)(idx - (long)i * L);
+  rowmap[idx] = t < len[i] ? off[t] + rank[i] : -1;
+}
+extern "C" int nnr_mask_cover(const uint8_t* mask, int n, int L, uint8_t* cover, hipStream_t stream) {
+  if (!mask || !cover || n <= 0 || L <= 0) return NNR_ERR_ARG;
+  hipLaunchKernelGGL(mask_cover_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, mask, n, L, cover);
+  NNR_CHECK_LAUNCH();
+  return NNR_OK;
+}
+extern "C" int nnr_seq_rowmap(const int* off, const int* rank, const int* len, int n, int L, int* rowmap, hipStream_t stream) {
+  if (!off || !rank || !len || !rowmap || n <= 0 || L <= 0) return NNR_ERR_ARG;
+  hipLaunchKernelGGL(seq_rowmap_kernel, dim3((unsigned)(((long)n * L + 255) / 256)), dim3(256), 0, stream, off, rank, len, n, L, rowmap);
+  NNR_CHECK_LAUNCH();
+  return NNR_OK;
+}

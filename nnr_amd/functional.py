@@ -26,6 +26,101 @@ class EmbedDropFn(torch.autograd.Function):
         return None, None, None, None
 
 
+# ---------------------------------------------------------------------------------------------- MHSA news encoder over PACKED token rows
+# (round 5)  The reference's MHSA news encoder multiplies all n * L padded positions through W_Q / W_K / W_V and the additive attention's
+# affine1 (newsEncoders.py:187-200, layers.py:134-136,168); ~64 % of those rows are padding whose keys are masked (-1e9) and whose pooled
+# weight is exactly 0.  Here only the rows ops.mask_cover names exist (every position up to a title's last valid one; ALL positions of a
+# fully masked title, whose softmax is uniform), packed time-major by nnr_seq_plan exactly like CNE's token streams; the attention core
+# finds position t of title i through a row map, the pool through the plan.  The original mask still masks keys and pooled positions.
+class MhsaPack:
+    """Plan + row map of one encoder call over `mask` [n, L] (bool / uint8) and `ids` [n, L] int32."""
+
+    def __init__(self, mask, ids):
+        cover = ops.mask_cover(mask)
+        self.plan = ops.SeqPlan(cover, ids.contiguous(), None)          # (its in-place mask[:, 0] = 1 acts on `cover`: a no-op there)
+        self.rowmap = ops.seq_rowmap(self.plan)
+        self.cover = cover
+
+
+class PackedEmbedDropFn(torch.autograd.Function):
+    """dropout(word_embedding(ids)) over the packed rows only; mask index = packed row * E + column."""
+
+    @staticmethod
+    def forward(ctx, table, pack, p, seed):
+        plan = pack.plan
+        out = ops.embed_gather(table, plan.tok, p, seed, dyn=plan.total)
+        ctx.table, ctx.plan, ctx.p, ctx.seed = table, plan, p, seed
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        plan = ctx.plan
+        ops.embed_scatter(dout.contiguous(), plan.tok, grad_of(ctx.table), ctx.p, ctx.seed, dyn=plan.total)
+        return None, None, None, None
+
+
+class PackedMhsaCoreFn(torch.autograd.Function):
+    """MhsaCoreFn over packed rows: qkv / out are [cap, .] with only the plan's live rows defined."""
+
+    @staticmethod
+    def forward(ctx, qkv, mask, pack, heads, dh, p=0.0, seed=0):
+        qkv = qkv.contiguous()
+        out = torch.empty((pack.plan.cap, heads * dh), device=qkv.device, dtype=torch.float32)
+        ops.mhsa_fwd_packed(qkv, mask, pack.rowmap, pack.plan, heads, dh, out, p, seed)
+        ctx.qkv, ctx.mask, ctx.pack, ctx.dims, ctx.drop = qkv, mask, pack, (heads, dh), (p, seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        heads, dh = ctx.dims
+        dqkv = torch.empty_like(ctx.qkv)
+        ops.mhsa_bwd_packed(ctx.qkv, ctx.mask, ctx.pack.rowmap, ctx.pack.plan, dout.contiguous(), heads, dh, dqkv, *ctx.drop)
+        return dqkv, None, None, None, None, None, None
+
+
+class PackedAttentionFn(torch.autograd.Function):
+    """layers.py:167-175 over packed rows [cap, F]: tanh GEMM on the live rows, then the packed softmax pool (w2 . tanh(.) score inside the
+    pool's pass, the ORIGINAL [n, L] mask applied to the scores); out [n, F] in the caller's row order."""
+
+    @staticmethod
+    def forward(ctx, feature, mod, mask, pack):
+        plan = pack.plan
+        cap, F = feature.shape
+        A = mod.affine1.weight.shape[0]
+        x = feature.contiguous()
+        f32 = dict(device=x.device, dtype=torch.float32)
+        th = torch.empty((cap, A), **f32)
+        ops.gemm(x, mod.affine1.weight, th, M=cap, N=A, K=F, lda=F, ldb=F, ldc=A, bias=mod.affine1.bias, act=ops.ACT_TANH, dyn=plan.total, dyn_dim=1)
+        alpha = torch.empty(cap, **f32)
+        out = torch.empty((plan.n, F), **f32)
+        if A <= 256 and A % 4 == 0:
+            ops.pool_fwd(x=x, ldx=F, D=F, n=plan.n, Lx=plan.L, plan=plan, mask=mask, th=th, w2=mod.affine2.weight, alpha=alpha, out=out, ldo=F)
+        else:
+            score = torch.empty(cap, **f32)
+            ops.rowdot(th, mod.affine2.weight, score, dyn=plan.total)
+            ops.pool_fwd(x=x, ldx=F, D=F, n=plan.n, Lx=plan.L, plan=plan, mask=mask, score=score, alpha=alpha, out=out, ldo=F)
+        ctx.mod, ctx.mask, ctx.plan, ctx.saved = mod, mask, plan, (x, th, alpha, F, A)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        mod, plan = ctx.mod, ctx.plan
+        x, th, alpha, F, A = ctx.saved
+        cap = plan.cap
+        f32 = dict(device=x.device, dtype=torch.float32)
+        dx = torch.empty((cap, F), **f32)
+        ds = torch.empty(cap, **f32)
+        ops.pool_bwd(x=x, ldx=F, D=F, n=plan.n, Lx=plan.L, plan=plan, mask=ctx.mask, alpha=alpha, dout=dout.contiguous(), lddo=F, dx=dx, lddx=F, dscore=ds)
+        ops.tanh_score_bwd(th, ds, mod.affine2.weight, grad_of(mod.affine2.weight), plan, A)          # th := d(pre-activation)
+        gw, gb = grad_of(mod.affine1.weight), grad_of(mod.affine1.bias)
+        ops.leaf_deferred(x.device, cap, lambda: ops.linear_bwd_weight(th, x, gw, db=gb, dyn=plan.total), th, x)
+        if ops.USE_WT and cap >= 1024 and (A & 3) == 0:
+            ops.gemm(th, ops.wt(mod.affine1.weight), dx, M=cap, N=F, K=A, lda=A, ldb=A, ldc=F, accumulate=True, dyn=plan.total, dyn_dim=1)
+        else:
+            ops.gemm(th, mod.affine1.weight, dx, M=cap, N=F, K=A, lda=A, ldb=F, ldc=F, trans_b=True, accumulate=True, dyn=plan.total, dyn_dim=1)
+        return dx, None, None, None
+
+
 class LinearFn(torch.autograd.Function):
     """y = dropout(act(x W^T + b)) for 2-D contiguous x;  act in {none, relu};  dropout mask keyed by the output element."""
 
@@ -71,45 +166,49 @@ class QKVFn(torch.autograd.Function):
         return (w, b) if w is not None and b is not None else (None, None)
 
     @staticmethod
-    def forward(ctx, x, mha):
+    def forward(ctx, x, mha, dyn=None):
+        """dyn: device int32 with the number of LIVE rows of x (packed token rows: the rest of the buffer is undefined)."""
         x = x.contiguous()
         M, K = x.shape
         HD = mha.W_Q.weight.shape[0]
         qkv = torch.empty((M, 3 * HD), device=x.device, dtype=torch.float32)
         w, b = QKVFn._stacked(mha)
+        dk = dict(dyn=dyn, dyn_dim=1) if dyn is not None else {}
         if w is not None:
-            ops.gemm(x, w, qkv, M=M, N=3 * HD, K=K, lda=K, ldb=K, ldc=3 * HD, bias=b)
+            ops.gemm(x, w, qkv, M=M, N=3 * HD, K=K, lda=K, ldb=K, ldc=3 * HD, bias=b, **dk)
         else:
             for s, lin in enumerate((mha.W_Q, mha.W_K, mha.W_V)):
-                ops.gemm(x, lin.weight, qkv[:, s * HD:], M=M, N=HD, K=K, lda=K, ldb=K, ldc=3 * HD, bias=lin.bias)
-        ctx.x, ctx.mha, ctx.HD = x, mha, HD
+                ops.gemm(x, lin.weight, qkv[:, s * HD:], M=M, N=HD, K=K, lda=K, ldb=K, ldc=3 * HD, bias=lin.bias, **dk)
+        ctx.x, ctx.mha, ctx.HD, ctx.dyn = x, mha, HD, dyn
         return qkv
 
     @staticmethod
     def backward(ctx, dqkv):
         dqkv = dqkv.contiguous()
-        x, mha, HD = ctx.x, ctx.mha, ctx.HD
+        x, mha, HD, dyn = ctx.x, ctx.mha, ctx.HD, ctx.dyn
         M, K = x.shape
         dx = torch.empty_like(x)
         w, _ = QKVFn._stacked(mha)
         gw, gb = QKVFn._stacked(mha, grads=True) if w is not None else (None, None)
+        d1 = dict(dyn=dyn, dyn_dim=1) if dyn is not None else {}        # live rows bound M of the data gradient ...
+        d2 = dict(dyn=dyn, dyn_dim=2) if dyn is not None else {}        # ... and the reduction of the weight gradient
         if gw is not None:
             # dW (+ the bias gradient, fused into the same launch) is a leaf: own stream, joined at the end of the pass
             ops.leaf_deferred(x.device, M, lambda: ops.gemm(dqkv, x, gw, M=3 * HD, N=K, K=M, lda=3 * HD, ldb=K, ldc=K, trans_a=True,
                                                          trans_b=True, split_k=ops.split_for(3 * HD, K, M, *ops.tn_tile(3 * HD, K, M)[1:]), atomic=True,
-                                                         colsum_out=gb, tile=ops.tn_tile(3 * HD, K, M)[0]), dqkv, x)
+                                                         colsum_out=gb, tile=ops.tn_tile(3 * HD, K, M)[0], **d2), dqkv, x)
             if ops.USE_WT and M >= 1024 and w.is_contiguous():
-                ops.gemm(dqkv, ops.wt(w), dx, M=M, N=K, K=3 * HD, lda=3 * HD, ldb=3 * HD, ldc=K)          # NT on [W_Q; W_K; W_V]^T
+                ops.gemm(dqkv, ops.wt(w), dx, M=M, N=K, K=3 * HD, lda=3 * HD, ldb=3 * HD, ldc=K, **d1)          # NT on [W_Q; W_K; W_V]^T
             else:
-                ops.gemm(dqkv, w, dx, M=M, N=K, K=3 * HD, lda=3 * HD, ldb=K, ldc=K, trans_b=True)
-            return dx, None
+                ops.gemm(dqkv, w, dx, M=M, N=K, K=3 * HD, lda=3 * HD, ldb=K, ldc=K, trans_b=True, **d1)
+            return dx, None, None
         for s, lin in enumerate((mha.W_Q, mha.W_K, mha.W_V)):
             d = dqkv[:, s * HD:]
-            ops.gemm(d, lin.weight, dx, M=M, N=K, K=HD, lda=3 * HD, ldb=K, ldc=K, trans_b=True, accumulate=(s > 0))
+            ops.gemm(d, lin.weight, dx, M=M, N=K, K=HD, lda=3 * HD, ldb=K, ldc=K, trans_b=True, accumulate=(s > 0), **d1)
             ops.gemm(d, x, grad_of(lin.weight), M=HD, N=K, K=M, lda=3 * HD, ldb=K, ldc=K, trans_a=True, trans_b=True,
-                     split_k=ops.split_for(HD, K, M), atomic=True)
-            ops.bias_grad(d, grad_of(lin.bias), rows=M)
-        return dx, None
+                     split_k=ops.split_for(HD, K, M), atomic=True, **d2)
+            ops.bias_grad(d, grad_of(lin.bias), rows=M, **({'dyn': dyn} if dyn is not None else {}))
+        return dx, None, None
 
 
 class MhsaCoreFn(torch.autograd.Function):

@@ -794,6 +794,16 @@ class CNE(NewsEncoder):
 
 
 # ================================================================================================== MHSA / CNN
+_MHSA_PACKED = os.environ.get('NNR_MHSA_PACKED', '1') != '0'      # A/B (round 5): MHSA news encoder over packed token rows
+
+
+def mhsa_packed(enc, title_text):
+    """Packed rows need the 4-head cooperative attention core (heads % 4 == 0, head_dim % 4 == 0, titles of at most 32 positions) and
+    device tensors; anything else takes the dense path."""
+    return (_MHSA_PACKED and title_text.is_cuda and enc.head_num % 4 == 0 and enc.head_dim % 4 == 0 and enc.head_dim <= 32
+            and enc.max_sentence_length <= 32 and enc.word_embedding_dim % 4 == 0)
+
+
 class MHSA(NewsEncoder):
     """newsEncoders.py:173-200: title only; embedding gather -> QKV GEMMs -> MFMA attention core -> dropout ->
     additive attention pool -> feature fusion."""
@@ -821,8 +831,16 @@ class MHSA(NewsEncoder):
         p = self.dropout_rate if self.training else 0.0
         seed = self._next_seed()
         mask = title_mask.view(n, Lx)
+        if mhsa_packed(self, title_text):
+            # only the token rows that can reach the result (functional.MhsaPack): ~36 % of n * L at MIND title lengths
+            pack = Fn.MhsaPack(mask, _i32(title_text).reshape(n, Lx))
+            w = Fn.PackedEmbedDropFn.apply(self.word_embedding.weight, pack, p, seed + 1)                   # [cap, E], live rows only
+            qkv = Fn.QKVFn.apply(w, self.multiheadAttention, pack.plan.total)
+            c = Fn.PackedMhsaCoreFn.apply(qkv, mask, pack, self.head_num, self.head_dim, p, seed + 2)       # [cap, h*d], dropout fused
+            rep = Fn.PackedAttentionFn.apply(c, self.attention, mask, pack)                                 # [n, h*d]
+            return Fn.FuseFn.apply(rep, self, category, subCategory, p, seed).view(B, N, self.news_embedding_dim)
         w = Fn.EmbedDropFn.apply(self.word_embedding.weight, title_text, p, seed + 1)                       # [n*L, E]
-        qkv = Fn.QKVFn.apply(w, self.multiheadAttention)
+        qkv = Fn.QKVFn.apply(w, self.multiheadAttention, None)
         c = Fn.MhsaCoreFn.apply(qkv, mask, n, Lx, self.head_num, self.head_dim, p, seed + 2)                # [n*L, h*d], dropout fused
         rep = self.attention(c.view(n, Lx, self.feature_dim), mask)                                         # [n, h*d]
         return Fn.FuseFn.apply(rep, self, category, subCategory, p, seed).view(B, N, self.news_embedding_dim)

@@ -1043,6 +1043,56 @@ def _mhsa_bwd(qkv, mask, prob, dout, n, Lq, heads, dh, dqkv, p, seed):
                                  C.c_float(p), C.c_uint32(seed & 0xFFFFFFFF), _s()), 'nnr_mhsa_bwd')
 
 
+def mask_cover(mask):
+    """cover[i][t] = 1 for t <= the last valid position of row i, all ones for a row without a valid position (csrc/seq_plan.hip)."""
+    m8 = mask.view(torch.uint8) if mask.dtype == torch.bool else mask
+    assert m8.is_contiguous() and m8.dim() == 2
+    out = torch.empty_like(m8)
+    L.check(L.lib().nnr_mask_cover(_p(m8), m8.shape[0], m8.shape[1], _p(out), _s()), 'nnr_mask_cover')
+    return out
+
+
+def seq_rowmap(plan):
+    """[n * L] int32: packed row of position t of sequence i (plan.off[t] + plan.rank[i]) or -1 beyond the sequence's length."""
+    out = torch.empty(plan.n * plan.L, device=plan.off.device, dtype=torch.int32)
+    L.check(L.lib().nnr_seq_rowmap(_p(plan.off), _p(plan.rank), _p(plan.len), plan.n, plan.L, _p(out), _s()), 'nnr_seq_rowmap')
+    return out
+
+
+def _mhsa_span_packed(family, plan, heads, dh, flop_units, arrays):
+    """MFMA work as the dense form (the kernel still multiplies 32 x 32 tiles); HBM bytes over the LIVE rows only."""
+    if not _prof.active():
+        return _NOSPAN
+    n, Lq = plan.n, plan.L
+
+    def flops(vals=None):
+        return flop_units * Lq * Lq * dh * heads * n
+
+    def nbytes(vals=None, total=plan.total):
+        rows = min(n * Lq, int(vals[total.data_ptr()]) if vals is not None else int(total.reshape(-1)[0].item()))
+        return arrays * 4.0 * rows * heads * dh
+    flops.dyn = [plan.total]
+    flops.bytes_fn = nbytes
+    flops.tag = 'n%d L%d h%d d%d packed' % (n, Lq, heads, dh)
+    return _prof.span(family, flops)
+
+
+def mhsa_fwd_packed(qkv, mask, rowmap, plan, heads, dh, out, p=0.0, seed=0):
+    if mask is not None and mask.dtype == torch.bool:
+        mask = mask.view(torch.uint8)
+    with _mhsa_span_packed('mhsa_fwd', plan, heads, dh, 4.0, 4.0):
+        L.check(L.lib().nnr_mhsa_fwd_packed(_p(qkv), _p(mask), _p(rowmap), plan.n, plan.L, heads, dh, C.c_float(1.0 / math.sqrt(dh)), _p(out),
+                                            C.c_float(p), C.c_uint32(seed & 0xFFFFFFFF), _s()), 'nnr_mhsa_fwd_packed')
+
+
+def mhsa_bwd_packed(qkv, mask, rowmap, plan, dout, heads, dh, dqkv, p=0.0, seed=0):
+    if mask is not None and mask.dtype == torch.bool:
+        mask = mask.view(torch.uint8)
+    with _mhsa_span_packed('mhsa_bwd', plan, heads, dh, 10.0, 7.0):
+        L.check(L.lib().nnr_mhsa_bwd_packed(_p(qkv), _p(mask), _p(rowmap), _p(dout), plan.n, plan.L, heads, dh, C.c_float(1.0 / math.sqrt(dh)),
+                                            _p(dqkv), C.c_float(p), C.c_uint32(seed & 0xFFFFFFFF), _s()), 'nnr_mhsa_bwd_packed')
+
+
 def mhsa_prob_size(n, Lq, heads):
     nb = 2 if Lq > 32 else 1
     return n * heads * nb * nb * 1024

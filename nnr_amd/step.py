@@ -78,19 +78,28 @@ def _mhsa_news_forward(ne, title_text, title_mask, category, subCategory):
     p = ne.dropout_rate if ne.training else 0.0
     seed = ne._next_seed()
     mask = title_mask.view(n, Lx)
+    from .news_encoders import mhsa_packed
+    if mhsa_packed(ne, title_text):
+        pack = Fn.MhsaPack(mask, title_text.reshape(n, Lx))
+        w, n1 = _fwd(Fn.PackedEmbedDropFn, ne.word_embedding.weight, pack, p, seed + 1)
+        qkv, n2 = _fwd(Fn.QKVFn, w, ne.multiheadAttention, pack.plan.total)
+        c, n3 = _fwd(Fn.PackedMhsaCoreFn, qkv, mask, pack, ne.head_num, ne.head_dim, p, seed + 2)
+        rep, n4 = _fwd(Fn.PackedAttentionFn, c, ne.attention, mask, pack)
+        out, n5 = _fwd(Fn.FuseFn, rep, ne, category, subCategory, p, seed)
+        return out.view(B, N, ne.news_embedding_dim), (n1, n2, n3, n4, n5, (n, Lx, True))
     w, n1 = _fwd(Fn.EmbedDropFn, ne.word_embedding.weight, title_text, p, seed + 1)
     qkv, n2 = _fwd(Fn.QKVFn, w, ne.multiheadAttention)
     c, n3 = _fwd(Fn.MhsaCoreFn, qkv, mask, n, Lx, ne.head_num, ne.head_dim, p, seed + 2)
     rep, n4 = _fwd(_AttentionFn, c.view(n, Lx, ne.feature_dim), ne.attention, mask)
     out, n5 = _fwd(Fn.FuseFn, rep, ne, category, subCategory, p, seed)
-    return out.view(B, N, ne.news_embedding_dim), (n1, n2, n3, n4, n5, (n, Lx))
+    return out.view(B, N, ne.news_embedding_dim), (n1, n2, n3, n4, n5, (n, Lx, False))
 
 
 def _mhsa_news_backward(ne, nodes, dout):
-    n1, n2, n3, n4, n5, (n, Lx) = nodes
+    n1, n2, n3, n4, n5, (n, Lx, packed) = nodes
     drep = _bwd(n5, dout.reshape(n, -1))[0]
     dc = _bwd(n4, drep)[0]
-    dqkv = _bwd(n3, dc.reshape(n * Lx, -1))[0]
+    dqkv = _bwd(n3, dc if packed else dc.reshape(n * Lx, -1))[0]
     dw = _bwd(n2, dqkv)[0]
     _bwd(n1, dw)
 

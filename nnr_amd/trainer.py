@@ -33,7 +33,7 @@ def _tape_budget_gb(dev):
 
 
 _SKIP_POLL = int(os.environ.get('NNR_SKIP_POLL', '8'))
-_SPLIT_NORM = os.environ.get('NNR_SPLIT_NORM', '1') != '0'      # A/B (round 5): the table bucket's share of the gradient norm on the helper stream
+_SPLIT_NORM = os.environ.get('NNR_SPLIT_NORM', '0') == '1'      # A/B (round 5), OFF: the table bucket's share of the gradient norm on the helper stream -- measured SLOWER (profiles/r05_ab.txt)
 _WARM_STEPS = 2          # eager steps before a tape is recorded (first-use allocations: workspaces, W^T copies, packed weights)
 
 

@@ -402,7 +402,7 @@ class MHSA(UserEncoder):
         from . import functional as Fn
         news_num = candidate_news_representation.size(1)
         B, Hn, D = history_embedding.shape
-        qkv = Fn.QKVFn.apply(history_embedding.reshape(B * Hn, D), self.multiheadAttention)
+        qkv = Fn.QKVFn.apply(history_embedding.reshape(B * Hn, D), self.multiheadAttention, None)
         h = Fn.MhsaCoreFn.apply(qkv, user_history_mask.contiguous(), B, Hn, self.head_num, self.head_dim)
         # relu(dropout(affine(h))) == dropout(relu(affine(h))): the mask scales by a non-negative factor
         h = Fn.LinearFn.apply(h, self.affine.weight, self.affine.bias, ops.ACT_RELU, 0.5 if self.training else 0.0, self._next_seed())

@@ -89,6 +89,7 @@ def cne_masks(model, batch_dev, union=True):
 
 def dense_news_masks(model, batch_dev):
     """MHSA / CNN news encoders: two calls (candidate, history), each with its own seed."""
+    from nnr_amd import news_encoders as NE, ops
     ne = model.news_encoder
     p = ne.dropout_rate
     E = ne.word_embedding_dim
@@ -97,8 +98,18 @@ def dense_news_masks(model, batch_dev):
     B, N = batch_dev['news_title_text'].shape[:2]
     Hn = batch_dev['user_title_text'].shape[1]
     out = {}
-    for call, n in ((0, B * N), (1, B * Hn)):
+    # round 5: the MHSA news encoder runs over PACKED token rows (functional.MhsaPack): its word-row and attention-output masks are
+    # indexed by (packed row, column), as CNE's are
+    packed = type(ne).__name__ == 'MHSA' and NE.mhsa_packed(ne, batch_dev['news_title_text'])
+    for call, n, key in ((0, B * N, 'news'), (1, B * Hn, 'user')):
         seed = _news_seed(ne, 1 + call)
+        if packed:
+            plan = ops.SeqPlan(ops.mask_cover(batch_dev[key + '_title_mask'].reshape(n, L).contiguous()), None)
+            out[('title', call)] = _packed_to_dense(plan, flat_keep(plan.cap * E, p, seed + 1).view(plan.cap, E), n, L, E).cpu()
+            out[('mid', call)] = _packed_to_dense(plan, flat_keep(plan.cap * F, p, seed + 2).view(plan.cap, F), n, L, F).cpu()
+            out[('cat', call)] = flat_keep(n * 50, p, seed + 3).view(n, 50).cpu()
+            out[('sub', call)] = flat_keep(n * 50, p, seed + 4).view(n, 50).cpu()
+            continue
         out[('title', call)] = flat_keep(n * L * E, p, seed + 1).view(n, L, E).cpu()
         out[('mid', call)] = flat_keep(n * L * F, p, seed + 2).view(n, L, F).cpu()
         out[('cat', call)] = flat_keep(n * 50, p, seed + 3).view(n, 50).cpu()

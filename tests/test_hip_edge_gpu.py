@@ -166,6 +166,29 @@ def test_mhsa_and_cnn_pairs_on_ragged_batch():
             assert float((p.grad.cpu().double() - rp[k].grad.double()).abs().max()) <= 1e-4 * max(1e-3, 0.05 * total), (ne, ue, k)
 
 
+@pytest.mark.parametrize('dropout', [0.0, 0.2])
+def test_mhsa_pair_with_fully_masked_and_gapped_titles(dropout):
+    """The MHSA news encoder runs over packed token rows (round 5); padding is observable in exactly one case -- a title whose mask is
+    ALL zero (no mask[:, 0] = 1 fix-up exists in the MHSA encoder, newsEncoders.py:187-200: every key is -1e9, both softmaxes are uniform
+    over all 32 positions).  The corpus never produces one (MIND_corpus.py:352 gives the <PAD> news one valid position), the kernels must
+    still agree with the reference's semantics: a fully masked history title, a fully masked CANDIDATE title, and a title with an
+    interior masked position, forward + every gradient against the oracle, with dropout off and on (HIP masks injected)."""
+    import hip_masks
+    cfg = make_config(['--news_encoder=MHSA', '--user_encoder=MHSA'], corpus_sizes=dict(vocabulary_size=800), dropout_rate=dropout, batch_size=4)
+    model, ref = _models(cfg, seed=11)
+    corpus = SynthCorpus(SynthSpec(vocabulary_size=cfg.vocabulary_size, news_pool=400, seed=13))
+    b = corpus.batch(4, np.random.default_rng(14))
+    b['user_title_mask'][1, 7, :] = False                      # fully masked history title (its ids stay: the rows still exist)
+    b['news_title_mask'][2, 3, :] = False                      # fully masked candidate title
+    b['user_title_mask'][0, 2, :6] = True
+    b['user_title_mask'][0, 2, 2] = False                      # an interior masked position
+    b = {k: np.ascontiguousarray(v) for k, v in b.items()}
+    if dropout > 0:
+        dev_batch = to_torch(b, 'cuda')
+        hip_masks.inject(model, ref, dict(zip(BATCH_FIELDS, dev_batch)))
+    _compare(model, ref, b)
+
+
 def test_deferred_weight_gradients_match_inline():
     """MHSA+MHSA and CNN+ATT on a GPU-bound step size (>= ops.LEAF_MIN_ROWS token rows): the weight-gradient GEMMs go to the
     leaf stream (ops.leaf_deferred), with W_Q|W_K|W_V fused through the trainer's flat layout, and the candidate encoder call

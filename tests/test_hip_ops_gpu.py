@@ -950,6 +950,75 @@ def test_sumsq_is_accurate_and_deterministic(n):
     assert torch.equal(out[0], out[1])
 
 
+def test_mhsa_core_over_packed_rows_equals_dense():
+    """Round 5 (newsEncoders.py:187-200 over the valid token rows only): nnr_mask_cover -> nnr_seq_plan -> nnr_seq_rowmap name the rows
+    that can reach the result -- every position up to a title's last valid one, ALL positions of a fully masked title --, and
+    nnr_mhsa_fwd_packed / _bwd_packed find them through the row map.  Against the dense kernels on the same values (padding rows of the
+    dense input filled with junk: masked keys and zero upstream gradients must make them irrelevant), prefix masks, a fully masked
+    title, a title with an interior masked position, with and without the fused dropout."""
+    from nnr_amd import ops
+    d = dev()
+    n, Lq, heads, dh = 96, 32, 20, 20
+    HD = heads * dh
+    g = torch.Generator().manual_seed(3)
+    lens = torch.randint(1, Lq + 1, (n,), generator=g)
+    mask = torch.arange(Lq)[None, :] < lens[:, None]
+    mask[5] = False                                   # fully masked: uniform softmax, all 32 positions are rows
+    mask[9, 3] = False                                # an interior masked position (lens[9] >= 5 below): a row that exists but is masked
+    mask[9, :6] = True
+    mask[9, 3] = False
+    md = mask.to(d)
+    cover = ops.mask_cover(md)
+    want_cover = mask.clone()
+    want_cover[5] = True
+    want_cover[9, 3] = True
+    assert torch.equal(cover.cpu().bool(), want_cover)
+    plan = ops.SeqPlan(cover, None)
+    rowmap = ops.seq_rowmap(plan)
+    rm = rowmap.cpu().view(n, Lq)
+    live = rm >= 0
+    assert torch.equal(live, want_cover) and int(plan.total.item()) == int(want_cover.sum())
+    assert sorted(rm[live].tolist()) == list(range(int(want_cover.sum())))          # a bijection onto the packed rows
+    qkv = rnd(n * Lq, 3 * HD, seed=4, scale=0.5)
+    qkv[~live.reshape(-1)] = 77.0                     # junk in the dense rows that do not exist in the packed form
+    dout = rnd(n * Lq, HD, seed=5)
+    dout[~live.reshape(-1)] = 0.0                     # (the pooled weight of a padded position is exactly 0: no gradient arrives there)
+    cap = plan.cap
+    qp = torch.full((cap, 3 * HD), float('nan'))
+    dp = torch.full((cap, HD), float('nan'))
+    qp[rm[live]] = qkv[live.reshape(-1)]
+    dp[rm[live]] = dout[live.reshape(-1)]
+    qd, qpd, dd, dpd = qkv.to(d), qp.to(d), dout.to(d), dp.to(d)
+    for p, seed in ((0.0, 0), (0.2, 1234)):
+        out = torch.empty(n * Lq, HD, device=d)
+        ops.mhsa_fwd(qd, md, n, Lq, heads, dh, out, None, 0.0, 0)
+        outp = torch.full((cap, HD), float('nan'), device=d)
+        ops.mhsa_fwd_packed(qpd, md, rowmap, plan, heads, dh, outp, p, seed)
+        got = outp.cpu()[rm[live]]
+        want = out.cpu()[live.reshape(-1)]
+        if p > 0:                                     # the fused dropout is keyed by (packed row, column)
+            keep = (ops.dropout(torch.ones(cap * HD, device=d), p, seed) > 0).view(cap, HD).cpu()[rm[live]]
+            want = want * keep / (1 - p)
+        assert bool(torch.isfinite(got).all())
+        assert float((got - want).abs().max()) <= 1e-6 * max(1.0, float(want.abs().max())), 'packed forward (p = %g)' % p
+        assert bool(torch.isnan(outp.cpu()[int(plan.total.item()):]).all())          # rows beyond the live count are never written
+        dq = torch.empty(n * Lq, 3 * HD, device=d)
+        if p > 0:
+            dk = torch.zeros(n * Lq, HD)
+            dk[live.reshape(-1)] = dout[live.reshape(-1)] * keep / (1 - p)
+            ops.mhsa_bwd(qd, md, None, dk.to(d), n, Lq, heads, dh, dq, 0.0, 0)
+        else:
+            ops.mhsa_bwd(qd, md, None, dd, n, Lq, heads, dh, dq, 0.0, 0)
+        dqp = torch.full((cap, 3 * HD), float('nan'), device=d)
+        ops.mhsa_bwd_packed(qpd, md, rowmap, plan, dpd, heads, dh, dqp, p, seed)
+        gotb = dqp.cpu()[rm[live]]
+        wantb = dq.cpu()[live.reshape(-1)]
+        assert bool(torch.isfinite(gotb).all())
+        assert float((gotb - wantb).abs().max()) <= 2e-6 * max(1.0, float(wantb.abs().max())), 'packed backward (p = %g)' % p
+    with pytest.raises(Exception):                    # the packed form is the 4-head cooperative path only
+        ops.mhsa_fwd_packed(qpd, md, rowmap, plan, 5, 20, outp)
+
+
 def test_sumsq_over_spans_chained_on_two_streams():
     """Round 5: the gradient norm in spans (nnr_sumsq_part): the word-embedding table's span on a helper stream with its own scratch slot
     WHILE another span is summed on the main stream, the partial sums chained in a fixed order -- accurate, and the same bits every time."""
