@@ -121,6 +121,9 @@ class PackedAttentionFn(torch.autograd.Function):
         return dx, None, None, None
 
 
+CAPTURE_RELU = [None]      # diagnostics / parity tests: set CAPTURE_RELU[0] = [] and every LinearFn with a ReLU appends its relu output r
+
+
 class LinearFn(torch.autograd.Function):
     """y = dropout(act(x W^T + b)) for 2-D contiguous x;  act in {none, relu};  dropout mask keyed by the output element."""
 
@@ -132,6 +135,8 @@ class LinearFn(torch.autograd.Function):
         y = torch.empty((M, N), device=x.device, dtype=torch.float32)
         r = torch.empty((M, N), device=x.device, dtype=torch.float32) if (act == ops.ACT_RELU) else None
         ops.gemm(x, weight, y, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias, act=act, aux_out=r, ldaux=N, drop=(3, p, seed, N))
+        if CAPTURE_RELU[0] is not None and r is not None:
+            CAPTURE_RELU[0].append(r)
         ctx.x, ctx.weight, ctx.bias, ctx.r, ctx.act, ctx.p, ctx.seed = x, weight, bias, r, act, p, seed
         return y
 

@@ -73,7 +73,7 @@ def probed_relu(z, site, u=None):
     `u`) of this user-encoder ReLU site, and optionally the ReLU's active set FORCED to a given mask (y = z * mask, derivative = mask).
     tests/test_hip_headline_gpu.py uses it to PROVE that a gradient deviation above the bar is a pre-activation that is zero to fp32
     rounding and landed on the other side of the kink in the HIP path: the oracle is re-run with the product's active set and must then
-    agree at the strict bar.  Sites: 'gcn0'..'gcn{L-1}' (layers.py:285-292), 'affine' (userEncoders.py:91)."""
+    agree at the strict bar.  Sites: 'gcn0'..'gcn{L-1}' (layers.py:285-292), 'affine' (userEncoders.py:91), 'mhsa_user' (userEncoders.py:171)."""
     pr = RELU_PROBE
     if pr is None:
         return torch.relu(z)
@@ -575,7 +575,11 @@ class MHSAUser(UserEncoder):
             # parity tests: the keep-mask of the HIP path's counter-based generator for this call, injected so that the
             # train-mode arithmetic of userEncoders.py:171 (p = 0.5, scale 2) can be compared element for element
             y = self.affine(h)
-            h = torch.relu(y * forced.to(y.dtype).view_as(y) * 2.0)
+            if RELU_PROBE is not None:
+                # (parity tests' kink proof: relu(2 m y) == 2 m relu(y) bit for bit for m in {0, 1}; the probe sees the pre-dropout y)
+                h = probed_relu(y, 'mhsa_user', h) * (forced.to(y.dtype).view_as(y) * 2.0)
+            else:
+                h = torch.relu(y * forced.to(y.dtype).view_as(y) * 2.0)
         else:
             h = torch.relu(F.dropout(self.affine(h), 0.5, self.training))
         return self.attention(h).unsqueeze(1).repeat(1, N, 1)        # unmasked pool, :172

@@ -183,9 +183,9 @@ def test_mhsa_pair_with_fully_masked_and_gapped_titles(dropout):
     b['user_title_mask'][0, 2, :6] = True
     b['user_title_mask'][0, 2, 2] = False                      # an interior masked position
     b = {k: np.ascontiguousarray(v) for k, v in b.items()}
-    if dropout > 0:
-        dev_batch = to_torch(b, 'cuda')
-        hip_masks.inject(model, ref, dict(zip(BATCH_FIELDS, dev_batch)))
+    # (train mode: the MHSA user encoder's hard-wired F.dropout(p = 0.5), userEncoders.py:171, is on in both parametrisations -- its mask,
+    # and with dropout > 0 the news encoder's word / attention-output / category masks, come from the HIP generator)
+    hip_masks.inject(model, ref, dict(zip(BATCH_FIELDS, to_torch(b, 'cuda'))))
     _compare(model, ref, b)
 
 

@@ -71,8 +71,12 @@ class _Bars:
 
 
 def _hip_relu_masks(sv, B, N):
-    """Active sets of the user encoder's ReLUs in the HIP step whose saved state is `sv` (nnr_amd.user_encoders.CAPTURE)."""
+    """Active sets of the user encoder's ReLUs in the HIP step whose saved state is `sv`: SUE's (nnr_amd.user_encoders.CAPTURE: the GCN
+    layers' and the cluster affine's relu outputs) or the MHSA user encoder's (nnr_amd.functional.CAPTURE_RELU: relu(affine(.)) before its
+    p = 0.5 dropout, userEncoders.py:171)."""
     torch.cuda.synchronize()
+    if isinstance(sv, dict) and 'mhsa_user' in sv:
+        return {'mhsa_user': (sv['mhsa_user'] > 0).cpu()}
     m = {'gcn%d' % l: (r > 0).cpu() for l, r in enumerate(sv['gcn']['rs'])}
     m['affine'] = (sv['rc'] > 0).cpu().view(B, N, sv['Cn'], sv['D'])
     return m
@@ -95,7 +99,7 @@ def prove_relu_flips(test, bars, ref, cpu_batch, model, sv, probe, rnorm, compar
         diff = (hm.view(z.shape) != (z > 0))
         idx = diff.nonzero()
         assert idx.shape[0] <= 64, '%s: %d ReLU decisions differ at %s -- not a rounding coincidence' % (test, idx.shape[0], site)
-        lin = ue.clusterFeatureAffine if site == 'affine' else ue.gcn.gcn_layers[int(site[3:])].W
+        lin = ue.clusterFeatureAffine if site == 'affine' else (ue.affine if site == 'mhsa_user' else ue.gcn.gcn_layers[int(site[3:])].W)
         u = probe['u'][site]
         for ix in idx.tolist():
             k = ix[-1]
@@ -123,7 +127,7 @@ def prove_relu_flips(test, bars, ref, cpu_batch, model, sv, probe, rnorm, compar
 
 
 def _check_step(model, ref, cfg, batch, lr_steps=1, inject_masks=False, test='eager step'):
-    from nnr_amd import ops, user_encoders as UE
+    from nnr_amd import functional as Fn, ops, user_encoders as UE
     from nnr_amd.trainer import Trainer
     from oracle import nnr_oracle as O
     trainer = Trainer(model, cfg)
@@ -140,10 +144,14 @@ def _check_step(model, ref, cfg, batch, lr_steps=1, inject_masks=False, test='ea
             elif k.startswith('gcn'):
                 assert abs(r - (1 - p / 2)) < 0.01, (k, r)
     UE.CAPTURE[0] = []
+    Fn.CAPTURE_RELU[0] = []
     try:
         logits, loss = trainer.train_step(dev_batch)
     finally:
         captured, UE.CAPTURE[0] = UE.CAPTURE[0], None
+        relus, Fn.CAPTURE_RELU[0] = Fn.CAPTURE_RELU[0], None
+    if not captured and type(model.user_encoder).__name__ == 'MHSA' and relus:
+        captured = [{'mhsa_user': relus[-1]}]               # the user encoder's relu(affine(.)) is the last LinearFn of the forward pass
     torch.cuda.synchronize()
     assert ops.lstm_sync_timeouts() == 0
     got_grads = {k: p.grad.detach().cpu().double() for k, p in model.named_parameters()}
@@ -175,7 +183,7 @@ def _check_step(model, ref, cfg, batch, lr_steps=1, inject_masks=False, test='ea
     bars = _Bars()
     compare(bars, ref_grads)
     if bars.over:
-        assert captured, 'gradient tensors above the bar in a model without the SUE user encoder: %s' % bars.over
+        assert captured, 'gradient tensors above the bar in a model whose ReLU sites are not captured: %s' % bars.over
         bars = prove_relu_flips(test, bars, ref, to_torch(batch), model, captured[-1], probe, rnorm, compare)
         ref_grads = {k: p.grad.detach().double().clone() for k, p in ref.named_parameters()}
     worst = bars.worst
