@@ -70,6 +70,7 @@ def parse(argv=None):
                     'workload, no instrumentation) and report it as the `sustained` object: clocks under a multi-second load; 0 = skip')
     ap.add_argument('--no_secondary', action='store_true', help='N = 1: skip the short secondary legs over the other BASELINE.json configs '
                     '(`secondary`: mhsa_mhsa_b64, cne_sue_shard_b8, cne_sue_large_shard_b16_v130000)')
+    ap.add_argument('--no_experimental', action='store_true', help='skip the experimental bf16x3 leg of `secondary`')
     ap.add_argument('--secondary_steps', type=int, default=10)
     ap.add_argument('--secondary_warmup', type=int, default=5, help='two call-by-call steps + the recording + one replay + the discarded timing '
                     'replay: the timed steps of a secondary leg are all native replays, like the headline window')
@@ -346,6 +347,12 @@ SECONDARY_LEGS = (
     ('cne_sue_shard_b8', 'CNE', 'SUE', '200k', 64, 8, 8, 60000),                       # configs[3]: one GPU's shard of batch 64 over 8 GPUs
     ('cne_sue_large_shard_b16_v130000', 'CNE', 'SUE', 'large', 128, 8, 16, 130000),    # configs[4]: MIND-large, batch 128 over 8 GPUs
 )
+# EXPERIMENTAL leg (not a BASELINE config, not the headline): the headline workload with the GPU-filling NT GEMMs on the BF16 matrix pipe as six
+# exact bf16 products with fp32 accumulation (NNR_BX3=1, off by default) -- so that the driver's line carries the number a
+# round-6 adoption decision needs
+EXPERIMENTAL_LEGS = (
+    ('experimental_bf16x3_nt_cne_sue_b64', 'CNE', 'SUE', '200k', 64, 1, 64, 60000),
+)
 
 
 def secondary_legs(a, prof, dp, torch, dev, rank_seed=0):
@@ -364,8 +371,12 @@ def secondary_legs(a, prof, dp, torch, dev, rank_seed=0):
     from nnr_amd.synth import SynthSpec, SynthCorpus
     from nnr_amd.trainer import Trainer
     out = {}
-    for name, ne, ue, dataset, gbatch, gworld, per_gpu, V in SECONDARY_LEGS:
+    from nnr_amd import ops as _ops
+    for name, ne, ue, dataset, gbatch, gworld, per_gpu, V in SECONDARY_LEGS + (() if a.no_experimental else EXPERIMENTAL_LEGS):
         t_leg = time.perf_counter()
+        experimental = name.startswith('experimental_')
+        bx3_before = _ops.BX3[0]
+        _ops.BX3[0] = bool(experimental) or bx3_before
         try:
             cfg = make_config(['--news_encoder=' + ne, '--user_encoder=' + ue, '--dataset=' + dataset, '--batch_size=%d' % gbatch,
                                '--world_size=%d' % gworld], corpus_sizes=dict(vocabulary_size=V))
@@ -397,8 +408,13 @@ def secondary_legs(a, prof, dp, torch, dev, rank_seed=0):
                 t.close()
             trainer.tapes.clear()
             del trainer, model, dc, order
+            if experimental:
+                leg['experimental'] = ('NNR_BX3=1, OFF by default: NT GEMMs (rows >= 2 048, weight operand) as six exact bf16 x bf16 MFMA products with fp32 '
+                                       'accumulation; same parity bars (tests/test_hip_headline_gpu.py::..._with_experimental_bf16x3_nt_gemms_...)')
         except Exception as e:                  # a secondary measurement never takes the headline line down with it
             leg = {'error': repr(e)}
+        finally:
+            _ops.BX3[0] = bx3_before
         gc.collect()
         torch.cuda.empty_cache()
         leg['leg_seconds'] = round(time.perf_counter() - t_leg, 1)

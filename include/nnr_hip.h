@@ -96,9 +96,19 @@ typedef struct nnr_gemm_args {
   const float* pre_add;     /* [M, ldpre]: added to the product before anything else (also without gate_bwd) */
   int ldpre;
   int gate_bwd;
+  /* EXPERIMENTAL (round 5, off by default): tile = 50 computes the same NT product on the BF16 matrix pipe as six exact bf16 x bf16 products
+   * with fp32 accumulation (an fp32 value is exactly the sum of three bf16 values; error vs fp64 a third of the fp32-MFMA kernels').  B3: the
+   * weight matrix B [N, K] pre-split by nnr_split_bf16x3 into three bf16 images [N, ldb3] (ldb3 % 8 == 0, zero-padded), image i at
+   * B3 + i * b3_stride elements. */
+  const void* B3;
+  long b3_stride;
+  int ldb3;
 } nnr_gemm_args;
 
 int nnr_gemm_f32(const nnr_gemm_args* args, hipStream_t stream);
+/* w [rows, cols] (row stride ld) -> three bf16 images out3[i * img_stride + r * ldo + c] with w == image0 + image1 + image2 EXACTLY (columns
+ * cols .. ldo-1 zero).  For nnr_gemm_args.B3 (experimental tile 50); weights change once per optimizer step. */
+int nnr_split_bf16x3(const float* w, int rows, int cols, int ld, int ldo, void* out3, long img_stride, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------ sequence planner
  * Replaces newsEncoders.py:106-120 (mask[:,0]=1 in place, lengths, torch.sort x2, index_select, pack_padded_sequence and

@@ -1204,6 +1204,161 @@ static bool pipe3_ok(const nnr_gemm_args& g) {
   return pipe_ok(g) && !g.a_idx && !g.c_idx && !g.atomic && g.vec_epi && g.drop_target != 4 && g.K >= 96;
 }
 
+// ------------------------------------------------------------------------------------------------ EXPERIMENTAL: NT GEMM on the BF16 matrix pipe (round 5)
+// OFF by default (tile 50, selected only when the caller passes pre-split weights: NNR_BX3=1 in nnr_amd/ops.py).  fp32 arithmetic without narrowing:
+// an fp32 value is EXACTLY x1 + x2 + x3 with three bf16 values (8 + 8 + 8 significant bits); the six products a_i b_j with i + j <= 4 carry everything
+// above 2^-26 |a b| (below the rounding of an fp32 product), a bf16 x bf16 product is exact in fp32 and v_mfma_f32_16x16x32_bf16 accumulates in
+// fp32 -- at 16x the issue rate of v_mfma_f32_16x16x4_f32.  Measured error vs fp64: a third of the fp32-MFMA kernel's (12 roundings of the hi
+// accumulator per 400-long dot product instead of 400); tools/micro/bf16x3_gemm.hip, profiles/r05_bf16x3.txt.
+//  * B (a weight matrix [N, K]) arrives PRE-SPLIT: three bf16 images [N, ldb3] (nnr_split_bf16x3, once per optimizer step);
+//  * A (activations, fp32) is LDS-DMA'd as fp32 and split in registers by the wave that owns the rows, right in front of its MFMAs;
+//  * two fp32 accumulators per output block: a1 b1 | the five small terms (added smallest first);
+//  * staging = gemm_nt_pipe_kernel's (per-lane-source LDS-DMA, zero page for k-chunks past K, counted vmcnt + one barrier per stage), BK = 32,
+//    2 stages x 31.7 KB, 2 workgroups per CU; epilogue = gemm_epilogue (every element-wise feature of the NT kernels).
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split3_bf16(float x, __bf16& h1, __bf16& h2, __bf16& h3) {
+  h1 = (__bf16)x;                       // round-to-nearest-even
+  const float r1 = x - (float)h1;       // exact: at most 16 significant bits remain
+  h2 = (__bf16)r1;
+  const float r2 = r1 - (float)h2;      // exact: at most 8 significant bits remain
+  h3 = (__bf16)r2;                      // exact
+}
+__global__ void split_bf16x3_kernel(const float* __restrict__ w, int rows, int cols, int ld, int ldo, __bf16* __restrict__ out, long img_stride) {
+  const long total = (long)rows * ldo;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / ldo), c = (int)(i - (long)r * ldo);
+    __bf16 a, b, d;
+    split3_bf16(c < cols ? w[(long)r * ld + c] : 0.f, a, b, d);      // columns cols .. ldo-1 are zero padding (16-byte aligned bf16 rows)
+    out[i] = a; out[img_stride + i] = b; out[2 * img_stride + i] = d;
+  }
+}
+__device__ __forceinline__ int bx3_swzA(int r) { return ((r >> 1) & 1) | (((r >> 3) & 1) << 2); }      // 128-B fp32 rows, two b128 reads per lane (brute-force checked)
+__device__ __forceinline__ int bx3_swzB(int r) { return (r >> 1) & 3; }                                  // 64-B bf16 rows, one b128 read per lane
+
+template <int TM, int TN>
+__global__ __launch_bounds__(256, 2) void gemm_nt_bx3_kernel(nnr_gemm_args g) {
+  constexpr int NS = 2, BM = 64 * TM, BN = 16 * TN, BK = 32;
+  constexpr int A_BYTES = BM * BK * 4, B_IMG_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + 3 * B_IMG_BYTES;
+  constexpr int NIA = A_BYTES / 1024, NIB1 = B_IMG_BYTES / 1024;
+  static_assert(A_BYTES % 1024 == 0 && B_IMG_BYTES % 1024 == 0 && NIA % 4 == 0, "tile shape");
+  constexpr int E_LD = BN + 4;
+  constexpr int LDS_BYTES = NS * STAGE_BYTES > 64 * E_LD * 4 ? NS * STAGE_BYTES : 64 * E_LD * 4;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds_raw[LDS_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;
+  int M = g.M;
+  if (g.dyn_dim == 1) M = min(M, *g.dyn_dev);
+  const int N = g.N, K = g.K;
+  const int nbm = (M + BM - 1) / BM, nbn = (N + BN - 1) / BN, nblk = nbm * nbn;
+  if ((int)blockIdx.x >= nblk) return;
+  int v;
+  {
+    const int b = blockIdx.x, qq = nblk >> 3, rem = nblk & 7, x = b & 7, slot = b >> 3;
+    v = x * qq + min(x, rem) + slot;
+  }
+  const int bm = v / nbn, bn = v - bm * nbn, m0 = bm * BM, n0 = bn * BN;
+  const int S = (K + BK - 1) / BK;
+  const unsigned lds_base = (unsigned)(uintptr_t)lds_raw;
+  const float* zero = nnr_zero_page;
+  asm volatile("" : "+s"(zero));
+  const float* __restrict__ A = g.A;
+  const __bf16* __restrict__ B3 = reinterpret_cast<const __bf16*>(g.B3);
+  // wave w issues the A instructions w, w + 4, ... (8 tile rows of 128 B each) and the B instructions idx = w, w + 4, ... of the 3 NIB1
+  // (16 rows of 64 B of one image each)
+  constexpr int NA = NIA / 4, NBW = (3 * NIB1 + 3) / 4;
+  const char* asrc[NA];
+  int akc[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int row = (w + 4 * i) * 8 + lane / 8, c = (lane % 8) ^ bx3_swzA(row & 15);
+    akc[i] = 4 * c;
+    asrc[i] = reinterpret_cast<const char*>(A + (long)min(m0 + row, M - 1) * g.lda + 4 * c);        // rows past the edge: clamped, never stored
+  }
+  const char* bsrc[NBW];
+  int bkc[NBW];
+  bool bon[NBW];
+#pragma unroll
+  for (int j = 0; j < NBW; ++j) {
+    const int idx = w + 4 * j;
+    bon[j] = idx < 3 * NIB1;
+    const int img = bon[j] ? idx / NIB1 : 0, jj = idx - img * NIB1, row = jj * 16 + lane / 4, c = (lane % 4) ^ bx3_swzB(row & 15);
+    bkc[j] = 8 * c;
+    bsrc[j] = reinterpret_cast<const char*>(B3 + (long)img * g.b3_stride + (long)min(n0 + row, N - 1) * g.ldb3 + 8 * c);
+  }
+  const bool full = w < (3 * NIB1) % 4 || (3 * NIB1) % 4 == 0;       // this wave has NBW (else NBW - 1) B instructions
+  auto issue = [&](int s) __attribute__((always_inline)) {
+    const int k0 = s * BK;
+    const unsigned sb = lds_base + (unsigned)((s % NS) * STAGE_BYTES);
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+      lds_dma16((k0 + akc[i] < K) ? reinterpret_cast<const float*>(asrc[i] + (long)k0 * 4) : zero, sb + (unsigned)((w + 4 * i) * 1024));
+#pragma unroll
+    for (int j = 0; j < NBW; ++j)
+      if (bon[j]) lds_dma16((k0 + bkc[j] < K) ? reinterpret_cast<const float*>(bsrc[j] + (long)k0 * 2) : zero, sb + A_BYTES + (unsigned)((w + 4 * j) * 1024));
+  };
+  f32x4 acc_hi[TM][TN], acc_lo[TM][TN];
+#pragma unroll
+  for (int m = 0; m < TM; ++m)
+#pragma unroll
+    for (int n = 0; n < TN; ++n) acc_hi[m][n] = acc_lo[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  issue(0);
+  for (int s = 0; s < S; ++s) {
+    wait_vmcnt<0>();                      // NS = 2: when a wave waits for stage s, that stage is the only one it has in flight
+    __builtin_amdgcn_s_barrier();
+    if (s + 1 < S) issue(s + 1);          // into the other buffer: every wave finished reading it before that barrier
+    const unsigned char* st = lds_raw + (s % NS) * STAGE_BYTES;
+    const float* As = reinterpret_cast<const float*>(st);
+    const __bf16* Bi = reinterpret_cast<const __bf16*>(st + A_BYTES);
+    bf16x8_t bf[3][TN];
+#pragma unroll
+    for (int img = 0; img < 3; ++img)
+#pragma unroll
+      for (int n = 0; n < TN; ++n)
+        bf[img][n] = *reinterpret_cast<const bf16x8_t*>(Bi + img * (BN * BK) + (n * 16 + r) * BK + ((q ^ bx3_swzB(r)) * 8));
+#pragma unroll
+    for (int m = 0; m < TM; ++m) {
+      const float* arow = As + ((w * TM + m) * 16 + r) * BK;
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(arow + 4 * ((2 * q) ^ bx3_swzA(r)));
+      const f32x4 x1 = *reinterpret_cast<const f32x4*>(arow + 4 * ((2 * q + 1) ^ bx3_swzA(r)));
+      bf16x8_t a1, a2, a3;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        __bf16 h1, h2, h3;
+        split3_bf16(x0[e], h1, h2, h3); a1[e] = h1; a2[e] = h2; a3[e] = h3;
+        split3_bf16(x1[e], h1, h2, h3); a1[4 + e] = h1; a2[4 + e] = h2; a3[4 + e] = h3;
+      }
+#pragma unroll
+      for (int n = 0; n < TN; ++n) {
+        acc_hi[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bf[0][n], acc_hi[m][n], 0, 0, 0);
+        acc_lo[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, bf[0][n], acc_lo[m][n], 0, 0, 0);
+        acc_lo[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bf[2][n], acc_lo[m][n], 0, 0, 0);
+        acc_lo[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, bf[1][n], acc_lo[m][n], 0, 0, 0);
+        acc_lo[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, bf[0][n], acc_lo[m][n], 0, 0, 0);
+        acc_lo[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bf[1][n], acc_lo[m][n], 0, 0, 0);
+      }
+    }
+  }
+  (void)full;
+#pragma unroll
+  for (int m = 0; m < TM; ++m)
+#pragma unroll
+    for (int n = 0; n < TN; ++n) acc_hi[m][n] += acc_lo[m][n];
+  __syncthreads();
+  gemm_epilogue<TM, TN>(g, acc_hi, reinterpret_cast<float*>(lds_raw), g.C, m0, n0, M, N, 0);
+}
+
+static bool bx3_ok(const nnr_gemm_args& g) {
+  auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+  return pipe_ok(g) && !g.a_idx && g.batch <= 1 && g.B3 && al(g.B3) && (g.ldb3 & 7) == 0 && g.ldb3 >= g.K && ((g.b3_stride * 2) & 15) == 0;
+}
+template <int TM, int TN>
+int launch_bx3(const nnr_gemm_args& g, hipStream_t s) {
+  constexpr int BM = 64 * TM, BN = 16 * TN;
+  const int nbm = (g.M + BM - 1) / BM, nbn = (g.N + BN - 1) / BN;
+  hipLaunchKernelGGL((gemm_nt_bx3_kernel<TM, TN>), dim3(nbm * nbn), dim3(256), 0, s, g);
+  NNR_CHECK_LAUNCH();
+  return NNR_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ pipelined TN GEMM (LDS-DMA)
 // C[M,N] += A[K,M]^T . B[K,N] over a slice of the (device-side) reduction range -- the weight-gradient GEMMs: both operands
 // are ACTIVATIONS stored row-major by token, i.e. K-major for this product, and K is the token count (10^5).
@@ -1962,6 +2117,7 @@ static int dispatch_tile(int tile, const nnr_gemm_args& g, hipStream_t stream) {
     case 37: if (!tn_pipe_ok(g)) return NNR_ERR_ARG; return launch_tn_pipe2<4, 10, 3, 1>(g, stream);              // gen-2 TN 256 x 160, 3 x 32 KB stages, 1 workgroup / CU
     case 38: if (!tn_pipe_ok(g)) return NNR_ERR_ARG; return launch_tn_pipe2<2, 10, 4, 1>(g, stream);              // gen-2 TN 128 x 160, 4 stages, 1 workgroup / CU
     case 39: if (!tn_pipe_ok(g)) return NNR_ERR_ARG; return launch_tn_pipe2<1, 10, 3, 3>(g, stream);              // gen-2 TN 64 x 160, 3 x 20 KB stages, 3 workgroups / CU
+    case 50: if (!bx3_ok(g)) return NNR_ERR_ARG; return launch_bx3<2, 5>(g, stream);           // EXPERIMENTAL bf16x3 NT 128 x 80 (needs args.B3: pre-split weights)
     case 40: if (!pipe3_ok(g)) return NNR_ERR_ARG; return launch_pipe3<2, 5, 2>(g, stream);     // gen-3 NT (persistent, continuous DMA pipeline, register epilogue) 128 x 80, 3 x 26 KB stages, 2 workgroups / CU
     case 41: if (!pipe3_ok(g)) return NNR_ERR_ARG; return launch_pipe3<2, 4, 2>(g, stream);     // gen-3 NT 128 x 64
     case 42: if (!pipe3_ok(g)) return NNR_ERR_ARG; return launch_pipe3<2, 10, 1>(g, stream);    // gen-3 NT 128 x 160, 3 x 36 KB stages, 1 workgroup / CU
@@ -1974,6 +2130,15 @@ static int dispatch_tile(int tile, const nnr_gemm_args& g, hipStream_t stream) {
       return launch_skinny(g, stream);
     default: return NNR_ERR_ARG;
   }
+}
+
+extern "C" int nnr_split_bf16x3(const float* w, int rows, int cols, int ld, int ldo, void* out3, long img_stride, hipStream_t stream) {
+  if (!w || !out3 || rows <= 0 || cols <= 0 || ld < cols || ldo < cols || (ldo & 7) || img_stride < (long)rows * ldo) return NNR_ERR_ARG;
+  const long total = (long)rows * ldo;
+  const int blocks = (int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
+  hipLaunchKernelGGL(split_bf16x3_kernel, dim3(blocks), dim3(256), 0, stream, w, rows, cols, ld, ldo, reinterpret_cast<__bf16*>(out3), img_stride);
+  NNR_CHECK_LAUNCH();
+  return NNR_OK;
 }
 
 extern "C" int nnr_gemm_f32(const nnr_gemm_args* a, hipStream_t stream) {

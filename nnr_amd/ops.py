@@ -371,11 +371,44 @@ def split_for(m, n, k, tile_m=64, tile_n=80, target_blocks=2048, kmin=256):
     return int(max(1, min((k + kmin - 1) // kmin, (target_blocks + tiles - 1) // tiles)))
 
 
+# ---------------------------------------------------------------------------------------------- EXPERIMENTAL: bf16x3 NT GEMMs (off by default)
+# NNR_BX3=1 sends the GPU-filling NT launches whose B operand is a weight (a parameter, a cached transpose, the packed LSTM input weights) to
+# csrc/gemm.hip:gemm_nt_bx3_kernel: fp32 arithmetic as six exact bf16 x bf16 products with fp32 accumulation.  The
+# weight's three bf16 images are cached per (storage, shape) and re-split when the parameters changed (layers.PARAM_EPOCH) -- one small
+# launch per weight and step, recorded in the launch tape like any other call.  Round 5: measurement only; the default path does not use it.
+BX3 = [os.environ.get('NNR_BX3', '0') == '1']
+_BX3_MIN_ROWS = int(os.environ.get('NNR_BX3_MIN_ROWS', '2048'))
+_B3 = {}
+
+
+def bx3_images(B, N, K, ldb):
+    """(images [3, N, ldo] bf16-as-int16, image stride in elements, ldo) of the [N, K] weight `B`, re-split once per parameter epoch."""
+    from .layers import PARAM_EPOCH
+    key = (B.data_ptr(), N, K, ldb)
+    e = _B3.get(key)
+    ldo = (K + 7) // 8 * 8
+    if e is None:
+        if len(_B3) > 512:
+            _B3.clear()
+        e = _B3[key] = [torch.empty((3, N, ldo), device=B.device, dtype=torch.int16), -1, None]
+    tape_keep(e[0])
+    if e[1] != PARAM_EPOCH[0] or e[2] != B._version:
+        L.check(L.lib().nnr_split_bf16x3(_p(B), N, K, ldb, ldo, _p(e[0]), C.c_long(N * ldo), _s()), 'nnr_split_bf16x3')
+        e[1], e[2] = PARAM_EPOCH[0], B._version
+    return e[0], N * ldo, ldo
+
+
+def _bx3_wanted(A, B, M, N, K, lda, ldb, trans_a, trans_b, a_idx, b_idx, c_idx, split_k, k_chunk, rowdot_w, colsum_out, atomic, batch, dyn_dim, drop):
+    return (not trans_a and not trans_b and a_idx is None and b_idx is None and split_k <= 1 and k_chunk <= 0 and rowdot_w is None
+            and colsum_out is None and batch <= 1 and dyn_dim in (0, 1) and M >= _BX3_MIN_ROWS and K >= 64 and N * K <= (1 << 22)
+            and (K | lda | ldb) & 3 == 0 and (A.data_ptr() | B.data_ptr()) & 15 == 0 and (drop is None or drop[0] in (3, 4) or drop[1] <= 0.0))
+
+
 def gemm(A, B, C_=None, *, M, N, K, lda, ldb, ldc=0, trans_a=False, trans_b=False, dyn=None, dyn_dim=0, a_idx=None, b_idx=None,
          drop=None, alpha=1.0, bias=None, rowvec=None, ldrv=0, rowvec_map=None, act=0, aux_out=None, ldaux=0, mul=None, ldmul=0,
          resid=None, ldres=0, accumulate=False, atomic=False, c_idx=None, split_k=1, rowdot_w=None, rowdot_out=None, batch=1,
          strideA=0, strideB=0, strideC=0, stride_aux=0, stride_res=0, tile=0, colsum_out=None, k_chunk=0, flop_scale=1.0, slab=None,
-         pre_add=None, ldpre=0, gate_bwd=False):
+         pre_add=None, ldpre=0, gate_bwd=False, b3=None):
     # flop_scale: algorithmic / padded work of this launch (the LSTM gate columns are padded 800 -> 832 per direction; the live
     # profile counts the true 8H columns, not the padded 2*NP)
     # ctypes zero-initialises the struct: only the fields a call actually uses are written (a field store costs ~0.2 us of host
@@ -430,6 +463,13 @@ def gemm(A, B, C_=None, *, M, N, K, lda, ldb, ldc=0, trans_a=False, trans_b=Fals
         g.pre_add, g.ldpre = pre_add.data_ptr(), ldpre
     if gate_bwd:
         g.gate_bwd = 1
+    if b3 is None and BX3[0] and tile in (0, 9, 15, 16) and _bx3_wanted(A, B, M, N, K, lda, ldb, trans_a, trans_b, a_idx, b_idx, c_idx, split_k, k_chunk, rowdot_w,
+                                                                    colsum_out, atomic, batch, dyn_dim, drop):
+        b3 = bx3_images(B, N, K, ldb)                    # EXPERIMENTAL (NNR_BX3=1): this NT launch on the BF16 matrix pipe, weights pre-split
+        tile = 50
+        g.tile = 50
+    if b3 is not None:
+        g.B3, g.b3_stride, g.ldb3 = b3[0].data_ptr(), b3[1], b3[2]
     if slab is None and TN_SLAB and trans_a and trans_b and split_k > 1 and not k_chunk and c_idx is None and (N & 3) == 0 and C_ is not None:
         slab = _slab_ws(A.device, int(split_k) * (M * N + M))      # reproducible split-K: partial results to a slab + fixed-order reduction
     if slab is not None:
@@ -470,7 +510,7 @@ def gemm(A, B, C_=None, *, M, N, K, lda, ldb, ldc=0, trans_a=False, trans_b=Fals
         t = 5 if not trans_b else 4
     fam = 'gemm_%s_%s' % ('tn' if trans_a else ('nn' if trans_b else 'nt'),
                           {1: '256x80', 2: '64x80', 3: '128x208', 4: '128x80', 5: '128x80k32', 6: '64x80k64', 7: '16x80skinny', 8: 'pipe128x80k32', 9: 'pipe2_128x80', 13: 'pipe128x80s4',
-                           15: 'pipe128x80', 16: 'pipe128x80s2', 20: 'pipe128x80', 26: 'pipe2_128x80', 27: 'pipe2_128x208', 30: 'pipe2_128x160', 31: 'pipe2_128x64', 32: 'pipe2_64x208', 33: 'pipe128x208', 34: 'pipe2_128x208', 36: 'pipe256x80', 22: 'pipe64x80', 23: 'pipe256x80', 24: 'pipe128x208', 25: 'pipe128x128', 40: 'pipe3_128x80', 41: 'pipe3_128x64', 42: 'pipe3_128x160'}.get(t, 'tile%d' % t))
+                           15: 'pipe128x80', 16: 'pipe128x80s2', 20: 'pipe128x80', 26: 'pipe2_128x80', 27: 'pipe2_128x208', 30: 'pipe2_128x160', 31: 'pipe2_128x64', 32: 'pipe2_64x208', 33: 'pipe128x208', 34: 'pipe2_128x208', 36: 'pipe256x80', 22: 'pipe64x80', 23: 'pipe256x80', 24: 'pipe128x208', 25: 'pipe128x128', 50: 'bx3_128x80', 40: 'pipe3_128x80', 41: 'pipe3_128x64', 42: 'pipe3_128x160'}.get(t, 'tile%d' % t))
 
     def flops(vals=None, M=M, N=N, K=K, dyn=dyn, dyn_dim=dyn_dim, batch=batch):
         # vals: {data_ptr of a device-side size: its value at the time of the launch} (replayed launches: the size buffers are

@@ -112,10 +112,12 @@ def test_secondary_legs_name_every_other_baseline_config():
     if os.path.exists(committed):                      # the shape of a real GPU line (committed with the round's profiles)
         line = json.load(open(committed))
         sec = line['secondary']
-        assert set(sec) == set(legs)
+        extra = {l[0]: l for l in bench.EXPERIMENTAL_LEGS}
+        assert set(legs) <= set(sec) <= set(legs) | set(extra)
         for name, leg in sec.items():
             assert 'error' not in leg, (name, leg)
-            assert leg['ms_per_step'] > 0 and leg['value'] > 0 and 0 < leg['step']['frac'] < 1 and leg['per_gpu_batch'] == legs[name][6]
+            assert leg['ms_per_step'] > 0 and leg['value'] > 0 and 0 < leg['step']['frac'] < 1 and leg['per_gpu_batch'] == dict(legs, **extra)[name][6]
+            assert ('experimental' in leg) == (name in extra)
         m = sec['mhsa_mhsa_b64']['roofline_mhsa']
         assert m['mhsa_fwd']['mfma_tflops'] > 0 and m['mhsa_bwd']['mfma_tflops'] > 0
         assert line['cpu_baseline']['headline_batch']['batch'] == 64

@@ -227,6 +227,47 @@ def test_gemm_persistent_nt_tiles(tile, M, N, K):
             ops.gemm(aa, bb2, torch.empty(bad['M'], bad['N'], device=d), lda=bad['K'], ldb=bad['K'], ldc=bad['N'], tile=tile, **bad)
 
 
+@pytest.mark.parametrize('M,N,K', [(70000, 400, 400), (33000, 1664, 300), (5000, 200, 200), (4352, 900, 900), (300, 84, 96), (129, 400, 104), (2500, 300, 1664)])
+def test_gemm_bf16x3_experimental_tile(M, N, K):
+    """EXPERIMENTAL tile 50 (csrc/gemm.hip: gemm_nt_bx3_kernel; off by default, NNR_BX3=1): the NT product on the BF16 matrix pipe as six exact
+    bf16 x bf16 products with fp32 accumulation, weights pre-split by nnr_split_bf16x3.  The split is EXACT (w == image0 + image1 + image2 bit for
+    bit), the product is at least as close to fp64 as the fp32-MFMA kernel's, and every element-wise epilogue / dynamic M / k-tail / ragged
+    edge behaves as in the other NT kernels."""
+    from nnr_amd import ops
+    d = dev()
+    a, b = rnd(M, K, seed=1).to(d), rnd(N, K, seed=2, scale=0.2).to(d)
+    img, stride, ldo = ops.bx3_images(b, N, K, K)
+    bf = img.view(torch.bfloat16).float()                       # [3, N, ldo]
+    assert ldo % 8 == 0 and ldo >= K and torch.equal((bf[0] + bf[1]) + bf[2], torch.nn.functional.pad(b, (0, ldo - K)))
+    b3 = (img, stride, ldo)
+    full = a.cpu().double() @ b.cpu().double().t()
+    out, ref = torch.empty(M, N, device=d), torch.empty(M, N, device=d)
+    ops.gemm(a, b, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, tile=50, b3=b3)
+    ops.gemm(a, b, ref, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, tile=15)
+    e50 = float((out.cpu().double() - full).norm() / full.norm())
+    e15 = float((ref.cpu().double() - full).norm() / full.norm())
+    assert e50 <= 1.05 * e15 + 1e-9, (e50, e15)
+    etol = 2e-5 * max(1.0, math.sqrt(K / 100.0))
+    close(out, full, tol=etol, what='bx3 plain')
+    bias, resid, mul, base = rnd(N, seed=4).to(d), rnd(M, N, seed=5).to(d), rnd(M, N, seed=6).to(d), rnd(M, N, seed=7).to(d)
+    rv, rmap = rnd(5, N, seed=8).to(d), torch.randint(0, 5, (M,), generator=torch.Generator().manual_seed(9)).int().to(d)
+    aux = torch.empty(M, N, device=d)
+    out = base.clone()
+    ops.gemm(a, b, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, alpha=0.5, bias=bias, rowvec=rv, ldrv=N, rowvec_map=rmap, act=ops.ACT_TANH, aux_out=aux, ldaux=N,
+             mul=mul, ldmul=N, resid=resid, ldres=N, accumulate=True, tile=50, b3=b3)
+    pre = torch.tanh(0.5 * full + bias.cpu().double() + rv.cpu().double()[rmap.cpu().long()])
+    close(aux, pre, tol=etol, what='bx3 aux')
+    close(out, base.cpu().double() + pre * mul.cpu().double() + resid.cpu().double(), tol=etol, what='bx3 full epilogue')
+    used = max(1, (M * 2) // 3)
+    out = torch.full((M, N), 7.0, device=d)
+    dyn = torch.tensor([used], dtype=torch.int32, device=d)
+    ops.gemm(a, b, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, dyn=dyn, dyn_dim=1, bias=bias, tile=50, b3=b3)
+    close(out[:used], (full + bias.cpu().double())[:used], tol=etol, what='bx3 dyn')
+    assert bool((out[used:] == 7.0).all())
+    with pytest.raises(Exception):                              # without the pre-split weights the tile is refused
+        ops.gemm(a, b, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, tile=50)
+
+
 def test_gemm_nn_accumulate_and_tn_splitk_dyn():
     from nnr_amd import ops
     dy, w = rnd(300, 225, seed=1), rnd(225, 900, seed=2)
