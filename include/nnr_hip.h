@@ -274,6 +274,16 @@ int nnr_gcn_aggregate_fwd(const float* graph, const float* z, const float* bias,
  * dz_b = graph_b^T . dy_b (ds / dx0 untouched). */
 int nnr_gcn_aggregate_bwd(const float* graph, const float* dy, const float* r, float* ds, float* dx0, float* dz, int B, int G, int D, float p,
                           uint32_t seed, hipStream_t stream);
+/* ONE launch per GCN layer and direction for small batches (B * G <= ~1 100 rows: per-GPU batch <= 16), replacing the chain
+ * [dense product on skinny tiles -> dispatch gap -> aggregate]: a workgroup owns (user b, 32 columns), computes T_b = IN_b . Wop^T with the
+ * K = D reduction split over its 8 waves, then A_b . T_b (forward) / A_b^T . T_b (backward) from LDS, then the layer's epilogue.
+ *   fwd: y = dropout(relu(A (x W^T) + bias) [-> r_out] + resid)        W [D, D] as nn.Linear stores it (layers.py:285-292,318-323)
+ *   bwd: dx = A^T (dS Wt^T) + (residual ? mask(dy) : 0),  dS = mask(dy) * (r > 0)   with Wt = W^T [D, D] contiguous (the data-gradient chain;
+ *        dS / dZ for the bias and weight gradients still come from nnr_gcn_aggregate_bwd, on a leaf stream).  G <= 80, D % 4 == 0. */
+int nnr_gcn_layer_small_fwd(const float* graph, const float* x, const float* W, const float* bias, const float* resid, float* r_out, float* y,
+                            int B, int G, int D, int relu, float p, uint32_t seed, hipStream_t stream);
+int nnr_gcn_layer_small_bwd(const float* graph, const float* dy, const float* r, const float* Wt, float* dx, int B, int G, int D, int residual,
+                            float p, uint32_t seed, hipStream_t stream);
 int nnr_relu_drop_bwd(const float* dy, const float* r, float* ds, float* dx, long n, float p, uint32_t seed, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------ multi-head self-attention core

@@ -1236,7 +1236,7 @@ __device__ __forceinline__ int bx3_swzA(int r) { return ((r >> 1) & 1) | (((r >>
 __device__ __forceinline__ int bx3_swzB(int r) { return (r >> 1) & 3; }                                  // 64-B bf16 rows, one b128 read per lane
 
 template <int TM, int TN>
-__global__ __launch_bounds__(256, 2) void gemm_nt_bx3_kernel(nnr_gemm_args g) {
+__global__ __launch_bounds__(256, (TM >= 4 ? 1 : 2)) void gemm_nt_bx3_kernel(nnr_gemm_args g) {
   constexpr int NS = 2, BM = 64 * TM, BN = 16 * TN, BK = 32;
   constexpr int A_BYTES = BM * BK * 4, B_IMG_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + 3 * B_IMG_BYTES;
   constexpr int NIA = A_BYTES / 1024, NIB1 = B_IMG_BYTES / 1024;
@@ -2118,6 +2118,9 @@ static int dispatch_tile(int tile, const nnr_gemm_args& g, hipStream_t stream) {
     case 38: if (!tn_pipe_ok(g)) return NNR_ERR_ARG; return launch_tn_pipe2<2, 10, 4, 1>(g, stream);              // gen-2 TN 128 x 160, 4 stages, 1 workgroup / CU
     case 39: if (!tn_pipe_ok(g)) return NNR_ERR_ARG; return launch_tn_pipe2<1, 10, 3, 3>(g, stream);              // gen-2 TN 64 x 160, 3 x 20 KB stages, 3 workgroups / CU
     case 50: if (!bx3_ok(g)) return NNR_ERR_ARG; return launch_bx3<2, 5>(g, stream);           // EXPERIMENTAL bf16x3 NT 128 x 80 (needs args.B3: pre-split weights)
+    case 51: if (!bx3_ok(g)) return NNR_ERR_ARG; return launch_bx3<1, 5>(g, stream);           // ... 64 x 80: 2 x 23 KB stages, 3 workgroups / CU
+    case 52: if (!bx3_ok(g)) return NNR_ERR_ARG; return launch_bx3<2, 4>(g, stream);           // ... 128 x 64
+    case 53: if (!bx3_ok(g)) return NNR_ERR_ARG; return launch_bx3<4, 5>(g, stream);           // ... 256 x 80: 2 x 47 KB stages, 1 workgroup / CU
     case 40: if (!pipe3_ok(g)) return NNR_ERR_ARG; return launch_pipe3<2, 5, 2>(g, stream);     // gen-3 NT (persistent, continuous DMA pipeline, register epilogue) 128 x 80, 3 x 26 KB stages, 2 workgroups / CU
     case 41: if (!pipe3_ok(g)) return NNR_ERR_ARG; return launch_pipe3<2, 4, 2>(g, stream);     // gen-3 NT 128 x 64
     case 42: if (!pipe3_ok(g)) return NNR_ERR_ARG; return launch_pipe3<2, 10, 1>(g, stream);    // gen-3 NT 128 x 160, 3 x 36 KB stages, 1 workgroup / CU

@@ -378,19 +378,25 @@ def split_for(m, n, k, tile_m=64, tile_n=80, target_blocks=2048, kmin=256):
 # launch per weight and step, recorded in the launch tape like any other call.  Round 5: measurement only; the default path does not use it.
 BX3 = [os.environ.get('NNR_BX3', '0') == '1']
 _BX3_MIN_ROWS = int(os.environ.get('NNR_BX3_MIN_ROWS', '2048'))
+_BX3_TILE = int(os.environ.get('NNR_BX3_TILE', '50'))          # A/B: 50 = 128 x 80 (2 workgroups / CU), 51 = 64 x 80 (3), 52 = 128 x 64, 53 = 256 x 80 (1)
 _B3 = {}
 
 
 def bx3_images(B, N, K, ldb):
-    """(images [3, N, ldo] bf16-as-int16, image stride in elements, ldo) of the [N, K] weight `B`, re-split once per parameter epoch."""
+    """(images [3, N, ldo] bf16-as-int16, image stride in elements, ldo) of the [N, K] weight `B`, re-split when the parameters changed.
+    Identity of a cached entry = the tensor OBJECT (weak reference) + its pointer + the parameter epoch + the tensor's version counter: a
+    pointer alone is not an identity (the caching allocator hands a freed model's addresses to the next model -- found by running the GPU
+    suite with NNR_BX3=1: 10 tests multiplied by the previous test's weights)."""
     from .layers import PARAM_EPOCH
-    key = (B.data_ptr(), N, K, ldb)
-    e = _B3.get(key)
+    e = _B3.get(id(B))
     ldo = (K + 7) // 8 * 8
+    if e is not None and (e[3]() is not B or e[4] != (B.data_ptr(), N, K, ldb)):
+        e = None
     if e is None:
         if len(_B3) > 512:
-            _B3.clear()
-        e = _B3[key] = [torch.empty((3, N, ldo), device=B.device, dtype=torch.int16), -1, None]
+            for k in [k for k, v in _B3.items() if v[3]() is None]:
+                del _B3[k]
+        e = _B3[id(B)] = [torch.empty((3, N, ldo), device=B.device, dtype=torch.int16), -1, None, weakref.ref(B), (B.data_ptr(), N, K, ldb)]
     tape_keep(e[0])
     if e[1] != PARAM_EPOCH[0] or e[2] != B._version:
         L.check(L.lib().nnr_split_bf16x3(_p(B), N, K, ldb, ldo, _p(e[0]), C.c_long(N * ldo), _s()), 'nnr_split_bf16x3')
@@ -466,8 +472,8 @@ def gemm(A, B, C_=None, *, M, N, K, lda, ldb, ldc=0, trans_a=False, trans_b=Fals
     if b3 is None and BX3[0] and tile in (0, 9, 15, 16) and _bx3_wanted(A, B, M, N, K, lda, ldb, trans_a, trans_b, a_idx, b_idx, c_idx, split_k, k_chunk, rowdot_w,
                                                                     colsum_out, atomic, batch, dyn_dim, drop):
         b3 = bx3_images(B, N, K, ldb)                    # EXPERIMENTAL (NNR_BX3=1): this NT launch on the BF16 matrix pipe, weights pre-split
-        tile = 50
-        g.tile = 50
+        tile = _BX3_TILE
+        g.tile = _BX3_TILE
     if b3 is not None:
         g.B3, g.b3_stride, g.ldb3 = b3[0].data_ptr(), b3[1], b3[2]
     if slab is None and TN_SLAB and trans_a and trans_b and split_k > 1 and not k_chunk and c_idx is None and (N & 3) == 0 and C_ is not None:
@@ -510,7 +516,7 @@ def gemm(A, B, C_=None, *, M, N, K, lda, ldb, ldc=0, trans_a=False, trans_b=Fals
         t = 5 if not trans_b else 4
     fam = 'gemm_%s_%s' % ('tn' if trans_a else ('nn' if trans_b else 'nt'),
                           {1: '256x80', 2: '64x80', 3: '128x208', 4: '128x80', 5: '128x80k32', 6: '64x80k64', 7: '16x80skinny', 8: 'pipe128x80k32', 9: 'pipe2_128x80', 13: 'pipe128x80s4',
-                           15: 'pipe128x80', 16: 'pipe128x80s2', 20: 'pipe128x80', 26: 'pipe2_128x80', 27: 'pipe2_128x208', 30: 'pipe2_128x160', 31: 'pipe2_128x64', 32: 'pipe2_64x208', 33: 'pipe128x208', 34: 'pipe2_128x208', 36: 'pipe256x80', 22: 'pipe64x80', 23: 'pipe256x80', 24: 'pipe128x208', 25: 'pipe128x128', 50: 'bx3_128x80', 40: 'pipe3_128x80', 41: 'pipe3_128x64', 42: 'pipe3_128x160'}.get(t, 'tile%d' % t))
+                           15: 'pipe128x80', 16: 'pipe128x80s2', 20: 'pipe128x80', 26: 'pipe2_128x80', 27: 'pipe2_128x208', 30: 'pipe2_128x160', 31: 'pipe2_128x64', 32: 'pipe2_64x208', 33: 'pipe128x208', 34: 'pipe2_128x208', 36: 'pipe256x80', 22: 'pipe64x80', 23: 'pipe256x80', 24: 'pipe128x208', 25: 'pipe128x128', 50: 'bx3_128x80', 51: 'bx3_64x80', 52: 'bx3_128x64', 53: 'bx3_256x80', 40: 'pipe3_128x80', 41: 'pipe3_128x64', 42: 'pipe3_128x160'}.get(t, 'tile%d' % t))
 
     def flops(vals=None, M=M, N=N, K=K, dyn=dyn, dyn_dim=dyn_dim, batch=batch):
         # vals: {data_ptr of a device-side size: its value at the time of the launch} (replayed launches: the size buffers are
@@ -919,6 +925,18 @@ def gcn_aggregate_fwd(graph, z, bias, resid, r_out, y, B, G, D, relu, p, seed):
     with _hbm_span('gcn_aggregate_fwd', 4.0 * (G * D * arrays + G * G), B):
         L.check(L.lib().nnr_gcn_aggregate_fwd(_p(graph), _p(z), _p(bias), _p(resid), _p(r_out), _p(y), B, G, D, int(relu), C.c_float(p),
                                               C.c_uint32(int(seed) & 0xFFFFFFFF), _s()), 'nnr_gcn_aggregate_fwd')
+
+
+def gcn_layer_small_fwd(graph, x, W, bias, resid, r_out, y, B, G, D, relu, p, seed):
+    """One launch for a whole GCN layer at small batches (csrc/gcn.hip gcn_layer_small_kernel): y = dropout(relu(A (x W^T) + b) -> r_out, + resid)."""
+    L.check(L.lib().nnr_gcn_layer_small_fwd(_p(graph), _p(x), _p(W), _p(bias), _p(resid), _p(r_out), _p(y), B, G, D, int(relu), C.c_float(p),
+                                            C.c_uint32(int(seed) & 0xFFFFFFFF), _s()), 'nnr_gcn_layer_small_fwd')
+
+
+def gcn_layer_small_bwd(graph, dy, r, Wt, dx, B, G, D, residual, p, seed):
+    """The layer's data-gradient chain in one launch: dx = A^T (dS W) + (residual ? mask(dy) : 0), dS = mask(dy) * (r > 0); Wt = W^T contiguous."""
+    L.check(L.lib().nnr_gcn_layer_small_bwd(_p(graph), _p(dy), _p(r), _p(Wt), _p(dx), B, G, D, int(residual), C.c_float(p),
+                                            C.c_uint32(int(seed) & 0xFFFFFFFF), _s()), 'nnr_gcn_layer_small_bwd')
 
 
 def gcn_aggregate_bwd(graph, dy, r, ds, dx0, dz, B, G, D, p, seed):
