@@ -377,6 +377,7 @@ def secondary_legs(a, prof, dp, torch, dev, rank_seed=0):
         experimental = name.startswith('experimental_')
         bx3_before = _ops.BX3[0]
         _ops.BX3[0] = bool(experimental) or bx3_before
+        _ops.BX3_SEEN.clear()
         try:
             cfg = make_config(['--news_encoder=' + ne, '--user_encoder=' + ue, '--dataset=' + dataset, '--batch_size=%d' % gbatch,
                                '--world_size=%d' % gworld], corpus_sizes=dict(vocabulary_size=V))
@@ -411,6 +412,9 @@ def secondary_legs(a, prof, dp, torch, dev, rank_seed=0):
             if experimental:
                 leg['experimental'] = ('NNR_BX3=1, OFF by default: NT GEMMs (rows >= 2 048, weight operand) as six exact bf16 x bf16 MFMA products with fp32 '
                                        'accumulation; same parity bars (tests/test_hip_headline_gpu.py::..._with_experimental_bf16x3_nt_gemms_...)')
+                # eager + recorded steps only (replays do not pass through ops.gemm): which NT shapes took the path ('weight') and which met every
+                # other condition but multiply by an activation ('other': left on the fp32 pipe)
+                leg['bx3_launch_classes'] = {'%dx%dx%d %s' % k: v for k, v in sorted(_ops.BX3_SEEN.items())}
         except Exception as e:                  # a secondary measurement never takes the headline line down with it
             leg = {'error': repr(e)}
         finally:

@@ -284,6 +284,7 @@ def wt(w):
         e.t = torch.empty((cols, rows), device=w.device, dtype=torch.float32)      # kept across refreshes: stable address
         _WT[id(w)] = e
         _WT_TABLE['ids'] = None
+        mark_weight(e.t)
     tape_keep(e.t)
     transpose2d(w, e.t, rows, cols)
     e.event = torch.cuda.Event()
@@ -380,27 +381,43 @@ BX3 = [os.environ.get('NNR_BX3', '0') == '1']
 _BX3_MIN_ROWS = int(os.environ.get('NNR_BX3_MIN_ROWS', '2048'))
 _BX3_TILE = int(os.environ.get('NNR_BX3_TILE', '50'))          # A/B: 50 = 128 x 80 (2 workgroups / CU), 51 = 64 x 80 (3), 52 = 128 x 64, 53 = 256 x 80 (1)
 _B3 = {}
+BX3_SEEN = {}                                                  # diagnostics: (M, N, K, 'weight' | 'other') -> launches that met every other condition
+
+
+def mark_weight(*tensors):
+    """`tensors` are derived weights (a cached transpose, a packed layout): rewritten only when the parameters change (layers.PARAM_EPOCH)."""
+    for t in tensors:
+        t._nnr_weight = True
 
 
 def bx3_images(B, N, K, ldb):
     """(images [3, N, ldo] bf16-as-int16, image stride in elements, ldo) of the [N, K] weight `B`, re-split when the parameters changed.
     Identity of a cached entry = the tensor OBJECT (weak reference) + its pointer + the parameter epoch + the tensor's version counter: a
     pointer alone is not an identity (the caching allocator hands a freed model's addresses to the next model -- found by running the GPU
-    suite with NNR_BX3=1: 10 tests multiplied by the previous test's weights)."""
+    suite with NNR_BX3=1: 10 tests multiplied by the previous test's weights).  The split runs on the stream of the first user; a user
+    on another HIP stream waits for the producer's event, as wt() does (the candidate and the history calls of one step share every
+    weight and run on two streams: without the wait the second one can read images that are still being written -- found by the
+    two-ranks-on-one-GPU test under NNR_BX3=1, 7.7e-2 gradient error)."""
     from .layers import PARAM_EPOCH
     e = _B3.get(id(B))
     ldo = (K + 7) // 8 * 8
+    cur = torch._C._cuda_getCurrentRawStream(_DEV_INDEX[0] if _DEV_INDEX else torch.cuda.current_device())
     if e is not None and (e[3]() is not B or e[4] != (B.data_ptr(), N, K, ldb)):
         e = None
     if e is None:
         if len(_B3) > 512:
             for k in [k for k, v in _B3.items() if v[3]() is None]:
                 del _B3[k]
-        e = _B3[id(B)] = [torch.empty((3, N, ldo), device=B.device, dtype=torch.int16), -1, None, weakref.ref(B), (B.data_ptr(), N, K, ldb)]
+        e = _B3[id(B)] = [torch.empty((3, N, ldo), device=B.device, dtype=torch.int16), -1, None, weakref.ref(B), (B.data_ptr(), N, K, ldb), None, None]
     tape_keep(e[0])
     if e[1] != PARAM_EPOCH[0] or e[2] != B._version:
+        # (write-after-read: last step's readers on every stream joined the main stream before the optimizer step that changed the epoch)
         L.check(L.lib().nnr_split_bf16x3(_p(B), N, K, ldb, ldo, _p(e[0]), C.c_long(N * ldo), _s()), 'nnr_split_bf16x3')
-        e[1], e[2] = PARAM_EPOCH[0], B._version
+        e[5] = torch.cuda.Event()
+        e[5].record()
+        e[1], e[2], e[6] = PARAM_EPOCH[0], B._version, cur
+    elif e[6] != cur:
+        torch.cuda.current_stream(B.device).wait_event(e[5])
     return e[0], N * ldo, ldo
 
 
@@ -471,9 +488,15 @@ def gemm(A, B, C_=None, *, M, N, K, lda, ldb, ldc=0, trans_a=False, trans_b=Fals
         g.gate_bwd = 1
     if b3 is None and BX3[0] and tile in (0, 9, 15, 16) and _bx3_wanted(A, B, M, N, K, lda, ldb, trans_a, trans_b, a_idx, b_idx, c_idx, split_k, k_chunk, rowdot_w,
                                                                     colsum_out, atomic, batch, dyn_dim, drop):
-        b3 = bx3_images(B, N, K, ldb)                    # EXPERIMENTAL (NNR_BX3=1): this NT launch on the BF16 matrix pipe, weights pre-split
-        tile = _BX3_TILE
-        g.tile = _BX3_TILE
+        # EXPERIMENTAL (NNR_BX3=1): this NT launch on the BF16 matrix pipe, weights pre-split.  Only when B IS a weight: a parameter or a
+        # marked derived weight -- an activation buffer is rewritten through the C-ABI without any version bump, so its cached images would go stale
+        is_w = isinstance(B, torch.nn.Parameter) or getattr(B, '_nnr_weight', False)
+        key = (M, N, K, 'weight' if is_w else 'other')
+        BX3_SEEN[key] = BX3_SEEN.get(key, 0) + 1
+        if is_w:
+            b3 = bx3_images(B, N, K, ldb)
+            tile = _BX3_TILE
+            g.tile = _BX3_TILE
     if b3 is not None:
         g.B3, g.b3_stride, g.ldb3 = b3[0].data_ptr(), b3[1], b3[2]
     if slab is None and TN_SLAB and trans_a and trans_b and split_k > 1 and not k_chunk and c_idx is None and (N & 3) == 0 and C_ is not None:
@@ -692,6 +715,7 @@ class LstmPacked:
         self.wf = torch.empty(2 * ub * 4 * ub * 256, **f)
         self.wb = torch.empty(2 * ub * (np_ // 16) * 256, **f)
         self.w_ihp_t = torch.empty((E, 2 * np_), **f)             # [E, 2*NP]: K-contiguous B operand of the dX GEMM (NT form)
+        mark_weight(self.w_ihp, self.w_ihp_t)
         L.check(L.lib().nnr_lstm_pack_weights(*[_p(t) for t in p], H, E, _p(self.w_ihp), _p(self.b_p), _p(self.wf), _p(self.wb),
                                               _p(self.w_ihp_t), _s()), 'nnr_lstm_pack_weights')
 

@@ -76,7 +76,9 @@ def _sue_side(dev):
     return _SIDE[key]
 
 
-_GCN_SMALL_ROWS = int(os.environ.get('NNR_GCN_SMALL_ROWS', '1100'))      # A/B (round 5): fused one-launch GCN layers up to this many node rows (B * G); 0 = off
+_GCN_SMALL_ROWS = int(os.environ.get('NNR_GCN_SMALL_ROWS', '0'))      # one-launch GCN layers up to this many node rows (B * G); 0 = off.  Round-5 A/B (profiles/r05_ab.txt):
+                                                                       # 1100 rows: batch 8 3.155 -> 3.17 ms, batch 16 4.29 -> 4.40 ms; 2200: batch 32 6.31 -> 6.73 ms -- the launches it
+                                                                       # saves were already hidden under the news encoder's streams; its 8-wave workgroups are not.  Kept for A/B + its unit test
 
 
 def _gcn_small(gcn, B, G, D):

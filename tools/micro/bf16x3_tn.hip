@@ -1,0 +1,231 @@
+// Exploratory micro-benchmark (round 5; NOT part of libnnr_hip.so): the WEIGHT-GRADIENT (TN) GEMM  C[M,N] = A[K,M]^T . B[K,N]  -- both operands
+// activations stored token-major (K = tokens, 10^5), i.e. K-major for this product -- on the BF16 matrix pipe as six exact bf16 x bf16 products
+// with fp32 accumulation (see bf16x3_gemm.hip for the arithmetic).  Both operands are split on the way INTO LDS (global fp32 -> registers ->
+// three bf16 images [32 tokens][columns], row-major as they come), and the MFMA fragments -- eight consecutive tokens of one column per lane --
+// are read with gfx950's hardware transpose read `ds_read_b64_tr_b16` (4 tokens x 16 columns per 16-lane group), so nothing is transposed by
+// software.  Split-K over blockIdx.z into per-slice slabs + a fixed-order reduction, as the product's reproducible form.
+// Compared with nnr_gemm_f32 (gemm_tn_pipe2_kernel<1, 13, 3, 2>, slab mode) on the dW shapes of the CNE step.
+//
+// Build:  hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/micro/bf16x3_tn.hip -o tools/micro/bf16x3_tn -Lnnr_amd -lnnr_hip -Wl,-rpath,$PWD/nnr_amd
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <vector>
+#include "../../include/nnr_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
+
+__device__ __forceinline__ void split3(float x, __bf16& h1, __bf16& h2, __bf16& h3) {
+  h1 = (__bf16)x;
+  const float r1 = x - (float)h1;
+  h2 = (__bf16)r1;
+  const float r2 = r1 - (float)h2;
+  h3 = (__bf16)r2;
+}
+// 4 tokens x 16 columns of a row-major bf16 image, transposed by the LDS: this lane gets its column's 4 consecutive tokens
+__device__ __forceinline__ bf16x4 tr_read(const __bf16* p) {
+  const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
+  return __builtin_bit_cast(bf16x4, v);
+}
+
+template <int TN>
+__global__ __launch_bounds__(256, 2) void gemm_tn_bx3(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ slab, int M, int N,
+                                                      int K, int kslice) {
+  constexpr int BM = 64, BN = 16 * TN, BK = 32;
+  constexpr int PA = BM + 8, PB = BN + 8;                     // pitches in bf16 elements (rows stay 16-byte aligned; +8: spreads the tr reads over the banks)
+  constexpr int A_IMG = BK * PA, B_IMG = BK * PB;
+  __shared__ __attribute__((aligned(16))) __bf16 lds[3 * (A_IMG + B_IMG)];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int nbn = (N + BN - 1) / BN;
+  const int bm = blockIdx.x / nbn, bn = blockIdx.x - bm * nbn, m0 = bm * BM, n0 = bn * BN, z = blockIdx.z;
+  const int kbeg = z * kslice, kend = min(K, kbeg + kslice);
+  const int S = (kend - kbeg + BK - 1) / BK;
+  // staging geometry: float4 i of the A tile = (row i / 16, columns 4 (i % 16)); of the B tile = (row i / (BN/4), columns 4 (i % (BN/4)))
+  constexpr int NA4 = BK * BM / 4 / 256, NB4T = BK * BN / 4, NB4 = (NB4T + 255) / 256;
+  f32x4 ra[NA4], rb[NB4];
+  auto gload = [&](int s) __attribute__((always_inline)) {
+    const int k0 = kbeg + s * BK;
+#pragma unroll
+    for (int j = 0; j < NA4; ++j) {
+      const int i = tid + 256 * j, row = i >> 4, c = (i & 15) * 4;
+      ra[j] = (k0 + row < kend && m0 + c < M) ? *reinterpret_cast<const f32x4*>(A + (long)(k0 + row) * M + m0 + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int j = 0; j < NB4; ++j) {
+      const int i = tid + 256 * j, row = i / (BN / 4), c = (i - row * (BN / 4)) * 4;
+      rb[j] = (i < NB4T && k0 + row < kend && n0 + c < N) ? *reinterpret_cast<const f32x4*>(B + (long)(k0 + row) * N + n0 + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto put = [&](const f32x4& v, __bf16* img0, int img_elems, int off) __attribute__((always_inline)) {
+    bf16x4 h1, h2, h3;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { __bf16 a, b, c; split3(v[e], a, b, c); h1[e] = a; h2[e] = b; h3[e] = c; }
+    *reinterpret_cast<bf16x4*>(img0 + off) = h1;
+    *reinterpret_cast<bf16x4*>(img0 + img_elems + off) = h2;
+    *reinterpret_cast<bf16x4*>(img0 + 2 * img_elems + off) = h3;
+  };
+  auto lstore = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < NA4; ++j) {
+      const int i = tid + 256 * j, row = i >> 4, c = (i & 15) * 4;
+      put(ra[j], lds, A_IMG, row * PA + c);
+    }
+#pragma unroll
+    for (int j = 0; j < NB4; ++j) {
+      const int i = tid + 256 * j, row = i / (BN / 4), c = (i - row * (BN / 4)) * 4;
+      if (i < NB4T) put(rb[j], lds + 3 * A_IMG, B_IMG, row * PB + c);
+    }
+  };
+  f32x4 acc_hi[TN], acc_lo[TN];
+#pragma unroll
+  for (int n = 0; n < TN; ++n) acc_hi[n] = acc_lo[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // this lane's transposed-read geometry: group g = lane >> 4 covers tokens 8g .. 8g+7; inside the group lane 4 qq + p supplies the address of
+  // token row 8g + qq (second read: + 4), columns 4p .. 4p+3 of the 16-column block
+  const int g = lane >> 4, qq = (lane & 15) >> 2, p = lane & 3;
+  const int rowoff = 8 * g + qq;
+  if (S > 0) gload(0);
+  for (int s = 0; s < S; ++s) {
+    __syncthreads();                         // every wave is done with the previous stage's images
+    lstore();
+    __syncthreads();
+    if (s + 1 < S) gload(s + 1);             // in flight under this stage's MFMAs
+    bf16x8 a[3];
+#pragma unroll
+    for (int img = 0; img < 3; ++img) {
+      const __bf16* ia = lds + img * A_IMG + w * 16 + 4 * p;
+      const bf16x4 lo = tr_read(ia + rowoff * PA), hi = tr_read(ia + (rowoff + 4) * PA);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { a[img][e] = lo[e]; a[img][4 + e] = hi[e]; }
+    }
+#pragma unroll
+    for (int n = 0; n < TN; ++n) {
+      bf16x8 b[3];
+#pragma unroll
+      for (int img = 0; img < 3; ++img) {
+        const __bf16* ib = lds + 3 * A_IMG + img * B_IMG + n * 16 + 4 * p;
+        const bf16x4 lo = tr_read(ib + rowoff * PB), hi = tr_read(ib + (rowoff + 4) * PB);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { b[img][e] = lo[e]; b[img][4 + e] = hi[e]; }
+      }
+      acc_hi[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc_hi[n], 0, 0, 0);
+      acc_lo[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], acc_lo[n], 0, 0, 0);
+      acc_lo[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], acc_lo[n], 0, 0, 0);
+      acc_lo[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], acc_lo[n], 0, 0, 0);
+      acc_lo[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], acc_lo[n], 0, 0, 0);
+      acc_lo[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], acc_lo[n], 0, 0, 0);
+    }
+  }
+  // slab[z][m][n]: this wave's rows m0 + 16 w + (lane >> 4) * 4 + reg, column n0 + 16 n + (lane & 15)
+  float* out = slab + (long)z * M * N;
+#pragma unroll
+  for (int n = 0; n < TN; ++n)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int row = m0 + 16 * w + (lane >> 4) * 4 + reg, col = n0 + 16 * n + (lane & 15);
+      if (row < M && col < N) out[(long)row * N + col] = acc_hi[n][reg] + acc_lo[n][reg];
+    }
+}
+
+__global__ void reduce_kernel(const float* __restrict__ slab, float* __restrict__ C, long mn, int Z) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < mn; i += (long)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int z = 0; z < Z; ++z) s += slab[(long)z * mn + i];
+    C[i] = s;
+  }
+}
+__global__ void ref64_kernel(const float* __restrict__ A, const float* __restrict__ B, double* __restrict__ C, double* __restrict__ CA, int M, int N, int K) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= (long)M * N) return;
+  const int m = (int)(i / N), n = (int)(i - (long)m * N);
+  double s = 0.0, sa = 0.0;
+  for (int k = 0; k < K; ++k) { const double p = (double)A[(long)k * M + m] * (double)B[(long)k * N + n]; s += p; sa += fabs(p); }
+  C[i] = s; CA[i] = sa;
+}
+static void fill(std::vector<float>& v, uint64_t seed, float scale) {
+  uint64_t s = seed * 0x9E3779B97F4A7C15ull + 1;
+  for (auto& x : v) {
+    float a = 0.f;
+    for (int i = 0; i < 4; ++i) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; a += (float)((s >> 40) & 0xFFFFFF) / 16777216.f - 0.5f; }
+    x = a * 1.7320508f * scale;
+  }
+}
+
+int main(int argc, char** argv) {
+  const int M = argc > 3 ? atoi(argv[1]) : 400, N = argc > 3 ? atoi(argv[2]) : 400, K = argc > 3 ? atoi(argv[3]) : 84000;
+  const int Z = argc > 4 ? atoi(argv[4]) : 46;
+  printf("bf16x3 TN (weight-gradient) micro-benchmark: C[%d,%d] = A[%d,%d]^T . B[%d,%d], %d slices\n", M, N, K, M, K, N, Z);
+  if (M % 4 || N % 4) { fprintf(stderr, "M, N multiples of 4\n"); return 1; }
+  std::vector<float> hA((size_t)K * M), hB((size_t)K * N);
+  fill(hA, 1, 0.3f); fill(hB, 2, 0.5f);
+  float *A, *B, *C0, *C1, *slab0, *slab1;
+  double *R, *RA;
+  CK(hipMalloc(&A, hA.size() * 4)); CK(hipMalloc(&B, hB.size() * 4));
+  CK(hipMalloc(&C0, (size_t)M * N * 4)); CK(hipMalloc(&C1, (size_t)M * N * 4));
+  CK(hipMalloc(&slab0, (size_t)Z * ((size_t)M * N + M) * 4)); CK(hipMalloc(&slab1, (size_t)Z * M * N * 4));
+  CK(hipMalloc(&R, (size_t)M * N * 8)); CK(hipMalloc(&RA, (size_t)M * N * 8));
+  CK(hipMemcpy(A, hA.data(), hA.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(B, hB.data(), hB.size() * 4, hipMemcpyHostToDevice));
+  hipStream_t st;
+  CK(hipStreamCreate(&st));
+  nnr_gemm_args g;
+  memset(&g, 0, sizeof(g));
+  g.A = A; g.B = B; g.C = C0; g.M = M; g.N = N; g.K = K; g.lda = M; g.ldb = N; g.ldc = N; g.alpha = 1.f; g.trans_a = 1; g.trans_b = 1;
+  g.split_k = Z; g.atomic = 1; g.slab = slab0; g.slab_floats = (long)Z * ((long)M * N + M); g.tile = (M <= 832 ? 32 : 30);
+  constexpr int TN = 13;
+  const int kslice = ((K + Z - 1) / Z + 31) / 32 * 32;
+  const int Zeff = (K + kslice - 1) / kslice;
+  const dim3 grid(((M + 63) / 64) * ((N + 16 * TN - 1) / (16 * TN)), 1, Zeff);
+  auto run_native = [&]() {
+    CK(hipMemsetAsync(C0, 0, (size_t)M * N * 4, st));
+    if (nnr_gemm_f32(&g, st) != 0) { fprintf(stderr, "nnr_gemm_f32 failed\n"); exit(3); }
+  };
+  auto run_x3 = [&]() {
+    hipLaunchKernelGGL((gemm_tn_bx3<TN>), grid, dim3(256), 0, st, A, B, slab1, M, N, K, kslice);
+    hipLaunchKernelGGL(reduce_kernel, dim3(256), dim3(256), 0, st, slab1, C1, (long)M * N, Zeff);
+  };
+  run_native(); run_x3();
+  CK(hipStreamSynchronize(st));
+  CK(hipGetLastError());
+  hipLaunchKernelGGL(ref64_kernel, dim3(((long)M * N + 255) / 256), dim3(256), 0, st, A, B, R, RA, M, N, K);
+  CK(hipStreamSynchronize(st));
+  std::vector<double> ref((size_t)M * N), absref((size_t)M * N);
+  std::vector<float> c0((size_t)M * N), c1((size_t)M * N);
+  CK(hipMemcpy(ref.data(), R, ref.size() * 8, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(absref.data(), RA, absref.size() * 8, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(c0.data(), C0, c0.size() * 4, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(c1.data(), C1, c1.size() * 4, hipMemcpyDeviceToHost));
+  auto err = [&](const std::vector<float>& c, double& l2, double& sc) {
+    double num = 0, den = 0; sc = 0;
+    for (size_t i = 0; i < ref.size(); ++i) { const double d = fabs((double)c[i] - ref[i]); num += d * d; den += ref[i] * ref[i]; sc = fmax(sc, d / absref[i]); }
+    l2 = sqrt(num / den);
+  };
+  double l0, s0, l1, s1;
+  err(c0, l0, s0); err(c1, l1, s1);
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  double best[2] = {1e9, 1e9};
+  for (int rd = 0; rd < 5; ++rd)
+    for (int which = 0; which < 2; ++which) {
+      CK(hipEventRecord(a, st));
+      for (int i = 0; i < 10; ++i) { if (which == 0) run_native(); else run_x3(); }
+      CK(hipEventRecord(b, st));
+      CK(hipEventSynchronize(b));
+      float ms;
+      CK(hipEventElapsedTime(&ms, a, b));
+      best[which] = fmin(best[which], ms / 10);
+    }
+  const double fl = 2.0 * M * N * K;
+  printf("  native f32 MFMA (nnr_gemm_f32, slab mode, incl. reduction + zero fill): best %.1f us = %.1f TFLOP/s | rel-L2 %.3e  max err / sum|ab| %.3e\n", 1e3 * best[0], fl / best[0] / 1e9, l0, s0);
+  printf("  bf16x3 TN (tr reads, 64 x %d tile, %d slices, incl. reduction):          best %.1f us = %.1f TFLOP/s-equivalent = %.2fx | rel-L2 %.3e  max err / sum|ab| %.3e\n",
+         16 * TN, Zeff, 1e3 * best[1], fl / best[1] / 1e9, best[0] / best[1], l1, s1);
+  printf("JSON {\"M\": %d, \"N\": %d, \"K\": %d, \"native_us\": %.2f, \"bf16x3_us\": %.2f, \"speedup\": %.3f, \"native_rel_l2\": %.3e, \"bf16x3_rel_l2\": %.3e}\n", M, N, K,
+         1e3 * best[0], 1e3 * best[1], best[0] / best[1], l0, l1);
+  return 0;
+}
