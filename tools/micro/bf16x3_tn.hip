@@ -35,11 +35,13 @@ __device__ __forceinline__ bf16x4 tr_read(const __bf16* p) {
   return __builtin_bit_cast(bf16x4, v);
 }
 
-template <int TN>
+// TM: 16-row tiles per wave (workgroup tile = 64 TM x 16 TN); DUAL: hi term and the five small terms in two accumulators (v1) or all six in one
+// (K / 32 x 6 roundings per output against the fp32 MFMA's K / 4: still below the native kernel's error); PADA / PADB: pitch padding in bf16 elements
+template <int TM, int TN, bool DUAL, int PADA, int PADB>
 __global__ __launch_bounds__(256, 2) void gemm_tn_bx3(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ slab, int M, int N,
                                                       int K, int kslice) {
-  constexpr int BM = 64, BN = 16 * TN, BK = 32;
-  constexpr int PA = BM + 8, PB = BN + 8;                     // pitches in bf16 elements (rows stay 16-byte aligned; +8: spreads the tr reads over the banks)
+  constexpr int BM = 64 * TM, BN = 16 * TN, BK = 32;
+  constexpr int PA = BM + PADA, PB = BN + PADB;               // pitches in bf16 elements (rows stay 8-byte aligned)
   constexpr int A_IMG = BK * PA, B_IMG = BK * PB;
   __shared__ __attribute__((aligned(16))) __bf16 lds[3 * (A_IMG + B_IMG)];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -54,7 +56,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bx3(const float* __restrict__ 
     const int k0 = kbeg + s * BK;
 #pragma unroll
     for (int j = 0; j < NA4; ++j) {
-      const int i = tid + 256 * j, row = i >> 4, c = (i & 15) * 4;
+      const int i = tid + 256 * j, row = i / (BM / 4), c = (i - row * (BM / 4)) * 4;
       ra[j] = (k0 + row < kend && m0 + c < M) ? *reinterpret_cast<const f32x4*>(A + (long)(k0 + row) * M + m0 + c) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bx3(const float* __restrict__ 
   auto lstore = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < NA4; ++j) {
-      const int i = tid + 256 * j, row = i >> 4, c = (i & 15) * 4;
+      const int i = tid + 256 * j, row = i / (BM / 4), c = (i - row * (BM / 4)) * 4;
       put(ra[j], lds, A_IMG, row * PA + c);
     }
 #pragma unroll
@@ -83,9 +85,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bx3(const float* __restrict__ 
       if (i < NB4T) put(rb[j], lds + 3 * A_IMG, B_IMG, row * PB + c);
     }
   };
-  f32x4 acc_hi[TN], acc_lo[TN];
+  f32x4 acc_hi[TM][TN], acc_lo[DUAL ? TM : 1][DUAL ? TN : 1];
 #pragma unroll
-  for (int n = 0; n < TN; ++n) acc_hi[n] = acc_lo[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int m = 0; m < TM; ++m)
+#pragma unroll
+    for (int n = 0; n < TN; ++n) acc_hi[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if constexpr (DUAL) {
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+      for (int n = 0; n < TN; ++n) acc_lo[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   // this lane's transposed-read geometry: group g = lane >> 4 covers tokens 8g .. 8g+7; inside the group lane 4 qq + p supplies the address of
   // token row 8g + qq (second read: + 4), columns 4p .. 4p+3 of the 16-column block
   const int g = lane >> 4, qq = (lane & 15) >> 2, p = lane & 3;
@@ -96,14 +106,16 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bx3(const float* __restrict__ 
     lstore();
     __syncthreads();
     if (s + 1 < S) gload(s + 1);             // in flight under this stage's MFMAs
-    bf16x8 a[3];
+    bf16x8 a[TM][3];
 #pragma unroll
-    for (int img = 0; img < 3; ++img) {
-      const __bf16* ia = lds + img * A_IMG + w * 16 + 4 * p;
-      const bf16x4 lo = tr_read(ia + rowoff * PA), hi = tr_read(ia + (rowoff + 4) * PA);
+    for (int m = 0; m < TM; ++m)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { a[img][e] = lo[e]; a[img][4 + e] = hi[e]; }
-    }
+      for (int img = 0; img < 3; ++img) {
+        const __bf16* ia = lds + img * A_IMG + (w * TM + m) * 16 + 4 * p;
+        const bf16x4 lo = tr_read(ia + rowoff * PA), hi = tr_read(ia + (rowoff + 4) * PA);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[m][img][e] = lo[e]; a[m][img][4 + e] = hi[e]; }
+      }
 #pragma unroll
     for (int n = 0; n < TN; ++n) {
       bf16x8 b[3];
@@ -114,23 +126,39 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bx3(const float* __restrict__ 
 #pragma unroll
         for (int e = 0; e < 4; ++e) { b[img][e] = lo[e]; b[img][4 + e] = hi[e]; }
       }
-      acc_hi[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc_hi[n], 0, 0, 0);
-      acc_lo[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], acc_lo[n], 0, 0, 0);
-      acc_lo[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], acc_lo[n], 0, 0, 0);
-      acc_lo[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], acc_lo[n], 0, 0, 0);
-      acc_lo[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], acc_lo[n], 0, 0, 0);
-      acc_lo[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], acc_lo[n], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < TM; ++m) {
+        if constexpr (DUAL) {
+          acc_hi[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][0], b[0], acc_hi[m][n], 0, 0, 0);
+          acc_lo[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][2], b[0], acc_lo[m][n], 0, 0, 0);
+          acc_lo[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][0], b[2], acc_lo[m][n], 0, 0, 0);
+          acc_lo[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][1], b[1], acc_lo[m][n], 0, 0, 0);
+          acc_lo[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][1], b[0], acc_lo[m][n], 0, 0, 0);
+          acc_lo[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][0], b[1], acc_lo[m][n], 0, 0, 0);
+        } else {                       // smallest terms first, the hi product last
+          acc_hi[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][2], b[0], acc_hi[m][n], 0, 0, 0);
+          acc_hi[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][0], b[2], acc_hi[m][n], 0, 0, 0);
+          acc_hi[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][1], b[1], acc_hi[m][n], 0, 0, 0);
+          acc_hi[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][1], b[0], acc_hi[m][n], 0, 0, 0);
+          acc_hi[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][0], b[1], acc_hi[m][n], 0, 0, 0);
+          acc_hi[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][0], b[0], acc_hi[m][n], 0, 0, 0);
+        }
+      }
     }
   }
-  // slab[z][m][n]: this wave's rows m0 + 16 w + (lane >> 4) * 4 + reg, column n0 + 16 n + (lane & 15)
+  // slab[z][m][n]: this wave's rows m0 + 16 (w TM + m) + (lane >> 4) * 4 + reg, column n0 + 16 n + (lane & 15)
   float* out = slab + (long)z * M * N;
 #pragma unroll
-  for (int n = 0; n < TN; ++n)
+  for (int m = 0; m < TM; ++m)
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int row = m0 + 16 * w + (lane >> 4) * 4 + reg, col = n0 + 16 * n + (lane & 15);
-      if (row < M && col < N) out[(long)row * N + col] = acc_hi[n][reg] + acc_lo[n][reg];
-    }
+    for (int n = 0; n < TN; ++n)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int row = m0 + 16 * (w * TM + m) + (lane >> 4) * 4 + reg, col = n0 + 16 * n + (lane & 15);
+        float v = acc_hi[m][n][reg];
+        if constexpr (DUAL) v += acc_lo[m][n][reg];
+        if (row < M && col < N) out[(long)row * N + col] = v;
+      }
 }
 
 __global__ void reduce_kernel(const float* __restrict__ slab, float* __restrict__ C, long mn, int Z) {
@@ -178,16 +206,30 @@ int main(int argc, char** argv) {
   memset(&g, 0, sizeof(g));
   g.A = A; g.B = B; g.C = C0; g.M = M; g.N = N; g.K = K; g.lda = M; g.ldb = N; g.ldc = N; g.alpha = 1.f; g.trans_a = 1; g.trans_b = 1;
   g.split_k = Z; g.atomic = 1; g.slab = slab0; g.slab_floats = (long)Z * ((long)M * N + M); g.tile = (M <= 832 ? 32 : 30);
-  constexpr int TN = 13;
+  const int variant = argc > 5 ? atoi(argv[5]) : 0;
   const int kslice = ((K + Z - 1) / Z + 31) / 32 * 32;
   const int Zeff = (K + kslice - 1) / kslice;
-  const dim3 grid(((M + 63) / 64) * ((N + 16 * TN - 1) / (16 * TN)), 1, Zeff);
+  int vbm = 64, vbn = 208;
+  const char* vname = "v1: 64 x 208, two accumulators, pitch + 8";
+  void (*kern)(const float*, const float*, float*, int, int, int, int) = gemm_tn_bx3<1, 13, true, 8, 8>;
+  switch (variant) {
+    case 1: kern = gemm_tn_bx3<1, 13, false, 8, 8>; vname = "64 x 208, one accumulator, pitch + 8"; break;
+    case 2: kern = gemm_tn_bx3<2, 13, false, 8, 8>; vbm = 128; vname = "128 x 208, one accumulator, pitch + 8"; break;
+    case 3: kern = gemm_tn_bx3<2, 13, false, 16, 16>; vbm = 128; vname = "128 x 208, one accumulator, pitch + 16"; break;
+    case 4: kern = gemm_tn_bx3<2, 13, false, 4, 4>; vbm = 128; vname = "128 x 208, one accumulator, pitch + 4"; break;
+    case 5: kern = gemm_tn_bx3<2, 13, false, 0, 0>; vbm = 128; vname = "128 x 208, one accumulator, pitch + 0"; break;
+    case 6: kern = gemm_tn_bx3<2, 10, false, 16, 16>; vbm = 128; vbn = 160; vname = "128 x 160, one accumulator, pitch + 16"; break;
+    case 7: kern = gemm_tn_bx3<2, 13, true, 16, 16>; vbm = 128; vname = "128 x 208, two accumulators, pitch + 16"; break;
+    case 8: kern = gemm_tn_bx3<1, 13, false, 16, 16>; vname = "64 x 208, one accumulator, pitch + 16"; break;
+    default: break;
+  }
+  const dim3 grid(((M + vbm - 1) / vbm) * ((N + vbn - 1) / vbn), 1, Zeff);
   auto run_native = [&]() {
     CK(hipMemsetAsync(C0, 0, (size_t)M * N * 4, st));
     if (nnr_gemm_f32(&g, st) != 0) { fprintf(stderr, "nnr_gemm_f32 failed\n"); exit(3); }
   };
   auto run_x3 = [&]() {
-    hipLaunchKernelGGL((gemm_tn_bx3<TN>), grid, dim3(256), 0, st, A, B, slab1, M, N, K, kslice);
+    hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, A, B, slab1, M, N, K, kslice);
     hipLaunchKernelGGL(reduce_kernel, dim3(256), dim3(256), 0, st, slab1, C1, (long)M * N, Zeff);
   };
   run_native(); run_x3();
@@ -223,9 +265,9 @@ int main(int argc, char** argv) {
     }
   const double fl = 2.0 * M * N * K;
   printf("  native f32 MFMA (nnr_gemm_f32, slab mode, incl. reduction + zero fill): best %.1f us = %.1f TFLOP/s | rel-L2 %.3e  max err / sum|ab| %.3e\n", 1e3 * best[0], fl / best[0] / 1e9, l0, s0);
-  printf("  bf16x3 TN (tr reads, 64 x %d tile, %d slices, incl. reduction):          best %.1f us = %.1f TFLOP/s-equivalent = %.2fx | rel-L2 %.3e  max err / sum|ab| %.3e\n",
-         16 * TN, Zeff, 1e3 * best[1], fl / best[1] / 1e9, best[0] / best[1], l1, s1);
-  printf("JSON {\"M\": %d, \"N\": %d, \"K\": %d, \"native_us\": %.2f, \"bf16x3_us\": %.2f, \"speedup\": %.3f, \"native_rel_l2\": %.3e, \"bf16x3_rel_l2\": %.3e}\n", M, N, K,
+  printf("  bf16x3 TN variant %d (%s; %d slices, incl. reduction): best %.1f us = %.1f TFLOP/s-equivalent = %.2fx | rel-L2 %.3e  max err / sum|ab| %.3e\n",
+         variant, vname, Zeff, 1e3 * best[1], fl / best[1] / 1e9, best[0] / best[1], l1, s1);
+  printf("JSON {\"variant\": %d, \"M\": %d, \"N\": %d, \"K\": %d, \"native_us\": %.2f, \"bf16x3_us\": %.2f, \"speedup\": %.3f, \"native_rel_l2\": %.3e, \"bf16x3_rel_l2\": %.3e}\n", variant, M, N, K,
          1e3 * best[0], 1e3 * best[1], best[0] / best[1], l0, l1);
   return 0;
 }
