@@ -29,6 +29,19 @@ __device__ __forceinline__ void split3(float x, __bf16& h1, __bf16& h2, __bf16& 
   const float r2 = r1 - (float)h2;
   h3 = (__bf16)r2;
 }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// two values at a time: one v_cvt_pk_bf16_f32 per pair and image, the bf16 -> fp32 widenings are a shift and a mask of the packed word
+__device__ __forceinline__ void split3_pk(f32x2 x, unsigned& p1, unsigned& p2, unsigned& p3) {
+  const bf16x2 h1 = __builtin_convertvector(x, bf16x2);
+  p1 = __builtin_bit_cast(unsigned, h1);
+  const f32x2 r1 = x - f32x2{__builtin_bit_cast(float, p1 << 16), __builtin_bit_cast(float, p1 & 0xffff0000u)};
+  const bf16x2 h2 = __builtin_convertvector(r1, bf16x2);
+  p2 = __builtin_bit_cast(unsigned, h2);
+  const f32x2 r2 = r1 - f32x2{__builtin_bit_cast(float, p2 << 16), __builtin_bit_cast(float, p2 & 0xffff0000u)};
+  p3 = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
+}
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 // 4 tokens x 16 columns of a row-major bf16 image, transposed by the LDS: this lane gets its column's 4 consecutive tokens
 __device__ __forceinline__ bf16x4 tr_read(const __bf16* p) {
   const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
@@ -161,6 +174,303 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bx3(const float* __restrict__ 
       }
 }
 
+// ---- v3: 128 x (16 TN) x 32 stages, LDS images double-buffered (one barrier per stage), one workgroup of four waves per CU (512 VGPRs per wave: the
+// two-accumulator form fits), the NEXT stage's split + image stores and the stage-after-next's global loads issued between the MFMAs of the current one
+// (item j of the 4 + 7 float4s a thread stages goes behind the MFMAs of column tile j), fragments of column tile n + 1 read under the MFMAs of tile n.
+// K must be a multiple of 32 per slice (micro-benchmark: no reduction tail); columns beyond M / N are clamped (they feed outputs that are never stored).
+// ABL (ablation, wrong results): 1 = no split / image stores in the loop, 2 = no global loads in the loop, 3 = neither, 4 = no MFMAs
+template <int TN, bool DUAL, bool SWZ, int ABL = 0, int SGB = 0>
+__global__ __launch_bounds__(256, 1) void gemm_tn_bx3_db(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ slab, int M, int N,
+                                                         int K, int kslice) {
+  constexpr int TM = 2, BM = 128, BN = 16 * TN, BK = 32;
+  constexpr int PA = BM + 16, PB = BN + 16, NBLKB = PB / 16;
+  constexpr int A_IMG = BK * PA, B_IMG = BK * PB, BUF = 3 * (A_IMG + B_IMG);
+  constexpr int NA4 = 4, NB4 = (BN / 4 + 7) / 8, NI = NA4 + NB4;           // float4 items per thread and stage
+  static_assert(NI <= TN, "one staged item per column tile");
+  __shared__ __attribute__((aligned(16))) __bf16 lds[2 * BUF];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int nbn = (N + BN - 1) / BN;
+  const int bm = blockIdx.x / nbn, bn = blockIdx.x - bm * nbn, m0 = bm * BM, n0 = bn * BN, z = blockIdx.z;
+  const int kbeg = z * kslice, kend = min(K, kbeg + kslice);
+  const int S = (kend - kbeg) / BK;
+  // staging geometry.  A: float4 i = tid + 256 j -> (row i >> 5, columns 4 (i & 31));  B: row tid >> 3, columns 4 ((tid & 7) + 8 j), clamped to the tile.
+  // SWZ: a transposed read serves lanes 0-31 in one LDS cycle = token rows 8g .. 8g + 7 of TWO 16-lane groups g; rows 8 apart are a multiple of 64 banks
+  // apart at any pitch that keeps the four rows of a group on distinct banks, so both groups would hit the same 32 banks (2-way conflict on every read):
+  // rows with bit 3 set keep their 16-column blocks 4 blocks (= 32 banks) further on -- A: block ^ 4 (8 blocks), B: (block + 4) mod 14 (13 blocks + the pad)
+  int offA[NA4], ldsA[NA4], offB[NB4], ldsB[NB4];
+#pragma unroll
+  for (int j = 0; j < NA4; ++j) {
+    const int i = tid + 256 * j, row = i >> 5, c = (i & 31) * 4;
+    offA[j] = row * M + min(m0 + c, M - 4);
+    ldsA[j] = row * PA + (SWZ ? (c ^ (((row >> 3) & 1) * 64)) : c);
+  }
+#pragma unroll
+  for (int j = 0; j < NB4; ++j) {
+    const int row = tid >> 3, c = min((tid & 7) + 8 * j, BN / 4 - 1) * 4;
+    offB[j] = row * N + min(n0 + c, N - 4);
+    const int blk = c >> 4, pblk = SWZ ? (blk + 4 * ((row >> 3) & 1)) % NBLKB : blk;
+    ldsB[j] = 3 * A_IMG + row * PB + pblk * 16 + (c & 15);
+  }
+  f32x4 rg[NI];
+  auto gload = [&](int s, int j) __attribute__((always_inline)) {
+    const long k0 = kbeg + (long)s * BK;
+    if (j < NA4) rg[j] = *reinterpret_cast<const f32x4*>(A + k0 * M + offA[j]);
+    else rg[j] = *reinterpret_cast<const f32x4*>(B + k0 * N + offB[j - NA4]);
+  };
+  auto put = [&](int buf, int j) __attribute__((always_inline)) {
+    __bf16* base = lds + buf * BUF + (j < NA4 ? ldsA[j] : ldsB[j - NA4]);
+    const int img = j < NA4 ? A_IMG : B_IMG;
+    const f32x4 v = rg[j];
+    unsigned a0, b0, c0, a1, b1, c1;
+    split3_pk(f32x2{v[0], v[1]}, a0, b0, c0);
+    split3_pk(f32x2{v[2], v[3]}, a1, b1, c1);
+    const u32x2 h1 = {a0, a1}, h2 = {b0, b1}, h3 = {c0, c1};
+    *reinterpret_cast<u32x2*>(base) = h1;
+    *reinterpret_cast<u32x2*>(base + img) = h2;
+    *reinterpret_cast<u32x2*>(base + 2 * img) = h3;
+  };
+  f32x4 acc_hi[TM][TN], acc_lo[DUAL ? TM : 1][DUAL ? TN : 1];
+#pragma unroll
+  for (int m = 0; m < TM; ++m)
+#pragma unroll
+    for (int n = 0; n < TN; ++n) {
+      acc_hi[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (DUAL) acc_lo[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  const int g = lane >> 4, qq = (lane & 15) >> 2, p = lane & 3;
+  const int rowoff = 8 * g + qq;
+  // fragment addresses: block offsets are compile-time immediates off two per-lane bases (rows of an odd group g read 4 blocks further on, modulo the block count)
+  const int gb = SWZ ? (g & 1) : 0;
+  const int fragA = rowoff * PA + 4 * p + gb * (w < 2 ? 64 : -64) + w * TM * 16;
+  const int fragB0 = 3 * A_IMG + rowoff * PB + 4 * p + gb * 64, fragB1 = 3 * A_IMG + rowoff * PB + 4 * p - gb * (NBLKB - 4) * 16;
+  auto read_a = [&](const __bf16* buf, int m, bf16x8 (&a)[3]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int img = 0; img < 3; ++img) {
+      const __bf16* ia = buf + img * A_IMG + fragA + m * 16;
+      const bf16x4 lo = tr_read(ia), hi = tr_read(ia + 4 * PA);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { a[img][e] = lo[e]; a[img][4 + e] = hi[e]; }
+    }
+  };
+  auto read_b = [&](const __bf16* buf, int n, bf16x8 (&b)[3]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int img = 0; img < 3; ++img) {
+      const __bf16* ib = buf + img * B_IMG + (n + 4 < NBLKB ? fragB0 : fragB1) + n * 16;
+      const bf16x4 lo = tr_read(ib), hi = tr_read(ib + 4 * PB);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { b[img][e] = lo[e]; b[img][4 + e] = hi[e]; }
+    }
+  };
+  if (S <= 0) return;
+  // prologue: stage 0 -> images of buffer 0, stage 1 -> registers
+#pragma unroll
+  for (int j = 0; j < NI; ++j) gload(0, j);
+#pragma unroll
+  for (int j = 0; j < NI; ++j) put(0, j);
+#pragma unroll
+  for (int j = 0; j < NI; ++j) gload(min(1, S - 1), j);
+  __syncthreads();
+  for (int s = 0; s < S; ++s) {
+    const __bf16* buf = lds + (s & 1) * BUF;
+    bf16x8 a[TM][3], b[2][3];
+    read_a(buf, 0, a[0]);
+    read_a(buf, 1, a[1]);
+    read_b(buf, 0, b[0]);
+#pragma unroll
+    for (int n = 0; n < TN; ++n) {
+      if (n + 1 < TN) read_b(buf, n + 1, b[(n + 1) & 1]);
+#pragma unroll
+      for (int m = 0; m < TM; ++m) {
+        const bf16x8(&bb)[3] = b[n & 1];
+        if constexpr (ABL == 4) {
+          acc_hi[m][n][0] += (float)a[m][0][0] + (float)bb[0][0] + (float)a[m][1][0] + (float)bb[1][0] + (float)a[m][2][0] + (float)bb[2][0];
+        } else if constexpr (DUAL) {
+          acc_hi[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][0], bb[0], acc_hi[m][n], 0, 0, 0);
+          acc_lo[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][2], bb[0], acc_lo[m][n], 0, 0, 0);
+          acc_lo[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][0], bb[2], acc_lo[m][n], 0, 0, 0);
+          acc_lo[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][1], bb[1], acc_lo[m][n], 0, 0, 0);
+          acc_lo[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][1], bb[0], acc_lo[m][n], 0, 0, 0);
+          acc_lo[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][0], bb[1], acc_lo[m][n], 0, 0, 0);
+        } else {
+          acc_hi[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][2], bb[0], acc_hi[m][n], 0, 0, 0);
+          acc_hi[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][0], bb[2], acc_hi[m][n], 0, 0, 0);
+          acc_hi[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][1], bb[1], acc_hi[m][n], 0, 0, 0);
+          acc_hi[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][1], bb[0], acc_hi[m][n], 0, 0, 0);
+          acc_hi[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][0], bb[1], acc_hi[m][n], 0, 0, 0);
+          acc_hi[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][0], bb[0], acc_hi[m][n], 0, 0, 0);
+        }
+      }
+      if (n < NI) {                      // the next stage's item n: split + image stores, then the stage after's load into the same registers
+        if constexpr (ABL != 1 && ABL != 3) put((s + 1) & 1, n);             // (past the last stage: a harmless re-split into the idle buffer / re-load of the last stage -- no branch, so
+        if constexpr (ABL != 2 && ABL != 3) gload(min(s + 2, S - 1), n);     //  the loop body stays one block and the load counter waits stay exact: vmcnt(NI - 1) in front of every split)
+      }
+      if constexpr (SGB == 1) {          // even interleave: the six fragment reads first, then one MFMA : two vector instructions, the image stores and the load spread between
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+        for (int q = 0; q < 2 * (DUAL ? 6 : 6); ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x2, 2, 0);
+          if (q == 5 || q == 8 || q == 11) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+          if (q == 11) __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  }
+  float* out = slab + (long)z * M * N;
+#pragma unroll
+  for (int m = 0; m < TM; ++m)
+#pragma unroll
+    for (int n = 0; n < TN; ++n)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int row = m0 + 16 * (w * TM + m) + (lane >> 4) * 4 + reg, col = n0 + 16 * n + (lane & 15);
+        float v = acc_hi[m][n][reg];
+        if constexpr (DUAL) v += acc_lo[m][n][reg];
+        if (row < M && col < N) out[(long)row * N + col] = v;
+      }
+}
+
+// ---- v4: v3's structure on v_mfma_f32_32x32x16_bf16 (one instruction per 32 cycles that holds the SIMD's vector issue for 8 of them, where two 16x16x32
+// hold it for 16: the split's ~260 VALU + ~120 LDS instructions per stage need those slots).  Workgroup tile 128 x 224 x 32, wave w owns rows [32 w, +32) x
+// all 7 column tiles; two 16-token MFMA steps per stage.  Images: A pitch 128, B pitch 256 (bf16 elements), 16-column blocks XOR-swizzled by 2 (row & 3): a
+// transposed read serves lanes 0-31 = four token rows x two adjacent blocks per LDS cycle, which then cover all 64 banks.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <bool DUAL>
+__global__ __launch_bounds__(256, 1) void gemm_tn_bx3_w32(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ slab, int M, int N,
+                                                          int K, int kslice) {
+  constexpr int BM = 128, TN = 7, BN = 32 * TN, BK = 32;
+  constexpr int PA = 128, PB = 256;
+  constexpr int A_IMG = BK * PA, B_IMG = BK * PB, BUF = 3 * (A_IMG + B_IMG);
+  constexpr int NA4 = 4, NB4 = 7, NI = NA4 + NB4;
+  __shared__ __attribute__((aligned(16))) __bf16 lds[2 * BUF];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int nbn = (N + BN - 1) / BN;
+  const int bm = blockIdx.x / nbn, bn = blockIdx.x - bm * nbn, m0 = bm * BM, n0 = bn * BN, z = blockIdx.z;
+  const int kbeg = z * kslice, kend = min(K, kbeg + kslice);
+  const int S = (kend - kbeg) / BK;
+  // (A: item j is 8 token rows below item 0 -- same columns, same swizzle: one register each for the global and the LDS offset)
+  unsigned offA[NA4], offB[NB4];
+  int ldsA[NA4], ldsB[NB4];
+#pragma unroll
+  for (int j = 0; j < NA4; ++j) {
+    const int i = tid + 256 * j, row = i >> 5, c = (i & 31) * 4;
+    offA[j] = (unsigned)(row * M + min(m0 + c, M - 4));
+    ldsA[j] = row * PA + (((c >> 4) ^ (2 * (row & 3))) << 4) + (c & 15);
+  }
+#pragma unroll
+  for (int j = 0; j < NB4; ++j) {
+    const int row = tid >> 3, c = ((tid & 7) + 8 * j) * 4;
+    offB[j] = (unsigned)(row * N + min(n0 + c, N - 4));
+    ldsB[j] = 3 * A_IMG + row * PB + (((c >> 4) ^ (2 * (row & 3))) << 4) + (c & 15);
+  }
+  f32x4 rg[NI];
+  auto gload = [&](int s, int j) __attribute__((always_inline)) {
+    const long k0 = kbeg + (long)s * BK;
+    const float* As = A + k0 * M;                                          // wave-uniform row base + a 32-bit lane offset: the scalar-base form of the load
+    const float* Bs = B + k0 * N;
+    if (j < NA4) rg[j] = *reinterpret_cast<const f32x4*>(As + offA[j]);
+    else rg[j] = *reinterpret_cast<const f32x4*>(Bs + offB[j - NA4]);
+  };
+  auto put = [&](int buf, int j) __attribute__((always_inline)) {
+    __bf16* base = lds + buf * BUF + (j < NA4 ? ldsA[j] : ldsB[j - NA4]);
+    const int img = j < NA4 ? A_IMG : B_IMG;
+    const f32x4 v = rg[j];
+    unsigned a0, b0, c0, a1, b1, c1;
+    split3_pk(f32x2{v[0], v[1]}, a0, b0, c0);
+    split3_pk(f32x2{v[2], v[3]}, a1, b1, c1);
+    const u32x2 h1 = {a0, a1}, h2 = {b0, b1}, h3 = {c0, c1};
+    *reinterpret_cast<u32x2*>(base) = h1;
+    *reinterpret_cast<u32x2*>(base + img) = h2;
+    *reinterpret_cast<u32x2*>(base + 2 * img) = h3;
+  };
+  f32x16 acc_hi[TN], acc_lo[DUAL ? TN : 1];
+#pragma unroll
+  for (int n = 0; n < TN; ++n) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc_hi[n][e] = 0.f;
+    if constexpr (DUAL) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc_lo[n][e] = 0.f;
+    }
+  }
+  // fragment geometry (32 x 16 operand: lane l holds 8 consecutive tokens 8 (l >> 5) .. + 7 of column l & 31): 16-lane group G = l >> 4 reads columns
+  // 16 (G & 1) .. + 15, token rows 8 (G >> 1) + (first read: 0 .. 3, second read: 4 .. 7); inside the group lane i supplies (row + (i >> 2), columns 4 (i & 3))
+  const int G = lane >> 4, qq = (lane & 15) >> 2, p = lane & 3;
+  const int frow = 8 * (G >> 1) + qq;                                     // + 4 for the second read, + 16 for the second MFMA step of the stage
+  const int sw = 2 * (frow & 3);                                          // (rows + 4, + 16 share row & 3)
+  auto frag_off = [&](int pitch, int blk) __attribute__((always_inline)) { return frow * pitch + (((blk + (G & 1)) ^ sw) << 4) + 4 * p; };
+  int fa, fb[TN];
+  fa = frag_off(PA, 2 * w);
+#pragma unroll
+  for (int n = 0; n < TN; ++n) fb[n] = 3 * A_IMG + frag_off(PB, 2 * n);
+  auto read_f = [&](const __bf16* base, int pitch, int img_elems, int ks, bf16x8 (&f)[3]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int img = 0; img < 3; ++img) {
+      const __bf16* q = base + img * img_elems + ks * 16 * pitch;
+      const bf16x4 lo = tr_read(q), hi = tr_read(q + 4 * pitch);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { f[img][e] = lo[e]; f[img][4 + e] = hi[e]; }
+    }
+  };
+  if (S <= 0) return;
+#pragma unroll
+  for (int j = 0; j < NI; ++j) gload(0, j);
+#pragma unroll
+  for (int j = 0; j < NI; ++j) put(0, j);
+#pragma unroll
+  for (int j = 0; j < NI; ++j) gload(min(1, S - 1), j);
+  __syncthreads();
+  for (int s = 0; s < S; ++s) {
+    const __bf16* buf = lds + (s & 1) * BUF;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 a[3], b[2][3];
+      read_f(buf + fa, PA, A_IMG, ks, a);
+      read_f(buf + fb[0], PB, B_IMG, ks, b[0]);
+#pragma unroll
+      for (int n = 0; n < TN; ++n) {
+        if (n + 1 < TN) read_f(buf + fb[n + 1], PB, B_IMG, ks, b[(n + 1) & 1]);
+        const bf16x8(&bb)[3] = b[n & 1];
+        if constexpr (DUAL) {
+          acc_hi[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bb[0], acc_hi[n], 0, 0, 0);
+          acc_lo[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], bb[0], acc_lo[n], 0, 0, 0);
+          acc_lo[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bb[2], acc_lo[n], 0, 0, 0);
+          acc_lo[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bb[1], acc_lo[n], 0, 0, 0);
+          acc_lo[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bb[0], acc_lo[n], 0, 0, 0);
+          acc_lo[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bb[1], acc_lo[n], 0, 0, 0);
+        } else {
+          acc_hi[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], bb[0], acc_hi[n], 0, 0, 0);
+          acc_hi[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bb[2], acc_hi[n], 0, 0, 0);
+          acc_hi[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bb[1], acc_hi[n], 0, 0, 0);
+          acc_hi[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bb[0], acc_hi[n], 0, 0, 0);
+          acc_hi[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bb[1], acc_hi[n], 0, 0, 0);
+          acc_hi[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bb[0], acc_hi[n], 0, 0, 0);
+        }
+        const int item = ks * TN + n;
+        if (item < NI) {
+          put((s + 1) & 1, item);
+          gload(min(s + 2, S - 1), item);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();
+  }
+  // 32 x 32 accumulator: lane l holds column l & 31, rows 8 (i / 4) + 4 (l >> 5) + i % 4 for register i
+  float* out = slab + (long)z * M * N;
+#pragma unroll
+  for (int n = 0; n < TN; ++n)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = m0 + 32 * w + 8 * (i >> 2) + 4 * (lane >> 5) + (i & 3), col = n0 + 32 * n + (lane & 31);
+      float v = acc_hi[n][i];
+      if constexpr (DUAL) v += acc_lo[n][i];
+      if (row < M && col < N) out[(long)row * N + col] = v;
+    }
+}
+
 __global__ void reduce_kernel(const float* __restrict__ slab, float* __restrict__ C, long mn, int Z) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < mn; i += (long)gridDim.x * blockDim.x) {
     float s = 0.f;
@@ -221,6 +531,16 @@ int main(int argc, char** argv) {
     case 6: kern = gemm_tn_bx3<2, 10, false, 16, 16>; vbm = 128; vbn = 160; vname = "128 x 160, one accumulator, pitch + 16"; break;
     case 7: kern = gemm_tn_bx3<2, 13, true, 16, 16>; vbm = 128; vname = "128 x 208, two accumulators, pitch + 16"; break;
     case 8: kern = gemm_tn_bx3<1, 13, false, 16, 16>; vname = "64 x 208, one accumulator, pitch + 16"; break;
+    case 10: kern = gemm_tn_bx3_db<13, true, false>; vbm = 128; vname = "v3: 128 x 208 double-buffered, 1 workgroup / CU, two accumulators"; break;
+    case 11: kern = gemm_tn_bx3_db<13, false, false>; vbm = 128; vname = "v3: 128 x 208 double-buffered, 1 workgroup / CU, one accumulator"; break;
+    case 12: kern = gemm_tn_bx3_db<13, true, true>; vbm = 128; vname = "v3 + bank swizzle: 128 x 208 double-buffered, 1 workgroup / CU, two accumulators"; break;
+    case 20: kern = gemm_tn_bx3_db<13, true, false, 1>; vbm = 128; vname = "ABLATION v3 without split + image stores"; break;
+    case 21: kern = gemm_tn_bx3_db<13, true, false, 2>; vbm = 128; vname = "ABLATION v3 without global loads"; break;
+    case 22: kern = gemm_tn_bx3_db<13, true, false, 3>; vbm = 128; vname = "ABLATION v3 without split, stores, loads (fragment reads + MFMAs only)"; break;
+    case 23: kern = gemm_tn_bx3_db<13, true, false, 4>; vbm = 128; vname = "ABLATION v3 without MFMAs"; break;
+    case 15: kern = gemm_tn_bx3_db<13, true, false, 0, 1>; vbm = 128; vname = "v3 + sched_group_barrier interleave (1 MFMA : 2 VALU)"; break;
+    case 13: kern = gemm_tn_bx3_w32<true>; vbm = 128; vbn = 224; vname = "v4: 128 x 224 on 32x32x16 MFMA, double-buffered, 1 workgroup / CU, two accumulators"; break;
+    case 14: kern = gemm_tn_bx3_w32<false>; vbm = 128; vbn = 224; vname = "v4: 128 x 224 on 32x32x16 MFMA, double-buffered, 1 workgroup / CU, one accumulator"; break;
     default: break;
   }
   const dim3 grid(((M + vbm - 1) / vbm) * ((N + vbn - 1) / vbn), 1, Zeff);
