@@ -2117,6 +2117,11 @@ static int dispatch_tile(int tile, const nnr_gemm_args& g, hipStream_t stream) {
     case 37: if (!tn_pipe_ok(g)) return NNR_ERR_ARG; return launch_tn_pipe2<4, 10, 3, 1>(g, stream);              // gen-2 TN 256 x 160, 3 x 32 KB stages, 1 workgroup / CU
     case 38: if (!tn_pipe_ok(g)) return NNR_ERR_ARG; return launch_tn_pipe2<2, 10, 4, 1>(g, stream);              // gen-2 TN 128 x 160, 4 stages, 1 workgroup / CU
     case 39: if (!tn_pipe_ok(g)) return NNR_ERR_ARG; return launch_tn_pipe2<1, 10, 3, 3>(g, stream);              // gen-2 TN 64 x 160, 3 x 20 KB stages, 3 workgroups / CU
+    // one-wave launches (round 5, verdict item 1b): tiles sized so that a WHOLE launch is <= 256 workgroups, one per CU -- 4 352 x 900: 17 x 15 = 255 tiles of
+    // 256 x 64 (128 x 80: 408 tiles on 512 slots, the CUs that carry two set the time); 6 080 x 900: 16 x 15 = 240 tiles of 384 x 64.
+    // MEASURED SLOWER alone (profiles/r05_ab.txt, call 15: 82.4 vs 90.7 TF and 76.7 vs 83.8 TF): four waves per CU do not cover the stage latency.  Opt-in ids only.
+    case 43: if (!pipe_ok(g) || g.a_idx) return NNR_ERR_ARG; return launch_pipe2<4, 4, 3, 1>(g, stream);          // gen-2 NT 256 x 64, 3 x 40 KB stages, 1 workgroup / CU
+    case 45: if (!pipe_ok(g)) return NNR_ERR_ARG; return launch_pipe<6, 4, 16, 3, 1>(g, stream);                  // gen-1 NT 384 x 64, BK 16, 3 x 28 KB stages, 1 workgroup / CU
     case 50: if (!bx3_ok(g)) return NNR_ERR_ARG; return launch_bx3<2, 5>(g, stream);           // EXPERIMENTAL bf16x3 NT 128 x 80 (needs args.B3: pre-split weights)
     case 51: if (!bx3_ok(g)) return NNR_ERR_ARG; return launch_bx3<1, 5>(g, stream);           // ... 64 x 80: 2 x 23 KB stages, 3 workgroups / CU
     case 52: if (!bx3_ok(g)) return NNR_ERR_ARG; return launch_bx3<2, 4>(g, stream);           // ... 128 x 64

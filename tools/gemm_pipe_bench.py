@@ -67,6 +67,8 @@ def main():
               ('sue 4352x900x900', 4352, 900, 900, 30), ('sue 6080x900x900', 6080, 900, 900, 30), ('title 36000x1664x300', 36000, 1664, 300, 10),
               ('cand 14000x400x400', 14000, 400, 400, 30), ('big 8192x8000x4096', 8192, 8000, 4096, 2)]
     tiles = [int(t) for t in os.environ.get('TILES', '5,2,8,13,15,16,17,18,19').split(',')]
+    only = os.environ.get('SHAPES', '')
+    shapes = [x for x in shapes if only in x[0]]
     out = {}
     for name, M, N, K, iters in shapes:
         a = torch.randn(M, K, device=d); b = torch.randn(N, K, device=d) * 0.05; c = torch.empty(M, N, device=d)
