@@ -106,6 +106,10 @@ typedef struct nnr_gemm_args {
 } nnr_gemm_args;
 
 int nnr_gemm_f32(const nnr_gemm_args* args, hipStream_t stream);
+/* tile = 47: fixed-order stream-K form of the plain NT product (one to two waves of 128 x 80 tiles: the SUE launches, userEncoders.py:85-98 /
+ * layers.py:285-292).  args.slab = a workspace of at least nnr_gemm_sk_workspace_floats(M, N) floats (slab_floats says how many), zeroed ONCE by the
+ * caller and then reused by launches that follow each other on one stream; results are bit-identical from run to run. */
+size_t nnr_gemm_sk_workspace_floats(int M, int N);
 /* w [rows, cols] (row stride ld) -> three bf16 images out3[i * img_stride + r * ldo + c] with w == image0 + image1 + image2 EXACTLY (columns
  * cols .. ldo-1 zero).  For nnr_gemm_args.B3 (experimental tile 50); weights change once per optimizer step. */
 int nnr_split_bf16x3(const float* w, int rows, int cols, int ld, int ldo, void* out3, long img_stride, hipStream_t stream);

@@ -848,6 +848,266 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_pipe2_kernel(nnr_gemm_args g
   gemm_epilogue<TM, TN>(g, acc, lds, C, m0, n0, M, N, z);
 }
 
+// ------------------------------------------------------------------------------------------------ fixed-order stream-K NT (round 5, verdict item 1b)
+// For launches of ONE to TWO waves of tiles (SUE: 4 352 x 900 x 900 = 408 tiles of 128 x 80 on 512 workgroup slots -- the CUs that carry two tiles set
+// the time, wave efficiency 0.80; the vendor library's stream-K kernel reaches 107 TF on that shape against 91 for gemm_nt_pipe2_kernel).  The launch is
+// W equal workgroups (W = 2 per CU); the linearised (tile, k-stage) space of nblk x SPT stages is cut into W equal ranges and workgroup i runs range i
+// with gemm_nt_pipe2_kernel's stage loop.  A range covers one to three tiles; its pieces ("fragments") are run in DESCENDING tile order:
+//   * a fragment that holds a whole tile: ordinary epilogue;
+//   * a fragment that holds a tile's END (the last k-stage): this workgroup OWNS the tile.  It is the workgroup's LAST fragment.  The k-stages in front of
+//     it belong to the one or two workgroups with the next-lower indices, which ran them FIRST (their highest tile) and left the partial accumulators in
+//     the workspace; the owner adds them in ascending-k order -- ((P0 + P1) + own): a FIXED order, results are bit-identical from run to run -- and runs
+//     the epilogue;
+//   * any other fragment (a tile's beginning or middle): accumulators -> workspace slot (this workgroup's distance from the tile's first workgroup), flag.
+// Dependencies only point to LOWER workgroup indices, which the dispatcher starts first: no deadlock whatever else occupies the chip; the spin is bounded
+// anyway (time-out -> NaN results, never a hang).  Exchange across XCDs (their L2s are not coherent): the partials are written with agent-scope relaxed
+// atomic stores (write-through), s_waitcnt vmcnt(0) = all of this wave's stores acknowledged, workgroup barrier, then the flag; the owner polls the flag
+// and reads the partials with agent-scope relaxed atomic loads.  No fence instruction (an agent-scope release writes back the XCD's whole L2: ~3.5 us).
+// Workspace (nnr_gemm_args.slab): [4 096 flag words (2 per tile, <= 2 048 tiles)][nblk x 2 x 256 x (TM TN 4) floats], zeroed once by the
+// caller; the owner resets the flags it consumed, so launches that follow each other on one stream reuse it.  One workspace per stream.
+template <int TM, int TN, int NS, int OCC>
+__global__ __launch_bounds__(256, OCC) void gemm_nt_sk_kernel(nnr_gemm_args g) {
+  constexpr int BK = 32, BM = 64 * TM, BN = 16 * TN, ROWS = BM + BN;
+  constexpr int KQ = BK / 4, RPI = 64 / KQ, NI = ROWS / RPI, NPW = (NI + 3) / 4, STAGE = ROWS * BK, E_LD = BN + 4;
+  constexpr int LDS_FLOATS = (NS * STAGE > 64 * E_LD) ? NS * STAGE : 64 * E_LD;
+  constexpr int PART = 256 * TM * TN * 4;                     // floats of one partial accumulator tile, in register order
+  static_assert(ROWS % RPI == 0 && NS >= 3, "tile shape");
+  __shared__ __attribute__((aligned(1024))) float lds[LDS_FLOATS];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, kk = lane >> 4;
+  int M = g.M;
+  if (g.dyn_dim == 1) M = min(M, *g.dyn_dev);
+  const int N = g.N, K = g.K;
+  const int nbm = (M + BM - 1) / BM, nbn = (N + BN - 1) / BN;
+  const int nblk = nbm * nbn;
+  const int SPT = (K + BK - 1) / BK;                          // k-stages per tile
+  const long total = (long)nblk * SPT;
+  const int wi = blockIdx.x;
+  const int W = min((int)gridDim.x, max(1, 2 * nblk));       // (a dyn row count can shrink nblk below the launch's: keep <= 3 ranges per tile -- two partial slots)
+  if (wi >= W) return;
+  const long lo = total * wi / W, hi = total * (wi + 1) / W;
+  if (lo >= hi) return;
+  const float* __restrict__ A = g.A;
+  const float* __restrict__ B = g.B;
+  float* __restrict__ C = g.C;
+  unsigned* flags = reinterpret_cast<unsigned*>(g.slab);
+  float* parts = g.slab + 4096;                               // flags: a FIXED 4 096-word region (launches of different shapes share one workspace: their flag words must never
+                                                              // land in another launch's partial tiles), partial tiles behind it
+  constexpr int NIA = BM / RPI, NIB = BN / RPI, NA = NIA / 4, NBMAX = (NIB + 3) / 4;
+  static_assert(NIA % 4 == 0 && NA <= 8 && NBMAX <= 8, "tile shape");
+  const float* zero = nnr_zero_page;
+  asm volatile("" : "+s"(zero));
+  const unsigned lds_base = (unsigned)(uintptr_t)lds;
+  const bool ktail = (K % BK) != 0;
+  const bool nb_hi = (NIB % 4 == 0) || (w < NIB % 4);
+  const int t_first = (int)(lo / SPT), t_last = (int)((hi - 1) / SPT);
+
+  for (int t = t_last; t >= t_first; --t) {
+    const int sb = (int)(max(lo, (long)t * SPT) - (long)t * SPT), se = (int)(min(hi, (long)(t + 1) * SPT) - (long)t * SPT);      // this fragment: k-stages [sb, se) of tile t
+    const int S = se - sb;
+    // XCD-aware tile order, as in gemm_nt_pipe2_kernel (consecutive ranges -> consecutive tiles of one XCD's share is not needed here: neighbours exchange through memory)
+    const int bm = t / nbn, bn = t - bm * nbn;
+    const int m0 = bm * BM, n0 = bn * BN;
+    unsigned voffA[8], voffB[8];
+    int kchA[NA], kchB[NBMAX];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) voffA[i] = voffB[i] = 0;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int tr = (w + 4 * i) * RPI + lane / KQ;
+      const int c = (lane % KQ) ^ swz<BK>(tr & 15);
+      kchA[i] = 4 * c;
+      voffA[i] = (unsigned)(((long)min(tr, M - 1 - m0) * g.lda + 4 * c) * 4);
+    }
+#pragma unroll
+    for (int j = 0; j < NBMAX; ++j) {
+      const int tr = (w + 4 * j) * RPI + lane / KQ;
+      const int c = (lane % KQ) ^ swz<BK>(tr & 15);
+      kchB[j] = 4 * c;
+      voffB[j] = (unsigned)(((long)min(tr, N - 1 - n0) * g.ldb + 4 * c) * 4);
+    }
+    const float* Abase = A + (long)m0 * g.lda + (long)sb * BK;      // stage s of the fragment = k-stage sb + s of the tile
+    const float* Bbase = B + (long)n0 * g.ldb + (long)sb * BK;
+    const bool tail_here = ktail && se == SPT;
+    auto issue_lean = [&](int s) {
+      const int k0 = s * BK;
+      const unsigned sbuf = lds_base + (unsigned)((s % NS) * STAGE * 4) + (unsigned)(w * 1024);
+      lds_dma16_block<NA>(Abase + k0, sbuf, voffA);
+      if (nb_hi) lds_dma16_block<NBMAX>(Bbase + k0, sbuf + NIA * 1024, voffB);
+      else if constexpr (NBMAX > 1) lds_dma16_block<NBMAX - 1>(Bbase + k0, sbuf + NIA * 1024, voffB);
+    };
+    auto issue = [&](int s) {
+      if (!(tail_here && s == S - 1)) { issue_lean(s); return; }
+      const int k0 = s * BK, kabs = (sb + s) * BK;
+      const unsigned sbuf = lds_base + (unsigned)((s % NS) * STAGE * 4) + (unsigned)(w * 1024);
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+        lds_dma16((kabs + kchA[i] < K) ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(Abase + k0) + voffA[i]) : zero, sbuf + i * 4096);
+#pragma unroll
+      for (int j = 0; j < NBMAX; ++j)
+        if (j < NBMAX - 1 || nb_hi)
+          lds_dma16((kabs + kchB[j] < K) ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(Bbase + k0) + voffB[j]) : zero,
+                    sbuf + NIA * 1024 + j * 4096);
+    };
+    auto wait_landed = [&](int ahead) {
+      if (NI % 4 == 0 || w < NI % 4) wait_stages<NPW, NS - 3>(ahead);
+      else wait_stages<NPW - 1, NS - 3>(ahead);
+    };
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+      for (int n = 0; n < TN; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+    auto rd = [&](int s, int kg, f32x4 (&a)[TM], f32x4 (&b)[TN]) {
+      const float* As = lds + (s % NS) * STAGE;
+      const float* Bs = As + BM * BK;
+#pragma unroll
+      for (int m = 0; m < TM; ++m)
+        a[m] = *reinterpret_cast<const f32x4*>(&As[((w * TM + m) * 16 + r) * BK + 4 * ((kg * 4 + kk) ^ swz<BK>(r))]);
+#pragma unroll
+      for (int n = 0; n < TN; ++n)
+        b[n] = *reinterpret_cast<const f32x4*>(&Bs[(n * 16 + r) * BK + 4 * ((kg * 4 + kk) ^ swz<BK>(r))]);
+    };
+    auto mm = [&](const f32x4 (&a)[TM], const f32x4 (&b)[TN]) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+          for (int n = 0; n < TN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][i], b[n][i], acc[m][n], 0, 0, 0);
+    };
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+      if (s < S) issue(s);
+    if (NI % 4 == 0 || w < NI % 4) wait_stages<NPW, NS - 2>(S - 1); else wait_stages<NPW - 1, NS - 2>(S - 1);
+    __builtin_amdgcn_s_barrier();
+    rd(0, 0, fa0, fb0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#define NNR_LGKM0() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0xC07F); } while (0)
+    int s = 0;
+    for (; s + NS < S; ++s) {
+      rd(s, 1, fa1, fb1);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(fa0, fb0);
+      NNR_LGKM0();
+      wait_landed(NS);
+      __builtin_amdgcn_s_barrier();
+      issue_lean(s + NS - 1);
+      rd(s + 1, 0, fa0, fb0);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(fa1, fb1);
+      NNR_LGKM0();
+    }
+    for (; s + 1 < S; ++s) {
+      rd(s, 1, fa1, fb1);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(fa0, fb0);
+      NNR_LGKM0();
+      wait_landed(S - 1 - (s + 1));
+      __builtin_amdgcn_s_barrier();
+      if (s + NS - 1 < S) issue(s + NS - 1);
+      rd(s + 1, 0, fa0, fb0);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(fa1, fb1);
+      NNR_LGKM0();
+    }
+#undef NNR_LGKM0
+    rd(S - 1, 1, fa1, fb1);
+    __builtin_amdgcn_sched_barrier(0);
+    mm(fa0, fb0);
+    mm(fa1, fb1);
+    __syncthreads();                                          // every wave is done with the stage buffers (the next fragment's DMAs / the epilogue reuse them)
+
+    // the first workgroup of tile t (the range that holds its k-stage 0) and this workgroup's distance from it; range i = [total i / W, total (i + 1) / W)
+    int first = (int)(((long)t * SPT * (long)W) / total);
+    while ((long)total * (first + 1) / W <= (long)t * SPT) ++first;
+    while ((long)total * first / W > (long)t * SPT) --first;
+    const int dist = wi - first;                              // 0: this fragment begins the tile; 1, 2: it continues it
+    if (se < SPT) {
+      // ---- not the tile's end: leave the partial accumulators for the owner
+      float* dst = parts + ((long)t * 2 + dist) * PART + tid * 4;      // register order: block (m, n) = 256 lanes x 16 bytes, fully coalesced
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+          for (int n = 0; n < TN; ++n)
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" ::"v"(dst + (m * TN + n) * 1024), "v"(acc[m][n]) : "memory");      // write-through (agent scope); the
+                              // wait states: a store wider than 64 bits reads the upper data registers AFTER issue, the compiler does not look inside an asm statement
+                              // for that hazard and re-uses the registers it copied the accumulators to (found by tests/test_hip_ops_gpu.py: wrong partial tiles)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's stores are acknowledged
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(flags + t * 2 + dist, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      continue;
+    }
+    if (dist > 0) {
+      // ---- the tile's end, begun by lower workgroups: add their partials in ascending-k order, then this fragment's
+      if (tid == 0) {
+        bool late = false;
+        for (int d = 0; d < dist; ++d) {
+          int spins = 0;
+          while (__hip_atomic_load(flags + t * 2 + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && spins < (1 << 24)) { __builtin_amdgcn_s_sleep(2); ++spins; }
+          late |= spins >= (1 << 24);
+        }
+        lds[0] = late ? __int_as_float(0x7fc00000) : 0.f;      // never hang: a partial that does not arrive poisons the tile (visible), as the recurrence's exchange does
+      }
+      __syncthreads();
+      const float poison = lds[0];
+      __syncthreads();
+      const float* p0 = parts + ((long)t * 2) * PART + tid * 4;
+      f32x4 pr[TM][TN];
+#pragma unroll
+      for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+          asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(pr[m][n]) : "v"(p0 + (m * TN + n) * 1024) : "memory");      // past the XCD's L2 (agent scope)
+      // (the wait statements carry the loaded registers as operands: the compiler must not move a use in front of them)
+#define NNR_LANDED(X) asm volatile("s_waitcnt vmcnt(0)" : "+v"(X)::"memory")
+      if (dist > 1) {
+        f32x4 p1[TM][TN];
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+          for (int n = 0; n < TN; ++n)
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(p1[m][n]) : "v"(p0 + PART + (m * TN + n) * 1024) : "memory");
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+          for (int n = 0; n < TN; ++n) { NNR_LANDED(pr[m][n]); NNR_LANDED(p1[m][n]); pr[m][n] += p1[m][n]; }
+      } else {
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+          for (int n = 0; n < TN; ++n) NNR_LANDED(pr[m][n]);
+      }
+#undef NNR_LANDED
+#pragma unroll
+      for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[m][n][e] = (pr[m][n][e] + acc[m][n][e]) + poison;
+      __syncthreads();
+      if (tid < dist) __hip_atomic_store(flags + t * 2 + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // consumed: the next launch finds them clear
+    }
+    gemm_epilogue<TM, TN>(g, acc, lds, C, m0, n0, M, N, 0);
+    __syncthreads();
+  }
+}
+
+template <int TM, int TN, int NS, int OCC>
+int launch_sk(const nnr_gemm_args& g, hipStream_t s) {
+  constexpr int BM = 64 * TM, BN = 16 * TN;
+  const int nblk = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+  const int spt = (g.K + 31) / 32;
+  int W = 256 * OCC;                                          // one range per workgroup slot of the chip
+  if (W > 2 * nblk) W = 2 * nblk;                             // a tile is shared by at most three ranges (two partial slots per tile)
+  if ((long)nblk * spt < W) W = (int)((long)nblk * spt);
+  nnr_gemm_args gg = g;
+  hipLaunchKernelGGL((gemm_nt_sk_kernel<TM, TN, NS, OCC>), dim3(W), dim3(256), 0, s, gg);
+  NNR_CHECK_LAUNCH();
+  return NNR_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ third-generation NT loop (round 5)
 // gemm_nt_pipe2_kernel's stage loop made PERSISTENT and CONTINUOUS across tiles.  A workgroup walks tiles b, b + grid, b + 2 grid ...
 // of the XCD-aware order; the LDS-DMA pipeline never drains at a tile boundary -- the first NS - 1 stages of the NEXT tile are issued
@@ -2122,6 +2382,10 @@ static int dispatch_tile(int tile, const nnr_gemm_args& g, hipStream_t stream) {
     // MEASURED SLOWER alone (profiles/r05_ab.txt, call 15: 82.4 vs 90.7 TF and 76.7 vs 83.8 TF): four waves per CU do not cover the stage latency.  Opt-in ids only.
     case 43: if (!pipe_ok(g) || g.a_idx) return NNR_ERR_ARG; return launch_pipe2<4, 4, 3, 1>(g, stream);          // gen-2 NT 256 x 64, 3 x 40 KB stages, 1 workgroup / CU
     case 45: if (!pipe_ok(g)) return NNR_ERR_ARG; return launch_pipe<6, 4, 16, 3, 1>(g, stream);                  // gen-1 NT 384 x 64, BK 16, 3 x 28 KB stages, 1 workgroup / CU
+    case 47:                                                                                                      // fixed-order stream-K NT 128 x 80 (args.slab = workspace, see nnr_gemm_sk_workspace_floats)
+      if (!pipe_ok(g) || g.a_idx || g.batch > 1 || !g.slab || (((uintptr_t)g.slab) & 15) || g.K < 96 || (long)((g.M + 127) / 128) * ((g.N + 79) / 80) > 2048 ||
+          g.slab_floats < (long)nnr_gemm_sk_workspace_floats(g.M, g.N)) return NNR_ERR_ARG;
+      return launch_sk<2, 5, 3, 2>(g, stream);
     case 50: if (!bx3_ok(g)) return NNR_ERR_ARG; return launch_bx3<2, 5>(g, stream);           // EXPERIMENTAL bf16x3 NT 128 x 80 (needs args.B3: pre-split weights)
     case 51: if (!bx3_ok(g)) return NNR_ERR_ARG; return launch_bx3<1, 5>(g, stream);           // ... 64 x 80: 2 x 23 KB stages, 3 workgroups / CU
     case 52: if (!bx3_ok(g)) return NNR_ERR_ARG; return launch_bx3<2, 4>(g, stream);           // ... 128 x 64
@@ -2138,6 +2402,11 @@ static int dispatch_tile(int tile, const nnr_gemm_args& g, hipStream_t stream) {
       return launch_skinny(g, stream);
     default: return NNR_ERR_ARG;
   }
+}
+
+extern "C" size_t nnr_gemm_sk_workspace_floats(int M, int N) {
+  const long nblk = (long)((M + 127) / 128) * ((N + 79) / 80);
+  return (size_t)(4096 + nblk * 2 * (256L * 2 * 5 * 4));
 }
 
 extern "C" int nnr_split_bf16x3(const float* w, int rows, int cols, int ld, int ldo, void* out3, long img_stride, hipStream_t stream) {
@@ -2179,7 +2448,7 @@ extern "C" int nnr_gemm_f32(const nnr_gemm_args* a, hipStream_t stream) {
   float* slab_C = nullptr;
   float* slab_cs = nullptr;
   int slab_ldc = 0;
-  if (g.slab != nullptr) {
+  if (g.slab != nullptr && g.tile != 47) {
     if (!(g.trans_a && g.trans_b) || g.split_k <= 1 || g.k_chunk > 0 || g.c_idx || (g.N & 3) || (((uintptr_t)g.slab) & 15) || !g.C || g.accumulate == 2 ||
         g.slab_floats < (long)g.split_k * ((long)g.M * g.N + g.M))
       return NNR_ERR_ARG;

@@ -1438,4 +1438,66 @@ def test_transpose_batch_and_weight_transpose_cache():
     torch.cuda.synchronize()
     assert torch.equal(ops.wt(w), w.detach().t().contiguous())
     w2 = torch.nn.Parameter(rnd(300, 200, seed=10).to(d))
-    assert torch.equal(ops.wt(w2), w2.detach().t().contiguous())
+    assert torch.equal(ops.wt(w2), w2.detach().t().contiguous())@pytest.mark.gpu
+@pytest.mark.parametrize('M, N, K', [(4352, 900, 900), (6080, 900, 900), (1300, 904, 2000), (700, 336, 1000), (128, 80, 96), (4352, 900, 96)])
+def test_gemm_stream_k_fixed_order(M, N, K):
+    """Fixed-order stream-K NT kernel (csrc/gemm.hip: gemm_nt_sk_kernel, tile 47; round 5, verdict item 1b): the (tile, k-stage) space cut into equal
+    ranges, partial accumulators handed to the tile's owner through the workspace and added in ascending-k order.  Shapes: the two SUE launches
+    (408 / 576 tiles on 512 ranges: every tile shared by two or three workgroups), more tiles than ranges' worth of stages per range (1 300 x 904 x
+    2 000: ranges that hold a whole tile in the middle), fewer tiles than CUs, ONE tile (two ranges), a three-stage reduction; K % 32 != 0
+    everywhere but one.  Against fp64, against the gen-2 kernel (same products, another summation order), BIT-IDENTICAL from launch to launch
+    (also with another stream keeping CUs busy), every epilogue form the user encoder uses, a dynamic row count, and the workspace shared by
+    launches of different shapes."""
+    from nnr_amd import ops
+    d = dev()
+    a, b = rnd(M, K, seed=1).to(d), rnd(N, K, seed=2, scale=0.2).to(d)
+    full = a.cpu().double() @ b.cpu().double().t()
+    etol = 2e-5 * max(1.0, math.sqrt(K / 100.0))
+    out, ref = torch.empty(M, N, device=d), torch.empty(M, N, device=d)
+    ops.gemm(a, b, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, tile=47)
+    close(out, full, tol=etol, what='stream-K plain')
+    ops.gemm(a, b, ref, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, tile=9)
+    close(out, ref.cpu().double(), tol=etol, what='stream-K vs gen-2')
+    # launch to launch, beside a stream that occupies workgroup slots with other GEMMs (ranges start at different times)
+    side = torch.cuda.Stream()
+    big_a, big_b, big_c = rnd(16384, 512, seed=3).to(d), rnd(512, 512, seed=4).to(d), torch.empty(16384, 512, device=d)
+    again = torch.empty(M, N, device=d)
+    for rep in range(6):
+        if rep >= 3:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(4):
+                    ops.gemm(big_a, big_b, big_c, M=16384, N=512, K=512, lda=512, ldb=512, ldc=512)
+        ops.gemm(a, b, again, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, tile=47)
+        assert torch.equal(out, again), 'stream-K result changed between launches (rep %d, max %.3e)' % (rep, float((out - again).abs().max()))
+    torch.cuda.current_stream().wait_stream(side)
+    # the user encoder's epilogues: bias + ReLU with the mask as aux (GCN layer), residual, accumulate
+    bias, resid, base = rnd(N, seed=4).to(d), rnd(M, N, seed=5).to(d), rnd(M, N, seed=7).to(d)
+    aux = torch.empty(M, N, device=d)
+    ops.gemm(a, b, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias, act=ops.ACT_TANH, aux_out=aux, ldaux=N, tile=47)
+    want = torch.tanh(full + bias.cpu().double())
+    close(out, want, tol=etol, what='stream-K bias tanh')
+    close(aux, want, tol=etol, what='stream-K bias tanh aux')
+    ops.gemm(a, b, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias, resid=resid, ldres=N, tile=47)
+    close(out, full + bias.cpu().double() + resid.cpu().double(), tol=etol, what='stream-K bias + residual')
+    out = base.clone()
+    ops.gemm(a, b, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, accumulate=True, tile=47)
+    close(out, base.cpu().double() + full, tol=etol, what='stream-K accumulate')
+    # a dynamic row count: rows beyond it untouched, the tile count (and with it every range) follows the device-side value
+    for live in (M, max(1, M // 3), 1):
+        dyn = torch.tensor([live], dtype=torch.int32, device=d)
+        out = torch.full((M, N), 7.0, device=d)
+        ops.gemm(a, b, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, dyn=dyn, dyn_dim=1, tile=47)
+        close(out[:live], full[:live], tol=etol, what='stream-K dyn rows %d' % live)
+        assert bool((out[live:] == 7.0).all()), 'stream-K wrote beyond the live rows'
+    # another shape through the same workspace (flag words must never alias another launch's partial tiles)
+    a2, b2 = rnd(2000, 800, seed=11).to(d), rnd(640, 800, seed=12, scale=0.2).to(d)
+    o2 = torch.empty(2000, 640, device=d)
+    ops.gemm(a2, b2, o2, M=2000, N=640, K=800, lda=800, ldb=800, ldc=640, tile=47)
+    close(o2, a2.cpu().double() @ b2.cpu().double().t(), tol=2e-5 * math.sqrt(8.0), what='stream-K second shape')
+    ops.gemm(a, b, again, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, tile=47)
+    ops.gemm(a, b, ref, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, tile=47)
+    assert torch.equal(again, ref)
+
+
+
