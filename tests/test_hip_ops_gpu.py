@@ -1438,7 +1438,9 @@ def test_transpose_batch_and_weight_transpose_cache():
     torch.cuda.synchronize()
     assert torch.equal(ops.wt(w), w.detach().t().contiguous())
     w2 = torch.nn.Parameter(rnd(300, 200, seed=10).to(d))
-    assert torch.equal(ops.wt(w2), w2.detach().t().contiguous())@pytest.mark.gpu
+    assert torch.equal(ops.wt(w2), w2.detach().t().contiguous())
+
+
 @pytest.mark.parametrize('M, N, K', [(4352, 900, 900), (6080, 900, 900), (1300, 904, 2000), (700, 336, 1000), (128, 80, 96), (4352, 900, 96)])
 def test_gemm_stream_k_fixed_order(M, N, K):
     """Fixed-order stream-K NT kernel (csrc/gemm.hip: gemm_nt_sk_kernel, tile 47; round 5, verdict item 1b): the (tile, k-stage) space cut into equal
@@ -1498,6 +1500,3 @@ def test_gemm_stream_k_fixed_order(M, N, K):
     ops.gemm(a, b, again, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, tile=47)
     ops.gemm(a, b, ref, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, tile=47)
     assert torch.equal(again, ref)
-
-
-

@@ -471,6 +471,145 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_bx3_w32(const float* __restric
     }
 }
 
+// ---- v5 (round-6 sizing): the SAME product from PRE-SPLIT operands -- three bf16 images per activation, token-major, as a producer kernel would write them
+// (6 bytes per element instead of 4) -- so the GEMM's loop has no split: 16-byte loads -> ds_write_b128 -> transposed fragment reads -> MFMAs.  v3's tile, buffers
+// and fragment pipeline.  M, N multiples of 8.  The split itself is timed as a separate HBM-bound pass (split_images_kernel) and reported beside it.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__global__ void split_images_kernel(const float* __restrict__ x, long n, __bf16* __restrict__ out) {      // out[img][i]
+  for (long i = (blockIdx.x * (long)blockDim.x + threadIdx.x) * 4; i < n; i += (long)gridDim.x * blockDim.x * 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + i);
+    unsigned a0, b0, c0, a1, b1, c1;
+    split3_pk(f32x2{v[0], v[1]}, a0, b0, c0);
+    split3_pk(f32x2{v[2], v[3]}, a1, b1, c1);
+    *reinterpret_cast<u32x2*>(out + i) = u32x2{a0, a1};
+    *reinterpret_cast<u32x2*>(out + n + i) = u32x2{b0, b1};
+    *reinterpret_cast<u32x2*>(out + 2 * n + i) = u32x2{c0, c1};
+  }
+}
+template <int TN, bool DUAL>
+__global__ __launch_bounds__(256, 1) void gemm_tn_bx3_pre(const __bf16* __restrict__ A3, const __bf16* __restrict__ B3, float* __restrict__ slab, int M, int N,
+                                                          int K, int kslice) {
+  constexpr int TM = 2, BM = 128, BN = 16 * TN, BK = 32;
+  constexpr int PA = BM + 16, PB = BN + 16;
+  constexpr int A_IMG = BK * PA, B_IMG = BK * PB, BUF = 3 * (A_IMG + B_IMG);
+  constexpr int CA = BK * BM / 8, CB = BK * BN / 8;                       // 16-byte chunks per image of a stage
+  constexpr int NA = 3 * CA / 256, NB = (3 * CB + 255) / 256, NI = NA + NB;
+  static_assert(3 * CA % 256 == 0 && NI <= 2 * TN, "staging map");
+  __shared__ __attribute__((aligned(16))) __bf16 lds[2 * BUF];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int nbn = (N + BN - 1) / BN;
+  const int bm = blockIdx.x / nbn, bn = blockIdx.x - bm * nbn, m0 = bm * BM, n0 = bn * BN, z = blockIdx.z;
+  const int kbeg = z * kslice, kend = min(K, kbeg + kslice);
+  const int S = (kend - kbeg) / BK;
+  const long imgA = (long)K * M, imgB = (long)K * N;
+  unsigned gofs[NI];                                                      // (element offsets inside the three images: < 2^31 for every shape of the step)
+  int lofs[NI];
+#pragma unroll
+  for (int j = 0; j < NA; ++j) {
+    const int i = tid + 256 * j, img = i / CA, rem = i - img * CA, row = rem / (BM / 8), c = (rem - row * (BM / 8)) * 8;
+    gofs[j] = (unsigned)(img * imgA + (long)row * M + min(m0 + c, M - 8));
+    lofs[j] = img * A_IMG + row * PA + c;
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int i = min(tid + 256 * j, 3 * CB - 1), img = i / CB, rem = i - img * CB, row = rem / (BN / 8), c = (rem - row * (BN / 8)) * 8;
+    gofs[NA + j] = (unsigned)(img * imgB + (long)row * N + min(n0 + c, N - 8));
+    lofs[NA + j] = 3 * A_IMG + img * B_IMG + row * PB + c;
+  }
+  u32x4 rg[NI];
+  auto gload = [&](int s, int j) __attribute__((always_inline)) {
+    const long k0 = kbeg + (long)s * BK;
+    rg[j] = *reinterpret_cast<const u32x4*>((j < NA ? A3 + k0 * M : B3 + k0 * N) + gofs[j]);
+  };
+  auto put = [&](int buf, int j) __attribute__((always_inline)) { *reinterpret_cast<u32x4*>(lds + buf * BUF + lofs[j]) = rg[j]; };
+  f32x4 acc_hi[TM][TN], acc_lo[DUAL ? TM : 1][DUAL ? TN : 1];
+#pragma unroll
+  for (int m = 0; m < TM; ++m)
+#pragma unroll
+    for (int n = 0; n < TN; ++n) {
+      acc_hi[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (DUAL) acc_lo[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  const int g = lane >> 4, qq = (lane & 15) >> 2, p = lane & 3;
+  const int rowoff = 8 * g + qq;
+  const int fragA = rowoff * PA + 4 * p + w * TM * 16, fragB = 3 * A_IMG + rowoff * PB + 4 * p;
+  auto read_a = [&](const __bf16* buf, int m, bf16x8 (&a)[3]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int img = 0; img < 3; ++img) {
+      const __bf16* ia = buf + img * A_IMG + fragA + m * 16;
+      const bf16x4 lo = tr_read(ia), hi = tr_read(ia + 4 * PA);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { a[img][e] = lo[e]; a[img][4 + e] = hi[e]; }
+    }
+  };
+  auto read_b = [&](const __bf16* buf, int n, bf16x8 (&b)[3]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int img = 0; img < 3; ++img) {
+      const __bf16* ib = buf + img * B_IMG + fragB + n * 16;
+      const bf16x4 lo = tr_read(ib), hi = tr_read(ib + 4 * PB);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { b[img][e] = lo[e]; b[img][4 + e] = hi[e]; }
+    }
+  };
+  if (S <= 0) return;
+#pragma unroll
+  for (int j = 0; j < NI; ++j) gload(0, j);
+#pragma unroll
+  for (int j = 0; j < NI; ++j) put(0, j);
+#pragma unroll
+  for (int j = 0; j < NI; ++j) gload(min(1, S - 1), j);
+  __syncthreads();
+  for (int s = 0; s < S; ++s) {
+    const __bf16* buf = lds + (s & 1) * BUF;
+    bf16x8 a[TM][3], b[2][3];
+    read_a(buf, 0, a[0]);
+    read_a(buf, 1, a[1]);
+    read_b(buf, 0, b[0]);
+#pragma unroll
+    for (int n = 0; n < TN; ++n) {
+      if (n + 1 < TN) read_b(buf, n + 1, b[(n + 1) & 1]);
+#pragma unroll
+      for (int m = 0; m < TM; ++m) {
+        const bf16x8(&bb)[3] = b[n & 1];
+        if constexpr (DUAL) {
+          acc_hi[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][0], bb[0], acc_hi[m][n], 0, 0, 0);
+          acc_lo[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][2], bb[0], acc_lo[m][n], 0, 0, 0);
+          acc_lo[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][0], bb[2], acc_lo[m][n], 0, 0, 0);
+          acc_lo[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][1], bb[1], acc_lo[m][n], 0, 0, 0);
+          acc_lo[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][1], bb[0], acc_lo[m][n], 0, 0, 0);
+          acc_lo[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][0], bb[1], acc_lo[m][n], 0, 0, 0);
+        } else {
+          acc_hi[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][2], bb[0], acc_hi[m][n], 0, 0, 0);
+          acc_hi[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][0], bb[2], acc_hi[m][n], 0, 0, 0);
+          acc_hi[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][1], bb[1], acc_hi[m][n], 0, 0, 0);
+          acc_hi[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][1], bb[0], acc_hi[m][n], 0, 0, 0);
+          acc_hi[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][0], bb[1], acc_hi[m][n], 0, 0, 0);
+          acc_hi[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][0], bb[0], acc_hi[m][n], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int item = n; item < NI; item += TN) {
+        put((s + 1) & 1, item);
+        gload(min(s + 2, S - 1), item);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  }
+  float* out = slab + (long)z * M * N;
+#pragma unroll
+  for (int m = 0; m < TM; ++m)
+#pragma unroll
+    for (int n = 0; n < TN; ++n)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int row = m0 + 16 * (w * TM + m) + (lane >> 4) * 4 + reg, col = n0 + 16 * n + (lane & 15);
+        float v = acc_hi[m][n][reg];
+        if constexpr (DUAL) v += acc_lo[m][n][reg];
+        if (row < M && col < N) out[(long)row * N + col] = v;
+      }
+}
+
 __global__ void reduce_kernel(const float* __restrict__ slab, float* __restrict__ C, long mn, int Z) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < mn; i += (long)gridDim.x * blockDim.x) {
     float s = 0.f;
@@ -539,19 +678,34 @@ int main(int argc, char** argv) {
     case 22: kern = gemm_tn_bx3_db<13, true, false, 3>; vbm = 128; vname = "ABLATION v3 without split, stores, loads (fragment reads + MFMAs only)"; break;
     case 23: kern = gemm_tn_bx3_db<13, true, false, 4>; vbm = 128; vname = "ABLATION v3 without MFMAs"; break;
     case 15: kern = gemm_tn_bx3_db<13, true, false, 0, 1>; vbm = 128; vname = "v3 + sched_group_barrier interleave (1 MFMA : 2 VALU)"; break;
+    case 30: vbm = 128; vname = "v5: PRE-SPLIT operands (three bf16 images each, written by a producer), 128 x 208 double-buffered, two accumulators; the split pass is timed separately"; break;
+    case 31: vbm = 128; vname = "v5: PRE-SPLIT operands, one accumulator"; break;
     case 13: kern = gemm_tn_bx3_w32<true>; vbm = 128; vbn = 224; vname = "v4: 128 x 224 on 32x32x16 MFMA, double-buffered, 1 workgroup / CU, two accumulators"; break;
     case 14: kern = gemm_tn_bx3_w32<false>; vbm = 128; vbn = 224; vname = "v4: 128 x 224 on 32x32x16 MFMA, double-buffered, 1 workgroup / CU, one accumulator"; break;
     default: break;
   }
   const dim3 grid(((M + vbm - 1) / vbm) * ((N + vbn - 1) / vbn), 1, Zeff);
+  __bf16 *A3 = nullptr, *B3 = nullptr;
+  const bool pre = variant == 30 || variant == 31;
+  if (pre) {
+    if ((M & 7) || (N & 7)) { fprintf(stderr, "pre-split variants: M, N multiples of 8\n"); return 1; }
+    CK(hipMalloc(&A3, hA.size() * 6)); CK(hipMalloc(&B3, hB.size() * 6));
+  }
+  auto run_split = [&]() {
+    hipLaunchKernelGGL(split_images_kernel, dim3(2048), dim3(256), 0, st, A, (long)K * M, A3);
+    hipLaunchKernelGGL(split_images_kernel, dim3(2048), dim3(256), 0, st, B, (long)K * N, B3);
+  };
   auto run_native = [&]() {
     CK(hipMemsetAsync(C0, 0, (size_t)M * N * 4, st));
     if (nnr_gemm_f32(&g, st) != 0) { fprintf(stderr, "nnr_gemm_f32 failed\n"); exit(3); }
   };
   auto run_x3 = [&]() {
-    hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, A, B, slab1, M, N, K, kslice);
+    if (variant == 30) hipLaunchKernelGGL((gemm_tn_bx3_pre<13, true>), grid, dim3(256), 0, st, A3, B3, slab1, M, N, K, kslice);
+    else if (variant == 31) hipLaunchKernelGGL((gemm_tn_bx3_pre<13, false>), grid, dim3(256), 0, st, A3, B3, slab1, M, N, K, kslice);
+    else hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, A, B, slab1, M, N, K, kslice);
     hipLaunchKernelGGL(reduce_kernel, dim3(256), dim3(256), 0, st, slab1, C1, (long)M * N, Zeff);
   };
+  if (pre) run_split();
   run_native(); run_x3();
   CK(hipStreamSynchronize(st));
   CK(hipGetLastError());
@@ -583,6 +737,20 @@ int main(int argc, char** argv) {
       CK(hipEventElapsedTime(&ms, a, b));
       best[which] = fmin(best[which], ms / 10);
     }
+  if (pre) {
+    double bs = 1e9;
+    for (int rd = 0; rd < 5; ++rd) {
+      CK(hipEventRecord(a, st));
+      for (int i = 0; i < 5; ++i) run_split();
+      CK(hipEventRecord(b, st));
+      CK(hipEventSynchronize(b));
+      float ms;
+      CK(hipEventElapsedTime(&ms, a, b));
+      bs = fmin(bs, ms / 5);
+    }
+    printf("  split pass of both operands (fp32 -> three bf16 images, standalone: 10 B / element of HBM traffic): %.1f us = %.2f TB/s; inside a producer's epilogue it is +2 B / element\n",
+           1e3 * bs, ((double)K * (M + N) * 10) / bs / 1e9);
+  }
   const double fl = 2.0 * M * N * K;
   printf("  native f32 MFMA (nnr_gemm_f32, slab mode, incl. reduction + zero fill): best %.1f us = %.1f TFLOP/s | rel-L2 %.3e  max err / sum|ab| %.3e\n", 1e3 * best[0], fl / best[0] / 1e9, l0, s0);
   printf("  bf16x3 TN variant %d (%s; %d slices, incl. reduction): best %.1f us = %.1f TFLOP/s-equivalent = %.2fx | rel-L2 %.3e  max err / sum|ab| %.3e\n",
