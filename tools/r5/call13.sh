@@ -5,7 +5,7 @@ OUT=gpurun_out/r05o_bf16x3_tn_ablation.txt
 rm -f $OUT
 for shape in "400 400 112640 32" "832 200 112640 36"; do
   for v in ${1:-10 20 21 22 23}; do
-    timeout 120 tools/micro/bf16x3_tn $shape $v 2>&1 | grep -E "variant" | grep -v JSON | cut -c1-200 >> $OUT
+    timeout 120 tools/micro/bf16x3_tn $shape $v 2>&1 | grep -E "variant|split pass" | grep -v JSON | sed -E "s/\(([^;)]{0,60})[^)]*\)/(\1)/" >> $OUT
   done
 done
 cat $OUT
