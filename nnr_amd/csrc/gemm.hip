@@ -617,34 +617,58 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_pipe_kernel(nnr_gemm_args g)
   for (int s = 0; s < NS - 1; ++s)
     if (s < S) issue(s);
 
-  for (int s = 0; s < S; ++s) {
-    // this wave's DMAs of stage s have landed once at most `ahead` newer stages of its own are still outstanding
-    const int ahead = S - 1 - s;
-    if (NI % 4 == 0 || w < NI % 4) wait_stages<NPW, NS - 2>(ahead);
-    else wait_stages<NPW - 1, NS - 2>(ahead);
-    __builtin_amdgcn_s_barrier();
-    if (s + NS - 1 < S) issue(s + NS - 1);              // into the buffer every wave finished reading before that barrier
+  // Ragged last column block (round 5): N = 200 / 300 / 900 are 2.5 / 3.75 / 11.25 tiles of 80 columns; the 16-column MFMA tiles of the last block that lie
+  // wholly beyond N (2 of 5 at N = 200: 13 % of the launch's matrix work; 1 of 5 at N = 300, 3 of 5 at N = 900: 5 %) only ever multiplied clamped rows into
+  // columns that are never stored.  Those workgroups take a second instantiation of the stage loop that skips them (uniform branches per tile); every
+  // accumulator that IS stored sees the same MFMAs in the same order: results are bit-identical.
+  const int nv = (g.sched & 1) ? min(TN, (N - n0 + 15) >> 4) : TN;      // (g.sched bit 0: set by the launcher unless NNR_RAGGED=0 -- A/B)
+  auto run = [&](auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    for (int s = 0; s < S; ++s) {
+      // this wave's DMAs of stage s have landed once at most `ahead` newer stages of its own are still outstanding
+      const int ahead = S - 1 - s;
+      if (NI % 4 == 0 || w < NI % 4) wait_stages<NPW, NS - 2>(ahead);
+      else wait_stages<NPW - 1, NS - 2>(ahead);
+      __builtin_amdgcn_s_barrier();
+      if (s + NS - 1 < S) issue(s + NS - 1);              // into the buffer every wave finished reading before that barrier
 
-    const float* As = lds + (s % NS) * STAGE;
-    const float* Bs = As + BM * BK;
+      const float* As = lds + (s % NS) * STAGE;
+      const float* Bs = As + BM * BK;
 #pragma unroll
-    for (int kg = 0; kg < NKG; ++kg) {
-      f32x4 af[TM], bf[TN];
-#pragma unroll
-      for (int m = 0; m < TM; ++m)
-        af[m] = *reinterpret_cast<const f32x4*>(&As[((w * TM + m) * 16 + r) * BK + 4 * ((kg * 4 + kk) ^ swz<BK>(r))]);
-#pragma unroll
-      for (int n = 0; n < TN; ++n)
-        bf[n] = *reinterpret_cast<const f32x4*>(&Bs[(n * 16 + r) * BK + 4 * ((kg * 4 + kk) ^ swz<BK>(r))]);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int kg = 0; kg < NKG; ++kg) {
+        f32x4 af[TM], bf[TN];
 #pragma unroll
         for (int m = 0; m < TM; ++m)
+          af[m] = *reinterpret_cast<const f32x4*>(&As[((w * TM + m) * 16 + r) * BK + 4 * ((kg * 4 + kk) ^ swz<BK>(r))]);
+        if constexpr (FULL) {
 #pragma unroll
           for (int n = 0; n < TN; ++n)
-            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][i], bf[n][i], acc[m][n], 0, 0, 0);
+            bf[n] = *reinterpret_cast<const f32x4*>(&Bs[(n * 16 + r) * BK + 4 * ((kg * 4 + kk) ^ swz<BK>(r))]);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+              for (int n = 0; n < TN; ++n)
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][i], bf[n][i], acc[m][n], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int n = 0; n < TN; ++n)
+            if (n < nv) bf[n] = *reinterpret_cast<const f32x4*>(&Bs[(n * 16 + r) * BK + 4 * ((kg * 4 + kk) ^ swz<BK>(r))]);
+#pragma unroll
+          for (int n = 0; n < TN; ++n)
+            if (n < nv) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int m = 0; m < TM; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][i], bf[n][i], acc[m][n], 0, 0, 0);
+            }
+        }
+      }
     }
-  }
+  };
+  if (nv == TN) run(std::true_type{});
+  else run(std::false_type{});
   __syncthreads();        // every wave is done with the stage buffers: the epilogue reuses them
   gemm_epilogue<TM, TN>(g, acc, lds, C, m0, n0, M, N, z);
 }
@@ -775,75 +799,113 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_pipe2_kernel(nnr_gemm_args g
 #pragma unroll
     for (int n = 0; n < TN; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
   f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
-  auto rd = [&](int s, int kg, f32x4 (&a)[TM], f32x4 (&b)[TN]) {
-    const float* As = lds + (s % NS) * STAGE;
-    const float* Bs = As + BM * BK;
-#pragma unroll
-    for (int m = 0; m < TM; ++m)
-      a[m] = *reinterpret_cast<const f32x4*>(&As[((w * TM + m) * 16 + r) * BK + 4 * ((kg * 4 + kk) ^ swz<BK>(r))]);
-#pragma unroll
-    for (int n = 0; n < TN; ++n)
-      b[n] = *reinterpret_cast<const f32x4*>(&Bs[(n * 16 + r) * BK + 4 * ((kg * 4 + kk) ^ swz<BK>(r))]);
-  };
-  auto mm = [&](const f32x4 (&a)[TM], const f32x4 (&b)[TN]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
+  // Ragged last column block / reduction tail (round 5; see gemm_nt_pipe_kernel): the workgroups of a last column block with nv < TN live 16-column tiles run a
+  // second instantiation of the loop that skips the dead tiles; the last stage only multiplies the 16-deep k-groups / MFMA steps that hold a k < K (K = 900: 4 live k in the last stage, its second group is skipped).
+  // Skipped MFMAs only ever added exact zeros / fed columns that are never stored: results are bit-identical.
+  const int nv = (g.sched & 1) ? min(TN, (N - n0 + 15) >> 4) : TN;
+  const int klast = (g.sched & 1) ? K - (S - 1) * BK : BK;         // valid reduction depth of the last stage (1 .. 32)
+  auto run = [&](auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    auto rd = [&](int s, int kg, f32x4 (&a)[TM], f32x4 (&b)[TN]) {
+      const float* As = lds + (s % NS) * STAGE;
+      const float* Bs = As + BM * BK;
 #pragma unroll
       for (int m = 0; m < TM; ++m)
+        a[m] = *reinterpret_cast<const f32x4*>(&As[((w * TM + m) * 16 + r) * BK + 4 * ((kg * 4 + kk) ^ swz<BK>(r))]);
 #pragma unroll
-        for (int n = 0; n < TN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][i], b[n][i], acc[m][n], 0, 0, 0);
-  };
+      for (int n = 0; n < TN; ++n)
+        if (FULL || n < nv) b[n] = *reinterpret_cast<const f32x4*>(&Bs[(n * 16 + r) * BK + 4 * ((kg * 4 + kk) ^ swz<BK>(r))]);
+    };
+    auto mm = [&](const f32x4 (&a)[TM], const f32x4 (&b)[TN], int steps) {      // steps: 4-deep k-steps of this 16-deep group to multiply (4 everywhere but in the tail)
+      if constexpr (FULL) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (i < steps) {
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+              for (int n = 0; n < TN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][i], b[n][i], acc[m][n], 0, 0, 0);
+          }
+      } else {
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+          if (n < nv) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (i < steps) {
+#pragma unroll
+                for (int m = 0; m < TM; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][i], b[n][i], acc[m][n], 0, 0, 0);
+              }
+          }
+      }
+    };
+    auto mm4 = [&](const f32x4 (&a)[TM], const f32x4 (&b)[TN]) {               // a whole 16-deep group: no step test in the steady-state body
+      if constexpr (FULL) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int n = 0; n < TN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][i], b[n][i], acc[m][n], 0, 0, 0);
+      } else {
+        mm(a, b, 4);
+      }
+    };
 
 #pragma unroll
-  for (int s = 0; s < NS - 1; ++s)
-    if (s < S) issue(s);
-  // stage 0 must be complete: with min(NS - 1, S) stages issued, the newer ones (at most NS - 2) may stay in flight
-  if (NI % 4 == 0 || w < NI % 4) wait_stages<NPW, NS - 2>(S - 1); else wait_stages<NPW - 1, NS - 2>(S - 1);
-  __builtin_amdgcn_s_barrier();
-  rd(0, 0, fa0, fb0);
-  // Three loops, so that the steady-state body is branch-free between the fragment reads and the MFMA blocks (any branch that
-  // merges there makes the compiler's lgkmcnt bookkeeping wait for the NEWEST reads): (1) stages whose refill is an ordinary
-  // stage, (2) the one whose refill is the last stage (possibly a k-tail), (3) the drain, no refill; the last stage is peeled.
-  // lgkmcnt(0), visible to the compiler (a builtin, not asm): scalar loads of kernel arguments still pending at the loop header
-  // would otherwise force EVERY in-loop LDS wait to lgkmcnt(0) (scalar loads return out of order), i.e. to wait for the reads
-  // just issued instead of the older ones the MFMAs need.
-  __builtin_amdgcn_s_waitcnt(0xC07F);
-  // After every MFMA block an lgkmcnt(0) the compiler can see: the reads it covers were issued a whole MFMA block earlier, so it
-  // never stalls, and it empties the compiler's pending-read list before the barrier / DMA / branch section -- where that list
-  // otherwise degrades to "wait for everything" at the next use.
+    for (int s = 0; s < NS - 1; ++s)
+      if (s < S) issue(s);
+    // stage 0 must be complete: with min(NS - 1, S) stages issued, the newer ones (at most NS - 2) may stay in flight
+    if (NI % 4 == 0 || w < NI % 4) wait_stages<NPW, NS - 2>(S - 1); else wait_stages<NPW - 1, NS - 2>(S - 1);
+    __builtin_amdgcn_s_barrier();
+    rd(0, 0, fa0, fb0);
+    // Three loops, so that the steady-state body is branch-free between the fragment reads and the MFMA blocks (any branch that
+    // merges there makes the compiler's lgkmcnt bookkeeping wait for the NEWEST reads): (1) stages whose refill is an ordinary
+    // stage, (2) the one whose refill is the last stage (possibly a k-tail), (3) the drain, no refill; the last stage is peeled.
+    // lgkmcnt(0), visible to the compiler (a builtin, not asm): scalar loads of kernel arguments still pending at the loop header
+    // would otherwise force EVERY in-loop LDS wait to lgkmcnt(0) (scalar loads return out of order), i.e. to wait for the reads
+    // just issued instead of the older ones the MFMAs need.
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    // After every MFMA block an lgkmcnt(0) the compiler can see: the reads it covers were issued a whole MFMA block earlier, so it
+    // never stalls, and it empties the compiler's pending-read list before the barrier / DMA / branch section -- where that list
+    // otherwise degrades to "wait for everything" at the next use.
 #define NNR_LGKM0() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0xC07F); } while (0)
-  int s = 0;
-  for (; s + NS < S; ++s) {                                   // refill = stage s + NS - 1 <= S - 2
-    rd(s, 1, fa1, fb1);
-    __builtin_amdgcn_sched_barrier(0);                        // keep the reads AHEAD of the MFMA block that hides them
-    mm(fa0, fb0);
-    NNR_LGKM0();
-    wait_landed(NS);                                          // stage s + 1: up to NS - 3 newer stages stay in flight
-    __builtin_amdgcn_s_barrier();
-    issue_lean(s + NS - 1);                                   // into the buffer of stage s - 1: free since the previous barrier
-    rd(s + 1, 0, fa0, fb0);
-    __builtin_amdgcn_sched_barrier(0);
-    mm(fa1, fb1);
-    NNR_LGKM0();
-  }
-  for (; s + 1 < S; ++s) {                                    // at most NS - 1 iterations
-    rd(s, 1, fa1, fb1);
-    __builtin_amdgcn_sched_barrier(0);
-    mm(fa0, fb0);
-    NNR_LGKM0();
-    wait_landed(S - 1 - (s + 1));
-    __builtin_amdgcn_s_barrier();
-    if (s + NS - 1 < S) issue(s + NS - 1);
-    rd(s + 1, 0, fa0, fb0);
-    __builtin_amdgcn_sched_barrier(0);
-    mm(fa1, fb1);
-    NNR_LGKM0();
-  }
+    int s = 0;
+    for (; s + NS < S; ++s) {                                   // refill = stage s + NS - 1 <= S - 2
+      rd(s, 1, fa1, fb1);
+      __builtin_amdgcn_sched_barrier(0);                        // keep the reads AHEAD of the MFMA block that hides them
+      mm4(fa0, fb0);
+      NNR_LGKM0();
+      wait_landed(NS);                                          // stage s + 1: up to NS - 3 newer stages stay in flight
+      __builtin_amdgcn_s_barrier();
+      issue_lean(s + NS - 1);                                   // into the buffer of stage s - 1: free since the previous barrier
+      rd(s + 1, 0, fa0, fb0);
+      __builtin_amdgcn_sched_barrier(0);
+      mm4(fa1, fb1);
+      NNR_LGKM0();
+    }
+    for (; s + 1 < S; ++s) {                                    // at most NS - 1 iterations
+      rd(s, 1, fa1, fb1);
+      __builtin_amdgcn_sched_barrier(0);
+      mm4(fa0, fb0);
+      NNR_LGKM0();
+      wait_landed(S - 1 - (s + 1));
+      __builtin_amdgcn_s_barrier();
+      if (s + NS - 1 < S) issue(s + NS - 1);
+      rd(s + 1, 0, fa0, fb0);
+      __builtin_amdgcn_sched_barrier(0);
+      mm4(fa1, fb1);
+      NNR_LGKM0();
+    }
 #undef NNR_LGKM0
-  rd(S - 1, 1, fa1, fb1);
-  __builtin_amdgcn_sched_barrier(0);
-  mm(fa0, fb0);
-  mm(fa1, fb1);
+    rd(S - 1, 1, fa1, fb1);
+    __builtin_amdgcn_sched_barrier(0);
+    // (MFMA step i of a 16-deep group multiplies k = 16 kg + 4 kk + i over the four lane groups kk: it holds a live k iff 16 kg + i < klast)
+    mm(fa0, fb0, min(4, klast));
+    if (klast > 16) mm(fa1, fb1, min(4, klast - 16));
+  };
+  if (nv == TN) run(std::true_type{});
+  else run(std::false_type{});
   __syncthreads();
   gemm_epilogue<TM, TN>(g, acc, lds, C, m0, n0, M, N, z);
 }
@@ -1431,9 +1493,16 @@ int launch_pipe3(const nnr_gemm_args& g, hipStream_t s) {
   return NNR_OK;
 }
 
+static int nt_ragged_bit() {
+  static const int on = [] { const char* e = getenv("NNR_RAGGED"); return (e && atoi(e) == 0) ? 0 : 1; }();      // A/B: 0 = every tile of a ragged last column block / reduction tail is multiplied
+  return on;
+}
+
 template <int TM, int TN, int NS, int OCC>
-int launch_pipe2(const nnr_gemm_args& g, hipStream_t s) {
+int launch_pipe2(const nnr_gemm_args& g0, hipStream_t s) {
   constexpr int BM = 64 * TM, BN = 16 * TN;
+  nnr_gemm_args g = g0;
+  g.sched = nt_ragged_bit();
   const int nbm = (g.M + BM - 1) / BM, nbn = (g.N + BN - 1) / BN;
   dim3 grid(nbm * nbn, 1, g.batch > 1 ? g.batch : 1), block(256);
   hipLaunchKernelGGL((gemm_nt_pipe2_kernel<TM, TN, NS, OCC>), grid, block, 0, s, g);
@@ -1442,8 +1511,10 @@ int launch_pipe2(const nnr_gemm_args& g, hipStream_t s) {
 }
 
 template <int TM, int TN, int BK, int NS, int OCC, int PRIO = 0>
-int launch_pipe(const nnr_gemm_args& g, hipStream_t s) {
+int launch_pipe(const nnr_gemm_args& g0, hipStream_t s) {
   constexpr int BM = 64 * TM, BN = 16 * TN;
+  nnr_gemm_args g = g0;
+  g.sched = nt_ragged_bit();
   const int nbm = (g.M + BM - 1) / BM, nbn = (g.N + BN - 1) / BN;
   dim3 grid(nbm * nbn, 1, g.batch > 1 ? g.batch : 1), block(256);
   hipLaunchKernelGGL((gemm_nt_pipe_kernel<TM, TN, BK, NS, OCC, PRIO>), grid, block, 0, s, g);
