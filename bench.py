@@ -61,8 +61,10 @@ def parse(argv=None):
     ap.add_argument('--dense', action='store_true', help='all titles/abstracts at full length (worst-case roofline variant)')
     ap.add_argument('--device_corpus', action='store_true', help='(default since round 4; kept for old command lines) build every batch '
                     'inside the timed step from the device-resident corpus (id-only batches: nnr_corpus_batch + nnr_history_graph)')
-    ap.add_argument('--roofline_every', type=int, default=10, help='instrument every n-th timed step with HIP events (the two events per '
-                    'launch cost ~5 %% of a step when all steps carry them)')
+    ap.add_argument('--roofline_steps', type=int, default=2, help='instrumented steps (HIP events around every GEMM / recurrence / HBM-bound call) run AFTER the '
+                    'timed window: the window itself and the secondary legs time un-instrumented replays (round-5 verdict: per-call events cost ~1.2 ms per '
+                    'instrumented batch-64 step and 15 %% of a batch-8 leg)')
+    ap.add_argument('--roofline_every', type=int, default=0, help='(rounds 1-5: instrument every n-th step INSIDE the timed window) accepted and ignored')
     ap.add_argument('--zipf_s', type=float, default=None, help='diagnostic: exponent of the synthetic word-id distribution (default: SynthSpec)')
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--no_isolated', action='store_true', help='skip the two serialised extra steps behind `roofline.isolated`')
@@ -70,7 +72,7 @@ def parse(argv=None):
                     'workload, no instrumentation) and report it as the `sustained` object: clocks under a multi-second load; 0 = skip')
     ap.add_argument('--no_secondary', action='store_true', help='N = 1: skip the short secondary legs over the other BASELINE.json configs '
                     '(`secondary`: mhsa_mhsa_b64, cne_sue_shard_b8, cne_sue_large_shard_b16_v130000)')
-    ap.add_argument('--no_experimental', action='store_true', help='skip the experimental bf16x3 leg of `secondary`')
+    ap.add_argument('--no_experimental', '--no_f32_leg', dest='no_experimental', action='store_true', help='skip the pure fp32-MFMA leg of `secondary`')
     ap.add_argument('--secondary_steps', type=int, default=10)
     ap.add_argument('--secondary_warmup', type=int, default=5, help='two call-by-call steps + the recording + one replay + the discarded timing '
                     'replay: the timed steps of a secondary leg are all native replays, like the headline window')
@@ -234,6 +236,41 @@ def plumbing_check(a):
     return 0 if ok else 4
 
 
+def matrix_path(ops, seen=None):
+    """`config.matrix_path`: which matrix instructions the step's products run on (`dtype` stays "f32": fp32 operands in, fp32 results out,
+    fp32 accumulation; the split is exact and the error against fp64 a third of the fp32-MFMA kernel's -- DESIGN.md section 9.4)."""
+    if not ops.BX3[0]:
+        return {'nt_weight_gemms': 'v_mfma_f32_16x16x4_f32', 'weight_gradient_gemms': 'v_mfma_f32_16x16x4_f32', 'recurrences': 'v_mfma_f32_16x16x4_f32 / 4x4x1',
+                'switch': 'NNR_BX3=0'}
+    out = {'nt_weight_gemms': 'bf16x3: each fp32 operand as three exact bf16 images, six v_mfma_f32_16x16x32_bf16 products, two fp32 accumulators '
+                              '(csrc/gemm.hip: gemm_nt_bx3_kernel); shape classes %s, rows >= %d' % (','.join(sorted(ops._BX3_CLASSES)), ops._BX3_MIN_ROWS),
+           'weight_gradient_gemms': 'v_mfma_f32_16x16x4_f32', 'recurrences': 'v_mfma_f32_16x16x4_f32 / 4x4x1', 'switch': 'NNR_BX3=1 (default)',
+           'pure_f32_leg': 'secondary.f32_mfma_only_cne_sue_b64'}
+    if seen:
+        # eager + recorded steps only (replays do not pass through ops.gemm): which NT shapes took the path ('weight') and which met every
+        # other condition but multiply by an activation ('other': left on the fp32 pipe)
+        out['launch_classes'] = {'%dx%dx%d %s' % k: v for k, v in sorted(seen.items())}
+    return out
+
+
+def scaling_ceiling(per_gpu, global_batch):
+    """N > 1: the ceiling the per-GPU batch sweep of the SAME build puts on this run before any exchange cost -- a rank's step cannot be
+    shorter than the 1-GPU step at its per-GPU batch (profiles/batch_sweep.json, written by tools/r6/collect.sh; build-id stamped)."""
+    try:
+        from nnr_amd import _lib
+        d = json.load(open(os.path.join(ROOT, 'profiles', 'batch_sweep.json')))
+        have, now = d.get('build_id') or {}, _lib.build_id()
+        same = have.get('src_sha256') == now['src_sha256'] or bool(have.get('lib_sha256') and have.get('lib_sha256') == now['lib_sha256'])
+        ms = d['ms_per_step'].get(str(per_gpu))
+        if ms is None:
+            return {'note': 'no 1-GPU measurement at per-GPU batch %d in profiles/batch_sweep.json' % per_gpu}
+        return {'per_gpu_batch': per_gpu, 'one_gpu_ms_per_step_at_that_batch': ms, 'value_ceiling': round(global_batch / ms * 1000.0, 1), 'unit': 'impressions/s',
+                'how': 'global batch / (1-GPU ms per step at the per-GPU batch): no exchange, no straggler; the measured value cannot exceed it',
+                'same_build': bool(same), 'source': 'profiles/batch_sweep.json'}
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def launch_path(trainer):
     if trainer.tapes:
         info = next(iter(trainer.tapes.values())).info()
@@ -294,26 +331,20 @@ def measure_exchange(trainer, torch, dev, world, a):
         return {'error': repr(e)}
 
 
-def timed_run(a, trainer, fresh, steps, warmup, prof, dp, torch, dev, world, instrument):
-    """W untimed + K timed steps bracketed by barrier + synchronize; returns the MAX over ranks of the elapsed seconds."""
+def timed_run(a, trainer, fresh, steps, warmup, prof, dp, torch, dev, world, prime_timing):
+    """W untimed + K timed steps bracketed by barrier + synchronize; returns the MAX over ranks of the elapsed seconds.  The window is
+    UN-INSTRUMENTED (no HIP event pair around any call of any timed step; round-5 verdict: two of the ten steps of a secondary leg carried
+    per-call events and made the batch-8 leg 15 % pessimistic); the roofline's per-call durations come from instrumented_steps() AFTER it."""
     for i in range(warmup):
-        # the last warm-up step is a TIMING replay whose spans are thrown away: the first one of a process pays the HIP runtime's lazy
-        # set-up of timed events (5-12 ms on a fresh box: 16.1 ms for the window's first step vs 11.1 in later processes, tools/r4_first_run.sh)
-        trainer.timing = bool(instrument and i == warmup - 1 and trainer.tapes)
+        # prime_timing: the last warm-up step is a TIMING replay whose spans are thrown away -- the first one of a process pays the HIP
+        # runtime's lazy set-up of timed events (5-12 ms on a fresh box), which must not land in the instrumented steps after the window
+        trainer.timing = bool(prime_timing and i == warmup - 1 and trainer.tapes)
         trainer.train_step(fresh(i))
     trainer.timing = False
-    if instrument:
-        trainer.collect_timings()                    # (discarded: prof.enable() below starts from empty records)
+    if prime_timing:
+        trainer.collect_timings()                    # (discarded: prof.enable() in instrumented_steps starts from empty records)
     dp.barrier()
     torch.cuda.synchronize()
-    from nnr_amd import step as native_step
-    taped = trainer.native and trainer.replay and native_step.supported(trainer.model)      # steps are replayed from a launch tape
-    if instrument:
-        # live HIP-event spans on every `roofline_every`-th step of the timed region (replayed steps: recorded natively by the tape
-        # around the same launches, on the launch streams)
-        prof.enable(every=a.roofline_every, eager=not taped)
-        for tape in trainer.tapes.values():          # (their HIP events exist before the window opens: no hipEventCreate inside it)
-            tape.prepare_timing(len(range(0, steps, max(1, a.roofline_every))))
     from nnr_amd import _lib
     calls0 = _lib.CALLS[0]
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if os.environ.get('NNR_BENCH_STEP_MARKS') == '1' else None
@@ -321,24 +352,37 @@ def timed_run(a, trainer, fresh, steps, warmup, prof, dp, torch, dev, world, ins
         marks[0].record()
     t0 = time.perf_counter()
     for i in range(steps):
-        if instrument:
-            trainer.timing = prof.begin_step(i) and taped
         trainer.train_step(fresh(warmup + i))
         if marks:
             marks[i + 1].record()
     dp.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    trainer.timing = False
     if marks:         # diagnostic: where inside the window the time went (one event per step on the main stream; stderr only)
         print('step marks (ms): ' + ' '.join('%.2f' % marks[i].elapsed_time(marks[i + 1]) for i in range(steps)), file=sys.stderr)
-    if instrument:
-        trainer.collect_timings()
-        prof.disable()
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     return float(tmax), (_lib.CALLS[0] - calls0) / max(1, steps)
+
+
+def instrumented_steps(trainer, fresh, n, first, prof, torch):
+    """n extra steps AFTER a timed window, each with a HIP event pair on the launch stream around every GEMM / recurrence / HBM-bound call
+    (replayed steps: recorded natively by the tape around the same launches; call-by-call steps: torch events): the live durations behind
+    `roofline`.  Same resident batches as the window (fresh(first + i)).  Returns n."""
+    from nnr_amd import step as native_step
+    taped = bool(trainer.native and trainer.replay and native_step.supported(trainer.model) and trainer.tapes)
+    prof.enable(every=1, eager=not taped)
+    for tape in trainer.tapes.values():              # (their HIP events exist before the steps: no hipEventCreate between the launches)
+        tape.prepare_timing(n)
+    for i in range(n):
+        trainer.timing = prof.begin_step(i) and taped
+        trainer.train_step(fresh(first + i))
+    torch.cuda.synchronize()
+    trainer.timing = False
+    trainer.collect_timings()
+    prof.disable()
+    return n
 
 
 SECONDARY_LEGS = (
@@ -347,11 +391,10 @@ SECONDARY_LEGS = (
     ('cne_sue_shard_b8', 'CNE', 'SUE', '200k', 64, 8, 8, 60000),                       # configs[3]: one GPU's shard of batch 64 over 8 GPUs
     ('cne_sue_large_shard_b16_v130000', 'CNE', 'SUE', 'large', 128, 8, 16, 130000),    # configs[4]: MIND-large, batch 128 over 8 GPUs
 )
-# EXPERIMENTAL leg (not a BASELINE config, not the headline): the headline workload with the GPU-filling NT GEMMs on the BF16 matrix pipe as six
-# exact bf16 products with fp32 accumulation (NNR_BX3=1, off by default) -- so that the driver's line carries the number a
-# round-6 adoption decision needs
-EXPERIMENTAL_LEGS = (
-    ('experimental_bf16x3_nt_cne_sue_b64', 'CNE', 'SUE', '200k', 64, 1, 64, 60000),
+# The headline workload on the PURE fp32-MFMA matrix path (NNR_BX3=0: no launch on the BF16 pipe), driver-timed beside the headline whose
+# weight-operand NT GEMMs run as six exact bf16 products with fp32 accumulation (`config.matrix_path`; round-5 verdict, item 1)
+F32_ONLY_LEGS = (
+    ('f32_mfma_only_cne_sue_b64', 'CNE', 'SUE', '200k', 64, 1, 64, 60000),
 )
 
 
@@ -372,11 +415,11 @@ def secondary_legs(a, prof, dp, torch, dev, rank_seed=0):
     from nnr_amd.trainer import Trainer
     out = {}
     from nnr_amd import ops as _ops
-    for name, ne, ue, dataset, gbatch, gworld, per_gpu, V in SECONDARY_LEGS + (() if a.no_experimental else EXPERIMENTAL_LEGS):
+    for name, ne, ue, dataset, gbatch, gworld, per_gpu, V in SECONDARY_LEGS + (() if a.no_experimental else F32_ONLY_LEGS):
         t_leg = time.perf_counter()
-        experimental = name.startswith('experimental_')
+        f32_only = name.startswith('f32_mfma_only_')
         bx3_before = _ops.BX3[0]
-        _ops.BX3[0] = bool(experimental) or bx3_before
+        _ops.BX3[0] = False if f32_only else bx3_before
         _ops.BX3_SEEN.clear()
         try:
             cfg = make_config(['--news_encoder=' + ne, '--user_encoder=' + ue, '--dataset=' + dataset, '--batch_size=%d' % gbatch,
@@ -392,29 +435,31 @@ def secondary_legs(a, prof, dp, torch, dev, rank_seed=0):
             steps, warm = a.secondary_steps, a.secondary_warmup
             dc = from_synth(SynthCorpus(spec), 2048, rng, dev, graph='build')
             order = [torch.from_numpy(rng.permutation(2048)[:per_gpu].astype(np.int32)).to(dev) for _ in range(steps + warm)]
-            a2 = argparse.Namespace(**vars(a))
-            a2.roofline_every = max(1, steps // 2)
-            dt, calls = timed_run(a2, trainer, lambda i: dc.train_batch(order[i % len(order)]), steps, warm, prof, dp, torch, dev, 1, True)
-            sampled = len(range(0, steps, a2.roofline_every))
+            src = lambda i: dc.train_batch(order[i % len(order)])
+            dt, calls = timed_run(a, trainer, src, steps, warm, prof, dp, torch, dev, 1, True)
+            sampled = instrumented_steps(trainer, src, max(1, a.roofline_steps), warm + steps, prof, torch)
             roof = prof.roofline(PEAK_F32_TFLOPS, sampled_steps=sampled, ms_per_step=1000 * dt / steps) or {}
+            for v in (roof.get('hbm') or {}).values():      # (the committed PMC passes are of the headline command only)
+                v['traffic'] = v['traffic_over_algorithmic'] = None
             leg = {'config': '%s+%s, --dataset=%s, dropout %.2f, V %d' % (ne, ue, dataset, cfg.dropout_rate, V),
                    'shard_of': None if gworld == 1 else {'global_batch': gbatch, 'gpus': gworld},
                    'per_gpu_batch': per_gpu, 'steps': steps, 'warmup': warm, 'ms_per_step': round(1000 * dt / steps, 3),
                    'value': round(steps * per_gpu / dt, 2), 'unit': 'impressions/s (this GPU\'s shard)',
+                   'timed_window': 'un-instrumented replays; per-call events from %d extra steps after it' % sampled,
+                   'matrix_path': matrix_path(_ops)['nt_weight_gemms'],
                    'step': roof.get('step'), 'abi_calls_per_step': round(calls, 1), 'launch_path': launch_path(trainer)['path'],
                    'dominant': {k: roof.get(k) for k in ('kernel', 'family', 'achieved', 'frac', 'avg_launch_us', 'launches', 'share_of_instrumented_time')} if roof else None}
+            # the HBM-bound families of THIS leg against the 8 TB/s peak (configs[4] = the "large-vocab embedding table, HBM-bound gather
+            # stress": gather / scatter / sumsq / clip_adam at V = 130 000, where the table-proportional traffic is ~1.3 GB per step)
+            leg['hbm'] = roof.get('hbm')
             if ne == 'MHSA':
                 leg['roofline_mhsa'] = prof.mhsa_roofline(PEAK_F32_TFLOPS)
             for t in list(trainer.tapes.values()):
                 t.close()
             trainer.tapes.clear()
             del trainer, model, dc, order
-            if experimental:
-                leg['experimental'] = ('NNR_BX3=1, OFF by default: NT GEMMs (rows >= 2 048, weight operand) as six exact bf16 x bf16 MFMA products with fp32 '
-                                       'accumulation; same parity bars (tests/test_hip_headline_gpu.py::..._with_experimental_bf16x3_nt_gemms_...)')
-                # eager + recorded steps only (replays do not pass through ops.gemm): which NT shapes took the path ('weight') and which met every
-                # other condition but multiply by an activation ('other': left on the fp32 pipe)
-                leg['bx3_launch_classes'] = {'%dx%dx%d %s' % k: v for k, v in sorted(_ops.BX3_SEEN.items())}
+            if f32_only:
+                leg['note'] = 'NNR_BX3=0: the headline workload with EVERY matrix product on v_mfma_f32_16x16x4_f32 (the default path of rounds 1-5)'
         except Exception as e:                  # a secondary measurement never takes the headline line down with it
             leg = {'error': repr(e)}
         finally:
@@ -488,8 +533,12 @@ def main():
     headline_batches = batch_source(per_gpu)      # the SAME resident batches serve the timed region, the sustained leg and the isolated leg (a
                                                   # MIND-shaped batch of 64 varies by +-6 % in tokens: other draws are another workload)
     dt, calls = timed_run(a, trainer, headline_batches, a.steps, a.warmup, prof, dp, torch, dev, world, True)
-    sampled = len(range(0, a.steps, max(1, a.roofline_every)))
+    bx3_seen_headline = dict(ops.BX3_SEEN)
+    sampled = instrumented_steps(trainer, headline_batches, max(1, a.roofline_steps), a.warmup + a.steps, prof, torch)
     roof = prof.roofline(PEAK_F32_TFLOPS, sampled_steps=sampled, ms_per_step=1000 * dt / a.steps)
+    if roof:
+        roof['timed_window'] = 'un-instrumented; per-call HIP events from %d extra steps after the window (same resident batches)' % sampled
+        roof['rocprof'] = prof.rocprof_block(roof, PEAK_F32_TFLOPS)
     headline = (a.news_encoder, a.user_encoder, per_gpu, a.dense) == ('CNE', 'SUE', 64, False)
     if roof and not headline:
         roof['traffic'] = None            # the committed PMC passes (profiles/pmc_traffic.json) are of the headline command only
@@ -572,6 +621,7 @@ def main():
             'config': {'workload': '%s+%s train step, MIND-200k-shaped synthetic batches, dropout %.2f, gcn_layer_num %d%s' %
                                    (a.news_encoder, a.user_encoder, cfg.dropout_rate, cfg.gcn_layer_num, ', dense lengths' if a.dense else ''),
                        'global_batch': global_batch, 'per_gpu_batch': per_gpu, 'parallelism': 'dp%d' % world,
+                       'matrix_path': matrix_path(ops, bx3_seen_headline),
                        'synth': {k: v for k, v in spec.describe().items() if k in ('vocabulary_size', 'title_len_mean', 'content_len_mean', 'news_pool', 'dense')},
                        'batches': ('device-resident corpus, id-only: a fresh batch is gathered / built in HBM inside every timed step (%d distinct id sets)' % nb)
                                   if device_corpus else 'pre-built, %d batches resident in HBM, re-used' % nb,
@@ -586,6 +636,8 @@ def main():
             out['sustained'] = sustained
         if exchange is not None:
             out['exchange'] = exchange
+        if world > 1:
+            out['scaling_ceiling'] = scaling_ceiling(per_gpu, global_batch)
         if other is not None:
             out['weak_scaling' if other['scaling'] == 'weak' else 'strong_scaling'] = other
         if secondary is not None:

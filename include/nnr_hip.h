@@ -96,8 +96,10 @@ typedef struct nnr_gemm_args {
   const float* pre_add;     /* [M, ldpre]: added to the product before anything else (also without gate_bwd) */
   int ldpre;
   int gate_bwd;
-  /* EXPERIMENTAL (round 5, off by default): tile = 50 computes the same NT product on the BF16 matrix pipe as six exact bf16 x bf16 products
-   * with fp32 accumulation (an fp32 value is exactly the sum of three bf16 values; error vs fp64 a third of the fp32-MFMA kernels').  B3: the
+  /* tile = 50 computes the same NT product on the BF16 matrix pipe as six exact bf16 x bf16 products with fp32 accumulation (an fp32 value is
+   * exactly the sum of three bf16 values; error vs fp64 a third of the fp32-MFMA kernels'; round 5: measured, round 6: the host's default for
+   * NT launches whose B is a weight).  Non-finite operands give non-finite outputs (+-Inf or NaN, not necessarily fp32's choice of the two); finite values up to FLT_MAX are
+   * exact (csrc/gemm.hip: split3_bf16).  B3: the
    * weight matrix B [N, K] pre-split by nnr_split_bf16x3 into three bf16 images [N, ldb3] (ldb3 % 8 == 0, zero-padded), image i at
    * B3 + i * b3_stride elements. */
   const void* B3;
@@ -409,6 +411,12 @@ int nnr_dp_init(const void* uid128, int rank, int world, nnr_dp_ctx** ctx);     
 int nnr_dp_allreduce(nnr_dp_ctx* ctx, float* flat, size_t n, hipStream_t stream);
 int nnr_dp_broadcast(nnr_dp_ctx* ctx, float* flat, size_t n, int root, hipStream_t stream);
 int nnr_dp_destroy(nnr_dp_ctx* ctx);
+/* Test hook for boxes with ONE GPU (RCCL refuses two ranks on one device): from now on every nnr_dp_allreduce of `ctx` behaves as if
+ * `ranks` ranks held the SAME buffer -- the sum is ranks x the local values (a scale kernel on the same stream right behind the
+ * collective, so it is part of whatever launch sequence the all-reduce is part of, recorded tapes included).  With a power of two the
+ * result is exact, and a bucket that was NOT exchanged shows as 1 x instead of ranks x its gradient (tests/test_hip_dp_gpu.py:
+ * the C-ABI binding + touched-row exchange over replayed steps).  ranks = 1 turns it off.  Never set by the product path. */
+int nnr_dp_emulate_ranks(nnr_dp_ctx* ctx, int ranks);
 /* Diagnostics: a stand-in for RCCL's RESIDENT ring kernels on a box with one GPU -- `workgroups` x 512 threads sweep their slice of buf
  * [n] `iters` times (read-modify-write through HBM), occupying as many CU slots for the duration.  The co-residency soak of the CU-pair
  * recurrence (tests/test_hip_dp_gpu.py, tools/replay_soak.py --busy) runs it on a side stream beside every step. */

@@ -47,7 +47,13 @@ Api* api() {
 }
 }  // namespace
 
-struct nnr_dp_ctx { ncclComm_t comm; int rank, world; };
+struct nnr_dp_ctx { ncclComm_t comm; int rank, world; int emulate; };
+
+namespace {
+__global__ void dp_scale_kernel(float* __restrict__ x, size_t n, float f) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) x[i] *= f;
+}
+}  // namespace
 
 extern "C" int nnr_dp_unique_id(void* out128) {
   static_assert(sizeof(ncclUniqueId) == 128, "the boundary carries the id as 128 opaque bytes");
@@ -66,14 +72,26 @@ extern "C" int nnr_dp_init(const void* uid128, int rank, int world, nnr_dp_ctx**
   memcpy(&id, uid128, sizeof(id));
   ncclComm_t comm;
   if (api()->CommInitRank(&comm, world, id, rank) != ncclSuccess) return NNR_ERR_LAUNCH;     // binds to the CURRENT HIP device
-  *ctx = new nnr_dp_ctx{comm, rank, world};
+  *ctx = new nnr_dp_ctx{comm, rank, world, 1};
   return NNR_OK;
 }
 
 extern "C" int nnr_dp_allreduce(nnr_dp_ctx* ctx, float* flat, size_t n, hipStream_t stream) {
   if (!ctx || !flat) return NNR_ERR_ARG;
   if (n == 0) return NNR_OK;
-  return api()->AllReduce(flat, flat, n, ncclFloat32, ncclSum, ctx->comm, stream) == ncclSuccess ? NNR_OK : NNR_ERR_LAUNCH;
+  if (api()->AllReduce(flat, flat, n, ncclFloat32, ncclSum, ctx->comm, stream) != ncclSuccess) return NNR_ERR_LAUNCH;
+  if (ctx->emulate > 1) {                 // test hook (nnr_dp_emulate_ranks): `emulate` ranks with identical buffers
+    const size_t b = (n + 255) / 256;
+    hipLaunchKernelGGL(dp_scale_kernel, dim3((unsigned)(b > 2048 ? 2048 : b)), dim3(256), 0, stream, flat, n, (float)ctx->emulate);
+    NNR_CHECK_LAUNCH();
+  }
+  return NNR_OK;
+}
+
+extern "C" int nnr_dp_emulate_ranks(nnr_dp_ctx* ctx, int ranks) {
+  if (!ctx || ranks < 1) return NNR_ERR_ARG;
+  ctx->emulate = ranks;
+  return NNR_OK;
 }
 
 extern "C" int nnr_dp_broadcast(nnr_dp_ctx* ctx, float* flat, size_t n, int root, hipStream_t stream) {

@@ -1535,8 +1535,9 @@ static bool pipe3_ok(const nnr_gemm_args& g) {
   return pipe_ok(g) && !g.a_idx && !g.c_idx && !g.atomic && g.vec_epi && g.drop_target != 4 && g.K >= 96;
 }
 
-// ------------------------------------------------------------------------------------------------ EXPERIMENTAL: NT GEMM on the BF16 matrix pipe (round 5)
-// OFF by default (tile 50, selected only when the caller passes pre-split weights: NNR_BX3=1 in nnr_amd/ops.py).  fp32 arithmetic without narrowing:
+// ------------------------------------------------------------------------------------------------ NT GEMM on the BF16 matrix pipe (round 5)
+// Tile 50, selected only when the caller passes pre-split weights (nnr_amd/ops.py: the default for weight-operand NT launches since round 6; NNR_BX3=0
+// keeps the fp32-MFMA kernels).  fp32 arithmetic without narrowing:
 // an fp32 value is EXACTLY x1 + x2 + x3 with three bf16 values (8 + 8 + 8 significant bits); the six products a_i b_j with i + j <= 4 carry everything
 // above 2^-26 |a b| (below the rounding of an fp32 product), a bf16 x bf16 product is exact in fp32 and v_mfma_f32_16x16x32_bf16 accumulates in
 // fp32 -- at 16x the issue rate of v_mfma_f32_16x16x4_f32.  Measured error vs fp64: a third of the fp32-MFMA kernel's (12 roundings of the hi
@@ -1547,9 +1548,20 @@ static bool pipe3_ok(const nnr_gemm_args& g) {
 //  * staging = gemm_nt_pipe_kernel's (per-lane-source LDS-DMA, zero page for k-chunks past K, counted vmcnt + one barrier per stage), BK = 32,
 //    2 stages x 31.7 KB, 2 workgroups per CU; epilogue = gemm_epilogue (every element-wise feature of the NT kernels).
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+// Edge behaviour (tests/test_hip_ops_gpu.py::test_gemm_bf16x3_edge_values):
+//  * |x| >= 0x7F7F8000 (the top half-ulp below bf16's largest value and everything above it) would ROUND to +-Inf as a bf16: the first image is
+//    TRUNCATED there instead, so a finite fp32 value -- FLT_MAX included -- stays three finite images that sum to it exactly;
+//  * +-Inf / NaN: first image = the value itself (NaN canonical), the other two 0.  Every output a non-finite operand reaches is NON-FINITE (Inf x b1
+//    is +-Inf, Inf x b2 has b2's sign: the partial sums meet as +-Inf or as Inf - Inf = NaN), as with the fp32 MFMA -- but WHICH of +-Inf / NaN is
+//    not kept (the training step only asks "is the gradient norm finite", nnr_clip_adam);
+//  * fp32 denormals: their images are bf16 denormals; the matrix pipe treats them as the fp32 MFMA treats denormal inputs to within 2^-126 of the
+//    operands' scale (far below any fp32 rounding of the sum).
 __device__ __forceinline__ void split3_bf16(float x, __bf16& h1, __bf16& h2, __bf16& h3) {
+  const unsigned u = __builtin_bit_cast(unsigned, x), mag = u & 0x7fffffffu;
+  const bool big = mag >= 0x7f7f8000u, nonfinite = mag >= 0x7f800000u;
   h1 = (__bf16)x;                       // round-to-nearest-even
-  const float r1 = x - (float)h1;       // exact: at most 16 significant bits remain
+  if (big) h1 = __builtin_bit_cast(__bf16, (unsigned short)((u >> 16) | (mag > 0x7f800000u ? 0x40u : 0u)));
+  const float r1 = nonfinite ? 0.f : x - (float)h1;       // exact: at most 16 significant bits remain
   h2 = (__bf16)r1;
   const float r2 = r1 - (float)h2;      // exact: at most 8 significant bits remain
   h3 = (__bf16)r2;                      // exact
@@ -2457,7 +2469,7 @@ static int dispatch_tile(int tile, const nnr_gemm_args& g, hipStream_t stream) {
       if (!pipe_ok(g) || g.a_idx || g.batch > 1 || !g.slab || (((uintptr_t)g.slab) & 15) || g.K < 96 || (long)((g.M + 127) / 128) * ((g.N + 79) / 80) > 2048 ||
           g.slab_floats < (long)nnr_gemm_sk_workspace_floats(g.M, g.N)) return NNR_ERR_ARG;
       return launch_sk<2, 5, 3, 2>(g, stream);
-    case 50: if (!bx3_ok(g)) return NNR_ERR_ARG; return launch_bx3<2, 5>(g, stream);           // EXPERIMENTAL bf16x3 NT 128 x 80 (needs args.B3: pre-split weights)
+    case 50: if (!bx3_ok(g)) return NNR_ERR_ARG; return launch_bx3<2, 5>(g, stream);           // bf16x3 NT 128 x 80 (needs args.B3: pre-split weights)
     case 51: if (!bx3_ok(g)) return NNR_ERR_ARG; return launch_bx3<1, 5>(g, stream);           // ... 64 x 80: 2 x 23 KB stages, 3 workgroups / CU
     case 52: if (!bx3_ok(g)) return NNR_ERR_ARG; return launch_bx3<2, 4>(g, stream);           // ... 128 x 64
     case 53: if (!bx3_ok(g)) return NNR_ERR_ARG; return launch_bx3<4, 5>(g, stream);           // ... 256 x 80: 2 x 47 KB stages, 1 workgroup / CU

@@ -330,11 +330,21 @@ class GradientExchange:
     def _native(self):
         return native_active(self.grad.is_cuda)
 
+    def _recordable(self):
+        """May this step's exchange be RECORDED into the launch tape (its Python never runs again on a replay)?  Only the dense form over
+        the C-ABI binding: nnr_dp_allreduce calls + stream joins are all it does, and the bookkeeping below (`_pending`, `_pending_table`)
+        opens and closes inside the one recorded step.  The touched-row form needs the host every step (the union's row count sizes the
+        collective), and then ALL THREE hooks -- early_ready, table_scatter_done, finish -- run as host callbacks of the tape, so that the
+        bookkeeping they share is re-run together on every replay.  (Round-5 advisor, high: with finish() recorded and
+        table_scatter_done a host callback, `_pending_table` was never cleared after the first replay and the table bucket was silently
+        left un-reduced from the second replay on.)"""
+        return self._native() and not self.touched
+
     def early_ready(self):
         """The early bucket's gradients are final on the CURRENT stream: start reducing them."""
         if self.early_span is None or not self.active():
             return
-        if self._native():
+        if self._recordable():
             return self._early_ready()           # RCCL through the C-ABI: the call itself is part of a recorded launch sequence
         from .tape import host_call              # torch.distributed: the host's own work, re-run between the segments of a replay
         host_call(self._early_ready)
@@ -367,7 +377,7 @@ class GradientExchange:
         launch tape is per batch shape, so the decision is part of what it records) and clear the touched-row flags."""
         self._table_events = []
         if self.touched_mode == 'auto' and per_gpu_batch is not None:
-            self.touched = bool(self.touched_capable and per_gpu_batch <= TOUCHED_MAX_BATCH and world_size() > 1)
+            self.touched = bool(self.touched_capable and self._rule(int(per_gpu_batch)))
         if not (self.touched and self.active()):
             return
         flags = self._touch_buffers()
@@ -377,6 +387,10 @@ class GradientExchange:
             ops.fill_zero(flags)
         else:
             flags.zero_()
+
+    def _rule(self, per_gpu_batch):
+        """The table bucket goes out as touched rows when ... (tests replace this to flip the form between batch shapes on one rank)."""
+        return per_gpu_batch <= TOUCHED_MAX_BATCH and world_size() > 1
 
     def note_tokens(self, tok, total=None):
         """The word ids of one token stream of this step (device int32 `tok`, live count `total` on the device or None): mark their
@@ -463,12 +477,18 @@ class GradientExchange:
                     self._pending_table = (None, None)
                     self._table_events = []
             return
-        if self._native() and not self.touched:
-            return self._table_scatter_done(expected)
+        if self._recordable():
+            return self._table_scatter_done(expected, False)
         from .tape import host_call              # (the touched-row exchange needs the host: the union's row count sizes the collective)
-        host_call(lambda: self._table_scatter_done(expected))
+        # the FORM is captured here, when the step is issued / recorded: begin_step's Python does not run on a replay, and an eager step of
+        # another batch shape in between (the epoch's last partial batch) may leave self.touched different from what this tape's launches
+        # (flag fill, nnr_rows_touch) were recorded for (round-5 advisor, medium)
+        touched = bool(self.touched)
+        host_call(lambda: self._table_scatter_done(expected, touched))
 
-    def _table_scatter_done(self, expected):
+    def _table_scatter_done(self, expected, touched=None):
+        if touched is None:
+            touched = self.touched
         if self._pending_table is not None:
             return
         ev = torch.cuda.Event()
@@ -485,7 +505,7 @@ class GradientExchange:
             if self.events is not None:
                 self.events['table_issued'] = torch.cuda.Event(enable_timing=True)
                 self.events['table_issued'].record()
-            if self.touched:
+            if touched:
                 # (NOT `and self._noted`: on a REPLAYED step note_tokens' Python never runs -- nnr_rows_touch and the flag fill are part
                 # of the tape --, and the exchange used to degrade silently to the dense all-reduce there; round-4 advisor.  Only CNE
                 # calls this hook, and it notes every token stream it scatters.  The events in _noted are an extra ordering edge of
@@ -502,7 +522,7 @@ class GradientExchange:
         w = world_size()
         if not self.active():
             return 1.0 / w
-        if self._native():
+        if self._recordable():
             return self._finish()
         from .tape import host_call
         return host_call(self._finish)

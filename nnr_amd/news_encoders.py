@@ -303,8 +303,10 @@ def _cne_fwd_pre(mod, title_text, title_mask, content_text, content_mask, catego
         # is recomputed by each of the 21 column blocks (-16 % on this GEMM and on the dW_ih GEMM of the backward)
         st['xd'] = ops.embed_gather(emb, plan.tok, p, st['seed'], dyn=plan.total)
         hook = mod.__dict__.get('_tokens_hook')
-        if hook is not None and mod.training:
-            hook(plan.tok, plan.total)                  # data parallel: the touched-row exchange of the table gradient learns this stream's words
+        if hook is not None and (mod.training or torch.is_grad_enabled()):
+            # data parallel: the touched-row exchange of the table gradient learns this stream's words -- whenever a backward pass may
+            # follow (also an eval-mode gradient check: the backward's table hook is unconditional; round-5 advisor)
+            hook(plan.tok, plan.total)
         if ops.SCATTER_SORTED and mod.training and E <= 320:
             # the backward's embedding-row gradient is a segmented reduction over the rows sorted by word id (reproducible, no atomic
             # ceiling): the sort needs only the planned ids and runs on the leaf stream under the forward pass

@@ -372,14 +372,35 @@ def split_for(m, n, k, tile_m=64, tile_n=80, target_blocks=2048, kmin=256):
     return int(max(1, min((k + kmin - 1) // kmin, (target_blocks + tiles - 1) // tiles)))
 
 
-# ---------------------------------------------------------------------------------------------- EXPERIMENTAL: bf16x3 NT GEMMs (off by default)
-# NNR_BX3=1 sends the GPU-filling NT launches whose B operand is a weight (a parameter, a cached transpose, the packed LSTM input weights) to
-# csrc/gemm.hip:gemm_nt_bx3_kernel: fp32 arithmetic as six exact bf16 x bf16 products with fp32 accumulation.  The
-# weight's three bf16 images are cached per (storage, shape) and re-split when the parameters changed (layers.PARAM_EPOCH) -- one small
-# launch per weight and step, recorded in the launch tape like any other call.  Round 5: measurement only; the default path does not use it.
-BX3 = [os.environ.get('NNR_BX3', '0') == '1']
+# ---------------------------------------------------------------------------------------------- bf16x3 NT GEMMs (the default matrix path since round 6)
+# The GPU-filling NT launches whose B operand is a weight (a parameter, a cached transpose, the packed LSTM input weights) run on
+# csrc/gemm.hip:gemm_nt_bx3_kernel: fp32 arithmetic as six exact bf16 x bf16 products with fp32 accumulation: the same
+# fp32 inputs, fp32 outputs, and a third of the fp32-MFMA kernel's error against fp64.  The weight's three bf16 images are cached per (storage,
+# shape) and re-split when the parameters changed (layers.PARAM_EPOCH) -- one small launch per weight and step, recorded in the launch tape
+# like any other call.  Round 5 measured it (off); round 6 made it the default after five interleaved same-box pairs + a per-shape-class A/B
+# (profiles/r06_bx3_phases.md: -0.33 ms of the 10.27 ms headline step, every class positive).  NNR_BX3=0 = the pure fp32-MFMA path
+# (bench.py keeps it as a `secondary` leg of the same workload so that both numbers are driver-timed).
+BX3 = [os.environ.get('NNR_BX3', '1') == '1']
 _BX3_MIN_ROWS = int(os.environ.get('NNR_BX3_MIN_ROWS', '2048'))
 _BX3_TILE = int(os.environ.get('NNR_BX3_TILE', '50'))          # A/B: 50 = 128 x 80 (2 workgroups / CU), 51 = 64 x 80 (3), 52 = 128 x 64, 53 = 256 x 80 (1)
+# shape classes the bf16x3 kernel takes (round 6: decided per class by same-box in-step A/Bs, profiles/r06_bx3_phases.md):
+#   dx   = long reductions (K >= 1024: the embedding-row gradient dX = dGates . W_ih, K = 2 NP = 1664)
+#   sue  = K >= 800 (the user encoder's 900 x 900 layers)
+#   proj = N >= 1024 (the LSTM input projection x . W_ih^T, N = 1664)
+#   gate = everything else (gate / attention projections, K, N = 200 .. 400)
+_BX3_CLASSES = set(c for c in os.environ.get('NNR_BX3_CLASSES', 'dx,sue,proj,gate').split(',') if c)
+
+
+def bx3_class(N, K):
+    if K >= 1024:
+        return 'dx'
+    if K >= 800:
+        return 'sue'
+    if N >= 1024:
+        return 'proj'
+    return 'gate'
+
+
 _B3 = {}
 BX3_SEEN = {}                                                  # diagnostics: (M, N, K, 'weight' | 'other') -> launches that met every other condition
 
@@ -498,12 +519,12 @@ def gemm(A, B, C_=None, *, M, N, K, lda, ldb, ldc=0, trans_a=False, trans_b=Fals
         slab = None
     if b3 is None and BX3[0] and tile in (0, 9, 15, 16) and _bx3_wanted(A, B, M, N, K, lda, ldb, trans_a, trans_b, a_idx, b_idx, c_idx, split_k, k_chunk, rowdot_w,
                                                                     colsum_out, atomic, batch, dyn_dim, drop):
-        # EXPERIMENTAL (NNR_BX3=1): this NT launch on the BF16 matrix pipe, weights pre-split.  Only when B IS a weight: a parameter or a
+        # (NNR_BX3, default on): this NT launch on the BF16 matrix pipe, weights pre-split.  Only when B IS a weight: a parameter or a
         # marked derived weight -- an activation buffer is rewritten through the C-ABI without any version bump, so its cached images would go stale
         is_w = isinstance(B, torch.nn.Parameter) or getattr(B, '_nnr_weight', False)
         key = (M, N, K, 'weight' if is_w else 'other')
         BX3_SEEN[key] = BX3_SEEN.get(key, 0) + 1
-        if is_w:
+        if is_w and bx3_class(N, K) in _BX3_CLASSES:
             b3 = bx3_images(B, N, K, ldb)
             tile = _BX3_TILE
             g.tile = _BX3_TILE
@@ -560,6 +581,7 @@ def gemm(A, B, C_=None, *, M, N, K, lda, ldb, ldc=0, trans_a=False, trans_b=Fals
             m, k = (min(M, d), K) if dyn_dim == 1 else (M, min(K, d))
         return 2.0 * m * N * k * max(1, batch) * flop_scale
     flops.dyn = [dyn] if dyn is not None else []
+    flops.scale = flop_scale                         # algorithmic / executed (padded gate columns): bench.py reports both sums
 
     def op_bytes(vals=None, M=M, N=N, K=K, dyn=dyn, dyn_dim=dyn_dim, batch=batch):
         # algorithmic HBM bytes of the launch: A and B read once, C written once (+ read when accumulated into), every extra
@@ -831,6 +853,7 @@ def _lstm_flops(items, H):
         tok = sum(float(vals[t.data_ptr()]) if vals is not None else float(t.item()) for t in totals)
         return tok * 2 * (2.0 * H * 4 * H)                                          # tokens x 2 directions x [1,H]x[H,4H]
     flops.dyn = totals
+    flops.scale = 4.0 * H / max(4 * H, -(-H // 16) * 64)      # the kernels multiply NP = ceil(H / 16) x 64 gate columns per direction (H = 200: 832 for 800)
     return flops
 
 

@@ -18,7 +18,7 @@ KERNEL_OF = {
     'gemm_nt_64x80k64': 'gemm_kernel<1, 5, false, false, 64>', 'gemm_nn_64x80k64': 'gemm_kernel<1, 5, false, true, 64>',
     'gemm_tn_64x80k64': 'gemm_kernel<1, 5, true, true, 64>',
     'gemm_nt_pipe128x80': 'gemm_nt_pipe_kernel<2, 5, 16, 3, 4, 0>', 'gemm_nt_pipe128x80s2': 'gemm_nt_pipe_kernel<2, 5, 16, 2, 5, 0>',
-    'gemm_nt_pipe3_128x80': 'gemm_nt_pipe3_kernel<2, 5, 2>', 'gemm_nt_pipe3_128x64': 'gemm_nt_pipe3_kernel<2, 4, 2>', 'gemm_nt_pipe3_128x160': 'gemm_nt_pipe3_kernel<2, 10, 1>',
+    'gemm_nt_bx3_128x80': 'gemm_nt_bx3_kernel<2, 5>', 'gemm_nt_bx3_64x80': 'gemm_nt_bx3_kernel<1, 5>',
     'gemm_nt_pipe2_128x80': 'gemm_nt_pipe2_kernel<2, 5, 3, 2>', 'gemm_nt_pipe2_128x64': 'gemm_nt_pipe2_kernel<2, 4, 3, 2>',
     'gemm_tn_pipe2_128x80': 'gemm_tn_pipe2_kernel<2, 5, 3, 3>', 'gemm_tn_pipe2_128x208': 'gemm_tn_pipe2_kernel<2, 13, 3, 2>', 'gemm_tn_pipe2_128x160': 'gemm_tn_pipe2_kernel<2, 10, 3, 2>', 'gemm_tn_pipe2_64x208': 'gemm_tn_pipe2_kernel<1, 13, 3, 2>',
     'gemm_tn_pipe128x80': 'gemm_tn_pipe_kernel<2, 5, 3, 3, 0>', 'gemm_tn_pipe128x208': 'gemm_tn_pipe_kernel<2, 13, 3, 2, 0>',
@@ -121,9 +121,11 @@ def summary(hbm=False):
     for family, fn, ms in _all_records():
         if bool(getattr(fn, 'hbm', False)) != bool(hbm):
             continue
-        d = fam.setdefault(family, dict(ms=0.0, flops=0.0, launches=0, bytes=0.0))
+        d = fam.setdefault(family, dict(ms=0.0, flops=0.0, launches=0, bytes=0.0, executed=0.0))
         d['ms'] += ms
-        d['flops'] += float(fn())
+        f = float(fn())
+        d['flops'] += f
+        d['executed'] += f / float(getattr(fn, 'scale', 1.0) or 1.0)
         d['launches'] += 1
         if hbm:
             d['bytes'] += _bytes_of(fn) or 0.0
@@ -322,6 +324,52 @@ def roofline(peak_tflops, sampled_steps=None, ms_per_step=None):
         # whole-step view: the launches of several HIP streams overlap, so per-kernel wall durations double-count the chip;
         # algorithmic FLOPs of all instrumented GEMM / recurrence launches of one step over the step time do not
         'hbm': hbm_roofline(),
+        # `gflop` = ALGORITHMIC work (hidden size 200: the launches over the padded gate columns -- NP = 832 per direction for 4 H = 800 --
+        # are counted at 800 / 832 of what they execute); `gflop_executed` = what the kernels multiply (round-5 verdict, item 4 iv)
         'step': (None if not (sampled_steps and ms_per_step) else (lambda tf: {'gflop': round(sum(v['flops'] for v in fam.values()) / sampled_steps / 1e9, 1),
-                 'tflops': round(tf, 2), 'frac': round(tf / peak_tflops, 4)})(sum(v['flops'] for v in fam.values()) / sampled_steps / (ms_per_step * 1e-3) / 1e12)),
+                 'tflops': round(tf, 2), 'frac': round(tf / peak_tflops, 4),
+                 'gflop_algorithmic': round(sum(v['flops'] for v in fam.values()) / sampled_steps / 1e9, 1),
+                 'gflop_executed': round(sum(v.get('executed', v['flops']) for v in fam.values()) / sampled_steps / 1e9, 1)})(
+                     sum(v['flops'] for v in fam.values()) / sampled_steps / (ms_per_step * 1e-3) / 1e12)),
     }
+
+
+def _kernel_stats_file():
+    """profiles/kernel_stats.json (tools/kernel_stats_json.py: the `rocprofv3 --kernel-trace --stats` tables of the headline command, in-step
+    and with every stream collapsed into one, stamped with the build id) if it belongs to THIS build, else (None, why)."""
+    import json
+    from . import _lib
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'kernel_stats.json')
+    try:
+        d = json.load(open(path))
+    except (OSError, ValueError):
+        return None, 'profiles/kernel_stats.json missing or unreadable'
+    have, now = d.get('build_id') or {}, _lib.build_id()
+    if have.get('src_sha256') == now['src_sha256'] or (have.get('lib_sha256') and have.get('lib_sha256') == now['lib_sha256']):
+        return d, 'build_id matches (%s)' % now['src_sha256']
+    return None, 'profiles/kernel_stats.json was collected on another build (%s, running %s): not quoted' % (have.get('src_sha256'), now['src_sha256'])
+
+
+def rocprof_block(roof, peak_tflops):
+    """`roofline.rocprof`: the dominant kernel's average launch duration from the committed rocprofv3 tables of the same command -- inside
+    the step (the launch shares the chip with up to four other HIP streams) and solo (NNR_ONE_STREAM=1) -- and the fractions of the fp32 MFMA
+    peak they give for the ALGORITHMIC FLOPs per launch measured live, so that `frac` can be reproduced from profiles/ (round-5 verdict:
+    0.178 in the line by HIP events that include queueing, 0.247 by rocprofv3's in-step average, 0.53 solo)."""
+    d, why = _kernel_stats_file()
+    out = {'source': 'profiles/kernel_stats.json <- rocprofv3 --kernel-trace --stats of `bench.py --steps 12 --warmup 4` (in_step) and the same under '
+                     'NNR_ONE_STREAM=1 (solo); ' + why}
+    if d is None or not roof or not roof.get('launches'):
+        out.update(in_step_avg_us=None, solo_avg_us=None, frac_in_step=None, frac_solo=None)
+        return out
+    kern = roof['kernel']
+    gflop_per_launch = roof['achieved'] * roof['avg_launch_us'] * 1e-3            # TFLOP/s x us = MFLOP -> x 1e-3 = GFLOP
+    ins = (d.get('in_step') or {}).get(kern)
+    solo = (d.get('solo') or {}).get(kern)
+    out['kernel'] = kern
+    out['gflop_per_launch_live'] = round(gflop_per_launch, 3)
+    out['in_step_avg_us'] = None if not ins else ins['avg_us']
+    out['solo_avg_us'] = None if not solo else solo['avg_us']
+    out['frac_in_step'] = None if not ins else round(gflop_per_launch / (ins['avg_us'] * 1e-6) / 1e3 / peak_tflops, 4)
+    out['frac_solo'] = None if not solo else round(gflop_per_launch / (solo['avg_us'] * 1e-6) / 1e3 / peak_tflops, 4)
+    return out
+

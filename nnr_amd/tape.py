@@ -23,7 +23,7 @@ from . import profile as _prof
 MASK64 = (1 << 64) - 1
 # entry points that are host-side queries / set-up (no stream argument): passed through, never recorded
 _PASS = {'nnr_version', 'nnr_lstm_dims', 'nnr_lstm_sync_bytes', 'nnr_lstm_sync_diag_offset', 'nnr_lstm_set_timeout_counter',
-         'nnr_slot_workspace_floats', 'nnr_dp_unique_id', 'nnr_dp_init', 'nnr_dp_destroy', 'nnr_adam_skipped_steps', 'nnr_adam_skipped_peek',
+         'nnr_slot_workspace_floats', 'nnr_dp_unique_id', 'nnr_dp_init', 'nnr_dp_destroy', 'nnr_dp_emulate_ranks', 'nnr_adam_skipped_steps', 'nnr_adam_skipped_peek',
          'nnr_token_sort_workspace_bytes', 'nnr_embed_scatter_sorted_workspace_floats'}
 _INT_TYPES = (C.c_int, C.c_long, C.c_size_t, C.c_uint32, C.c_ulong, C.c_int64, C.c_uint64)
 ACTIVE = [None]            # the tape that is recording right now

@@ -94,7 +94,7 @@ class _Const:
 
     def __init__(self, fn, value):
         self.value = value
-        for k in ('tag', 'tn_dims', 'op_bytes', 'hbm'):
+        for k in ('tag', 'tn_dims', 'op_bytes', 'hbm', 'scale'):
             if hasattr(fn, k):
                 setattr(self, k, getattr(fn, k))
 

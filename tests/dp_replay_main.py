@@ -1,0 +1,137 @@
+#!/usr/bin/env python3
+"""One-GPU check of the gradient exchange over REPLAYED steps with the C-ABI RCCL binding (reference: DistributedDataParallel's
+all-reduce inside every backward pass, trainer.py:212-219,297).  RCCL refuses two ranks on one device, so the communicator has ONE rank
+and `nnr_dp_emulate_ranks(ctx, 2)` makes every all-reduce return 2 x the local buffer (= two ranks holding identical shards; exact in
+fp32).  The learning rate is 0, so the parameters never move and every step's gradient can be compared with an exchange-free trainer
+on the same batches: EVERY span of the flat gradient (early = user encoder, table = word embedding, late = the rest) must be exactly
+2 x the local gradient on EVERY step -- eager, recorded and replayed.  A bucket the replay forgets to exchange shows as 1 x.
+
+    dp_replay_main.py <touched: 0|1|flip> [native|torch] [--replays 4]
+
+`flip`: the form is decided by rule per step, and the rule is replaced by "touched rows iff per-GPU batch <= 4": the batch-8 tape is
+recorded DENSE, the odd-shaped (batch 4) eager step in between leaves the exchange in touched-row form, and the replays after it must
+still run the recorded form (round-5 advisor, medium).  Binding `torch` (torch.distributed's all_reduce, host callbacks between tape
+segments): a one-rank sum is the identity, so there the check is the SEQUENCE of exchange calls per step (same for every batch-8 step).
+
+Prints one JSON line.  (Round-5 advisor, high: with the touched-row exchange -- the default by rule at per-GPU batch <= 16 -- and the
+native binding, the table bucket was left un-reduced from the second replay on.)"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+touched = sys.argv[1] if len(sys.argv) > 1 else '1'
+binding = sys.argv[2] if len(sys.argv) > 2 and sys.argv[2] in ('native', 'torch') else 'native'
+replays = int(sys.argv[sys.argv.index('--replays') + 1]) if '--replays' in sys.argv else 4
+os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=os.environ.get('MASTER_PORT', '29541'),
+                  NNR_DP_FORCE='1', NNR_DP_NATIVE='1' if binding == 'native' else '0')
+if touched in ('0', '1'):
+    os.environ['NNR_DP_TOUCHED_ROWS'] = touched
+else:
+    os.environ.pop('NNR_DP_TOUCHED_ROWS', None)
+import numpy as np
+import torch
+import torch.distributed as dist
+from nnr_amd import _lib as L, dp
+from nnr_amd.config import make_config
+from nnr_amd.model import Model
+from nnr_amd.synth import SynthSpec, SynthCorpus, to_torch
+from nnr_amd.trainer import Trainer
+
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', init_method='env://', world_size=1, rank=0)
+B, V = 8, 3000
+cfg = make_config(['--news_encoder=CNE', '--user_encoder=SUE', '--dataset=200k', '--batch_size=%d' % B, '--lr=0'],
+                  corpus_sizes=dict(vocabulary_size=V), dropout_rate=0.0, tie_order='stable')
+corpus = SynthCorpus(SynthSpec(vocabulary_size=V, news_pool=1500))
+rng = np.random.default_rng(7)
+batches = [to_torch(corpus.batch(B, rng), 'cuda') for _ in range(4)]
+# a second batch shape (the epoch's last partial batch): run EAGERLY between the replays of the first shape -- under `auto` its
+# begin_step may flip the exchange's form, which must not leak into the recorded tape's callbacks (round-5 advisor, medium)
+odd = to_torch(corpus.batch(B // 2, rng), 'cuda')
+
+
+def build():
+    torch.manual_seed(0)
+    m = Model(cfg)
+    m.initialize()
+    with torch.no_grad():
+        for p in m.parameters():                 # proxy nodes / M biases are zero at init: make every path carry signal
+            if float(p.abs().max()) == 0.0:
+                p.normal_(0, 0.05)
+    return m.cuda().train()
+
+
+tr = Trainer(build(), cfg)
+ex = tr.exchange
+assert ex.active() and ex.early_span is not None and ex.table_span is not None
+factor = 1.0
+if binding == 'native':
+    nx = dp._native_exchange()
+    assert nx is not None, 'the C-ABI binding did not come up: %s' % dp._native_state
+    L.check(L.lib().nnr_dp_emulate_ranks(nx.ctx, 2), 'nnr_dp_emulate_ranks')
+    factor = 2.0
+else:
+    assert dp._native_exchange() is None
+if touched == 'flip':
+    ex._rule = lambda b: b <= 4
+# the sequence of exchange calls the HOST makes per step (host callbacks of a replay re-run them; recorded calls do not appear)
+calls = []
+_rows, _red = ex.table_rows_exchange, ex._reduce
+ex.table_rows_exchange = lambda: (calls.append('rows'), _rows())[1]
+ex._reduce = lambda view, async_op: (calls.append(int(view.numel())), _red(view, async_op))[1]
+os.environ['NNR_DP_FORCE'] = '0'
+ref = Trainer(build(), cfg)
+ref.exchange.force = False
+assert not ref.exchange.active()
+
+spans = {'early': ex.early_span, 'table': ex.table_span}
+late = ex.late_spans
+steps = []
+n_steps = 3 + replays
+paths = []
+worst = {'early': 0.0, 'table': 0.0, 'late': 0.0}
+ok = True
+for i in range(n_steps):
+    b = batches[i % 4]
+    del calls[:]
+    tr.train_step(b)
+    paths.append(tr.last_path)
+    got = tr.flat.grad.clone()
+    ref.train_step(b)
+    want = ref.flat.grad.clone() * factor
+    torch.cuda.synchronize()
+    scale = float(want.abs().max())
+    # (the packed-row all-reduce's size is the step's union of touched rows: batch dependent -> only its presence is compared)
+    row = {'step': i, 'path': tr.last_path, 'host_exchange_calls': ['rows' if c == 'rows' else ('packed' if 'rows' in calls and c % 300 == 0 and c < V * 300 else c) for c in calls]}
+    for name, (a, z) in list(spans.items()) + [('late', s) for s in late]:
+        d = float((got[a:z] - want[a:z]).abs().max()) / scale
+        one_x = float((got[a:z] - want[a:z] / factor).abs().max()) / scale    # what an un-exchanged bucket would look like
+        row[name] = max(row.get(name, 0.0), d)
+        worst[name] = max(worst[name], d)
+        if d > 1e-6:
+            ok = False
+            row[name + '_looks_unexchanged'] = bool(factor > 1 and one_x < 1e-6)
+    steps.append(row)
+    if i == n_steps - 2:
+        # an eager step of ANOTHER batch shape between two replays
+        tr.train_step(odd)
+        ref.train_step(odd)
+        got, want = tr.flat.grad.clone(), ref.flat.grad.clone() * factor
+        torch.cuda.synchronize()
+        d = float((got - want).abs().max()) / float(want.abs().max())
+        steps.append({'step': 'odd-shaped eager step', 'path': tr.last_path, 'all': d})
+        ok = ok and d <= 1e-6
+tape = next(iter(tr.tapes.values())) if tr.tapes else None
+# every replay of the batch-8 tape makes the same host-side exchange calls as the step that recorded it
+rec = [r for r in steps if r.get('path') == 'record']
+rep = [r for r in steps if r.get('path') == 'replay']
+same_calls = bool(rec) and all(r['host_exchange_calls'] == rec[0]['host_exchange_calls'] for r in rep)
+ok = ok and same_calls
+out = {'ok': bool(ok and paths.count('replay') >= replays), 'touched_mode': touched, 'replays_make_the_recorded_steps_host_calls': same_calls, 'touched_form_used': bool(ex.touched), 'paths': paths,
+       'worst_rel_diff_vs_2x_local': worst, 'steps': steps, 'binding': ex.describe()['binding'],
+       'tape_segments': tape.info()['segments'] if tape is not None else None,
+       'touched_rows_last_step': ex.last_touched}
+print(json.dumps(out))
+dist.destroy_process_group()
+sys.exit(0 if out['ok'] else 1)

@@ -99,6 +99,28 @@ def test_rccl_all_visible_gpus():
     assert out['binding'].startswith('C-ABI nnr_dp_allreduce')             # the default binding of an RCCL job
 
 
+@pytest.mark.parametrize('touched,binding', [('1', 'native'), ('flip', 'native'), ('flip', 'torch')])
+def test_exchange_over_replayed_steps_on_an_emulated_two_rank_communicator(touched, binding):
+    """Round-5 advisor (high + medium): tests/dp_replay_main.py.  C-ABI binding + touched-row exchange: every span of the gradient is
+    exactly 2 x the local one on the eager, the recorded and FOUR replayed steps (the table bucket used to stay un-reduced from the second
+    replay on); `flip`: an eager step of another batch shape changes the exchange's form between two replays of a tape recorded with the
+    other form -- the replays keep the recorded form (same host-side exchange calls as the recording step), under both bindings."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'NNR_DP_NATIVE', 'NNR_DP_TOUCHED_ROWS', 'NNR_DP_FORCE')}
+    env['MASTER_PORT'] = str(29541 + 3 * (binding == 'torch') + (touched == 'flip'))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'dp_replay_main.py'), touched, binding], capture_output=True, text=True, env=env, timeout=600)
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert lines, (r.stdout[-2000:], r.stderr[-4000:])
+    out = json.loads(lines[-1])
+    print({k: v for k, v in out.items() if k != 'steps'})
+    assert r.returncode == 0 and out['ok'], out
+    assert out['paths'].count('replay') >= 4 and out['replays_make_the_recorded_steps_host_calls']
+    assert max(out['worst_rel_diff_vs_2x_local'].values()) <= 1e-6
+    assert out['binding'].startswith('C-ABI nnr_dp_allreduce' if binding == 'native' else 'torch.distributed all_reduce')
+    if touched == '1':
+        assert out['touched_rows_last_step'] is not None and 0 < out['touched_rows_last_step'][0] <= 3000
+        assert out['tape_segments'] > 1            # the touched-row form needs the host once per step: host callbacks between segments
+
+
 def test_pair_recurrence_beside_resident_ring_kernels():
     """Round-4 verdict, item 6a: the CU-pair recurrence needs both workgroups of a pair resident at once; a one-rank communicator's
     all-reduce is a copy, not RCCL's ring kernels that HOLD CU slots for the whole collective.  Here 48 resident 512-thread workgroups

@@ -229,7 +229,7 @@ def test_gemm_persistent_nt_tiles(tile, M, N, K):
 
 @pytest.mark.parametrize('M,N,K', [(70000, 400, 400), (33000, 1664, 300), (5000, 200, 200), (4352, 900, 900), (300, 84, 96), (129, 400, 104), (2500, 300, 1664)])
 def test_gemm_bf16x3_experimental_tile(M, N, K):
-    """EXPERIMENTAL tile 50 (csrc/gemm.hip: gemm_nt_bx3_kernel; off by default, NNR_BX3=1): the NT product on the BF16 matrix pipe as six exact
+    """Tile 50 (csrc/gemm.hip: gemm_nt_bx3_kernel; the default matrix path of weight-operand NT launches since round 6, NNR_BX3=0 turns it off): the NT product on the BF16 matrix pipe as six exact
     bf16 x bf16 products with fp32 accumulation, weights pre-split by nnr_split_bf16x3.  The split is EXACT (w == image0 + image1 + image2 bit for
     bit), the product is at least as close to fp64 as the fp32-MFMA kernel's, and every element-wise epilogue / dynamic M / k-tail / ragged
     edge behaves as in the other NT kernels."""
@@ -266,6 +266,83 @@ def test_gemm_bf16x3_experimental_tile(M, N, K):
     assert bool((out[used:] == 7.0).all())
     with pytest.raises(Exception):                              # without the pre-split weights the tile is refused
         ops.gemm(a, b, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, tile=50)
+
+
+def test_gemm_bf16x3_edge_values():
+    """The bf16x3 matrix path (default since round 6) on inputs a normal(0, sigma) test never produces (round-5 verdict):
+      * magnitudes mixed over 1e-20 .. 1e20 inside one dot product;  * catastrophic cancellation (pairs +x, -x (1 - 2^-20): the sum is 2^-20 of the
+        terms);  * fp32 denormals;  * values at and next to FLT_MAX (a bf16 ROUNDING of them is +-Inf: the split truncates there and stays exact);
+      * +-Inf / NaN: every output they reach is non-finite (+-Inf or NaN), every other output is untouched -- non-finite never becomes finite.
+    Error measure: |got - fp64| <= bound x sum_k |a_k b_k| (the forward error bound of any dot product), with the fp32-MFMA kernel as the yardstick."""
+    from nnr_amd import ops
+    d = dev()
+    M, N, K = 4096, 160, 256
+    g = torch.Generator().manual_seed(11)
+
+    def run(a, b, tile_ref=15):
+        a, b = a.to(d).contiguous(), b.to(d).contiguous()
+        img, stride, ldo = ops.bx3_images(b, N, K, K)
+        bf = img.view(torch.bfloat16).float()
+        fin = torch.isfinite(b)
+        assert torch.equal(((bf[0] + bf[1]) + bf[2])[:, :K][fin], b[fin]), 'the split of a finite fp32 value must be exact'
+        out, ref = torch.empty(M, N, device=d), torch.empty(M, N, device=d)
+        ops.gemm(a, b, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, tile=50, b3=(img, stride, ldo))
+        ops.gemm(a, b, ref, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, tile=tile_ref)
+        return out.cpu().double(), ref.cpu().double()
+
+    def check(a, b, what):
+        out, ref = run(a, b)
+        full = a.double() @ b.double().t()
+        scale = a.double().abs() @ b.double().abs().t()
+        e50 = float(((out - full).abs() / scale.clamp_min(1e-300)).max())
+        e15 = float(((ref - full).abs() / scale.clamp_min(1e-300)).max())
+        assert bool(torch.isfinite(out).all()), what
+        assert e50 <= max(1.05 * e15, 2.0 ** -22), (what, e50, e15)        # (2^-22: a few fp32 roundings of the accumulated sum)
+        return e50, e15
+
+    # 1. mixed magnitudes: exponents uniform over +-20 decades, per element
+    a = torch.randn(M, K, generator=g) * 10.0 ** (torch.rand(M, K, generator=g) * 40 - 20)
+    b = torch.randn(N, K, generator=g) * 10.0 ** (torch.rand(N, K, generator=g) * 30 - 15)
+    check(a, b, 'mixed magnitudes')
+    # 2. catastrophic cancellation: columns 2j, 2j + 1 hold +x and -x (1 - 2^-20) against equal weights
+    x = torch.randn(M, K // 2, generator=g)
+    a = torch.stack([x, -x * (1 - 2.0 ** -20)], dim=2).reshape(M, K)
+    w = torch.randn(N, K // 2, generator=g)
+    b = torch.stack([w, w], dim=2).reshape(N, K)
+    e50, e15 = check(a, b, 'cancellation')
+    out, _ = run(a, b)
+    full = a.double() @ b.double().t()
+    assert float((out - full).norm() / full.norm()) <= 2e-2          # the RESULT (2^-20 of the terms) still has ~6 of its bits right in fp32 arithmetic
+    # 3. denormals (and a few normal values so the result is not all-zero)
+    a = torch.randn(M, K, generator=g) * 1e-39
+    a[:, ::7] = torch.randn(M, (K + 6) // 7, generator=g)
+    b = torch.randn(N, K, generator=g)
+    b[:, 1::5] *= 1e-40
+    check(a, b, 'denormals')
+    # 4. at and next to FLT_MAX: one huge value per row against weights <= 2^-8 so that the exact result stays finite
+    big = torch.tensor([3.4028234663852886e38, 3.3895313892515355e38, 3.3961775292304325e38, -3.4028234663852886e38])      # FLT_MAX, bf16 max, bf16 max + half ulp, -FLT_MAX
+    a = torch.randn(M, K, generator=g)
+    a[:, 3] = big[torch.arange(M) % 4]
+    b = torch.randn(N, K, generator=g) * 2.0 ** -9
+    check(a, b, 'near FLT_MAX')
+    # ... and huge WEIGHTS (the pre-split side)
+    a = torch.randn(M, K, generator=g) * 2.0 ** -9
+    b = torch.randn(N, K, generator=g)
+    b[:, 5] = big[torch.arange(N) % 4]
+    check(a, b, 'near FLT_MAX weights')
+    # 5. non-finite: rows 0 / 1 / 2 of A carry +Inf / -Inf / NaN, column 7 of the weights carries +Inf in row 3
+    a = torch.randn(M, K, generator=g)
+    b = torch.randn(N, K, generator=g)
+    a[0, 10], a[1, 11], a[2, 12] = float('inf'), float('-inf'), float('nan')
+    b[3, 7] = float('inf')
+    out, ref = run(a, b)
+    bad = torch.zeros(M, N, dtype=torch.bool)
+    bad[:3, :] = True
+    bad[:, 3] = True
+    assert not bool(torch.isfinite(out[bad]).any()), 'a non-finite operand must give a non-finite value in every output it reaches'
+    assert not bool(torch.isfinite(ref[bad]).any())                  # (the fp32-MFMA kernel: +-Inf or NaN there)
+    full = torch.nan_to_num(a, nan=0.0, posinf=0.0, neginf=0.0).double() @ torch.nan_to_num(b, posinf=0.0).double().t()
+    assert bool(torch.isfinite(out[~bad]).all()) and float((out[~bad] - full[~bad]).abs().max()) <= 1e-4
 
 
 def test_gemm_nn_accumulate_and_tn_splitk_dyn():

@@ -51,11 +51,70 @@ def test_roofline_arithmetic_and_dominant_family(records):
     assert list(r['families']) == ['gemm_tn_pipe2_64x208', 'gemm_nt_pipe2_128x80', 'lstm_bwd']                # by time, descending
     assert r['families']['gemm_nt_pipe2_128x80'] == {'ms': 0.3, 'tflops': 30.0, 'launches': 1}
     total = 2 * f + 9.0e9 + 3.4e10
-    assert r['step'] == {'gflop': round(total / 1e9, 1), 'tflops': round(total / 2.0e-3 / 1e12, 2), 'frac': round(total / 2.0e-3 / 1e12 / PEAK, 4)}
+    assert r['step'] == {'gflop': round(total / 1e9, 1), 'tflops': round(total / 2.0e-3 / 1e12, 2), 'frac': round(total / 2.0e-3 / 1e12 / PEAK, 4),
+                         'gflop_algorithmic': round(total / 1e9, 1), 'gflop_executed': round(total / 1e9, 1)}
     assert r['algorithmic_bytes_per_launch'] == round((records['K'] * (records['M'] + records['N']) + records['M'] * records['N']) * 4.0)
     # operand bytes of the token reduction alone (what the counter traffic of a weight-gradient family is compared with)
     tn = profile.tn_operand_bytes()['gemm_tn_pipe2_64x208']
     assert tn['launches'] == 2 and tn['bytes'] == pytest.approx(2 * records['K'] * (records['M'] + records['N']) * 4.0)
+
+
+def test_executed_flops_beside_the_algorithmic_ones(records):
+    """A launch over padded gate columns (NP = 832 for 4 H = 800) carries scale = 800 / 832: `gflop` / `gflop_algorithmic` count the hidden
+    size the model has, `gflop_executed` what the kernel multiplies (round-5 verdict, item 4 iv)."""
+    f = _fn(8.0e9)
+    f.scale = 800.0 / 832.0
+    profile.TAPE_RECORDS.append(('gemm_nt_bx3_128x80', f, 0.1))
+    r = profile.roofline(PEAK, sampled_steps=1, ms_per_step=2.0)
+    total = 2 * records['tn_flops'] + 9.0e9 + 3.4e10 + 8.0e9
+    assert r['step']['gflop_algorithmic'] == r['step']['gflop'] == round(total / 1e9, 1)
+    assert r['step']['gflop_executed'] == round((total + 8.0e9 * (832.0 / 800.0 - 1.0)) / 1e9, 1)
+    assert profile.KERNEL_OF['gemm_nt_bx3_128x80'] == 'gemm_nt_bx3_kernel<2, 5>'
+
+
+def test_rocprof_block_reproduces_frac_from_the_committed_tables(records, monkeypatch, tmp_path):
+    """`roofline.rocprof` = {in_step_avg_us, solo_avg_us, frac_in_step, frac_solo}: the dominant kernel's rocprofv3 averages from
+    profiles/kernel_stats.json (build-id gated, like the counter traffic) against the algorithmic FLOPs per launch measured live."""
+    r = profile.roofline(PEAK, sampled_steps=1, ms_per_step=2.0)
+    d = json.load(open(os.path.join(ROOT, 'profiles', 'kernel_stats.json')))
+    assert set(d['build_id']) == {'src_sha256', 'lib_sha256'} and len(d['in_step']) >= 20 and len(d['solo']) >= 20
+    kern = r['kernel']
+    assert kern in d['in_step'] and kern in d['solo']
+    monkeypatch.setattr(_lib, 'build_id', lambda: {'src_sha256': 'x' * 16, 'lib_sha256': 'y' * 16})
+    b = profile.rocprof_block(r, PEAK)
+    assert b['in_step_avg_us'] is None and b['frac_solo'] is None and 'collected on another build' in b['source']
+    monkeypatch.setattr(_lib, 'build_id', lambda: d['build_id'])
+    b = profile.rocprof_block(r, PEAK)
+    g = records['tn_flops'] / 1e9                                  # GFLOP per launch of the dominant family
+    assert b['kernel'] == kern and b['gflop_per_launch_live'] == pytest.approx(g, rel=1e-3)
+    assert b['in_step_avg_us'] == d['in_step'][kern]['avg_us'] and b['solo_avg_us'] == d['solo'][kern]['avg_us']
+    assert b['frac_in_step'] == pytest.approx(g / (b['in_step_avg_us'] * 1e-6) / 1e3 / PEAK, rel=2e-3)
+    assert b['frac_solo'] == pytest.approx(g / (b['solo_avg_us'] * 1e-6) / 1e3 / PEAK, rel=2e-3)
+    assert b['frac_solo'] > b['frac_in_step'] > 0
+
+
+def test_bench_line_carries_the_round6_keys():
+    """Shape of what bench.py adds in round 6 (no GPU: the helpers only): config.matrix_path names the split and the pure-f32 leg; the
+    N > 1 line quotes the batch-sweep ceiling; secondary legs exist for every other BASELINE config + the pure fp32-MFMA leg."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from nnr_amd import ops
+    mp = bench.matrix_path(ops, {(450560, 400, 400, 'weight'): 2})
+    if ops.BX3[0]:
+        assert 'bf16x3' in mp['nt_weight_gemms'] and mp['pure_f32_leg'] == 'secondary.f32_mfma_only_cne_sue_b64' and mp['launch_classes'] == {'450560x400x400 weight': 2}
+    else:
+        assert mp['nt_weight_gemms'] == 'v_mfma_f32_16x16x4_f32'
+    assert mp['weight_gradient_gemms'] == 'v_mfma_f32_16x16x4_f32'
+    assert [l[0] for l in bench.SECONDARY_LEGS] == ['mhsa_mhsa_b64', 'cne_sue_shard_b8', 'cne_sue_large_shard_b16_v130000']
+    assert [l[0] for l in bench.F32_ONLY_LEGS] == ['f32_mfma_only_cne_sue_b64']
+    c = bench.scaling_ceiling(8, 64)
+    sweep = json.load(open(os.path.join(ROOT, 'profiles', 'batch_sweep.json')))
+    assert c['per_gpu_batch'] == 8 and c['one_gpu_ms_per_step_at_that_batch'] == sweep['ms_per_step']['8']
+    assert c['value_ceiling'] == round(64 / sweep['ms_per_step']['8'] * 1000.0, 1)
+    a = bench.parse(['--roofline_every', '7'])
+    assert a.roofline_steps == 2                                   # the timed window carries no events; two extra steps after it do
 
 
 def test_counter_traffic_is_quoted_only_for_the_build_it_was_collected_on(records, monkeypatch):

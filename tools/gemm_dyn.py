@@ -4,7 +4,7 @@ import torch
 from nnr_amd import ops
 from tools.gemm_bench import timeit
 d = torch.device('cuda')
-cap, live, E, NP2 = 409600, 131072, 300, 1664
+cap, live, E, NP2 = 450560, 80000, 300, 1664
 x = torch.randn(cap, E, device=d); w = torch.randn(NP2, E, device=d) * 0.05; out = torch.empty(cap, NP2, device=d)
 dyn = torch.tensor([live], device=d, dtype=torch.int32)
 fl = 2.0 * live * NP2 * E
