@@ -1554,8 +1554,9 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 //  * +-Inf / NaN: first image = the value itself (NaN canonical), the other two 0.  Every output a non-finite operand reaches is NON-FINITE (Inf x b1
 //    is +-Inf, Inf x b2 has b2's sign: the partial sums meet as +-Inf or as Inf - Inf = NaN), as with the fp32 MFMA -- but WHICH of +-Inf / NaN is
 //    not kept (the training step only asks "is the gradient norm finite", nnr_clip_adam);
-//  * fp32 denormals: their images are bf16 denormals; the matrix pipe treats them as the fp32 MFMA treats denormal inputs to within 2^-126 of the
-//    operands' scale (far below any fp32 rounding of the sum).
+//  * tiny values: the three images are exact while the third image's last bit (2^-24 |x|) is representable, i.e. |x| >= 2^-109; below that the
+//    bits under bf16's smallest subnormal (2^-133) underflow -- absolute error <= 2^-133 per operand, five decades below fp32's smallest
+//    normal value (fp32 denormals themselves are of that size).
 __device__ __forceinline__ void split3_bf16(float x, __bf16& h1, __bf16& h2, __bf16& h3) {
   const unsigned u = __builtin_bit_cast(unsigned, x), mag = u & 0x7fffffffu;
   const bool big = mag >= 0x7f7f8000u, nonfinite = mag >= 0x7f800000u;
@@ -1577,6 +1578,37 @@ __global__ void split_bf16x3_kernel(const float* __restrict__ w, int rows, int c
 }
 __device__ __forceinline__ int bx3_swzA(int r) { return ((r >> 1) & 1) | (((r >> 3) & 1) << 2); }      // 128-B fp32 rows, two b128 reads per lane (brute-force checked)
 __device__ __forceinline__ int bx3_swzB(int r) { return (r >> 1) & 3; }                                  // 64-B bf16 rows, one b128 read per lane
+
+// In-loop split of the ACTIVATION operand (round 6).  The round-5 form (three round-to-nearest conversions per value + the edge guards of split3_bf16)
+// compiled to ~330 vector instructions per stage and wave beside 60 MFMAs: the kernel was bound by its VALU work (2 waves per SIMD x (960 MFMA
+// cycles + ~1300 VALU cycles) = the measured ~3 100 cycles per stage), 120 TF-equivalent at the step's shapes where the micro-benchmark had shown 160.
+// Here the images are taken by TRUNCATION, which needs no conversion and no guard: image 1 = the high 16 bits of the fp32 word (one v_perm_b32 packs
+// two of them), remainder = x - image1 exactly (one v_pk_add_f32 for two values), image 2 = the high 16 bits of the remainder, image 3 = the high 16
+// bits of the second remainder (<= 8 significant bits: exact).  x = a1 + a2 + a3 exactly as before (8 + 8 + 8 bits); |a1| <= |x|, so nothing ever
+// rounds up to Inf (FLT_MAX included); +-Inf -> (Inf, NaN, NaN) and NaN -> non-finite images: non-finite in, non-finite out.  9 instructions per two
+// values.  The dropped terms (a2 b3 + a3 b2 + a3 b3) stay below 2^-22 |a b| with the weights' images rounded to nearest (zero-mean in b2, b3).
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned hi16_pair(float odd, float even) {     // {high 16 bits of odd : high 16 bits of even}
+  return __builtin_amdgcn_perm(__float_as_uint(odd), __float_as_uint(even), 0x07060302u);
+}
+__device__ __forceinline__ void split3_trunc8(const f32x4& x0, const f32x4& x1, bf16x8_t& a1, bf16x8_t& a2, bf16x8_t& a3) {
+  // (scalars only: with the pair held as an ext_vector and its elements bit-cast one by one, hipcc 7.0 fed the SAME register to both
+  //  sources of v_perm_b32 -- every odd element became a copy of its even neighbour)
+  const float xs[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+  unsigned w1[4], w2[4], w3[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const float xe = xs[2 * p], xo = xs[2 * p + 1];
+    const unsigned h1 = hi16_pair(xo, xe);
+    const float re = xe - __uint_as_float(h1 << 16), ro = xo - __uint_as_float(h1 & 0xffff0000u);
+    const unsigned h2 = hi16_pair(ro, re);
+    const float se = re - __uint_as_float(h2 << 16), so = ro - __uint_as_float(h2 & 0xffff0000u);
+    w1[p] = h1; w2[p] = h2; w3[p] = hi16_pair(so, se);
+  }
+  a1 = __builtin_bit_cast(bf16x8_t, u32x4_t{w1[0], w1[1], w1[2], w1[3]});
+  a2 = __builtin_bit_cast(bf16x8_t, u32x4_t{w2[0], w2[1], w2[2], w2[3]});
+  a3 = __builtin_bit_cast(bf16x8_t, u32x4_t{w3[0], w3[1], w3[2], w3[3]});
+}
 
 template <int TM, int TN>
 __global__ __launch_bounds__(256, (TM >= 4 ? 1 : 2)) void gemm_nt_bx3_kernel(nnr_gemm_args g) {
@@ -1603,40 +1635,49 @@ __global__ __launch_bounds__(256, (TM >= 4 ? 1 : 2)) void gemm_nt_bx3_kernel(nnr
   const unsigned lds_base = (unsigned)(uintptr_t)lds_raw;
   const float* zero = nnr_zero_page;
   asm volatile("" : "+s"(zero));
-  const float* __restrict__ A = g.A;
-  const __bf16* __restrict__ B3 = reinterpret_cast<const __bf16*>(g.B3);
   // wave w issues the A instructions w, w + 4, ... (8 tile rows of 128 B each) and the B instructions idx = w, w + 4, ... of the 3 NIB1
-  // (16 rows of 64 B of one image each)
+  // (16 rows of 64 B of one image each).  Per lane and instruction a CONSTANT byte offset from a wave-uniform stage base (SGPR), as in
+  // gemm_nt_pipe2_kernel: a full stage is issued without any vector ALU work; only a k-tail stage (K % 32 != 0) selects the zero page per lane.
   constexpr int NA = NIA / 4, NBW = (3 * NIB1 + 3) / 4;
-  const char* asrc[NA];
-  int akc[NA];
+  static_assert(NA <= 8 && NBW <= 8, "tile shape");
+  unsigned voffA[8], voffB[8];
+  int akc[NA], bkc[NBW];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) voffA[i] = voffB[i] = 0;
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     const int row = (w + 4 * i) * 8 + lane / 8, c = (lane % 8) ^ bx3_swzA(row & 15);
     akc[i] = 4 * c;
-    asrc[i] = reinterpret_cast<const char*>(A + (long)min(m0 + row, M - 1) * g.lda + 4 * c);        // rows past the edge: clamped, never stored
+    voffA[i] = (unsigned)(((long)min(row, M - 1 - m0) * g.lda + 4 * c) * 4);          // rows past the edge: clamped, never stored
   }
-  const char* bsrc[NBW];
-  int bkc[NBW];
-  bool bon[NBW];
 #pragma unroll
   for (int j = 0; j < NBW; ++j) {
-    const int idx = w + 4 * j;
-    bon[j] = idx < 3 * NIB1;
-    const int img = bon[j] ? idx / NIB1 : 0, jj = idx - img * NIB1, row = jj * 16 + lane / 4, c = (lane % 4) ^ bx3_swzB(row & 15);
+    const int idx = min(w + 4 * j, 3 * NIB1 - 1);
+    const int img = idx / NIB1, jj = idx - img * NIB1, row = jj * 16 + lane / 4, c = (lane % 4) ^ bx3_swzB(row & 15);
     bkc[j] = 8 * c;
-    bsrc[j] = reinterpret_cast<const char*>(B3 + (long)img * g.b3_stride + (long)min(n0 + row, N - 1) * g.ldb3 + 8 * c);
+    voffB[j] = (unsigned)(((long)img * g.b3_stride + (long)min(row, N - 1 - n0) * g.ldb3 + 8 * c) * 2);
   }
-  const bool full = w < (3 * NIB1) % 4 || (3 * NIB1) % 4 == 0;       // this wave has NBW (else NBW - 1) B instructions
+  const float* Abase = g.A + (long)m0 * g.lda;                                          // wave-uniform stage bases
+  const char* Bbase = reinterpret_cast<const char*>(reinterpret_cast<const __bf16*>(g.B3) + (long)n0 * g.ldb3);
+  const bool nb_hi = ((3 * NIB1) % 4 == 0) || (w < (3 * NIB1) % 4);                     // this wave has NBW (else NBW - 1) B instructions
+  const bool ktail = (K % BK) != 0;
   auto issue = [&](int s) __attribute__((always_inline)) {
     const int k0 = s * BK;
-    const unsigned sb = lds_base + (unsigned)((s % NS) * STAGE_BYTES);
+    const unsigned sb = lds_base + (unsigned)((s % NS) * STAGE_BYTES) + (unsigned)(w * 1024);
+    if (!(ktail && s == S - 1)) {
+      lds_dma16_block<NA>(Abase + k0, sb, voffA);
+      const float* bb = reinterpret_cast<const float*>(Bbase + 2L * k0);
+      if (nb_hi) lds_dma16_block<NBW>(bb, sb + A_BYTES, voffB);
+      else if constexpr (NBW > 1) lds_dma16_block<NBW - 1>(bb, sb + A_BYTES, voffB);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < NA; ++i)
-      lds_dma16((k0 + akc[i] < K) ? reinterpret_cast<const float*>(asrc[i] + (long)k0 * 4) : zero, sb + (unsigned)((w + 4 * i) * 1024));
+      lds_dma16((k0 + akc[i] < K) ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(Abase + k0) + voffA[i]) : zero, sb + (unsigned)(i * 4096));
 #pragma unroll
     for (int j = 0; j < NBW; ++j)
-      if (bon[j]) lds_dma16((k0 + bkc[j] < K) ? reinterpret_cast<const float*>(bsrc[j] + (long)k0 * 2) : zero, sb + A_BYTES + (unsigned)((w + 4 * j) * 1024));
+      if (j < NBW - 1 || nb_hi)
+        lds_dma16((k0 + bkc[j] < K) ? reinterpret_cast<const float*>(Bbase + 2L * k0 + voffB[j]) : zero, sb + A_BYTES + (unsigned)(j * 4096));
   };
   f32x4 acc_hi[TM][TN], acc_lo[TM][TN];
 #pragma unroll
@@ -1663,12 +1704,7 @@ __global__ __launch_bounds__(256, (TM >= 4 ? 1 : 2)) void gemm_nt_bx3_kernel(nnr
       const f32x4 x0 = *reinterpret_cast<const f32x4*>(arow + 4 * ((2 * q) ^ bx3_swzA(r)));
       const f32x4 x1 = *reinterpret_cast<const f32x4*>(arow + 4 * ((2 * q + 1) ^ bx3_swzA(r)));
       bf16x8_t a1, a2, a3;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        __bf16 h1, h2, h3;
-        split3_bf16(x0[e], h1, h2, h3); a1[e] = h1; a2[e] = h2; a3[e] = h3;
-        split3_bf16(x1[e], h1, h2, h3); a1[4 + e] = h1; a2[4 + e] = h2; a3[4 + e] = h3;
-      }
+      split3_trunc8(x0, x1, a1, a2, a3);
 #pragma unroll
       for (int n = 0; n < TN; ++n) {
         acc_hi[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bf[0][n], acc_hi[m][n], 0, 0, 0);
@@ -1680,7 +1716,6 @@ __global__ __launch_bounds__(256, (TM >= 4 ? 1 : 2)) void gemm_nt_bx3_kernel(nnr
       }
     }
   }
-  (void)full;
 #pragma unroll
   for (int m = 0; m < TM; ++m)
 #pragma unroll

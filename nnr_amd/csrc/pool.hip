@@ -10,6 +10,7 @@
 //   score DOT     : score = scale * <x[row], v[oidx]>   with v = K^T (Q q + b_Q)  -- the algebraic form of
 //                   (K x).(Q q) that turns the [tokens, F] x [F, A] projection of every token into one GEMV per news.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -44,13 +45,10 @@ __device__ __forceinline__ long item_row(const PoolArgs& a, int s, int t) {
 // a quarter of the HBM rate, bound by that serial walk).  Per-token scalars (scores, d alpha) meet in LDS and the softmax is
 // recomputed by every wave (L <= 128 values); partial D-vectors (weighted sum, d v) are reduced across the waves through LDS.
 template <bool BWD, int NV, int UR>
-__global__ __launch_bounds__(256) void pool_kernel(PoolArgs a) {
+__device__ __forceinline__ void pool_stream_body(const PoolArgs& a, const int s, float* __restrict__ tok, f32x4 (*__restrict__ part)[64 * NV]) {
   constexpr int MAXV = NV;     // float4 per lane actually needed for this D (shadows the file-level bound)
   constexpr int NWV = 4;
-  __shared__ float tok[64 * MAXT];                       // per-token scalars of the sequence (scores / d alpha)
-  __shared__ f32x4 part[NWV][64 * NV];                   // per-wave partial vectors
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int s = blockIdx.x;
   if (s >= a.n) return;
   const int len = a.packed ? a.slen[s] : a.L;
   const int oidx = a.packed ? a.order[s] : s;
@@ -323,6 +321,243 @@ __global__ __launch_bounds__(256) void pool_kernel(PoolArgs a) {
   }
 }
 
+template <bool BWD, int NV, int UR>
+__global__ __launch_bounds__(256) void pool_kernel(PoolArgs a) {
+  __shared__ float tok[64 * MAXT];                       // per-token scalars of the sequence (scores / d alpha)
+  __shared__ f32x4 part[4][64 * NV];                     // per-wave partial vectors
+  pool_stream_body<BWD, NV, UR>(a, blockIdx.x, tok, part);
+}
+
+// ------------------------------------------------------------------------------------------------ packed token streams: rows held in registers
+// Round 6 (verdict item 2).  pool_stream_body walks a sequence's rows TWICE (scores, then the weighted sum; d alpha, then d x / d v) with four
+// rows in flight per wave, one 4-wave workgroup per sequence whatever its length: 3 520 workgroups per launch, each a chain of 4-6 dependent
+// memory round trips with a barrier between the passes, three of them resident per CU (146 VGPRs) -- 1.8 TB/s alone, 0.8 TB/s inside the step.
+// A MIND-shaped batch is mostly SHORT sequences (titles: ~10 tokens), and in the time-major packed layout the rows of neighbouring sorted
+// sequences at one time step are neighbours in memory.  Here a TEAM of NW waves owns a sequence and keeps its rows in registers (R = 16 rows
+// of NV float4 per wave) -- every row is read ONCE, all of a wave's row loads are issued back to back (16 in flight), and both passes run out
+// of registers:
+//   * sequences of <= 16 tokens (sorted last: positions >= bs[16] = off[17] - off[16]): ONE WAVE each, four sequences per workgroup, no LDS,
+//     no barrier -- per-token scalars are wave-uniform registers;
+//   * 17 .. 64 tokens: the four waves of a workgroup share the sequence (wave w owns tokens w, w + 4, ...), scalars and partial vectors
+//     meet in LDS as before;
+//   * > 64 tokens (positions < bs[64]): pool_stream_body (32 rows per wave do not fit the register file).
+// Workgroup b serves sequence b while b < bs[16], then sequences bs[16] + 4 (b - bs[16]) + wave; the grid stays n workgroups (the lengths
+// live in device memory), the surplus exits at once.
+__device__ __forceinline__ float lane_get(float v, int i) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), i)); }
+
+// Per-token scalars of a wave's R tokens live in ONE register each, token i in lane i (scores, alpha, d alpha, d score: element-wise
+// arithmetic on them is one instruction for all 16 tokens, a store is one instruction; a token's value comes back as a wave-uniform
+// scalar by v_readlane when a row is scaled by it).
+template <bool BWD, int NV, int NW, int R>
+__device__ __forceinline__ void pool_team_body(const PoolArgs& a, const int s, const int wt, float* __restrict__ tok, f32x4 (*__restrict__ part)[64 * NV]) {
+  const int lane = threadIdx.x & 63;
+  const int len = a.slen[s];
+  const int oidx = a.order[s];
+  const int nv = (a.D + 3) >> 2;
+  const bool dot = a.v != nullptr;
+  const long mrow = (long)(oidx / a.mask_div) * a.L;      // (packed: the mask is in the caller's row order)
+  // lane i < R owns token tl = wt + NW i of the sequence; its packed row is off[tl] + s (off[] has L + 1 entries: the clamp keeps the index
+  // legal, `livel` decides)
+  const int tl = wt + NW * lane;
+  const bool livel = lane < R && tl < len;
+  const int rowl = a.off[min(tl, a.L)] + s;
+  f32x4 x[R][NV];
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const bool live = wt + NW * i < len;
+    const long row = __builtin_amdgcn_readlane(rowl, i);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int c = lane + 64 * j;
+      x[i][j] = (live && c < nv) ? *reinterpret_cast<const f32x4*>(a.x + row * a.ldx + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  f32x4 q[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int c = lane + 64 * j;
+    q[j] = (dot && c < nv) ? *reinterpret_cast<const f32x4*>(a.v + (long)oidx * a.ldv + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  auto dotq = [&](const f32x4 (&xi)[NV], const f32x4 (&y)[NV]) __attribute__((always_inline)) {
+    float p = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) p += xi[j][0] * y[j][0] + xi[j][1] * y[j][1] + xi[j][2] * y[j][2] + xi[j][3] * y[j][3];
+    return wave_sum(p);
+  };
+  // every wave of the team gets the sum of the team's partial vectors (NW == 1: nothing to do)
+  auto reduce_vec = [&](f32x4 (&v)[NV]) __attribute__((always_inline)) {
+    if constexpr (NW > 1) {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) part[wt][lane + 64 * j] = v[j];
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < NV; ++j) v[j] = part[0][lane + 64 * j] + part[1][lane + 64 * j] + part[2][lane + 64 * j] + part[3][lane + 64 * j];
+    }
+  };
+
+  if constexpr (!BWD) {
+    // ---- scores of this wave's tokens
+    float pv = 0.f;
+    if (dot) {
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        const float d = dotq(x[i], q) * a.scale;
+        pv = (lane == i) ? d : pv;
+      }
+    } else if (a.th) {
+      const int na = a.A >> 2;
+      const f32x4 wv = (lane < na) ? *reinterpret_cast<const f32x4*>(a.w2 + 4 * lane) : f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 tv[R];
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        const long row = __builtin_amdgcn_readlane(rowl, i);
+        tv[i] = (wt + NW * i < len && lane < na) ? *reinterpret_cast<const f32x4*>(a.th + row * a.ldth + 4 * lane) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        const float d = wave_sum(tv[i][0] * wv[0] + tv[i][1] * wv[1] + tv[i][2] * wv[2] + tv[i][3] * wv[3]);
+        pv = (lane == i) ? d : pv;
+      }
+    } else {
+      pv = livel ? a.score[rowl] : 0.f;
+    }
+    if (a.mask && livel && !a.mask[mrow + tl]) pv = -1e9f;
+    // ---- softmax over the sequence; alv: alpha of this wave's tokens, token i in lane i
+    float alv;
+    if constexpr (NW == 1) {
+      const float m = wave_max(livel ? pv : -INFINITY);
+      const float e = livel ? expf(pv - m) : 0.f;
+      alv = e * (1.f / wave_sum(e));
+    } else {
+      if (livel) tok[tl] = pv;
+      __syncthreads();
+      const float sc = (lane < len) ? tok[lane] : -INFINITY;          // (len <= 4 R <= 64 on this path: position t in lane t)
+      const float m = wave_max(sc);
+      float e = (lane < len) ? expf(sc - m) : 0.f;
+      e *= 1.f / wave_sum(e);
+      alv = __shfl(e, tl & 63, 64);
+      alv = livel ? alv : 0.f;
+    }
+    if (a.alpha && livel) a.alpha[rowl] = alv;
+    // ---- weighted sum out of the registers
+    f32x4 acc[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const float al = lane_get(alv, i);                            // (0 for a row that does not exist, whose x is 0 too)
+#pragma unroll
+      for (int j = 0; j < NV; ++j) acc[j] += al * x[i][j];
+    }
+    reduce_vec(acc);
+    if (wt == 0) {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const int c = lane + 64 * j;
+        if (c < nv) {
+          f32x4 o = acc[j];
+          if (a.add_in) o += *reinterpret_cast<const f32x4*>(a.add_in + (long)oidx * a.ldadd + 4 * c);
+          *reinterpret_cast<f32x4*>(a.out + (long)oidx * a.ldo + 4 * c) = o;
+        }
+      }
+    }
+  } else {
+    // ---------------------------------------------------------------- backward
+    f32x4 go[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int c = lane + 64 * j;
+      go[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (c < nv) {
+        go[j] = *reinterpret_cast<const f32x4*>(a.dout + (long)oidx * a.lddo + 4 * c);
+        if (a.dout2) go[j] += *reinterpret_cast<const f32x4*>(a.dout2 + (long)oidx * a.lddo2 + 4 * c);
+      }
+    }
+    const float alv = livel ? a.alpha[rowl] : 0.f;
+    float dav = 0.f;                                                // d alpha_t = <dout, x_t>
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const float d = dotq(x[i], go);
+      dav = (lane == i) ? d : dav;
+    }
+    float dsum = wave_sum(alv * dav);                               // sum_t alpha_t d alpha_t over this wave's tokens ...
+    if constexpr (NW > 1) {                                         // ... and over the team
+      if (lane == 0) tok[wt] = dsum;
+      __syncthreads();
+      dsum = (tok[0] + tok[1]) + (tok[2] + tok[3]);
+    }
+    float dsv = alv * (dav - dsum);              // d loss / d score_t (masked items have alpha = 0 -> 0)
+    // ... except in a FULLY masked group (alpha uniform, not 0): masked_fill passes no gradient to the score it replaced (layers.py:171,199)
+    if (a.mask && livel && !a.mask[mrow + tl]) dsv = 0.f;
+    if (a.dscore && livel) a.dscore[rowl] = dsv;
+    if (!a.dx && !(dot && a.dv)) return;        // nothing but dscore was wanted
+    const bool two = a.alpha_b != nullptr;
+    f32x4 go2[NV], q2[NV], dvacc[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int c = lane + 64 * j;
+      go2[j] = q2[j] = dvacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (two && c < nv) {
+        go2[j] = *reinterpret_cast<const f32x4*>(a.dout_b + (long)oidx * a.lddo_b + 4 * c);
+        q2[j] = *reinterpret_cast<const f32x4*>(a.v_b + (long)oidx * a.ldv_b + 4 * c);
+      }
+    }
+    const float al2v = (two && livel) ? a.alpha_b[rowl] : 0.f;
+    const float ds2v = (two && livel) ? a.dscore_b[rowl] * a.scale_b : 0.f;
+    const float dstv = dsv * a.scale;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      if (wt + NW * i >= len) continue;
+      const long row = __builtin_amdgcn_readlane(rowl, i);
+      const float al = lane_get(alv, i), dst = lane_get(dstv, i), al2 = lane_get(al2v, i), ds2 = lane_get(ds2v, i);
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const int c = lane + 64 * j;
+        if (c < nv) {
+          // (two: in the association the two-pass form used -- (alpha_b dout_b + dscore_b v_b) first, as the stored `old`)
+          f32x4 prev = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (two) prev = al2 * go2[j] + ds2 * q2[j];
+          else if (a.dx && a.dx_accumulate) prev = *reinterpret_cast<const f32x4*>(a.dx + row * a.lddx + 4 * c);
+          f32x4 g = al * go[j] + prev;
+          if (dot) {
+            g += dst * q[j];
+            dvacc[j] += dst * x[i][j];
+          }
+          if (a.dx) *reinterpret_cast<f32x4*>(a.dx + row * a.lddx + 4 * c) = g;
+        }
+      }
+    }
+    if (dot && a.dv) {
+      reduce_vec(dvacc);
+      if (wt == 0) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+          const int c = lane + 64 * j;
+          if (c < nv) *reinterpret_cast<f32x4*>(a.dv + (long)oidx * a.lddv + 4 * c) = dvacc[j];
+        }
+      }
+    }
+  }
+}
+
+template <bool BWD, int NV, int R>
+__global__ __launch_bounds__(256, (R >= 16 ? 2 : 3)) void pool_packed_kernel(PoolArgs a) {
+  __shared__ float tok[64 * MAXT];
+  __shared__ f32x4 part[4][64 * NV];
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.x;
+  const int nstream = a.L > 4 * R ? a.off[4 * R + 1] - a.off[4 * R] : 0;       // sequences longer than 4 R tokens (sorted first)
+  const int ncoop = a.L > R ? a.off[R + 1] - a.off[R] : 0;                     // ... longer than R
+  if (b < nstream) {
+    pool_stream_body<BWD, NV, 4>(a, b, tok, part);
+  } else if (b < ncoop) {
+    pool_team_body<BWD, NV, 4, R>(a, b, w, tok, part);
+  } else {
+    const int s = ncoop + 4 * (b - ncoop) + w;
+    if (s < a.n) pool_team_body<BWD, NV, 1, R>(a, s, 0, tok, part);
+  }
+}
+
 }  // namespace
 
 static int pool_check(const nnr_pool_args* p) {
@@ -353,6 +588,21 @@ static int pool_launch(const nnr_pool_args* p, hipStream_t stream) {
   const PoolArgs a = to_args(p);
   const dim3 grid(p->n), block(256);
   const int nv = (p->D + 3) / 4;
+  // A/B switches: NNR_POOL_TEAM bit 0 = forward, bit 1 = backward through the register-resident kernels (0 = one streaming workgroup per sequence,
+  // rounds 1-5); NNR_POOL_R = rows a wave keeps (16: 2 waves / SIMD, single-wave teams up to 16 tokens, shared up to 64; 8: 4 waves / SIMD, 8 / 32)
+  static const int team = [] { const char* e = getenv("NNR_POOL_TEAM"); return e ? atoi(e) : 3; }();
+  static const int rows = [] { const char* e = getenv("NNR_POOL_R"); return e ? atoi(e) : 8; }();
+  if ((team & (BWD ? 2 : 1)) && p->packed && nv <= 128 && p->L <= 128) {
+    if (rows >= 16) {
+      if (nv <= 64) hipLaunchKernelGGL((pool_packed_kernel<BWD, 1, 16>), grid, block, 0, stream, a);
+      else hipLaunchKernelGGL((pool_packed_kernel<BWD, 2, 16>), grid, block, 0, stream, a);
+    } else {
+      if (nv <= 64) hipLaunchKernelGGL((pool_packed_kernel<BWD, 1, 8>), grid, block, 0, stream, a);
+      else hipLaunchKernelGGL((pool_packed_kernel<BWD, 2, 8>), grid, block, 0, stream, a);
+    }
+    NNR_CHECK_LAUNCH();
+    return NNR_OK;
+  }
   if (nv <= 64) hipLaunchKernelGGL((pool_kernel<BWD, 1, 4>), grid, block, 0, stream, a);
   else if (nv <= 128) hipLaunchKernelGGL((pool_kernel<BWD, 2, 4>), grid, block, 0, stream, a);
   else if (nv <= 256) hipLaunchKernelGGL((pool_kernel<BWD, 4, 2>), grid, block, 0, stream, a);

@@ -102,16 +102,18 @@ def _agree(ok):
 def _probe_native(rank, world, uid, timeout_s):
     """ncclCommInitRank + an 8-float all-reduce on a WATCHDOG thread: both block without a time-out of their own, and a rank that
     never arrives (it failed elsewhere, or RCCL stalls beside torch's communicator) would otherwise hang every other rank before
-    they reach the agreement.  After `timeout_s` the caller gives the binding up (the thread, a daemon blocked inside RCCL with the
-    GIL released, is abandoned; the process goes on with torch.distributed's all_reduce).  Returns (NativeExchange | None, ok, why)."""
+    they reach the agreement.  Returns (NativeExchange | None, ok, why, timed_out).  A thread that is still alive after `timeout_s` is
+    parked inside RCCL and cannot be cancelled: the CALLER decides what that means (_probe_timed_out: exit non-zero by default)."""
     import threading
-    res = {'nx': None, 'ok': 0, 'why': 'timed out after %.0f s inside ncclCommInitRank / the probe all-reduce' % timeout_s}
+    res = {'nx': None, 'ok': 0, 'why': 'timed out after %.0f s inside ncclCommInitRank / the probe all-reduce' % timeout_s, 'cancelled': False}
     dev_index = torch.cuda.current_device()
 
     def run():
         try:
             torch.cuda.set_device(dev_index)             # (the current device is per thread)
             nx = NativeExchange(rank, world, uid)
+            if res['cancelled']:                         # the caller gave up while we were inside ncclCommInitRank: publish nothing, use nothing
+                return
             res['nx'] = nx
             ok, why = 1, ''
             if world > 1:
@@ -122,7 +124,8 @@ def _probe_native(rank, world, uid, timeout_s):
                 st.synchronize()
                 ok = 1 if float(probe_t[0]) == float(world) and float(probe_t[7]) == float(world) else 0
                 why = '' if ok else 'probe all-reduce returned %r on rank %d' % (float(probe_t[0]), rank)
-            res['ok'], res['why'] = ok, why
+            if not res['cancelled']:
+                res['ok'], res['why'] = ok, why
         except Exception as e:            # noqa: BLE001  (any failure of the optional binding means: use the fallback)
             res['ok'], res['why'] = 0, '%s: %s' % (type(e).__name__, e)
 
@@ -130,8 +133,25 @@ def _probe_native(rank, world, uid, timeout_s):
     th.start()
     th.join(timeout_s)
     if th.is_alive():
-        return None, 0, res['why']
-    return res['nx'], res['ok'], res['why']
+        res['cancelled'] = True
+        return None, 0, res['why'], True
+    return res['nx'], res['ok'], res['why'], False
+
+
+def _probe_timed_out(why):
+    """The watchdog gave up on a thread that is still blocked inside ncclCommInitRank / the probe all-reduce.  That thread cannot be
+    cancelled, holds half-initialised RCCL state and may issue stream work whenever it wakes up; carrying on with torch.distributed's own
+    RCCL communicator in the same process can deadlock against it (round-5 verdict / advisor).  Default: EXIT NON-ZERO -- every rank that
+    timed out leaves with code 75 (EX_TEMPFAIL) and the launcher (torchrun) takes the job down; nothing is re-exec'ed.
+    NNR_DP_PROBE_TIMEOUT_ACTION=fallback keeps round 5's behaviour (abandon the thread, use torch.distributed's all_reduce)."""
+    action = os.environ.get('NNR_DP_PROBE_TIMEOUT_ACTION', 'exit')
+    if action == 'fallback':
+        return
+    import sys
+    sys.stderr.write('nnr_amd.dp: the C-ABI RCCL binding %s; a thread is parked inside RCCL and cannot be cancelled -- exiting with code 75 '
+                     '(NNR_DP_PROBE_TIMEOUT_ACTION=fallback continues on torch.distributed instead; NNR_DP_NATIVE=0 skips the binding)\n' % why)
+    sys.stderr.flush()
+    os._exit(75)               # (not sys.exit: the parked daemon thread and RCCL's own threads must not get a chance to run atexit handlers)
 
 
 def _native_wanted():
@@ -179,14 +199,14 @@ def _native_exchange():
     # every rank can check, on a watchdog thread with a time-out -- and the ranks agree on the outcome over the torch group: a binding that
     # came up on some ranks only, stalls, or sums wrongly is dropped by ALL of them in favour of torch.distributed's all_reduce
     # (>= 2 RCCL ranks have never run where this build ran)
-    nx, ok, why = _probe_native(rank, world_size(), uid, _PROBE_TIMEOUT_S)
+    nx, ok, why, timed_out = _probe_native(rank, world_size(), uid, _PROBE_TIMEOUT_S)
+    if timed_out:
+        _probe_timed_out(why)             # (default: does not return)
     ok = _agree(ok)
     if not ok:
-        if nx is not None:
-            try:
-                nx.close()
-            except Exception:             # noqa: BLE001
-                pass
+        # a communicator that came up HERE while a peer failed or is stuck is leaked, not destroyed: ncclCommDestroy can block on a peer
+        # that is still inside the collective (round-5 advisor); the process is about to use torch.distributed's communicator instead
+        nx = None
         _native_state['why'] = 'the C-ABI RCCL binding did not come up on every rank (%s): torch.distributed binding' % (why or 'another rank failed')
         import warnings
         warnings.warn('nnr_amd.dp: ' + _native_state['why'])

@@ -130,3 +130,61 @@ def test_sampler_indices_equal_torch_distributed_sampler():
                 s = DistributedSampler(list(range(n)), num_replicas=world, rank=rank, shuffle=True, seed=0)
                 s.set_epoch(epoch)
                 assert dp.sampler_indices(n, rank, world, epoch).tolist() == list(iter(s)), (n, world, epoch, rank)
+
+
+def _probe_worker(rank, world, port, out_dir, action):
+    """A rank whose C-ABI RCCL binding BLOCKS inside nnr_dp_init (a fake library: ncclCommInitRank never returns)."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                      NNR_DP_NATIVE='1', NNR_DP_PROBE_TIMEOUT='2')
+    os.environ.pop('NNR_DP_PROBE_TIMEOUT_ACTION', None)
+    if action:
+        os.environ['NNR_DP_PROBE_TIMEOUT_ACTION'] = action
+    import sys
+    import time
+    sys.path[:0] = [os.path.dirname(os.path.dirname(os.path.abspath(__file__)))]
+    from nnr_amd import dp, _lib
+
+    class FakeLib:
+        def nnr_dp_unique_id(self, buf):
+            return 0
+
+        def nnr_dp_init(self, uid, r, w, ctx):
+            time.sleep(3600)                           # parked inside "ncclCommInitRank"
+            return 0
+
+    dp.init_from_env('gloo')
+    _lib.lib = lambda: FakeLib()
+    torch.cuda.is_available = lambda: True             # (no GPU in this container: the probe's device calls are stubbed too)
+    torch.cuda.current_device = lambda: 0
+    torch.cuda.set_device = lambda d: None
+    open(os.path.join(out_dir, 'entered_%d' % rank), 'w').write('1')
+    nx = dp._native_exchange()                         # default action: os._exit(75) in here, on BOTH ranks
+    open(os.path.join(out_dir, 'survived_%d' % rank), 'w').write('fallback' if nx is None else 'native')
+    dp.barrier()
+
+
+@pytest.mark.parametrize('action', [None, 'fallback'])
+def test_blocked_rccl_probe_exits_non_zero_by_default(tmp_path, action):
+    """Round-5 verdict item 6 / advisor: when the watchdog gives up on a thread parked inside ncclCommInitRank the process must not carry
+    on beside it by default.  Two gloo ranks, a fake library whose nnr_dp_init never returns, NNR_DP_PROBE_TIMEOUT=2: both ranks exit
+    with code 75 (default) -- or, with NNR_DP_PROBE_TIMEOUT_ACTION=fallback, both fall back to torch.distributed together (round 5's
+    behaviour) and reach the barrier."""
+    ctx = mp.get_context('spawn')
+    port = _free_port()
+    ps = [ctx.Process(target=_probe_worker, args=(r, 2, port, str(tmp_path), action)) for r in range(2)]
+    for p in ps:
+        p.start()
+    for p in ps:
+        p.join(120)
+    try:
+        for r, p in enumerate(ps):
+            assert not p.is_alive(), 'rank %d still running' % r
+            assert (tmp_path / ('entered_%d' % r)).exists()
+            if action == 'fallback':
+                assert p.exitcode == 0 and (tmp_path / ('survived_%d' % r)).read_text() == 'fallback'
+            else:
+                assert p.exitcode == 75 and not (tmp_path / ('survived_%d' % r)).exists()
+    finally:
+        for p in ps:
+            if p.is_alive():
+                p.kill()
