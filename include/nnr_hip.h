@@ -99,8 +99,7 @@ typedef struct nnr_gemm_args {
   /* tile = 50 computes the same NT product on the BF16 matrix pipe as six exact bf16 x bf16 products with fp32 accumulation (an fp32 value is
    * exactly the sum of three bf16 values; error vs fp64 a third of the fp32-MFMA kernels'; round 5: measured, round 6: the host's default for
    * NT launches whose B is a weight).  Non-finite operands give non-finite outputs (+-Inf or NaN, not necessarily fp32's choice of the two); finite values up to FLT_MAX are
-   * exact (csrc/gemm.hip: split3_bf16).  B3: the
-   * weight matrix B [N, K] pre-split by nnr_split_bf16x3 into three bf16 images [N, ldb3] (ldb3 % 8 == 0, zero-padded), image i at
+   * exact (csrc/gemm.hip: split3_bf16, split3_trunc8).  B3: the weight matrix B [N, K] pre-split by nnr_split_bf16x3 into three bf16 images [N, ldb3] (ldb3 % 8 == 0, zero-padded), image i at
    * B3 + i * b3_stride elements. */
   const void* B3;
   long b3_stride;
@@ -108,10 +107,6 @@ typedef struct nnr_gemm_args {
 } nnr_gemm_args;
 
 int nnr_gemm_f32(const nnr_gemm_args* args, hipStream_t stream);
-/* tile = 47: fixed-order stream-K form of the plain NT product (one to two waves of 128 x 80 tiles: the SUE launches, userEncoders.py:85-98 /
- * layers.py:285-292).  args.slab = a workspace of at least nnr_gemm_sk_workspace_floats(M, N) floats (slab_floats says how many), zeroed ONCE by the
- * caller and then reused by launches that follow each other on one stream; results are bit-identical from run to run. */
-size_t nnr_gemm_sk_workspace_floats(int M, int N);
 /* w [rows, cols] (row stride ld) -> three bf16 images out3[i * img_stride + r * ldo + c] with w == image0 + image1 + image2 EXACTLY (columns
  * cols .. ldo-1 zero).  For nnr_gemm_args.B3 (experimental tile 50); weights change once per optimizer step. */
 int nnr_split_bf16x3(const float* w, int rows, int cols, int ld, int ldo, void* out3, long img_stride, hipStream_t stream);
@@ -280,16 +275,6 @@ int nnr_gcn_aggregate_fwd(const float* graph, const float* z, const float* bias,
  * dz_b = graph_b^T . dy_b (ds / dx0 untouched). */
 int nnr_gcn_aggregate_bwd(const float* graph, const float* dy, const float* r, float* ds, float* dx0, float* dz, int B, int G, int D, float p,
                           uint32_t seed, hipStream_t stream);
-/* ONE launch per GCN layer and direction for small batches (B * G <= ~1 100 rows: per-GPU batch <= 16), replacing the chain
- * [dense product on skinny tiles -> dispatch gap -> aggregate]: a workgroup owns (user b, 32 columns), computes T_b = IN_b . Wop^T with the
- * K = D reduction split over its 8 waves, then A_b . T_b (forward) / A_b^T . T_b (backward) from LDS, then the layer's epilogue.
- *   fwd: y = dropout(relu(A (x W^T) + bias) [-> r_out] + resid)        W [D, D] as nn.Linear stores it (layers.py:285-292,318-323)
- *   bwd: dx = A^T (dS Wt^T) + (residual ? mask(dy) : 0),  dS = mask(dy) * (r > 0)   with Wt = W^T [D, D] contiguous (the data-gradient chain;
- *        dS / dZ for the bias and weight gradients still come from nnr_gcn_aggregate_bwd, on a leaf stream).  G <= 80, D % 4 == 0. */
-int nnr_gcn_layer_small_fwd(const float* graph, const float* x, const float* W, const float* bias, const float* resid, float* r_out, float* y,
-                            int B, int G, int D, int relu, float p, uint32_t seed, hipStream_t stream);
-int nnr_gcn_layer_small_bwd(const float* graph, const float* dy, const float* r, const float* Wt, float* dx, int B, int G, int D, int residual,
-                            float p, uint32_t seed, hipStream_t stream);
 int nnr_relu_drop_bwd(const float* dy, const float* r, float* ds, float* dx, long n, float p, uint32_t seed, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------ multi-head self-attention core

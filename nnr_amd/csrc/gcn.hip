@@ -135,154 +135,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
 }
 
 
-// ---- one launch per GCN layer and direction for SMALL batches (round 5; verdict items of rounds 3-5).  At per-GPU batch <= 16 a layer is a
-// chain of two latency-bound launches: the dense product on 16 x 80 skinny tiles (K split over the waves; 28 us at batch 8) and the aggregate above
-// (15-18 us) with a dispatch gap between them.  Here one workgroup owns (user b, BN = 16 TN columns):
-//   stage 1   T_b[GR, BN] = IN_b[G, D] . Wop[BN cols, D]^T     -- all MT row tiles of the user at once (every B fragment feeds MT MFMAs), the
-//                                                                K = D reduction split over the 8 waves, fragments straight from global
-//                                                                memory with two k-groups in flight, partials reduced through LDS in wave order;
-//   stage 2   OUT_b = A_b . T_b  (forward)   /   A_b^T . T_b  (backward)       -- the (A X) W^T = A (X W^T) order of gcn_aggregate, 17 k-steps from LDS;
-//   epilogue  forward : u + bias -> relu -> r ; + resid ; dropout -> y            (GCNLayer.forward / GCN.forward, layers.py:285-292,318-323)
-//             backward: + mask(dy) (the residual branch) -> dx, with IN = dS = mask(dy) * (r > 0) formed in the stage-1 loader;
-//                       Wop = W^T, i.e. dx = A^T (dS W) = (A^T dS) W  (associativity; dS and dZ = A^T dS for the weight gradient are leaves
-//                       and come from gcn_aggregate_kernel<1> on the leaf stream).
-template <int MODE, int MT, int TN>
-__global__ __launch_bounds__(512) void gcn_layer_small_kernel(const float* __restrict__ graph, const float* __restrict__ in, const float* __restrict__ rin,
-                                                              const float* __restrict__ Wop, const float* __restrict__ bias, const float* __restrict__ resid,
-                                                              float* __restrict__ out_r, float* __restrict__ out, int G, int D, int relu, int residual,
-                                                              uint32_t seed, uint32_t thr, float scale) {
-  constexpr int NW = 8, BN = 16 * TN, Z_LD = BN + 4, ROWS = MT * 16;
-  // static LDS (a dynamic allocation above 64 KB would need a function attribute): A_b, the reduced T_b, the waves' partial tiles
-  __shared__ __attribute__((aligned(16))) float As[ROWS * (ROWS | 1)];      // [GR][A_LD]
-  __shared__ __attribute__((aligned(16))) float Zs[ROWS * Z_LD];            // [ROWS][Z_LD]: the reduced T_b
-  __shared__ __attribute__((aligned(16))) float red[NW * ROWS * Z_LD];      // [NW][ROWS][Z_LD]
-  const int ks_n = (G + 3) >> 2, GR = ks_n * 4, A_LD = GR | 1;
-  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r16 = lane & 15, kk = lane >> 4;
-  const int n0 = blockIdx.x * BN;
-  const long base = (long)b * G * D;
-  const float* A = graph + (long)b * G * G;
-  for (int i = tid; i < GR * A_LD; i += 64 * NW) {
-    const int row = i / A_LD, col = i - row * A_LD;
-    As[i] = (row < G && col < G) ? A[row * G + col] : 0.f;
-  }
-  // ---- stage 1
-  int arow[MT];
-#pragma unroll
-  for (int m = 0; m < MT; ++m) arow[m] = min(m * 16 + r16, G - 1);          // rows >= G: clamped, they only feed T rows >= G (never used: stage 2 reduces over j < GR <= ROWS... zeroed below)
-  auto load_frags = [&](int k0, f32x4 (&af)[MT], f32x4 (&bf)[TN]) __attribute__((always_inline)) {
-    const int k = k0 + 4 * kk;
-    const bool kok = k < D;                                  // (D % 4 == 0)
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      af[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (kok) {
-        const long idx = base + (long)arow[m] * D + k;
-        f32x4 v = *reinterpret_cast<const f32x4*>(in + idx);
-        if (MODE == 1) {
-          if (thr) {
-            bool kp[4];
-            nnr_keep4(seed, (uint64_t)idx, thr, kp);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = kp[e] ? v[e] * scale : 0.f;
-          }
-          const f32x4 rv = *reinterpret_cast<const f32x4*>(rin + idx);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = rv[e] > 0.f ? v[e] : 0.f;
-        }
-        af[m] = v;
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = n0 + 16 * j + r16;
-      bf[j] = (kok && col < D) ? *reinterpret_cast<const f32x4*>(Wop + (long)col * D + k) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-  };
-  f32x4 acc[MT][TN];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  constexpr int KS = 16 * NW;
-  f32x4 af[MT], bf[TN], a1[MT], b1[TN];
-#pragma unroll
-  for (int m = 0; m < MT; ++m) af[m] = a1[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int j = 0; j < TN; ++j) bf[j] = b1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  int k0 = w * 16;
-  if (k0 < D) load_frags(k0, af, bf);
-  if (k0 + KS < D) load_frags(k0 + KS, a1, b1);
-  for (; k0 < D; k0 += KS) {
-    f32x4 an[MT], bn_[TN];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) an[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < TN; ++j) bn_[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (k0 + 2 * KS < D) load_frags(k0 + 2 * KS, an, bn_);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][i], bf[j][i], acc[m][j], 0, 0, 0);
-#pragma unroll
-    for (int m = 0; m < MT; ++m) { af[m] = a1[m]; a1[m] = an[m]; }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) { bf[j] = b1[j]; b1[j] = bn_[j]; }
-  }
-  float* mine = red + w * ROWS * Z_LD;
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) mine[(m * 16 + 4 * kk + e) * Z_LD + 16 * j + r16] = acc[m][j][e];
-  __syncthreads();
-  for (int i = tid; i < ROWS * BN; i += 64 * NW) {
-    const int row = i / BN, c = i - row * BN;
-    float x = 0.f;
-#pragma unroll
-    for (int q = 0; q < NW; ++q) x += red[q * ROWS * Z_LD + row * Z_LD + c];            // fixed order
-    Zs[row * Z_LD + c] = row < G ? x : 0.f;                  // (rows >= G came from clamped loads)
-  }
-  __syncthreads();
-  // ---- stage 2 + epilogue: output tile t = m * TN + j; wave w takes t = w, w + 8, ...
-  for (int t = w; t < MT * TN; t += NW) {
-    const int m = t / TN, j = t - m * TN;
-    const int ar = min(m * 16 + r16, GR - 1);
-    f32x4 o = {0.f, 0.f, 0.f, 0.f};
-    for (int ks = 0; ks < ks_n; ++ks) {
-      const float a = MODE == 0 ? As[ar * A_LD + 4 * ks + kk] : As[(4 * ks + kk) * A_LD + ar];
-      const float bz = Zs[(4 * ks + kk) * Z_LD + 16 * j + r16];
-      o = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bz, o, 0, 0, 0);
-    }
-    const int col = n0 + 16 * j + r16;
-    if (col >= D) continue;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int row = m * 16 + 4 * kk + e;
-      if (row >= G) continue;
-      const long idx = base + (long)row * D + col;
-      float x = o[e];
-      if (MODE == 0) {
-        if (bias) x += bias[col];
-        if (relu) x = fmaxf(x, 0.f);
-        if (out_r) out_r[idx] = x;
-        if (resid) x += resid[idx];
-        if (thr) x = nnr_keep(seed, (uint64_t)idx, thr) ? x * scale : 0.f;
-        out[idx] = x;
-      } else {
-        if (residual) {
-          float d = in[idx];
-          if (thr) d = nnr_keep(seed, (uint64_t)idx, thr) ? d * scale : 0.f;
-          x += d;
-        }
-        out[idx] = x;
-      }
-    }
-  }
-}
-
 }  // namespace
 
 extern "C" int nnr_gcn_aggregate_fwd(const float* graph, const float* z, const float* bias, const float* resid, float* r_out, float* y, int B,
@@ -311,32 +163,4 @@ extern "C" int nnr_gcn_aggregate_bwd(const float* graph, const float* dy, const 
 #undef GCN_CASE
   NNR_CHECK_LAUNCH();
   return NNR_OK;
-}
-
-// One launch per GCN layer (forward) / per layer's data-gradient chain (backward) at small batches: see gcn_layer_small_kernel.
-template <int MODE>
-static int gcn_layer_small_launch(const float* graph, const float* in, const float* rin, const float* Wop, const float* bias, const float* resid,
-                                  float* out_r, float* out, int B, int G, int D, int relu, int residual, float p, uint32_t seed, hipStream_t stream) {
-  if (!graph || !in || !Wop || !out || B <= 0 || G <= 0 || D <= 0) return NNR_ERR_ARG;
-  if (G > 80 || (D & 3) || (((uintptr_t)in | (uintptr_t)Wop | (uintptr_t)(rin ? rin : in)) & 15)) return NNR_ERR_UNSUPPORTED;
-  constexpr int TN = 2, BN = 16 * TN, NW = 8;
-  const float sc = p > 0.f ? 1.f / (1.f - p) : 1.f;
-  const int gr = (G + 3) / 4 * 4, mt = (G + 15) / 16;
-  const dim3 grid((D + BN - 1) / BN, B);
-  (void)gr;
-#define GCNS_CASE(MT_) case MT_: hipLaunchKernelGGL((gcn_layer_small_kernel<MODE, MT_, TN>), grid, dim3(64 * NW), 0, stream, graph, in, rin, Wop, bias, resid, out_r, out, \
-                                                    G, D, relu, residual, seed, nnr_drop_thresh(p), sc); break;
-  switch (mt) { GCNS_CASE(1) GCNS_CASE(2) GCNS_CASE(3) GCNS_CASE(4) GCNS_CASE(5) default: return NNR_ERR_UNSUPPORTED; }
-#undef GCNS_CASE
-  NNR_CHECK_LAUNCH();
-  return NNR_OK;
-}
-extern "C" int nnr_gcn_layer_small_fwd(const float* graph, const float* x, const float* W, const float* bias, const float* resid, float* r_out, float* y,
-                                       int B, int G, int D, int relu, float p, uint32_t seed, hipStream_t stream) {
-  return gcn_layer_small_launch<0>(graph, x, nullptr, W, bias, resid, r_out, y, B, G, D, relu, 0, p, seed, stream);
-}
-extern "C" int nnr_gcn_layer_small_bwd(const float* graph, const float* dy, const float* r, const float* Wt, float* dx, int B, int G, int D, int residual,
-                                       float p, uint32_t seed, hipStream_t stream) {
-  if (!r) return NNR_ERR_ARG;
-  return gcn_layer_small_launch<1>(graph, dy, r, Wt, nullptr, nullptr, nullptr, dx, B, G, D, 0, residual, p, seed, stream);
 }

@@ -910,589 +910,6 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_pipe2_kernel(nnr_gemm_args g
   gemm_epilogue<TM, TN>(g, acc, lds, C, m0, n0, M, N, z);
 }
 
-// ------------------------------------------------------------------------------------------------ fixed-order stream-K NT (round 5, verdict item 1b)
-// For launches of ONE to TWO waves of tiles (SUE: 4 352 x 900 x 900 = 408 tiles of 128 x 80 on 512 workgroup slots -- the CUs that carry two tiles set
-// the time, wave efficiency 0.80; the vendor library's stream-K kernel reaches 107 TF on that shape against 91 for gemm_nt_pipe2_kernel).  The launch is
-// W equal workgroups (W = 2 per CU); the linearised (tile, k-stage) space of nblk x SPT stages is cut into W equal ranges and workgroup i runs range i
-// with gemm_nt_pipe2_kernel's stage loop.  A range covers one to three tiles; its pieces ("fragments") are run in DESCENDING tile order:
-//   * a fragment that holds a whole tile: ordinary epilogue;
-//   * a fragment that holds a tile's END (the last k-stage): this workgroup OWNS the tile.  It is the workgroup's LAST fragment.  The k-stages in front of
-//     it belong to the one or two workgroups with the next-lower indices, which ran them FIRST (their highest tile) and left the partial accumulators in
-//     the workspace; the owner adds them in ascending-k order -- ((P0 + P1) + own): a FIXED order, results are bit-identical from run to run -- and runs
-//     the epilogue;
-//   * any other fragment (a tile's beginning or middle): accumulators -> workspace slot (this workgroup's distance from the tile's first workgroup), flag.
-// Dependencies only point to LOWER workgroup indices, which the dispatcher starts first: no deadlock whatever else occupies the chip; the spin is bounded
-// anyway (time-out -> NaN results, never a hang).  Exchange across XCDs (their L2s are not coherent): the partials are written with agent-scope relaxed
-// atomic stores (write-through), s_waitcnt vmcnt(0) = all of this wave's stores acknowledged, workgroup barrier, then the flag; the owner polls the flag
-// and reads the partials with agent-scope relaxed atomic loads.  No fence instruction (an agent-scope release writes back the XCD's whole L2: ~3.5 us).
-// Workspace (nnr_gemm_args.slab): [4 096 flag words (2 per tile, <= 2 048 tiles)][nblk x 2 x 256 x (TM TN 4) floats], zeroed once by the
-// caller; the owner resets the flags it consumed, so launches that follow each other on one stream reuse it.  One workspace per stream.
-template <int TM, int TN, int NS, int OCC>
-__global__ __launch_bounds__(256, OCC) void gemm_nt_sk_kernel(nnr_gemm_args g) {
-  constexpr int BK = 32, BM = 64 * TM, BN = 16 * TN, ROWS = BM + BN;
-  constexpr int KQ = BK / 4, RPI = 64 / KQ, NI = ROWS / RPI, NPW = (NI + 3) / 4, STAGE = ROWS * BK, E_LD = BN + 4;
-  constexpr int LDS_FLOATS = (NS * STAGE > 64 * E_LD) ? NS * STAGE : 64 * E_LD;
-  constexpr int PART = 256 * TM * TN * 4;                     // floats of one partial accumulator tile, in register order
-  static_assert(ROWS % RPI == 0 && NS >= 3, "tile shape");
-  __shared__ __attribute__((aligned(1024))) float lds[LDS_FLOATS];
-  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r = lane & 15, kk = lane >> 4;
-  int M = g.M;
-  if (g.dyn_dim == 1) M = min(M, *g.dyn_dev);
-  const int N = g.N, K = g.K;
-  const int nbm = (M + BM - 1) / BM, nbn = (N + BN - 1) / BN;
-  const int nblk = nbm * nbn;
-  const int SPT = (K + BK - 1) / BK;                          // k-stages per tile
-  const long total = (long)nblk * SPT;
-  const int wi = blockIdx.x;
-  const int W = min((int)gridDim.x, max(1, 2 * nblk));       // (a dyn row count can shrink nblk below the launch's: keep <= 3 ranges per tile -- two partial slots)
-  if (wi >= W) return;
-  const long lo = total * wi / W, hi = total * (wi + 1) / W;
-  if (lo >= hi) return;
-  const float* __restrict__ A = g.A;
-  const float* __restrict__ B = g.B;
-  float* __restrict__ C = g.C;
-  unsigned* flags = reinterpret_cast<unsigned*>(g.slab);
-  float* parts = g.slab + 4096;                               // flags: a FIXED 4 096-word region (launches of different shapes share one workspace: their flag words must never
-                                                              // land in another launch's partial tiles), partial tiles behind it
-  constexpr int NIA = BM / RPI, NIB = BN / RPI, NA = NIA / 4, NBMAX = (NIB + 3) / 4;
-  static_assert(NIA % 4 == 0 && NA <= 8 && NBMAX <= 8, "tile shape");
-  const float* zero = nnr_zero_page;
-  asm volatile("" : "+s"(zero));
-  const unsigned lds_base = (unsigned)(uintptr_t)lds;
-  const bool ktail = (K % BK) != 0;
-  const bool nb_hi = (NIB % 4 == 0) || (w < NIB % 4);
-  const int t_first = (int)(lo / SPT), t_last = (int)((hi - 1) / SPT);
-
-  for (int t = t_last; t >= t_first; --t) {
-    const int sb = (int)(max(lo, (long)t * SPT) - (long)t * SPT), se = (int)(min(hi, (long)(t + 1) * SPT) - (long)t * SPT);      // this fragment: k-stages [sb, se) of tile t
-    const int S = se - sb;
-    // XCD-aware tile order, as in gemm_nt_pipe2_kernel (consecutive ranges -> consecutive tiles of one XCD's share is not needed here: neighbours exchange through memory)
-    const int bm = t / nbn, bn = t - bm * nbn;
-    const int m0 = bm * BM, n0 = bn * BN;
-    unsigned voffA[8], voffB[8];
-    int kchA[NA], kchB[NBMAX];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) voffA[i] = voffB[i] = 0;
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const int tr = (w + 4 * i) * RPI + lane / KQ;
-      const int c = (lane % KQ) ^ swz<BK>(tr & 15);
-      kchA[i] = 4 * c;
-      voffA[i] = (unsigned)(((long)min(tr, M - 1 - m0) * g.lda + 4 * c) * 4);
-    }
-#pragma unroll
-    for (int j = 0; j < NBMAX; ++j) {
-      const int tr = (w + 4 * j) * RPI + lane / KQ;
-      const int c = (lane % KQ) ^ swz<BK>(tr & 15);
-      kchB[j] = 4 * c;
-      voffB[j] = (unsigned)(((long)min(tr, N - 1 - n0) * g.ldb + 4 * c) * 4);
-    }
-    const float* Abase = A + (long)m0 * g.lda + (long)sb * BK;      // stage s of the fragment = k-stage sb + s of the tile
-    const float* Bbase = B + (long)n0 * g.ldb + (long)sb * BK;
-    const bool tail_here = ktail && se == SPT;
-    auto issue_lean = [&](int s) {
-      const int k0 = s * BK;
-      const unsigned sbuf = lds_base + (unsigned)((s % NS) * STAGE * 4) + (unsigned)(w * 1024);
-      lds_dma16_block<NA>(Abase + k0, sbuf, voffA);
-      if (nb_hi) lds_dma16_block<NBMAX>(Bbase + k0, sbuf + NIA * 1024, voffB);
-      else if constexpr (NBMAX > 1) lds_dma16_block<NBMAX - 1>(Bbase + k0, sbuf + NIA * 1024, voffB);
-    };
-    auto issue = [&](int s) {
-      if (!(tail_here && s == S - 1)) { issue_lean(s); return; }
-      const int k0 = s * BK, kabs = (sb + s) * BK;
-      const unsigned sbuf = lds_base + (unsigned)((s % NS) * STAGE * 4) + (unsigned)(w * 1024);
-#pragma unroll
-      for (int i = 0; i < NA; ++i)
-        lds_dma16((kabs + kchA[i] < K) ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(Abase + k0) + voffA[i]) : zero, sbuf + i * 4096);
-#pragma unroll
-      for (int j = 0; j < NBMAX; ++j)
-        if (j < NBMAX - 1 || nb_hi)
-          lds_dma16((kabs + kchB[j] < K) ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(Bbase + k0) + voffB[j]) : zero,
-                    sbuf + NIA * 1024 + j * 4096);
-    };
-    auto wait_landed = [&](int ahead) {
-      if (NI % 4 == 0 || w < NI % 4) wait_stages<NPW, NS - 3>(ahead);
-      else wait_stages<NPW - 1, NS - 3>(ahead);
-    };
-    f32x4 acc[TM][TN];
-#pragma unroll
-    for (int m = 0; m < TM; ++m)
-#pragma unroll
-      for (int n = 0; n < TN; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
-    auto rd = [&](int s, int kg, f32x4 (&a)[TM], f32x4 (&b)[TN]) {
-      const float* As = lds + (s % NS) * STAGE;
-      const float* Bs = As + BM * BK;
-#pragma unroll
-      for (int m = 0; m < TM; ++m)
-        a[m] = *reinterpret_cast<const f32x4*>(&As[((w * TM + m) * 16 + r) * BK + 4 * ((kg * 4 + kk) ^ swz<BK>(r))]);
-#pragma unroll
-      for (int n = 0; n < TN; ++n)
-        b[n] = *reinterpret_cast<const f32x4*>(&Bs[(n * 16 + r) * BK + 4 * ((kg * 4 + kk) ^ swz<BK>(r))]);
-    };
-    auto mm = [&](const f32x4 (&a)[TM], const f32x4 (&b)[TN]) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int m = 0; m < TM; ++m)
-#pragma unroll
-          for (int n = 0; n < TN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][i], b[n][i], acc[m][n], 0, 0, 0);
-    };
-#pragma unroll
-    for (int s = 0; s < NS - 1; ++s)
-      if (s < S) issue(s);
-    if (NI % 4 == 0 || w < NI % 4) wait_stages<NPW, NS - 2>(S - 1); else wait_stages<NPW - 1, NS - 2>(S - 1);
-    __builtin_amdgcn_s_barrier();
-    rd(0, 0, fa0, fb0);
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-#define NNR_LGKM0() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0xC07F); } while (0)
-    int s = 0;
-    for (; s + NS < S; ++s) {
-      rd(s, 1, fa1, fb1);
-      __builtin_amdgcn_sched_barrier(0);
-      mm(fa0, fb0);
-      NNR_LGKM0();
-      wait_landed(NS);
-      __builtin_amdgcn_s_barrier();
-      issue_lean(s + NS - 1);
-      rd(s + 1, 0, fa0, fb0);
-      __builtin_amdgcn_sched_barrier(0);
-      mm(fa1, fb1);
-      NNR_LGKM0();
-    }
-    for (; s + 1 < S; ++s) {
-      rd(s, 1, fa1, fb1);
-      __builtin_amdgcn_sched_barrier(0);
-      mm(fa0, fb0);
-      NNR_LGKM0();
-      wait_landed(S - 1 - (s + 1));
-      __builtin_amdgcn_s_barrier();
-      if (s + NS - 1 < S) issue(s + NS - 1);
-      rd(s + 1, 0, fa0, fb0);
-      __builtin_amdgcn_sched_barrier(0);
-      mm(fa1, fb1);
-      NNR_LGKM0();
-    }
-#undef NNR_LGKM0
-    rd(S - 1, 1, fa1, fb1);
-    __builtin_amdgcn_sched_barrier(0);
-    mm(fa0, fb0);
-    mm(fa1, fb1);
-    __syncthreads();                                          // every wave is done with the stage buffers (the next fragment's DMAs / the epilogue reuse them)
-
-    // the first workgroup of tile t (the range that holds its k-stage 0) and this workgroup's distance from it; range i = [total i / W, total (i + 1) / W)
-    int first = (int)(((long)t * SPT * (long)W) / total);
-    while ((long)total * (first + 1) / W <= (long)t * SPT) ++first;
-    while ((long)total * first / W > (long)t * SPT) --first;
-    const int dist = wi - first;                              // 0: this fragment begins the tile; 1, 2: it continues it
-    if (se < SPT) {
-      // ---- not the tile's end: leave the partial accumulators for the owner
-      float* dst = parts + ((long)t * 2 + dist) * PART + tid * 4;      // register order: block (m, n) = 256 lanes x 16 bytes, fully coalesced
-#pragma unroll
-        for (int m = 0; m < TM; ++m)
-#pragma unroll
-          for (int n = 0; n < TN; ++n)
-            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" ::"v"(dst + (m * TN + n) * 1024), "v"(acc[m][n]) : "memory");      // write-through (agent scope); the
-                              // wait states: a store wider than 64 bits reads the upper data registers AFTER issue, the compiler does not look inside an asm statement
-                              // for that hazard and re-uses the registers it copied the accumulators to (found by tests/test_hip_ops_gpu.py: wrong partial tiles)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's stores are acknowledged
-      __syncthreads();
-      if (tid == 0) __hip_atomic_store(flags + t * 2 + dist, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      continue;
-    }
-    if (dist > 0) {
-      // ---- the tile's end, begun by lower workgroups: add their partials in ascending-k order, then this fragment's
-      if (tid == 0) {
-        bool late = false;
-        for (int d = 0; d < dist; ++d) {
-          int spins = 0;
-          while (__hip_atomic_load(flags + t * 2 + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && spins < (1 << 24)) { __builtin_amdgcn_s_sleep(2); ++spins; }
-          late |= spins >= (1 << 24);
-        }
-        lds[0] = late ? __int_as_float(0x7fc00000) : 0.f;      // never hang: a partial that does not arrive poisons the tile (visible), as the recurrence's exchange does
-      }
-      __syncthreads();
-      const float poison = lds[0];
-      __syncthreads();
-      const float* p0 = parts + ((long)t * 2) * PART + tid * 4;
-      f32x4 pr[TM][TN];
-#pragma unroll
-      for (int m = 0; m < TM; ++m)
-#pragma unroll
-        for (int n = 0; n < TN; ++n)
-          asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(pr[m][n]) : "v"(p0 + (m * TN + n) * 1024) : "memory");      // past the XCD's L2 (agent scope)
-      // (the wait statements carry the loaded registers as operands: the compiler must not move a use in front of them)
-#define NNR_LANDED(X) asm volatile("s_waitcnt vmcnt(0)" : "+v"(X)::"memory")
-      if (dist > 1) {
-        f32x4 p1[TM][TN];
-#pragma unroll
-        for (int m = 0; m < TM; ++m)
-#pragma unroll
-          for (int n = 0; n < TN; ++n)
-            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(p1[m][n]) : "v"(p0 + PART + (m * TN + n) * 1024) : "memory");
-#pragma unroll
-        for (int m = 0; m < TM; ++m)
-#pragma unroll
-          for (int n = 0; n < TN; ++n) { NNR_LANDED(pr[m][n]); NNR_LANDED(p1[m][n]); pr[m][n] += p1[m][n]; }
-      } else {
-#pragma unroll
-        for (int m = 0; m < TM; ++m)
-#pragma unroll
-          for (int n = 0; n < TN; ++n) NNR_LANDED(pr[m][n]);
-      }
-#undef NNR_LANDED
-#pragma unroll
-      for (int m = 0; m < TM; ++m)
-#pragma unroll
-        for (int n = 0; n < TN; ++n)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc[m][n][e] = (pr[m][n][e] + acc[m][n][e]) + poison;
-      __syncthreads();
-      if (tid < dist) __hip_atomic_store(flags + t * 2 + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // consumed: the next launch finds them clear
-    }
-    gemm_epilogue<TM, TN>(g, acc, lds, C, m0, n0, M, N, 0);
-    __syncthreads();
-  }
-}
-
-template <int TM, int TN, int NS, int OCC>
-int launch_sk(const nnr_gemm_args& g, hipStream_t s) {
-  constexpr int BM = 64 * TM, BN = 16 * TN;
-  const int nblk = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
-  const int spt = (g.K + 31) / 32;
-  int W = 256 * OCC;                                          // one range per workgroup slot of the chip
-  if (W > 2 * nblk) W = 2 * nblk;                             // a tile is shared by at most three ranges (two partial slots per tile)
-  if ((long)nblk * spt < W) W = (int)((long)nblk * spt);
-  nnr_gemm_args gg = g;
-  hipLaunchKernelGGL((gemm_nt_sk_kernel<TM, TN, NS, OCC>), dim3(W), dim3(256), 0, s, gg);
-  NNR_CHECK_LAUNCH();
-  return NNR_OK;
-}
-
-// ------------------------------------------------------------------------------------------------ third-generation NT loop (round 5)
-// gemm_nt_pipe2_kernel's stage loop made PERSISTENT and CONTINUOUS across tiles.  A workgroup walks tiles b, b + grid, b + 2 grid ...
-// of the XCD-aware order; the LDS-DMA pipeline never drains at a tile boundary -- the first NS - 1 stages of the NEXT tile are issued
-// during the last NS - 1 stages of the current one (into the stage buffers its reads have left), and the epilogue runs out of the
-// accumulator REGISTERS (no LDS staging: a 4 x 4 lane transpose by DPP gives every lane four consecutive columns of one row, so all
-// global traffic of the epilogue is float4), between the last MFMA block of a tile and the first of the next, whose fragments are
-// already in registers.  The short-reduction GEMMs of the step (K = 200-400: 25 / 13 stages of 16 / 32) paid a cold pipeline
-// (DMA round trip) and an LDS-staged epilogue with two barriers per 64 rows on every tile, all workgroups of a CU in lockstep.
-// Same MFMA order as the other NT kernels (results are bit-identical for the same tile); epilogue = the float4 path of
-// gemm_epilogue (vec_epi launches only: the dispatcher sends everything else to the older kernels).
-__device__ __forceinline__ float quad_xor1(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true)); }   // lanes 1,0,3,2
-__device__ __forceinline__ float quad_xor2(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, true)); }   // lanes 2,3,0,1
-// lane i of a quad holds a[0..3]; afterwards it holds element i of lanes 0..3 (4 x 4 transpose inside every quad of lanes)
-__device__ __forceinline__ f32x4 quad_transpose(f32x4 a, int lane) {
-  const bool x = lane & 1, y = lane & 2;
-  const float s0 = quad_xor1(a[0]), s1 = quad_xor1(a[1]), s2 = quad_xor1(a[2]), s3 = quad_xor1(a[3]);
-  const float b0 = x ? s1 : a[0], b1 = x ? a[1] : s0, b2 = x ? s3 : a[2], b3 = x ? a[3] : s2;
-  const float t0 = quad_xor2(b0), t1 = quad_xor2(b1), t2 = quad_xor2(b2), t3 = quad_xor2(b3);
-  return f32x4{y ? t2 : b0, y ? t3 : b1, y ? b2 : t0, y ? b3 : t1};
-}
-
-// Epilogue of one tile straight from the accumulators.  acc[m][n] = rows (w*TM + m)*16 + kk*4 + reg, column n*16 + r of the tile.
-// The element-wise operands a launch reads (PRE: pre_add, CO: the old C of accumulate = 1 / 2, MU: mul, RE: resid, RV: rowvec) are
-// template flags: the loads of a whole row group (TN float4 per operand) are issued together, BEFORE the arithmetic and the stores of the
-// group -- one round trip per 16 rows instead of one per 16 x 16 block.  The kernel picks the instantiation by (uniform) launch flags;
-// combinations outside the list take the all-flags-off instantiation's serial loads (GEN).
-template <int TM, int TN, bool PRE, bool CO, bool MU, bool RE, bool RV, bool GEN>
-__device__ __forceinline__ void gemm_epilogue_reg(const nnr_gemm_args& g, f32x4 (&acc)[TM][TN], float* __restrict__ C, int m0, int n0, int M,
-                                                  int N, int z, int lane, int w) {
-  const int r = lane & 15, kk = lane >> 4;
-  const uint32_t dthr = g.drop_thresh;
-  const float dscale = g.drop_scale;
-  float* __restrict__ aux = g.aux_out;
-  const float* __restrict__ res = g.resid;
-  const float* __restrict__ mulp = g.mul;
-  if (g.batch > 1) {
-    if (aux) aux += (long)z * g.stride_aux;
-    if (res) res += (long)z * g.stride_res;
-  }
-  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int m = 0; m < TM; ++m) {
-    const int row = m0 + (w * TM + m) * 16 + kk * 4 + (r & 3);
-    const bool rok = row < M;
-    const int rvrow = (g.rowvec && rok) ? (g.rowvec_map ? g.rowvec_map[row] : row) : 0;
-    f32x4 p_pre[PRE ? TN : 1], p_co[CO ? TN : 1], p_mu[MU ? TN : 1], p_re[RE ? TN : 1], p_rv[RV ? TN : 1], p_bi[TN];
-#pragma unroll
-    for (int n = 0; n < TN; ++n) {
-      const int col = n0 + n * 16 + 4 * (r >> 2);
-      const bool ok = rok && col < N;
-      if constexpr (PRE) p_pre[n] = ok ? *reinterpret_cast<const f32x4*>(g.pre_add + (long)row * g.ldpre + col) : zero4;
-      if constexpr (CO) p_co[n] = ok ? *reinterpret_cast<const f32x4*>(C + (long)row * g.ldc + col) : zero4;
-      if constexpr (MU) p_mu[n] = ok ? *reinterpret_cast<const f32x4*>(mulp + (long)row * g.ldmul + col) : zero4;
-      if constexpr (RE) p_re[n] = ok ? *reinterpret_cast<const f32x4*>(res + (long)row * g.ldres + col) : zero4;
-      if constexpr (RV) p_rv[n] = ok ? *reinterpret_cast<const f32x4*>(g.rowvec + (long)rvrow * g.ldrv + col) : zero4;
-      p_bi[n] = (g.bias && col < N) ? *reinterpret_cast<const f32x4*>(g.bias + col) : zero4;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int n = 0; n < TN; ++n) {
-      const int col = n0 + n * 16 + 4 * (r >> 2);
-      const bool ok = rok && col < N;
-      f32x4 v = quad_transpose(acc[m][n], lane) * g.alpha;
-      if (ok) {
-        if constexpr (PRE) v += p_pre[n];
-        else if (GEN && g.pre_add) v += *reinterpret_cast<const f32x4*>(g.pre_add + (long)row * g.ldpre + col);
-        if (g.gate_bwd) {
-          f32x4 gv, hv;
-          if constexpr (MU) gv = p_mu[n]; else gv = *reinterpret_cast<const f32x4*>(mulp + (long)row * g.ldmul + col);
-          if constexpr (RE) hv = p_re[n]; else hv = *reinterpret_cast<const f32x4*>(res + (long)row * g.ldres + col);
-          *reinterpret_cast<f32x4*>(aux + (long)row * g.ldaux + col) = v * hv * gv * (1.f - gv);
-          *reinterpret_cast<f32x4*>(C + (long)row * g.ldc + col) = v * gv;
-        } else {
-          if (g.accumulate == 2) {
-            if constexpr (CO) v += p_co[n]; else v += *reinterpret_cast<const f32x4*>(C + (long)row * g.ldc + col);
-          }
-          v += p_bi[n];
-          if constexpr (RV) v += p_rv[n];
-          else if (GEN && g.rowvec) v += *reinterpret_cast<const f32x4*>(g.rowvec + (long)rvrow * g.ldrv + col);
-          if (g.act == 1) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-          } else if (g.act == 2) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fast_tanh(v[e]);
-          } else if (g.act == 3) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fast_sigmoid(v[e]);
-          }
-          if (aux) *reinterpret_cast<f32x4*>(aux + (long)row * g.ldaux + col) = v;
-          if constexpr (MU) v *= p_mu[n];
-          else if (GEN && mulp) v *= *reinterpret_cast<const f32x4*>(mulp + (long)row * g.ldmul + col);
-          if constexpr (RE) v += p_re[n];
-          else if (GEN && res) v += *reinterpret_cast<const f32x4*>(res + (long)row * g.ldres + col);
-          if (g.drop_target == 3) {
-            bool kp[4];
-            nnr_keep4(g.drop_seed, (uint64_t)(row + (long)z * g.M) * g.drop_cols + col, dthr, kp);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = kp[e] ? v[e] * dscale : 0.f;
-          }
-          if (C) {
-            f32x4* cp = reinterpret_cast<f32x4*>(C + (long)row * g.ldc + col);
-            if (g.accumulate == 1) {
-              if constexpr (CO) v += p_co[n]; else v += *cp;
-            }
-            *cp = v;
-          }
-        }
-      }
-      if constexpr (GEN) __builtin_amdgcn_sched_barrier(0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
-// the instantiation for a launch's operand set (wave-uniform flags)
-template <int TM, int TN>
-__device__ __forceinline__ void gemm_epilogue_reg_any(const nnr_gemm_args& g, f32x4 (&acc)[TM][TN], float* __restrict__ C, int m0, int n0, int M,
-                                                      int N, int z, int lane, int w) {
-  const bool pre = g.pre_add != nullptr, co = g.accumulate != 0 && C != nullptr, mu = g.mul != nullptr, re = g.resid != nullptr, rv = g.rowvec != nullptr;
-  if (!pre && !co && !mu && !re && !rv) gemm_epilogue_reg<TM, TN, false, false, false, false, false, false>(g, acc, C, m0, n0, M, N, z, lane, w);      // bias / activation / aux / dropout only
-  else if (!pre && !co && mu && !re && rv) gemm_epilogue_reg<TM, TN, false, false, true, false, true, false>(g, acc, C, m0, n0, M, N, z, lane, w);   // gate forward
-  else if (pre && !co && mu && re && !rv) gemm_epilogue_reg<TM, TN, true, false, true, true, false, false>(g, acc, C, m0, n0, M, N, z, lane, w);     // gate backward inside the dHt GEMM
-  else if (!pre && co && !mu && !re && !rv) gemm_epilogue_reg<TM, TN, false, true, false, false, false, false>(g, acc, C, m0, n0, M, N, z, lane, w); // accumulate into C
-  else if (!pre && !co && !mu && re && !rv) gemm_epilogue_reg<TM, TN, false, false, false, true, false, false>(g, acc, C, m0, n0, M, N, z, lane, w); // residual (GCN-style)
-  else gemm_epilogue_reg<TM, TN, false, false, false, false, false, true>(g, acc, C, m0, n0, M, N, z, lane, w);                                      // anything else: serial loads
-}
-
-template <int TM, int TN, int OCC>
-__global__ __launch_bounds__(256, OCC) void gemm_nt_pipe3_kernel(nnr_gemm_args g) {
-  constexpr int NS = 3;
-  constexpr int BK = 32, BM = 64 * TM, BN = 16 * TN, ROWS = BM + BN;
-  constexpr int KQ = BK / 4, RPI = 64 / KQ, NI = ROWS / RPI, STAGE = ROWS * BK;
-  static_assert(ROWS % RPI == 0, "tile shape");
-  __shared__ __attribute__((aligned(1024))) float lds[NS * STAGE];
-  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r = lane & 15, kk = lane >> 4;
-  int M = g.M;
-  if (g.dyn_dim == 1) M = min(M, *g.dyn_dev);
-  const int N = g.N, K = g.K;
-  const int nbm = (M + BM - 1) / BM, nbn = (N + BN - 1) / BN;
-  const int nblk = nbm * nbn;
-  if ((int)blockIdx.x >= nblk) return;
-  const int z = blockIdx.z;
-  const float* __restrict__ A = g.A;
-  const float* __restrict__ B = g.B;
-  float* __restrict__ C = g.C;
-  if (g.batch > 1) {
-    A += (long)z * g.strideA;
-    B += (long)z * g.strideB;
-    C += (long)z * g.strideC;
-  }
-  constexpr int NIA = BM / RPI, NIB = BN / RPI, NA = NIA / 4, NBMAX = (NIB + 3) / 4;
-  static_assert(NIA % 4 == 0 && NA <= 8 && NBMAX <= 8, "tile shape");
-  const bool nb_hi = (NIB % 4 == 0) || (w < NIB % 4);      // this wave has NBMAX (else NBMAX - 1) B instructions
-  const float* zero = nnr_zero_page;
-  asm volatile("" : "+s"(zero));
-  const unsigned lds_base = (unsigned)(uintptr_t)lds;
-  const int S = (K + BK - 1) / BK;                           // >= NS (dispatcher)
-  const bool ktail = (K % BK) != 0;
-  const int q8 = nblk >> 3, rem8 = nblk & 7;
-  auto tile_of = [&](int b) { const int x = b & 7, slot = b >> 3; return x * q8 + min(x, rem8) + slot; };   // XCD-aware order (gridDim.x % 8 == 0 or == nblk)
-
-  // ---- the tile the DMA issue currently points at
-  unsigned voffA[8], voffB[8];
-  int kchA[NA], kchB[NBMAX];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) voffA[i] = voffB[i] = 0;
-  const float* Abase;
-  const float* Bbase;
-  auto point_at = [&](int v) {
-    const int bm = v / nbn, bn = v - bm * nbn, m0 = bm * BM, n0 = bn * BN;
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const int tr = (w + 4 * i) * RPI + lane / KQ;
-      const int c = (lane % KQ) ^ swz<BK>(tr & 15);
-      kchA[i] = 4 * c;
-      voffA[i] = (unsigned)(((long)min(tr, M - 1 - m0) * g.lda + 4 * c) * 4);
-    }
-#pragma unroll
-    for (int j = 0; j < NBMAX; ++j) {
-      const int tr = (w + 4 * j) * RPI + lane / KQ;
-      const int c = (lane % KQ) ^ swz<BK>(tr & 15);
-      kchB[j] = 4 * c;
-      voffB[j] = (unsigned)(((long)min(tr, N - 1 - n0) * g.ldb + 4 * c) * 4);
-    }
-    Abase = A + (long)m0 * g.lda;
-    Bbase = B + (long)n0 * g.ldb;
-  };
-  // stage s (0 .. S-1) of the pointed-at tile into stage buffer `buf`
-  auto issue = [&](int s, int buf) {
-    const int k0 = s * BK;
-    const unsigned sb = lds_base + (unsigned)(buf * STAGE * 4) + (unsigned)(w * 1024);
-    if (!(ktail && s == S - 1)) {
-      lds_dma16_block<NA>(Abase + k0, sb, voffA);
-      if (nb_hi) lds_dma16_block<NBMAX>(Bbase + k0, sb + NIA * 1024, voffB);
-      else if constexpr (NBMAX > 1) lds_dma16_block<NBMAX - 1>(Bbase + k0, sb + NIA * 1024, voffB);
-      return;
-    }
-#pragma unroll
-    for (int i = 0; i < NA; ++i)
-      lds_dma16((k0 + kchA[i] < K) ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(Abase + k0) + voffA[i]) : zero, sb + i * 4096);
-#pragma unroll
-    for (int j = 0; j < NBMAX; ++j)
-      if (j < NBMAX - 1 || nb_hi)
-        lds_dma16((k0 + kchB[j] < K) ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(Bbase + k0) + voffB[j]) : zero,
-                  sb + NIA * 1024 + j * 4096);
-  };
-  f32x4 acc[TM][TN];
-#pragma unroll
-  for (int m = 0; m < TM; ++m)
-#pragma unroll
-    for (int n = 0; n < TN; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
-  auto rd = [&](int buf, int kg, f32x4 (&a)[TM], f32x4 (&b)[TN]) {
-    const float* As = lds + buf * STAGE;
-    const float* Bs = As + BM * BK;
-#pragma unroll
-    for (int m = 0; m < TM; ++m)
-      a[m] = *reinterpret_cast<const f32x4*>(&As[((w * TM + m) * 16 + r) * BK + 4 * ((kg * 4 + kk) ^ swz<BK>(r))]);
-#pragma unroll
-    for (int n = 0; n < TN; ++n)
-      b[n] = *reinterpret_cast<const f32x4*>(&Bs[(n * 16 + r) * BK + 4 * ((kg * 4 + kk) ^ swz<BK>(r))]);
-  };
-  auto mm = [&](const f32x4 (&a)[TM], const f32x4 (&b)[TN]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int m = 0; m < TM; ++m)
-#pragma unroll
-        for (int n = 0; n < TN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][i], b[n][i], acc[m][n], 0, 0, 0);
-  };
-#define NNR_LGKM0() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0xC07F); } while (0)
-  // NS = 3: when a wave waits for a stage, that stage is the only one it can have in flight (the next is issued right behind the barrier)
-  // -- plus, at the first stage of a tile, the previous tile's epilogue stores: vmcnt(0) everywhere
-  int b = blockIdx.x;
-  int v = tile_of(b);
-  point_at(v);
-  int buf = 0;                                               // stage buffer of the stage about to be computed; refills go to (buf + 2) % 3
-  issue(0, 0);
-  issue(1, 1);
-  if (nb_hi) wait_vmcnt<NA + NBMAX>(); else wait_vmcnt<NA + NBMAX - 1>();      // stage 0 landed: only this wave's DMAs of stage 1 may stay in flight
-  __builtin_amdgcn_s_barrier();
-  rd(0, 0, fa0, fb0);
-  __builtin_amdgcn_s_waitcnt(0xC07F);
-  for (;;) {
-    const int bm_e = v / nbn, bn_e = v - bm_e * nbn, m0_e = bm_e * BM, n0_e = bn_e * BN;      // the tile being computed (epilogue coordinates)
-    const int bnext = b + (int)gridDim.x;
-    const bool has_next = bnext < nblk;
-    int s = 0;
-    for (; s + NS < S; ++s) {                                  // refill = stage s + 2 <= S - 2 of this tile: lean, branch-free
-      rd(buf, 1, fa1, fb1);
-      __builtin_amdgcn_sched_barrier(0);
-      mm(fa0, fb0);
-      NNR_LGKM0();
-      wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();
-      const int nb1 = buf == 2 ? 0 : buf + 1, nb2 = nb1 == 2 ? 0 : nb1 + 1;
-      issue(s + 2, nb2);
-      rd(nb1, 0, fa0, fb0);
-      __builtin_amdgcn_sched_barrier(0);
-      mm(fa1, fb1);
-      NNR_LGKM0();
-      buf = nb1;
-    }
-    for (; s + 1 < S; ++s) {                                   // the last stages: refill = this tile's last stage, then the next tile's stages 0 .. NS - 3
-      rd(buf, 1, fa1, fb1);
-      __builtin_amdgcn_sched_barrier(0);
-      mm(fa0, fb0);
-      NNR_LGKM0();
-      wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();
-      const int nb1 = buf == 2 ? 0 : buf + 1, nb2 = nb1 == 2 ? 0 : nb1 + 1;
-      if (s + 2 < S) issue(s + 2, nb2);
-      else if (has_next) { point_at(tile_of(bnext)); issue(s + 2 - S, nb2); }
-      rd(nb1, 0, fa0, fb0);
-      __builtin_amdgcn_sched_barrier(0);
-      mm(fa1, fb1);
-      NNR_LGKM0();
-      buf = nb1;
-    }
-    // last stage of the tile: its second k-group, the hand-over to the next tile's stage 0 (already in flight), then the epilogue
-    rd(buf, 1, fa1, fb1);
-    __builtin_amdgcn_sched_barrier(0);
-    mm(fa0, fb0);
-    NNR_LGKM0();
-    if (has_next) {
-      wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();
-      const int nb1 = buf == 2 ? 0 : buf + 1, nb2 = nb1 == 2 ? 0 : nb1 + 1;
-      issue(1, nb2);                                            // (S >= NS: stage 1 of the next tile is an ordinary or a k-tail stage of its own)
-      rd(nb1, 0, fa0, fb0);
-      __builtin_amdgcn_sched_barrier(0);
-      buf = nb1;
-    }
-    mm(fa1, fb1);
-    NNR_LGKM0();
-    gemm_epilogue_reg_any<TM, TN>(g, acc, C, m0_e, n0_e, M, N, z, lane, w);
-    if (!has_next) break;
-#pragma unroll
-    for (int m = 0; m < TM; ++m)
-#pragma unroll
-      for (int n = 0; n < TN; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    b = bnext;
-    v = tile_of(b);
-  }
-#undef NNR_LGKM0
-}
-
-template <int TM, int TN, int OCC>
-int launch_pipe3(const nnr_gemm_args& g, hipStream_t s) {
-  constexpr int BM = 64 * TM, BN = 16 * TN;
-  const int nbm = (g.M + BM - 1) / BM, nbn = (g.N + BN - 1) / BN, nblk = nbm * nbn;
-  // persistent: one workgroup per resident slot (256 CUs x OCC), a multiple of 8 so that a workgroup's tiles stay in one XCD's range
-  static const int slots_env = [] { const char* e = getenv("NNR_P3_SLOTS"); return e ? atoi(e) : 0; }();
-  const int slots = slots_env > 0 ? slots_env : 256 * OCC;
-  const int grid_x = nblk <= slots ? nblk : slots;
-  dim3 grid(grid_x, 1, g.batch > 1 ? g.batch : 1), block(256);
-  hipLaunchKernelGGL((gemm_nt_pipe3_kernel<TM, TN, OCC>), grid, block, 0, s, g);
-  NNR_CHECK_LAUNCH();
-  return NNR_OK;
-}
-
 static int nt_ragged_bit() {
   static const int on = [] { const char* e = getenv("NNR_RAGGED"); return (e && atoi(e) == 0) ? 0 : 1; }();      // A/B: 0 = every tile of a ragged last column block / reduction tail is multiplied
   return on;
@@ -1528,11 +945,6 @@ static bool pipe_ok(const nnr_gemm_args& g) {
   return !g.trans_a && !g.trans_b && !g.b_idx && g.split_k <= 1 && g.k_chunk <= 0 && !g.rowdot_w && !g.colsum_out &&
          (g.drop_target == 0 || g.drop_target == 3 || g.drop_target == 4) && (g.K & 3) == 0 && (g.lda & 3) == 0 && (g.ldb & 3) == 0 &&
          al(g.A) && al(g.B) && (g.batch <= 1 || (((g.strideA | g.strideB) & 3) == 0)) && (g.dyn_dim == 0 || g.dyn_dim == 1);
-}
-
-// what the gen-3 kernel accepts: a plain NT launch whose epilogue is the float4 path (g.vec_epi is set by nnr_gemm_f32 before the dispatch)
-static bool pipe3_ok(const nnr_gemm_args& g) {
-  return pipe_ok(g) && !g.a_idx && !g.c_idx && !g.atomic && g.vec_epi && g.drop_target != 4 && g.K >= 96;
 }
 
 // ------------------------------------------------------------------------------------------------ NT GEMM on the BF16 matrix pipe (round 5)
@@ -2448,10 +1860,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // tile id -> (rows, columns, stage depth, workgroups per CU the kernel is built for, 1 = LDS-DMA TN tile with the device-side slice count)
 static bool tile_shape(int tile, int* bm, int* bn, int* bk, int* occ, int* kind) {
   struct T { int tile, bm, bn, bk, occ, kind; };
-  static const T tab[] = {{1, 256, 80, 16, 1, 0}, {2, 64, 80, 16, 1, 0}, {3, 128, 208, 16, 1, 0}, {4, 128, 80, 16, 1, 0}, {5, 128, 80, 32, 1, 0}, {6, 64, 80, 64, 1, 0},
-                          {20, 128, 80, 16, 3, 1}, {21, 128, 80, 16, 3, 1}, {22, 64, 80, 16, 4, 1}, {23, 256, 80, 16, 2, 1}, {24, 128, 208, 16, 2, 1},
-                          {25, 128, 128, 16, 2, 1}, {26, 128, 80, 16, 3, 1}, {27, 128, 208, 16, 2, 1}, {28, 128, 80, 16, 2, 1}, {29, 256, 80, 16, 2, 1},
-                          {30, 128, 160, 16, 2, 1}, {32, 64, 208, 16, 2, 1}, {37, 256, 160, 16, 1, 1}, {38, 128, 160, 16, 1, 1}, {39, 64, 160, 16, 3, 1}};
+  static const T tab[] = {{2, 64, 80, 16, 1, 0}, {3, 128, 208, 16, 1, 0}, {4, 128, 80, 16, 1, 0}, {5, 128, 80, 32, 1, 0}, {6, 64, 80, 64, 1, 0},
+                          {20, 128, 80, 16, 3, 1}, {26, 128, 80, 16, 3, 1}, {27, 128, 208, 16, 2, 1}, {30, 128, 160, 16, 2, 1}, {32, 64, 208, 16, 2, 1}};
   for (const T& t : tab)
     if (t.tile == tile) { *bm = t.bm; *bn = t.bn; *bk = t.bk; *occ = t.occ; *kind = t.kind; return true; }
   return false;
@@ -2459,58 +1869,20 @@ static bool tile_shape(int tile, int* bm, int* bn, int* bk, int* occ, int* kind)
 
 static int dispatch_tile(int tile, const nnr_gemm_args& g, hipStream_t stream) {
   switch (tile) {
-    case 1: return launch_cfg<4, 5, 16>(g, stream);    // 256 x 80
     case 2: return launch_cfg<1, 5, 16>(g, stream);    //  64 x 80
     case 3: return launch_cfg<2, 13, 16>(g, stream);   // 128 x 208 (whole rows in one wave: fused row-dot)
     case 4: return launch_cfg<2, 5, 16>(g, stream);    // 128 x 80 (4 waves/SIMD: more workgroups in flight per CU)
     case 5: return launch_cfg<2, 5, 32>(g, stream);   // 128 x 80, BK = 32: half the barriers per FLOP, 3 workgroups per CU
     case 6: return launch_cfg<1, 5, 64>(g, stream);   //  64 x 80, BK = 64: latency-bound small launches (few stages, 74 KB LDS)
-    case 8:  if (!pipe_ok(g)) return NNR_ERR_ARG; return launch_pipe<2, 5, 32, 3, 2>(g, stream);   // 128 x 80, 3 x 26 KB stages, 2 workgroups / CU
     case 9:  if (!pipe_ok(g) || g.a_idx) return NNR_ERR_ARG; return launch_pipe2<2, 5, 3, 2>(g, stream);    // gen-2 loop, 128 x 80, 3 x 26 KB stages, 2 workgroups / CU
-    case 10: if (!pipe_ok(g) || g.a_idx) return NNR_ERR_ARG; return launch_pipe2<2, 5, 4, 1>(g, stream);   // gen-2 loop, 128 x 80, 4 stages, 1 workgroup / CU
-    case 11: if (!pipe_ok(g) || g.a_idx) return NNR_ERR_ARG; return launch_pipe2<2, 10, 3, 1>(g, stream);  // gen-2 loop, 128 x 160, 3 x 36 KB stages
-    case 12: if (!pipe_ok(g) || g.a_idx) return NNR_ERR_ARG; return launch_pipe2<4, 5, 3, 1>(g, stream);   // gen-2 loop, 256 x 80, 3 x 42 KB stages
-    case 13: if (!pipe_ok(g)) return NNR_ERR_ARG; return launch_pipe<2, 5, 16, 4, 3>(g, stream);   // 128 x 80, BK 16, 4 x 13 KB stages, 3 workgroups / CU
-    case 14: if (!pipe_ok(g) || g.a_idx) return NNR_ERR_ARG; return launch_pipe2<2, 10, 4, 1>(g, stream);  // gen-2 loop, 128 x 160, 4 stages
     case 15: if (!pipe_ok(g)) return NNR_ERR_ARG; return launch_pipe<2, 5, 16, 3, 4>(g, stream);   // 128 x 80, BK 16, 3 x 13 KB stages, 4 workgroups / CU
     case 16: if (!pipe_ok(g)) return NNR_ERR_ARG; return launch_pipe<2, 5, 16, 2, 5>(g, stream);   // 128 x 80, BK 16, 2 stages, 5-6 workgroups / CU
-    case 17: if (!pipe_ok(g)) return NNR_ERR_ARG; return launch_pipe<1, 5, 16, 4, 4>(g, stream);   //  64 x 80, BK 16, 4 x 9 KB stages
-    case 18: if (!pipe_ok(g)) return NNR_ERR_ARG; return launch_pipe<4, 5, 16, 3, 2>(g, stream);   // 256 x 80, BK 16, 3 x 21 KB stages
-    case 19: if (!pipe_ok(g)) return NNR_ERR_ARG; return launch_pipe<2, 10, 16, 3, 2>(g, stream);  // 128 x 160, BK 16, 3 x 18 KB stages
     case 20: if (!tn_pipe_ok(g)) return NNR_ERR_ARG; return launch_tn_pipe<2, 5, 3, 3>(g, stream);   // TN 128 x 80, 3 x 16 KB stages
-    case 21: if (!tn_pipe_ok(g)) return NNR_ERR_ARG; return launch_tn_pipe<2, 5, 3, 3, 1>(g, stream);   // t20 + static priorities
-    case 22: if (!tn_pipe_ok(g)) return NNR_ERR_ARG; return launch_tn_pipe<1, 5, 3, 4>(g, stream);   // TN  64 x 80, 3 x 12 KB stages, 4 workgroups / CU
-    case 23: if (!tn_pipe_ok(g)) return NNR_ERR_ARG; return launch_tn_pipe<4, 5, 3, 2>(g, stream);   // TN 256 x 80, 3 x 24 KB stages
-    case 24: if (!tn_pipe_ok(g)) return NNR_ERR_ARG; return launch_tn_pipe<2, 13, 3, 2>(g, stream);  // TN 128 x 208, 3 x 24 KB stages
-    case 25: if (!tn_pipe_ok(g)) return NNR_ERR_ARG; return launch_tn_pipe<2, 8, 3, 2>(g, stream);   // TN 128 x 128
     case 26: if (!tn_pipe_ok(g) || g.b_idx) return NNR_ERR_ARG; return launch_tn_pipe2<2, 5, 3, 3>(g, stream);    // gen-2 TN 128 x 80 (no gather)
     case 27: if (!tn_pipe_ok(g)) return NNR_ERR_ARG; return launch_tn_pipe2<2, 13, 3, 2>(g, stream);              // gen-2 TN 128 x 208
-    case 28: if (!tn_pipe_ok(g) || g.b_idx) return NNR_ERR_ARG; return launch_tn_pipe2<2, 5, 4, 2>(g, stream);    // gen-2 TN 128 x 80, 4 stages
-    case 29: if (!tn_pipe_ok(g) || g.b_idx) return NNR_ERR_ARG; return launch_tn_pipe2<4, 5, 3, 2>(g, stream);    // gen-2 TN 256 x 80
     case 30: if (!tn_pipe_ok(g)) return NNR_ERR_ARG; return launch_tn_pipe2<2, 10, 3, 2>(g, stream);              // gen-2 TN 128 x 160 (N = 300 in two column blocks)
-    case 31: if (!pipe_ok(g) || g.a_idx) return NNR_ERR_ARG; return launch_pipe2<2, 4, 3, 2>(g, stream);          // gen-2 NT 128 x 64, 3 x 24 KB stages, 2 workgroups / CU
-    case 33: if (!pipe_ok(g)) return NNR_ERR_ARG; return launch_pipe<2, 13, 16, 3, 2>(g, stream);   // NT 128 x 208, BK 16, 3 x 21 KB stages, 2 workgroups / CU (N = 1664 = 8 x 208)
-    case 34: if (!pipe_ok(g) || g.a_idx) return NNR_ERR_ARG; return launch_pipe2<2, 13, 3, 1>(g, stream);          // gen-2 NT 128 x 208, 3 x 43 KB stages, 1 workgroup / CU
-    case 36: if (!pipe_ok(g)) return NNR_ERR_ARG; return launch_pipe<4, 5, 16, 3, 3>(g, stream);    // NT 256 x 80, BK 16, 3 x 21 KB stages, 3 workgroups / CU
-    case 37: if (!tn_pipe_ok(g)) return NNR_ERR_ARG; return launch_tn_pipe2<4, 10, 3, 1>(g, stream);              // gen-2 TN 256 x 160, 3 x 32 KB stages, 1 workgroup / CU
-    case 38: if (!tn_pipe_ok(g)) return NNR_ERR_ARG; return launch_tn_pipe2<2, 10, 4, 1>(g, stream);              // gen-2 TN 128 x 160, 4 stages, 1 workgroup / CU
-    case 39: if (!tn_pipe_ok(g)) return NNR_ERR_ARG; return launch_tn_pipe2<1, 10, 3, 3>(g, stream);              // gen-2 TN 64 x 160, 3 x 20 KB stages, 3 workgroups / CU
-    // one-wave launches (round 5, verdict item 1b): tiles sized so that a WHOLE launch is <= 256 workgroups, one per CU -- 4 352 x 900: 17 x 15 = 255 tiles of
-    // 256 x 64 (128 x 80: 408 tiles on 512 slots, the CUs that carry two set the time); 6 080 x 900: 16 x 15 = 240 tiles of 384 x 64.
-    // MEASURED SLOWER alone (profiles/r05_ab.txt, call 15: 82.4 vs 90.7 TF and 76.7 vs 83.8 TF): four waves per CU do not cover the stage latency.  Opt-in ids only.
-    case 43: if (!pipe_ok(g) || g.a_idx) return NNR_ERR_ARG; return launch_pipe2<4, 4, 3, 1>(g, stream);          // gen-2 NT 256 x 64, 3 x 40 KB stages, 1 workgroup / CU
-    case 45: if (!pipe_ok(g)) return NNR_ERR_ARG; return launch_pipe<6, 4, 16, 3, 1>(g, stream);                  // gen-1 NT 384 x 64, BK 16, 3 x 28 KB stages, 1 workgroup / CU
-    case 47:                                                                                                      // fixed-order stream-K NT 128 x 80 (args.slab = workspace, see nnr_gemm_sk_workspace_floats)
-      if (!pipe_ok(g) || g.a_idx || g.batch > 1 || !g.slab || (((uintptr_t)g.slab) & 15) || g.K < 96 || (long)((g.M + 127) / 128) * ((g.N + 79) / 80) > 2048 ||
-          g.slab_floats < (long)nnr_gemm_sk_workspace_floats(g.M, g.N)) return NNR_ERR_ARG;
-      return launch_sk<2, 5, 3, 2>(g, stream);
     case 50: if (!bx3_ok(g)) return NNR_ERR_ARG; return launch_bx3<2, 5>(g, stream);           // bf16x3 NT 128 x 80 (needs args.B3: pre-split weights)
     case 51: if (!bx3_ok(g)) return NNR_ERR_ARG; return launch_bx3<1, 5>(g, stream);           // ... 64 x 80: 2 x 23 KB stages, 3 workgroups / CU
-    case 52: if (!bx3_ok(g)) return NNR_ERR_ARG; return launch_bx3<2, 4>(g, stream);           // ... 128 x 64
-    case 53: if (!bx3_ok(g)) return NNR_ERR_ARG; return launch_bx3<4, 5>(g, stream);           // ... 256 x 80: 2 x 47 KB stages, 1 workgroup / CU
-    case 40: if (!pipe3_ok(g)) return NNR_ERR_ARG; return launch_pipe3<2, 5, 2>(g, stream);     // gen-3 NT (persistent, continuous DMA pipeline, register epilogue) 128 x 80, 3 x 26 KB stages, 2 workgroups / CU
-    case 41: if (!pipe3_ok(g)) return NNR_ERR_ARG; return launch_pipe3<2, 4, 2>(g, stream);     // gen-3 NT 128 x 64
-    case 42: if (!pipe3_ok(g)) return NNR_ERR_ARG; return launch_pipe3<2, 10, 1>(g, stream);    // gen-3 NT 128 x 160, 3 x 36 KB stages, 1 workgroup / CU
     case 32: if (!tn_pipe_ok(g)) return NNR_ERR_ARG; return launch_tn_pipe2<1, 13, 3, 2>(g, stream);              // gen-2 TN 64 x 208, 3 x 20 KB stages: row tiles of 64 fit M = 200 / 400 / 832
                                                                                                                   // (256 / 448 / 832 rows of MFMA work instead of 256 / 512 / 896)
     case 7:
@@ -2520,11 +1892,6 @@ static int dispatch_tile(int tile, const nnr_gemm_args& g, hipStream_t stream) {
       return launch_skinny(g, stream);
     default: return NNR_ERR_ARG;
   }
-}
-
-extern "C" size_t nnr_gemm_sk_workspace_floats(int M, int N) {
-  const long nblk = (long)((M + 127) / 128) * ((N + 79) / 80);
-  return (size_t)(4096 + nblk * 2 * (256L * 2 * 5 * 4));
 }
 
 extern "C" int nnr_split_bf16x3(const float* w, int rows, int cols, int ld, int ldo, void* out3, long img_stride, hipStream_t stream) {
@@ -2566,7 +1933,7 @@ extern "C" int nnr_gemm_f32(const nnr_gemm_args* a, hipStream_t stream) {
   float* slab_C = nullptr;
   float* slab_cs = nullptr;
   int slab_ldc = 0;
-  if (g.slab != nullptr && g.tile != 47) {
+  if (g.slab != nullptr) {
     if (!(g.trans_a && g.trans_b) || g.split_k <= 1 || g.k_chunk > 0 || g.c_idx || (g.N & 3) || (((uintptr_t)g.slab) & 15) || !g.C || g.accumulate == 2 ||
         g.slab_floats < (long)g.split_k * ((long)g.M * g.N + g.M))
       return NNR_ERR_ARG;
@@ -2589,15 +1956,6 @@ extern "C" int nnr_gemm_f32(const nnr_gemm_args* a, hipStream_t stream) {
     else if (use_pipe && use_t9 && pipe_ok(g) && !g.a_idx && g.K >= 800 && wg64 > 512) {
       tile = 9;              // long reductions (dX: K = 1664, SUE: K = 900): the
                              // software-pipelined loop with the lean DMA issue, 2 workgroups / CU (130 vs 112 TF, 93 vs 79 TF)
-      // Launches of one or two waves of workgroups (SUE: 4 352 / 6 080 rows x 900 columns) are bound by the CU that carries the most
-      // tiles: 4 352 x 900 is 408 tiles of 128 x 80 (the busiest CU works through 2 x 80 columns of a 128-row stripe) but 510 tiles of
-      // 128 x 64 (2 x 64 columns, and no column padding: 900 = 14.06 x 64 vs 11.25 x 80) -- take the narrower tile when that wins by > 8 %.
-      static const bool use_n64 = [] { const char* e = getenv("NNR_NT64"); return e && atoi(e) == 1; }();   // opt-in: measured no better in the step (11.38-11.44 vs 11.27-11.31 ms, sustained equal)
-      if (use_n64 && !g.dyn_dev && g.batch <= 1) {
-        const long nbm = (g.M + 127) / 128, t80 = nbm * ((g.N + 79) / 80), t64 = nbm * ((g.N + 63) / 64);
-        const long load80 = ((t80 + 255) / 256) * 80, load64 = ((t64 + 255) / 256) * 64;
-        if (t80 < 1024 && load64 * 100 < load80 * 92) tile = 31;
-      }
     }
     else if (use_pipe && pipe_ok(g) && (g.dyn_dev || wg128 >= 640)) tile = 15;   // GPU-filling NT: LDS-DMA staged 128 x 80, BK 16, 4 workgroups / CU
                              // (112 vs 98 TF on the 131 072-row CNE shapes, tools/gemm_pipe_bench.py)

@@ -507,16 +507,6 @@ def gemm(A, B, C_=None, *, M, N, K, lda, ldb, ldc=0, trans_a=False, trans_b=Fals
         g.pre_add, g.ldpre = pre_add.data_ptr(), ldpre
     if gate_bwd:
         g.gate_bwd = 1
-    if (SK[0] and tile in (0, 9) and slab is None and not trans_a and not trans_b and a_idx is None and b_idx is None and c_idx is None and dyn is None
-            and batch <= 1 and not atomic and split_k <= 1 and k_chunk <= 0 and rowdot_w is None and colsum_out is None and K >= 800
-            and _SK_MIN_TILES < ((M + 127) // 128) * ((N + 79) // 80) <= _SK_MAX_TILES and (K | lda | ldb) & 3 == 0 and (A.data_ptr() | B.data_ptr()) & 15 == 0
-            and (drop is None or drop[0] in (3, 4) or drop[1] <= 0.0)):
-        tile = 47                                         # one to two waves of 128 x 80 tiles with a long reduction (SUE): fixed-order stream-K
-        g.tile = 47
-    if tile == 47:
-        slab = _sk_ws(A.device, L.lib().nnr_gemm_sk_workspace_floats(M, N))
-        g.slab, g.slab_floats = slab.data_ptr(), slab.numel()
-        slab = None
     if b3 is None and BX3[0] and tile in (0, 9, 15, 16) and _bx3_wanted(A, B, M, N, K, lda, ldb, trans_a, trans_b, a_idx, b_idx, c_idx, split_k, k_chunk, rowdot_w,
                                                                     colsum_out, atomic, batch, dyn_dim, drop):
         # (NNR_BX3, default on): this NT launch on the BF16 matrix pipe, weights pre-split.  Only when B IS a weight: a parameter or a
@@ -569,8 +559,8 @@ def gemm(A, B, C_=None, *, M, N, K, lda, ldb, ldc=0, trans_a=False, trans_b=Fals
     else:
         t = 5 if not trans_b else 4
     fam = 'gemm_%s_%s' % ('tn' if trans_a else ('nn' if trans_b else 'nt'),
-                          {1: '256x80', 2: '64x80', 3: '128x208', 4: '128x80', 5: '128x80k32', 6: '64x80k64', 7: '16x80skinny', 8: 'pipe128x80k32', 9: 'pipe2_128x80', 13: 'pipe128x80s4',
-                           15: 'pipe128x80', 16: 'pipe128x80s2', 20: 'pipe128x80', 26: 'pipe2_128x80', 27: 'pipe2_128x208', 30: 'pipe2_128x160', 31: 'pipe2_128x64', 47: 'sk_128x80', 32: 'pipe2_64x208', 33: 'pipe128x208', 34: 'pipe2_128x208', 36: 'pipe256x80', 22: 'pipe64x80', 23: 'pipe256x80', 24: 'pipe128x208', 25: 'pipe128x128', 50: 'bx3_128x80', 51: 'bx3_64x80', 52: 'bx3_128x64', 53: 'bx3_256x80', 40: 'pipe3_128x80', 41: 'pipe3_128x64', 42: 'pipe3_128x160'}.get(t, 'tile%d' % t))
+                          {2: '64x80', 3: '128x208', 4: '128x80', 5: '128x80k32', 6: '64x80k64', 7: '16x80skinny', 9: 'pipe2_128x80', 15: 'pipe128x80', 16: 'pipe128x80s2',
+                           20: 'pipe128x80', 26: 'pipe2_128x80', 27: 'pipe2_128x208', 30: 'pipe2_128x160', 32: 'pipe2_64x208', 50: 'bx3_128x80', 51: 'bx3_64x80'}.get(t, 'tile%d' % t))
 
     def flops(vals=None, M=M, N=N, K=K, dyn=dyn, dyn_dim=dyn_dim, batch=batch):
         # vals: {data_ptr of a device-side size: its value at the time of the launch} (replayed launches: the size buffers are
@@ -648,24 +638,6 @@ _SLOT_WS = {}
 _SLAB_WS = {}
 _SK_WS = {}
 # fixed-order stream-K for the one-to-two-wave NT launches of the user encoder (csrc/gemm.hip: gemm_nt_sk_kernel; round 5, verdict item 1b)
-SK = [os.environ.get('NNR_SK', '0') == '1']
-_SK_MIN_TILES = int(os.environ.get('NNR_SK_MIN_TILES', '512'))      # above one full wave of 512 workgroup slots (alone: 6 080 x 900 x 900, 576 tiles, 84.5 -> 98.7 TF;
-_SK_MAX_TILES = int(os.environ.get('NNR_SK_MAX_TILES', '2048'))     # 4 352 x 900 x 900, 408 tiles -- EVERY tile shared by two ranges -- 89 -> 90 TF: not worth the exchange)
-
-
-def _sk_ws(dev, floats):
-    """Stream-K workspace of the CURRENT stream (flags + partial accumulator tiles, nnr_gemm_sk_workspace_floats): zeroed once -- the kernel clears
-    the flags it consumes --, shared by the launches of one stream (they run in order), grown when a bigger launch comes along."""
-    key = torch._C._cuda_getCurrentRawStream(dev.index if dev.index is not None else torch.cuda.current_device())
-    ws = _SK_WS.get(key)
-    if ws is None or ws.numel() < floats:
-        ws = torch.zeros(int(floats), device=dev, dtype=torch.float32)
-        _SK_WS[key] = ws
-    tape_keep(ws)
-    return ws
-TN_SLAB = os.environ.get('NNR_TN_SLAB', '1') != '0'      # split-K weight gradients through slabs + a fixed-order reduction (0: f32 atomics)
-
-
 def _slab_ws(dev, floats):
     """Split-K slab workspace of the CURRENT stream (nnr_gemm_args.slab): a launch's slices store their partial results there and the
     reduction that follows it on the same stream consumes them, so launches of one stream share one buffer (grown when a bigger
@@ -999,18 +971,6 @@ def gcn_aggregate_fwd(graph, z, bias, resid, r_out, y, B, G, D, relu, p, seed):
     with _hbm_span('gcn_aggregate_fwd', 4.0 * (G * D * arrays + G * G), B):
         L.check(L.lib().nnr_gcn_aggregate_fwd(_p(graph), _p(z), _p(bias), _p(resid), _p(r_out), _p(y), B, G, D, int(relu), C.c_float(p),
                                               C.c_uint32(int(seed) & 0xFFFFFFFF), _s()), 'nnr_gcn_aggregate_fwd')
-
-
-def gcn_layer_small_fwd(graph, x, W, bias, resid, r_out, y, B, G, D, relu, p, seed):
-    """One launch for a whole GCN layer at small batches (csrc/gcn.hip gcn_layer_small_kernel): y = dropout(relu(A (x W^T) + b) -> r_out, + resid)."""
-    L.check(L.lib().nnr_gcn_layer_small_fwd(_p(graph), _p(x), _p(W), _p(bias), _p(resid), _p(r_out), _p(y), B, G, D, int(relu), C.c_float(p),
-                                            C.c_uint32(int(seed) & 0xFFFFFFFF), _s()), 'nnr_gcn_layer_small_fwd')
-
-
-def gcn_layer_small_bwd(graph, dy, r, Wt, dx, B, G, D, residual, p, seed):
-    """The layer's data-gradient chain in one launch: dx = A^T (dS W) + (residual ? mask(dy) : 0), dS = mask(dy) * (r > 0); Wt = W^T contiguous."""
-    L.check(L.lib().nnr_gcn_layer_small_bwd(_p(graph), _p(dy), _p(r), _p(Wt), _p(dx), B, G, D, int(residual), C.c_float(p),
-                                            C.c_uint32(int(seed) & 0xFFFFFFFF), _s()), 'nnr_gcn_layer_small_bwd')
 
 
 def gcn_aggregate_bwd(graph, dy, r, ds, dx0, dz, B, G, D, p, seed):

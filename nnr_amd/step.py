@@ -13,6 +13,7 @@ import torch
 from . import ops
 from .news_encoders import cne_forward_many, cne_backward_many, _CNE_UNION
 
+_BX3_MHSA = os.environ.get('NNR_BX3_MHSA', '0') == '1'
 _MHSA_NATIVE = os.environ.get('NNR_MHSA_NATIVE', '1') != '0'      # A/B: MHSA+MHSA through autograd (round 3) instead of the native step
 
 
@@ -184,6 +185,15 @@ def forward_backward(trainer, batch):
     Returns (logits [B, N], loss []) -- fresh tensors of this call."""
     model = trainer.model
     if kind(model) == 'mhsa':
+        # The MHSA + MHSA step keeps its GEMMs on the fp32-MFMA kernels: its products are small (~100 GFLOP per step, 40 k live title rows) and
+        # interleaved with the attention-core launches; with the bf16x3 tiles (63 KB of LDS, two workgroups per CU) the step measured SLOWER on three
+        # same-box pairs (2.18 vs 2.24 ms, profiles/r06_ab.txt).  NNR_BX3_MHSA=1 sends them there all the same.
+        if ops.BX3[0] and not _BX3_MHSA:
+            ops.BX3[0] = False
+            try:
+                return forward_backward_mhsa(trainer, batch)
+            finally:
+                ops.BX3[0] = True
         return forward_backward_mhsa(trainer, batch)
     ne, ue = model.news_encoder, model.user_encoder
     (user_ID, user_category, user_subCategory, user_title_text, user_title_mask, user_title_entity, user_content_text, user_content_mask,

@@ -76,15 +76,6 @@ def _sue_side(dev):
     return _SIDE[key]
 
 
-_GCN_SMALL_ROWS = int(os.environ.get('NNR_GCN_SMALL_ROWS', '0'))      # one-launch GCN layers up to this many node rows (B * G); 0 = off.  Round-5 A/B (profiles/r05_ab.txt):
-                                                                       # 1100 rows: batch 8 3.155 -> 3.17 ms, batch 16 4.29 -> 4.40 ms; 2200: batch 32 6.31 -> 6.73 ms -- the launches it
-                                                                       # saves were already hidden under the news encoder's streams; its 8-wave workgroups are not.  Kept for A/B + its unit test
-
-
-def _gcn_small(gcn, B, G, D):
-    return _GCN_FUSED and 0 < B * G <= _GCN_SMALL_ROWS and G <= 80 and D % 4 == 0
-
-
 def gcn_forward(gcn, x0, graph, seed0, training):
     """GCN.forward (layers.py:318-323) over GCNLayer.forward (:285-292):  X <- dropout(relu(LN?((A X) W^T + b)) + X).  The dense
     product runs first (X W^T on all B*G rows), then the per-user G x G aggregate as a batched GEMM whose epilogue applies bias /
@@ -94,19 +85,10 @@ def gcn_forward(gcn, x0, graph, seed0, training):
     Lg = gcn.num_layers
     xs, rs, lns = [x0], [], []
     x = x0
-    small = _gcn_small(gcn, B, G, D)
     for l, layer in enumerate(gcn.gcn_layers):
         y = torch.empty((B, G, D), **f32)
         r = torch.empty((B, G, D), **f32)
         pl = (gcn.dropout_rate if training else 0.0) if l + 1 < Lg else 0.0
-        if small and not getattr(layer, 'layer_norm', False):
-            # per-GPU batch <= 16: dense product + aggregate + epilogue of the layer in ONE launch (csrc/gcn.hip gcn_layer_small_kernel)
-            ops.gcn_layer_small_fwd(graph, x, layer.W.weight, layer.W.bias, x if gcn.residual else None, r, y, B, G, D, True, pl, seed0 + l)
-            lns.append(None)
-            xs.append(y)
-            rs.append(r)
-            x = y
-            continue
         z = ops.linear_fwd(x.view(B * G, D), layer.W.weight)                       # X W^T  (bias goes after the aggregate)
         if getattr(layer, 'layer_norm', False):
             u = torch.empty((B, G, D), **f32)
@@ -141,19 +123,6 @@ def gcn_backward(gcn, gsv, dy, graph, leaf):
         pl = (gcn.dropout_rate if gsv['training'] else 0.0) if l + 1 < Lg else 0.0
         dS = torch.empty((B, G, D), **f32)
         dx = torch.empty((B, G, D), **f32)
-        if _gcn_small(gcn, B, G, D) and gsv['lns'][l] is None and ops.USE_WT:
-            # small batches: the data-gradient chain of the layer in ONE launch, dx = A^T (dS W) + mask(dy); dS and dZ = A^T dS (bias and
-            # weight gradients: nobody downstream reads them) are formed by the aggregate kernel on the LEAF stream
-            ops.gcn_layer_small_bwd(graph, dy, gsv['rs'][l], ops.wt(layer.W.weight), dx, B, G, D, bool(gcn.residual), pl, gsv['seed0'] + l)
-            dz = torch.empty((B, G, D), **f32)
-
-            def leaf_part(dy=dy, dS=dS, dz=dz, l=l, layer=layer, pl=pl):
-                ops.gcn_aggregate_bwd(graph, dy, gsv['rs'][l], dS, None, dz, B, G, D, pl, gsv['seed0'] + l)
-                ops.bias_grad(dS.view(B * G, D), grad_of(layer.W.bias))
-                ops.linear_bwd_weight(dz.view(B * G, D), gsv['xs'][l].view(B * G, D), grad_of(layer.W.weight))
-            leaf(leaf_part, dy, dS, dz)
-            dy = dx
-            continue
         if _GCN_FUSED and G <= 128 and D % 4 == 0 and gsv['lns'][l] is None:
             # mask + ReLU gradient applied while dY is loaded, then dZ_b = A_b^T dS_b, one launch (csrc/gcn.hip)
             dz = torch.empty((B, G, D), **f32)

@@ -374,19 +374,21 @@ def test_relu_kink_proof_rejects_a_real_error_and_accepts_a_forced_flip():
             prove_relu_flips('self-test', bars, ref, to_torch(batch), model, captured[-1], probe, rnorm, compare_with(bad))
 
 
-def test_cne_sue_batch64_REPLAYED_step_with_experimental_bf16x3_nt_gemms_matches_oracle():
-    """The EXPERIMENTAL path (NNR_BX3=1, off by default): every GPU-filling NT GEMM of the step on the BF16 matrix pipe as six
-    exact bf16 products with fp32 accumulation.  Same test, same bars as the fp32-MFMA path: logits 1e-4, loss 2e-5, every gradient element
-    within 1e-4 of its scale (kink proof included), clipped norm, Adam step -- what a round-6 adoption has to keep."""
+def test_cne_sue_batch64_REPLAYED_step_on_the_pure_fp32_mfma_path_matches_oracle():
+    """Round 6: the weight-operand NT GEMMs of the step run on the BF16 matrix pipe by default (six exact bf16 products, fp32 accumulation;
+    DESIGN.md section 9.4) -- every other test of this file exercises that path.  This one is the SAME check with NNR_BX3=0 (every matrix product
+    on v_mfma_f32_16x16x4_f32, the default of rounds 1-5, bench.py's `secondary.f32_mfma_only_cne_sue_b64`): logits 1e-4, loss 2e-5, every
+    gradient element within 1e-4 of its scale (kink proof included), clipped norm, Adam step."""
     from nnr_amd import ops
     cfg = make_config(['--news_encoder=CNE', '--user_encoder=SUE', '--dataset=200k', '--batch_size=64'],
                       corpus_sizes=dict(vocabulary_size=60000), tie_order='stable')
-    ops.BX3[0] = True
+    before = ops.BX3[0]
+    ops.BX3[0] = False
     try:
         err, worst, info = _replayed_step_check(cfg, 64, 5, 105)
     finally:
-        ops.BX3[0] = False
-    print('CNE+SUE batch 64, dropout ON, REPLAYED step, bf16x3 NT GEMMs: logits max|diff| %.2e, worst gradient deviation %.2e, tape %s' % (err, worst, info))
+        ops.BX3[0] = before
+    print('CNE+SUE batch 64, dropout ON, REPLAYED step, fp32-MFMA GEMMs only: logits max|diff| %.2e, worst gradient deviation %.2e, tape %s' % (err, worst, info))
 
 
 def test_cne_sue_config4_shard_batch8_vocab60000_REPLAYED_dropout_on_matches_oracle():

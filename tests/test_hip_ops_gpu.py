@@ -83,8 +83,8 @@ def test_gemm_skinny_tile_all_epilogues(M, N, K):
     close(ob, ab.double() @ bb.double(), what='skinny batched NN')
 
 
-PIPE_TILES = [8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 31]
-PIPE2_TILES = [9, 10, 11, 12, 14, 31]
+PIPE_TILES = [9, 15, 16]
+PIPE2_TILES = [9]
 
 
 @pytest.mark.parametrize('tile', PIPE_TILES)
@@ -147,88 +147,8 @@ def test_gemm_pipelined_nt_tiles(tile, M, N, K):
         close(ob, ab.double() @ bb.double().transpose(1, 2), what='pipe batched')
 
 
-@pytest.mark.parametrize('tile', [40, 41, 42])
-@pytest.mark.parametrize('M,N,K', [(70000, 400, 400), (33000, 1664, 300), (5000, 200, 200), (4352, 900, 900), (300, 84, 96), (129, 400, 104)])
-def test_gemm_persistent_nt_tiles(tile, M, N, K):
-    """Third-generation NT kernel (csrc/gemm.hip: gemm_nt_pipe3_kernel, round 5): persistent workgroups, the LDS-DMA pipeline continuous
-    across tile boundaries, epilogue from the accumulator registers.  Shapes: several tiles per workgroup (70 000 x 400: 2 735 tiles on
-    512 slots), a k-tail in every stage count class (K = 300 / 400 / 200 / 900 / 104), the minimum of three stages (K = 96), ragged M
-    and N.  Plain results must be BIT-IDENTICAL to the second-generation kernel on the same tile (same MFMA order); every operand set
-    of the register epilogue (bias + activation; gate forward; gate backward; accumulate 1 / 2; residual + dropout-free GCN form; the
-    serial any-combination form) against fp64; dynamic M with untouched rows beyond the live count."""
-    from nnr_amd import ops
-    d = dev()
-    a, b = rnd(M, K, seed=1).to(d), rnd(N, K, seed=2, scale=0.2).to(d)
-    ad, bd = a.cpu().double(), b.cpu().double()
-    full = ad @ bd.t()
-    etol = 2e-5 * max(1.0, math.sqrt(K / 100.0))
-    out = torch.empty(M, N, device=d)
-    ops.gemm(a, b, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, tile=tile)
-    close(out, full, tol=etol, what='pipe3 plain')
-    twin = {40: 9, 41: 31, 42: 11}[tile]
-    ref = torch.empty(M, N, device=d)
-    ops.gemm(a, b, ref, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, tile=twin)
-    assert torch.equal(out, ref), 'pipe3 tile %d differs from the gen-2 kernel on the same tile (max %.3e)' % (tile, float((out - ref).abs().max()))
-    bias, resid, mul, base, pre = (rnd(N, seed=4).to(d), rnd(M, N, seed=5).to(d), rnd(M, N, seed=6).to(d), rnd(M, N, seed=7).to(d), rnd(M, N, seed=8).to(d))
-    R = 7
-    rv, rmap = rnd(R, N, seed=9).to(d), torch.randint(0, R, (M,), generator=torch.Generator().manual_seed(9)).int().to(d)
-    rvd = rv.cpu().double()[rmap.cpu().long()]
-    # bias + tanh (+ aux)
-    aux = torch.empty(M, N, device=d)
-    ops.gemm(a, b, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias, act=ops.ACT_TANH, aux_out=aux, ldaux=N, tile=tile)
-    want = torch.tanh(full + bias.cpu().double())
-    close(out, want, tol=etol, what='pipe3 bias tanh')
-    close(aux, want, tol=etol, what='pipe3 bias tanh aux')
-    # gate forward: sigmoid(x + rowvec[map]) -> aux, * mul -> C   (newsEncoders.py:128-131)
-    ops.gemm(a, b, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, rowvec=rv, ldrv=N, rowvec_map=rmap, act=ops.ACT_SIGMOID, aux_out=aux, ldaux=N, mul=mul, ldmul=N, tile=tile)
-    gate = torch.sigmoid(full + rvd)
-    close(aux, gate, tol=etol, what='pipe3 gate aux')
-    close(out, gate * mul.cpu().double(), tol=etol, what='pipe3 gate out')
-    # gate backward in the epilogue: x = acc + pre_add; aux = x * resid * mul * (1 - mul); C = x * mul
-    gpos = torch.sigmoid(mul)
-    ops.gemm(a, b, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, pre_add=pre, ldpre=N, gate_bwd=True, mul=gpos, ldmul=N, resid=resid, ldres=N, aux_out=aux, ldaux=N, tile=tile)
-    x = full + pre.cpu().double()
-    gp = gpos.cpu().double()
-    close(out, x * gp, tol=etol, what='pipe3 gate_bwd dH')
-    close(aux, x * resid.cpu().double() * gp * (1 - gp), tol=etol, what='pipe3 gate_bwd dpre')
-    # accumulate (1: after the epilogue; 2: before bias / activation)
-    out = base.clone()
-    ops.gemm(a, b, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, accumulate=True, tile=tile)
-    close(out, base.cpu().double() + full, tol=etol, what='pipe3 accumulate')
-    out = base.clone()
-    ops.gemm(a, b, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias, act=ops.ACT_RELU, accumulate=2, tile=tile)
-    close(out, torch.relu(base.cpu().double() + full + bias.cpu().double()), tol=etol, what='pipe3 accumulate 2')
-    # residual form (GCN layer: relu(x + b) -> aux, + resid)
-    ops.gemm(a, b, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias, act=ops.ACT_RELU, aux_out=aux, ldaux=N, resid=resid, ldres=N, tile=tile)
-    close(out, torch.relu(full + bias.cpu().double()) + resid.cpu().double(), tol=etol, what='pipe3 residual')
-    # everything at once (the serial any-combination instantiation)
-    out = base.clone()
-    ops.gemm(a, b, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, alpha=0.5, bias=bias, rowvec=rv, ldrv=N, rowvec_map=rmap, act=ops.ACT_TANH, aux_out=aux, ldaux=N,
-             mul=mul, ldmul=N, resid=resid, ldres=N, accumulate=True, tile=tile)
-    pr = torch.tanh(0.5 * full + bias.cpu().double() + rvd)
-    close(aux, pr, tol=etol, what='pipe3 full aux')
-    close(out, base.cpu().double() + pr * mul.cpu().double() + resid.cpu().double(), tol=etol, what='pipe3 full epilogue')
-    # dynamic M: rows beyond the live count untouched
-    used = max(1, (M * 2) // 3)
-    out = torch.full((M, N), 7.0, device=d)
-    dyn = torch.tensor([used], dtype=torch.int32, device=d)
-    ops.gemm(a, b, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, dyn=dyn, dyn_dim=1, bias=bias, tile=tile)
-    close(out[:used], (full + bias.cpu().double())[:used], tol=etol, what='pipe3 dyn')
-    assert bool((out[used:] == 7.0).all())
-    if M <= 5000:
-        ab, bb = rnd(3, M, K, seed=20).to(d), rnd(3, N, K, seed=21, scale=0.2).to(d)
-        ob = torch.empty(3, M, N, device=d)
-        ops.gemm(ab, bb, ob, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, batch=3, strideA=M * K, strideB=N * K, strideC=M * N, tile=tile)
-        close(ob, ab.cpu().double() @ bb.cpu().double().transpose(1, 2), tol=etol, what='pipe3 batched')
-    # what the kernel does not take is refused, not mis-run: unaligned N, row scatter, short K
-    for bad in (dict(M=64, N=82, K=128), dict(M=64, N=80, K=64)):
-        aa, bb2 = rnd(bad['M'], bad['K'], seed=1).to(d), rnd(bad['N'], bad['K'], seed=2).to(d)
-        with pytest.raises(Exception):
-            ops.gemm(aa, bb2, torch.empty(bad['M'], bad['N'], device=d), lda=bad['K'], ldb=bad['K'], ldc=bad['N'], tile=tile, **bad)
-
-
 @pytest.mark.parametrize('M,N,K', [(70000, 400, 400), (33000, 1664, 300), (5000, 200, 200), (4352, 900, 900), (300, 84, 96), (129, 400, 104), (2500, 300, 1664)])
-def test_gemm_bf16x3_experimental_tile(M, N, K):
+def test_gemm_bf16x3_tile(M, N, K):
     """Tile 50 (csrc/gemm.hip: gemm_nt_bx3_kernel; the default matrix path of weight-operand NT launches since round 6, NNR_BX3=0 turns it off): the NT product on the BF16 matrix pipe as six exact
     bf16 x bf16 products with fp32 accumulation, weights pre-split by nnr_split_bf16x3.  The split is EXACT (w == image0 + image1 + image2 bit for
     bit), the product is at least as close to fp64 as the fp32-MFMA kernel's, and every element-wise epilogue / dynamic M / k-tail / ragged
@@ -807,46 +727,6 @@ def test_packed_seq_sum_matches_index_add(n, Lx, D):
     close(out, ref, tol=1e-5, what='packed_seq_sum')
 
 
-@pytest.mark.parametrize('B,G,D', [(8, 68, 900), (16, 68, 900), (3, 21, 52), (2, 80, 72), (4, 16, 20), (3, 50, 132), (1, 5, 64)])
-def test_gcn_layer_in_one_launch_for_small_batches(B, G, D):
-    """Round 5 (verdict items of rounds 3-5): a whole GCN layer -- dense product, per-user aggregate, bias / ReLU / residual / dropout epilogue
-    (layers.py:285-292,318-323) -- and its data-gradient chain as ONE launch each at per-GPU batch <= 16 (csrc/gcn.hip gcn_layer_small_kernel),
-    against fp64 and against the two-launch form (skinny GEMM + gcn_aggregate) with the SAME dropout mask."""
-    from nnr_amd import ops
-    d = dev()
-    f32 = dict(device=d, dtype=torch.float32)
-    A = (torch.rand(B, G, G, generator=torch.Generator().manual_seed(1)) < 0.3).float() * torch.rand(B, G, G, generator=torch.Generator().manual_seed(2))
-    x, W, bias = rnd(B, G, D, seed=3), rnd(D, D, seed=4, scale=1.0 / math.sqrt(D)), rnd(D, seed=5)
-    Ad, xd, Wd, bd = A.to(d), x.to(d), W.to(d), bias.to(d)
-    u = torch.bmm(A.double(), x.double() @ W.double().t()) + bias.double()
-    pre = torch.relu(u)
-    tol = 3e-5 * max(1.0, math.sqrt(D / 100.0))
-    for p, seed, resid in ((0.0, 7, True), (0.3, 12345, True), (0.3, 99, False)):
-        r, y = torch.empty((B, G, D), **f32), torch.empty((B, G, D), **f32)
-        ops.gcn_layer_small_fwd(Ad, xd, Wd, bd, xd if resid else None, r, y, B, G, D, True, p, seed)
-        # the two-launch form
-        z = ops.linear_fwd(xd.view(B * G, D), Wd)
-        r2, y2 = torch.empty((B, G, D), **f32), torch.empty((B, G, D), **f32)
-        ops.gcn_aggregate_fwd(Ad, z, bd, xd if resid else None, r2, y2, B, G, D, True, p, seed)
-        close(r, pre, tol=tol, what='fused gcn r')
-        assert torch.equal(y == 0, y2 == 0) or p == 0.0                          # the same dropout mask (a relu zero + no residual is also 0)
-        close(y, y2.double(), tol=tol, what='fused gcn y vs two launches')
-        if p == 0.0:
-            close(y, pre + x.double(), tol=tol, what='fused gcn y')
-        # backward chain: dx = A^T (dS W) + mask(dy)
-        dy = rnd(B, G, D, seed=6).to(d)
-        Wt = Wd.t().contiguous()
-        dx = torch.full((B, G, D), 7.0, **f32)
-        ops.gcn_layer_small_bwd(Ad, dy, r, Wt, dx, B, G, D, resid, p, seed)
-        keep = (ops.dropout(torch.ones(B * G * D, device=d), p, seed) > 0).view(B, G, D).cpu().double() / (1 - p) if p > 0 else torch.ones(B, G, D, dtype=torch.double)
-        dm = dy.cpu().double() * keep
-        ds = dm * (pre > 0)
-        want = torch.bmm(A.double().transpose(1, 2), ds) @ W.double() + (dm if resid else 0)
-        close(dx, want, tol=tol, what='fused gcn dx')
-    with pytest.raises(Exception):
-        ops.gcn_layer_small_fwd(Ad, xd, Wd, bd, None, None, torch.empty((B, 96, D), **f32), B, 96, D, True, 0.0, 0)      # G > 80: the two-launch form
-
-
 @pytest.mark.parametrize('dot', [False, True])
 def test_pool_packed_forward_backward(dot):
     from nnr_amd import ops
@@ -1416,7 +1296,7 @@ def test_sorted_segmented_embedding_gradient_is_exact_and_reproducible(V, E, cap
     close(outs[0], want, tol=2e-6, what='sorted vs fp64')
 
 
-TN_PIPE_TILES = [20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 32]
+TN_PIPE_TILES = [20, 26, 27, 30, 32]
 TN_NO_GATHER = [26, 28, 29]          # gen-2 loop: gathered B rows only with the 256-float pitch (tile 27)
 
 
@@ -1524,62 +1404,3 @@ def test_transpose_batch_and_weight_transpose_cache():
     assert torch.equal(ops.wt(w2), w2.detach().t().contiguous())
 
 
-@pytest.mark.parametrize('M, N, K', [(4352, 900, 900), (6080, 900, 900), (1300, 904, 2000), (700, 336, 1000), (128, 80, 96), (4352, 900, 96)])
-def test_gemm_stream_k_fixed_order(M, N, K):
-    """Fixed-order stream-K NT kernel (csrc/gemm.hip: gemm_nt_sk_kernel, tile 47; round 5, verdict item 1b): the (tile, k-stage) space cut into equal
-    ranges, partial accumulators handed to the tile's owner through the workspace and added in ascending-k order.  Shapes: the two SUE launches
-    (408 / 576 tiles on 512 ranges: every tile shared by two or three workgroups), more tiles than ranges' worth of stages per range (1 300 x 904 x
-    2 000: ranges that hold a whole tile in the middle), fewer tiles than CUs, ONE tile (two ranges), a three-stage reduction; K % 32 != 0
-    everywhere but one.  Against fp64, against the gen-2 kernel (same products, another summation order), BIT-IDENTICAL from launch to launch
-    (also with another stream keeping CUs busy), every epilogue form the user encoder uses, a dynamic row count, and the workspace shared by
-    launches of different shapes."""
-    from nnr_amd import ops
-    d = dev()
-    a, b = rnd(M, K, seed=1).to(d), rnd(N, K, seed=2, scale=0.2).to(d)
-    full = a.cpu().double() @ b.cpu().double().t()
-    etol = 2e-5 * max(1.0, math.sqrt(K / 100.0))
-    out, ref = torch.empty(M, N, device=d), torch.empty(M, N, device=d)
-    ops.gemm(a, b, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, tile=47)
-    close(out, full, tol=etol, what='stream-K plain')
-    ops.gemm(a, b, ref, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, tile=9)
-    close(out, ref.cpu().double(), tol=etol, what='stream-K vs gen-2')
-    # launch to launch, beside a stream that occupies workgroup slots with other GEMMs (ranges start at different times)
-    side = torch.cuda.Stream()
-    big_a, big_b, big_c = rnd(16384, 512, seed=3).to(d), rnd(512, 512, seed=4).to(d), torch.empty(16384, 512, device=d)
-    again = torch.empty(M, N, device=d)
-    for rep in range(6):
-        if rep >= 3:
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(4):
-                    ops.gemm(big_a, big_b, big_c, M=16384, N=512, K=512, lda=512, ldb=512, ldc=512)
-        ops.gemm(a, b, again, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, tile=47)
-        assert torch.equal(out, again), 'stream-K result changed between launches (rep %d, max %.3e)' % (rep, float((out - again).abs().max()))
-    torch.cuda.current_stream().wait_stream(side)
-    # the user encoder's epilogues: bias + ReLU with the mask as aux (GCN layer), residual, accumulate
-    bias, resid, base = rnd(N, seed=4).to(d), rnd(M, N, seed=5).to(d), rnd(M, N, seed=7).to(d)
-    aux = torch.empty(M, N, device=d)
-    ops.gemm(a, b, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias, act=ops.ACT_TANH, aux_out=aux, ldaux=N, tile=47)
-    want = torch.tanh(full + bias.cpu().double())
-    close(out, want, tol=etol, what='stream-K bias tanh')
-    close(aux, want, tol=etol, what='stream-K bias tanh aux')
-    ops.gemm(a, b, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, bias=bias, resid=resid, ldres=N, tile=47)
-    close(out, full + bias.cpu().double() + resid.cpu().double(), tol=etol, what='stream-K bias + residual')
-    out = base.clone()
-    ops.gemm(a, b, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, accumulate=True, tile=47)
-    close(out, base.cpu().double() + full, tol=etol, what='stream-K accumulate')
-    # a dynamic row count: rows beyond it untouched, the tile count (and with it every range) follows the device-side value
-    for live in (M, max(1, M // 3), 1):
-        dyn = torch.tensor([live], dtype=torch.int32, device=d)
-        out = torch.full((M, N), 7.0, device=d)
-        ops.gemm(a, b, out, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, dyn=dyn, dyn_dim=1, tile=47)
-        close(out[:live], full[:live], tol=etol, what='stream-K dyn rows %d' % live)
-        assert bool((out[live:] == 7.0).all()), 'stream-K wrote beyond the live rows'
-    # another shape through the same workspace (flag words must never alias another launch's partial tiles)
-    a2, b2 = rnd(2000, 800, seed=11).to(d), rnd(640, 800, seed=12, scale=0.2).to(d)
-    o2 = torch.empty(2000, 640, device=d)
-    ops.gemm(a2, b2, o2, M=2000, N=640, K=800, lda=800, ldb=800, ldc=640, tile=47)
-    close(o2, a2.cpu().double() @ b2.cpu().double().t(), tol=2e-5 * math.sqrt(8.0), what='stream-K second shape')
-    ops.gemm(a, b, again, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, tile=47)
-    ops.gemm(a, b, ref, M=M, N=N, K=K, lda=K, ldb=K, ldc=N, tile=47)
-    assert torch.equal(again, ref)
