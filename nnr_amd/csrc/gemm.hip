@@ -1022,9 +1022,9 @@ __device__ __forceinline__ void split3_trunc8(const f32x4& x0, const f32x4& x1, 
   a3 = __builtin_bit_cast(bf16x8_t, u32x4_t{w3[0], w3[1], w3[2], w3[3]});
 }
 
-template <int TM, int TN>
-__global__ __launch_bounds__(256, (TM >= 4 ? 1 : 2)) void gemm_nt_bx3_kernel(nnr_gemm_args g) {
-  constexpr int NS = 2, BM = 64 * TM, BN = 16 * TN, BK = 32;
+template <int TM, int TN, int NS>
+__global__ __launch_bounds__(256, (NS * (64 * TM * 128 + 3 * 16 * TN * 64) > 80 * 1024 ? 1 : 2)) void gemm_nt_bx3_kernel(nnr_gemm_args g) {
+  constexpr int BM = 64 * TM, BN = 16 * TN, BK = 32;
   constexpr int A_BYTES = BM * BK * 4, B_IMG_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + 3 * B_IMG_BYTES;
   constexpr int NIA = A_BYTES / 1024, NIB1 = B_IMG_BYTES / 1024;
   static_assert(A_BYTES % 1024 == 0 && B_IMG_BYTES % 1024 == 0 && NIA % 4 == 0, "tile shape");
@@ -1096,11 +1096,16 @@ __global__ __launch_bounds__(256, (TM >= 4 ? 1 : 2)) void gemm_nt_bx3_kernel(nnr
   for (int m = 0; m < TM; ++m)
 #pragma unroll
     for (int n = 0; n < TN; ++n) acc_hi[m][n] = acc_lo[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-  issue(0);
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < S) issue(s);
   for (int s = 0; s < S; ++s) {
-    wait_vmcnt<0>();                      // NS = 2: when a wave waits for stage s, that stage is the only one it has in flight
+    // this wave's DMAs of stage s have landed once at most min(NS - 2, stages issued beyond s) newer stages of its own are outstanding
+    // (NS = 2: vmcnt(0); NS = 3: the loads of stage s + 1 stay in flight across the wait and the barrier)
+    if (nb_hi) wait_stages<NA + NBW, NS - 2>(S - 1 - s);
+    else wait_stages<NA + NBW - 1, NS - 2>(S - 1 - s);
     __builtin_amdgcn_s_barrier();
-    if (s + 1 < S) issue(s + 1);          // into the other buffer: every wave finished reading it before that barrier
+    if (s + NS - 1 < S) issue(s + NS - 1);          // into the buffer every wave finished reading before that barrier
     const unsigned char* st = lds_raw + (s % NS) * STAGE_BYTES;
     const float* As = reinterpret_cast<const float*>(st);
     const __bf16* Bi = reinterpret_cast<const __bf16*>(st + A_BYTES);
@@ -1140,11 +1145,11 @@ static bool bx3_ok(const nnr_gemm_args& g) {
   auto al = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
   return pipe_ok(g) && !g.a_idx && g.batch <= 1 && g.B3 && al(g.B3) && (g.ldb3 & 7) == 0 && g.ldb3 >= g.K && ((g.b3_stride * 2) & 15) == 0;
 }
-template <int TM, int TN>
+template <int TM, int TN, int NS>
 int launch_bx3(const nnr_gemm_args& g, hipStream_t s) {
   constexpr int BM = 64 * TM, BN = 16 * TN;
   const int nbm = (g.M + BM - 1) / BM, nbn = (g.N + BN - 1) / BN;
-  hipLaunchKernelGGL((gemm_nt_bx3_kernel<TM, TN>), dim3(nbm * nbn), dim3(256), 0, s, g);
+  hipLaunchKernelGGL((gemm_nt_bx3_kernel<TM, TN, NS>), dim3(nbm * nbn), dim3(256), 0, s, g);
   NNR_CHECK_LAUNCH();
   return NNR_OK;
 }
@@ -1881,8 +1886,8 @@ static int dispatch_tile(int tile, const nnr_gemm_args& g, hipStream_t stream) {
     case 26: if (!tn_pipe_ok(g) || g.b_idx) return NNR_ERR_ARG; return launch_tn_pipe2<2, 5, 3, 3>(g, stream);    // gen-2 TN 128 x 80 (no gather)
     case 27: if (!tn_pipe_ok(g)) return NNR_ERR_ARG; return launch_tn_pipe2<2, 13, 3, 2>(g, stream);              // gen-2 TN 128 x 208
     case 30: if (!tn_pipe_ok(g)) return NNR_ERR_ARG; return launch_tn_pipe2<2, 10, 3, 2>(g, stream);              // gen-2 TN 128 x 160 (N = 300 in two column blocks)
-    case 50: if (!bx3_ok(g)) return NNR_ERR_ARG; return launch_bx3<2, 5>(g, stream);           // bf16x3 NT 128 x 80 (needs args.B3: pre-split weights)
-    case 51: if (!bx3_ok(g)) return NNR_ERR_ARG; return launch_bx3<1, 5>(g, stream);           // ... 64 x 80: 2 x 23 KB stages, 3 workgroups / CU
+    case 50: if (!bx3_ok(g)) return NNR_ERR_ARG; return launch_bx3<2, 5, 2>(g, stream);           // bf16x3 NT 128 x 80 (needs args.B3: pre-split weights)
+    case 51: if (!bx3_ok(g)) return NNR_ERR_ARG; return launch_bx3<1, 5, 2>(g, stream);        // ... 64 x 80: 2 x 23 KB stages, 3 workgroups / CU
     case 32: if (!tn_pipe_ok(g)) return NNR_ERR_ARG; return launch_tn_pipe2<1, 13, 3, 2>(g, stream);              // gen-2 TN 64 x 208, 3 x 20 KB stages: row tiles of 64 fit M = 200 / 400 / 832
                                                                                                                   // (256 / 448 / 832 rows of MFMA work instead of 256 / 512 / 896)
     case 7:

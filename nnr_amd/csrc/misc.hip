@@ -444,15 +444,27 @@ __device__ __forceinline__ void sue_members(const int* cid, int Hn, int C, int* 
   __syncthreads();
 }
 
-// forward: grid (B*N, ceil(D/256)) -- every workgroup recomputes the (tiny) scores and segment softmax of its (b, n) and
-// produces one 256-column slice of the C cluster features, walking each cluster's member list once
+// forward: one workgroup per (b, n, 256-column slice) -- every workgroup recomputes the (tiny) scores and segment softmax of its (b, n) and
+// produces one slice of the C cluster features, walking each cluster's member list once.
+// Round 6: the N candidates of a user all read the user's g [Hn, D] (180 KB; the launch's algorithmic bytes count it ONCE), and consecutive
+// workgroup ids go to different XCDs, whose L2s do not share: as a (B N, slices) grid the five readers of a g slice sat in five L2s and the counter
+// traffic was 2.6x the algorithmic bytes.  The grid is 1-D now and workgroup id -> (XCD x = id & 7, slot = id >> 3) -> user b = 8 (slot / (N S)) + x:
+// every workgroup of a user runs on ONE XCD, the N readers of a slice back to back (n fastest).
+__device__ __forceinline__ bool sue_xcd_map(int id, int B, int per_user, int* b, int* w) {
+  const int x = id & 7, slot = id >> 3;
+  *b = (slot / per_user) * 8 + x;
+  *w = slot % per_user;
+  return *b < B;
+}
 __global__ __launch_bounds__(256) void sue_intra_fwd_kernel(const float* __restrict__ kf, const float* __restrict__ qc,
                                                             const float* __restrict__ g, const long* __restrict__ cidx,
-                                                            int N, int Hn, int C, int A, int D, float inv_scale,
+                                                            int B, int N, int Hn, int C, int A, int D, float inv_scale,
                                                             float* __restrict__ alpha, float* __restrict__ feat) {
   __shared__ float sc[SUE_MAXH], al[SUE_MAXH], cmax[SUE_MAXC], csum[SUE_MAXC];
   __shared__ int cid[SUE_MAXH], order[SUE_MAXH], ccnt[SUE_MAXC], cstart[SUE_MAXC];
-  const int bn = blockIdx.x, b = bn / N;
+  int b, wi;
+  if (!sue_xcd_map(blockIdx.x, B, N * ((D + 255) / 256), &b, &wi)) return;
+  const int slice = wi / N, bn = b * N + (wi - slice * N);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   for (int j = tid; j < Hn; j += 256) cid[j] = (int)cidx[(long)b * Hn + j];
   const float* q = qc + (long)bn * A;
@@ -488,10 +500,10 @@ __global__ __launch_bounds__(256) void sue_intra_fwd_kernel(const float* __restr
   for (int j = tid; j < Hn; j += 256) {
     const float v = expf(sc[j] - cmax[cid[j]]) / csum[cid[j]];
     al[j] = v;
-    if (blockIdx.y == 0) alpha[(long)bn * Hn + j] = v;
+    if (slice == 0) alpha[(long)bn * Hn + j] = v;
   }
   __syncthreads();
-  const int col = blockIdx.y * 256 + tid;
+  const int col = slice * 256 + tid;
   if (col >= D) return;
   const float* gb = g + (long)b * Hn * D + col;
   float* fo = feat + (long)bn * C * D + col;
@@ -533,11 +545,13 @@ __global__ __launch_bounds__(256) void sue_intra_fwd_kernel(const float* __restr
 // weight-gradient GEMM of the other stream.  The kernel is written for any multiple of 64 threads.)
 __global__ __launch_bounds__(256) void sue_intra_bwd_ds_kernel(const float* __restrict__ kf, const float* __restrict__ g,
                                                                 const long* __restrict__ cidx, const float* __restrict__ alpha,
-                                                                const float* __restrict__ dfeat, int N, int Hn, int C, int A, int D,
+                                                                const float* __restrict__ dfeat, int B, int N, int Hn, int C, int A, int D,
                                                                 float inv_scale, float* __restrict__ ds_ws, float* __restrict__ dqc) {
   __shared__ float al[SUE_MAXH], da[SUE_MAXH], ds[SUE_MAXH], csum[SUE_MAXC];
   __shared__ int cid[SUE_MAXH];
-  const int bn = blockIdx.x, b = bn / N, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  int b, ni;
+  if (!sue_xcd_map(blockIdx.x, B, N, &b, &ni)) return;             // (the N workgroups of a user read the same g[b]: one XCD, see the forward)
+  const int bn = b * N + ni, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int nt = blockDim.x, nw = nt >> 6;
   for (int j = tid; j < Hn; j += nt) { cid[j] = (int)cidx[(long)b * Hn + j]; al[j] = alpha[(long)bn * Hn + j]; }
   __syncthreads();
@@ -1081,7 +1095,7 @@ extern "C" int nnr_relu_bwd(const float* dy, const float* y, float* dx, long n, 
 extern "C" int nnr_sue_intra_fwd(const float* kf, const float* qc, const float* g, const long* cidx, int B, int N, int Hn, int C, int A,
                                  int D, float* alpha, float* feat, hipStream_t stream) {
   if (Hn > SUE_MAXH || C > SUE_MAXC) return NNR_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(sue_intra_fwd_kernel, dim3(B * N, (D + 255) / 256), dim3(256), 0, stream, kf, qc, g, cidx, N, Hn, C, A, D,
+  hipLaunchKernelGGL(sue_intra_fwd_kernel, dim3((B + 7) / 8 * 8 * N * ((D + 255) / 256)), dim3(256), 0, stream, kf, qc, g, cidx, B, N, Hn, C, A, D,
                      1.f / sqrtf((float)A), alpha, feat);
   NNR_CHECK_LAUNCH();
   return NNR_OK;
@@ -1091,7 +1105,7 @@ extern "C" int nnr_sue_intra_bwd(const float* kf, const float* qc, const float* 
                                  float* ds_ws, hipStream_t stream) {
   if (Hn > SUE_MAXH || C > SUE_MAXC || N > 8) return NNR_ERR_UNSUPPORTED;
   if (!ds_ws) return NNR_ERR_ARG;
-  hipLaunchKernelGGL(sue_intra_bwd_ds_kernel, dim3(B * N), dim3(256), 0, stream, kf, g, cidx, alpha, dfeat, N, Hn, C, A, D,
+  hipLaunchKernelGGL(sue_intra_bwd_ds_kernel, dim3((B + 7) / 8 * 8 * N), dim3(256), 0, stream, kf, g, cidx, alpha, dfeat, B, N, Hn, C, A, D,
                      1.f / sqrtf((float)A), ds_ws, dqc);
   NNR_CHECK_LAUNCH();
   hipLaunchKernelGGL(sue_intra_bwd_dg_kernel, dim3(B, (D + 255) / 256 + 1, C >= 3 ? 3 : 1), dim3(256), 0, stream, qc, cidx, alpha, dfeat, ds_ws, N, Hn, C,

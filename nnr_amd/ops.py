@@ -636,7 +636,7 @@ def rowdot(x, w, out, dyn=None, rows=None):
 
 _SLOT_WS = {}
 _SLAB_WS = {}
-_SK_WS = {}
+TN_SLAB = os.environ.get('NNR_TN_SLAB', '1') != '0'      # split-K weight gradients through slabs + a fixed-order reduction (0: f32 atomics)
 # fixed-order stream-K for the one-to-two-wave NT launches of the user encoder (csrc/gemm.hip: gemm_nt_sk_kernel; round 5, verdict item 1b)
 def _slab_ws(dev, floats):
     """Split-K slab workspace of the CURRENT stream (nnr_gemm_args.slab): a launch's slices store their partial results there and the

@@ -6,6 +6,7 @@ Same kernels, same order, same HIP streams and the same dropout seeds as `loss.b
 news_encoders / user_encoders / model (tests/test_hip_tape_gpu.py compares the two); what is gone is the framework in between:
 autograd's bookkeeping, its gradient-accumulation / fill / cat kernels, and every host-side tensor op that is not a call into
 libnnr_hip.so.  That makes the step RECORDABLE: nnr_amd.tape captures the calls of one such step and replays them natively."""
+import contextlib
 import os
 
 import torch
@@ -28,6 +29,21 @@ def kind(model):
     if type(model.news_encoder) is NE.MHSA and type(model.user_encoder) is UE.MHSA and _MHSA_NATIVE:
         return 'mhsa'
     return None
+
+
+@contextlib.contextmanager
+def matrix_path(model):
+    """The matrix path of one step of `model`: bf16x3 NT GEMMs (ops.BX3) unless its news encoder is the MHSA one (see forward_backward).
+    Used by the native step AND by the trainer's autograd path, so that both run the same kernels."""
+    from . import news_encoders as NE
+    off = bool(ops.BX3[0]) and not _BX3_MHSA and type(getattr(model, 'news_encoder', None)) is NE.MHSA
+    if off:
+        ops.BX3[0] = False
+    try:
+        yield
+    finally:
+        if off:
+            ops.BX3[0] = True
 
 
 def supported(model):
@@ -188,13 +204,8 @@ def forward_backward(trainer, batch):
         # The MHSA + MHSA step keeps its GEMMs on the fp32-MFMA kernels: its products are small (~100 GFLOP per step, 40 k live title rows) and
         # interleaved with the attention-core launches; with the bf16x3 tiles (63 KB of LDS, two workgroups per CU) the step measured SLOWER on three
         # same-box pairs (2.18 vs 2.24 ms, profiles/r06_ab.txt).  NNR_BX3_MHSA=1 sends them there all the same.
-        if ops.BX3[0] and not _BX3_MHSA:
-            ops.BX3[0] = False
-            try:
-                return forward_backward_mhsa(trainer, batch)
-            finally:
-                ops.BX3[0] = True
-        return forward_backward_mhsa(trainer, batch)
+        with matrix_path(model):
+            return forward_backward_mhsa(trainer, batch)
     ne, ue = model.news_encoder, model.user_encoder
     (user_ID, user_category, user_subCategory, user_title_text, user_title_mask, user_title_entity, user_content_text, user_content_mask,
      user_content_entity, user_history_mask, user_history_graph, user_history_category_mask, user_history_category_indices, news_category,

@@ -183,9 +183,11 @@ class Trainer:
         self.last_path = 'autograd'
         self.exchange.begin_step(int(batch[0].shape[0]))
         self.flat.zero_grad()
-        logits = model(*batch)
-        loss = negative_log_softmax(logits)
-        loss.backward()
+        from . import step as native_step
+        with native_step.matrix_path(model):             # (same kernels as the native step of this model would run)
+            logits = model(*batch)
+            loss = negative_log_softmax(logits)
+            loss.backward()
         ops.join_extra_streams()
         scale = self.exchange.finish()
         self.optimizer_step(scale)
