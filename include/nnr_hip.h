@@ -295,6 +295,18 @@ int nnr_mhsa_fwd_packed(const float* qkv, const uint8_t* mask, const int* rowmap
                         float drop_p, uint32_t seed, hipStream_t stream);
 int nnr_mhsa_bwd_packed(const float* qkv, const uint8_t* mask, const int* rowmap, const float* dout, int n, int Lq, int heads, int dh, float scale,
                         float* dqkv, float drop_p, uint32_t seed, hipStream_t stream);
+/* Round 6: PAIRED short titles.  The attention core multiplies 32 x 32 blocks whatever a title's length, and 85 % of MIND-shaped titles cover <= 16
+ * positions; nnr_mhsa_pair_map lays the titles of a packed call (Lq = 32) out as virtual samples in the plan's sorted order -- the titles covering
+ * more than 16 positions alone, the others two to a sample (positions 0..15 / 16..31) -- and nnr_mhsa_fwd_paired / _bwd_paired run the core over
+ * them, with -inf scores between the two titles of a pair (exact zeros in every product that follows).  Same results as nnr_mhsa_*_packed up to
+ * the order of fp32 additions inside a softmax row; ~0.6x of its matrix work.  vrowmap / vmask: [n, 32]; off: the plan's offsets (off[17] - off[16]
+ * = the number of unpaired titles).  layers.py:132-148. */
+int nnr_mhsa_pair_map(const int* off, const int* slen, const int* order, const uint8_t* mask, int n, int L, int* vrowmap, uint8_t* vmask,
+                      hipStream_t stream);
+int nnr_mhsa_fwd_paired(const float* qkv, const uint8_t* vmask, const int* vrowmap, const int* off, int n, int heads, int dh, float scale,
+                        float* out, float drop_p, uint32_t seed, hipStream_t stream);
+int nnr_mhsa_bwd_paired(const float* qkv, const uint8_t* vmask, const int* vrowmap, const int* off, const float* dout, int n, int heads, int dh,
+                        float scale, float* dqkv, float drop_p, uint32_t seed, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------ SUE (userEncoders.py:68-98) */
 /* cmask_fix (optional): the [B, Kc + 1] cluster mask; its last column is set to 1 in place by the same launch (:73).

@@ -59,7 +59,7 @@ SYMBOLS = [
     'nnr_tanh_score_bwd', 'nnr_slot_workspace_floats', 'nnr_colsum', 'nnr_rowdot', 'nnr_small_embed_fwd', 'nnr_small_embed_bwd', 'nnr_add', 'nnr_add_atomic', 'nnr_add2d', 'nnr_dropout',
     'nnr_layernorm_fwd', 'nnr_layernorm_bwd', 'nnr_relu_bwd', 'nnr_relu_drop_bwd', 'nnr_gcn_aggregate_fwd', 'nnr_gcn_aggregate_bwd', 'nnr_sue_x0_fwd', 'nnr_sue_x0_bwd', 'nnr_sue_slice_fwd', 'nnr_sue_slice_bwd',
     'nnr_sue_intra_fwd', 'nnr_sue_intra_bwd', 'nnr_logits_loss_fwd', 'nnr_logits_fwd', 'nnr_nls_loss', 'nnr_logits_bwd', 'nnr_sumsq', 'nnr_sumsq_part', 'nnr_clip_adam',
-    'nnr_mhsa_fwd', 'nnr_mhsa_bwd', 'nnr_mhsa_fwd_packed', 'nnr_mhsa_bwd_packed', 'nnr_mask_cover', 'nnr_seq_rowmap', 'nnr_embed_gather', 'nnr_embed_scatter', 'nnr_embed_scatter_dyn', 'nnr_transpose2d', 'nnr_transpose_batch', 'nnr_corpus_batch', 'nnr_history_graph', 'nnr_rank_metrics',
+    'nnr_mhsa_fwd', 'nnr_mhsa_bwd', 'nnr_mhsa_fwd_packed', 'nnr_mhsa_bwd_packed', 'nnr_mhsa_pair_map', 'nnr_mhsa_fwd_paired', 'nnr_mhsa_bwd_paired', 'nnr_mask_cover', 'nnr_seq_rowmap', 'nnr_embed_gather', 'nnr_embed_scatter', 'nnr_embed_scatter_dyn', 'nnr_transpose2d', 'nnr_transpose_batch', 'nnr_corpus_batch', 'nnr_history_graph', 'nnr_rank_metrics',
     'nnr_dp_unique_id', 'nnr_dp_init', 'nnr_dp_allreduce', 'nnr_dp_broadcast', 'nnr_dp_destroy', 'nnr_dp_emulate_ranks', 'nnr_dp_busy',
     'nnr_fill_zero', 'nnr_copy_bytes', 'nnr_fill_column_u8', 'nnr_adam_skipped_steps', 'nnr_adam_skipped_peek', 'nnr_fusion_rows_fwd', 'nnr_fusion_rows_bwd', 'nnr_click_loss',
     'nnr_tape_create', 'nnr_tape_destroy', 'nnr_tape_fn_id', 'nnr_tape_fn_nargs', 'nnr_tape_call', 'nnr_tape_wait_stream', 'nnr_tape_event_record',

@@ -34,7 +34,30 @@ struct MhsaArgs {
   uint32_t seed, thr; float dscale;        // dropout on the attention output (thr == 0: off): out = keep(idx) ? O * dscale : 0
                                            // with idx = the flat element index in out / dout [n*Lq, heads*dh]
   const int* rowmap;                       // round 5, PACKED token rows (NULL: dense): position q of sample s lives at row rowmap[s*Lq + q] of
-};                                         // qkv / out / dout / dqkv, -1 = the row does not exist (a padded position: reads as zero, is not stored)
+                                           // qkv / out / dout / dqkv, -1 = the row does not exist (a padded position: reads as zero, is not stored)
+  const int* pair_off;                     // round 6, PAIRED short titles (NULL: off; needs rowmap, Lq == 32): the plan's off[] -- see mhsa_pairing()
+};
+
+// Round 6: SHORT titles share one 32 x 32 attention problem -- two of <= 16 positions, four of <= 8.  The attention core multiplies 32 x 32 blocks
+// whatever the title's length; 85 % of MIND-shaped titles cover <= 16 positions and a third <= 8: their problems were mostly padding.
+// nnr_mhsa_pair_map lays the samples out as VIRTUAL samples in the plan's sorted order (descending cover length), with n16 = off[17] - off[16]
+// titles covering more than 16 positions (fully masked titles cover all 32) and n8 = off[9] - off[8] covering more than 8:
+//   v < n16                : the title at sorted position v alone;
+//   n16 <= v < n16 + P     : P = ceil((n8 - n16) / 2) pairs -- sorted positions n16 + 2 k (+1) at positions 0..15 / 16..31;
+//   n16 + P <= v < nv      : Q = ceil((n - n8) / 4) quads -- sorted positions n8 + 4 k (+1, +2, +3) at positions 0..7 / 8..15 / 16..23 / 24..31.
+// A query of one title must not see the keys of another: their scores are -inf (weight exactly 0 -- unlike the -1e9 of a masked key, which matters
+// only inside a fully masked title, and those are never grouped), so every product that follows (P V, dP, dS, dQ, dK, dV) sees exact zeros across
+// the titles of a group.  `xmask` of a sample: query i and key j belong to different titles iff (i ^ j) & xmask  (0 / 16 / 24).
+struct MhsaPairing { int n16, np, nv; };
+__device__ __forceinline__ MhsaPairing mhsa_pairing(const MhsaArgs& a) {
+  if (!a.pair_off) return MhsaPairing{a.n, 0, a.n};
+  const int n16 = a.pair_off[17] - a.pair_off[16], n8 = a.pair_off[9] - a.pair_off[8];
+  const int np = (n8 - n16 + 1) / 2;
+  return MhsaPairing{n16, np, n16 + np + (a.n - n8 + 3) / 4};
+}
+__device__ __forceinline__ int mhsa_xmask(const MhsaArgs& a, const MhsaPairing& pg, int smp) {
+  return !a.pair_off || smp < pg.n16 ? 0 : (smp < pg.n16 + pg.np ? 16 : 24);
+}
 
 // stage the [Lq, dh] slice (row stride ld) of one head into LDS as [LP][SD], zero rows >= Lq
 __device__ __forceinline__ void stage(float* dst, const float* src, int ld, int Lq, int dh, int LP, int SD, int lane) {
@@ -184,7 +207,7 @@ __device__ __forceinline__ unsigned long long key_bits(const MhsaArgs& a, int sm
 
 // key mask + softmax over keys (rows) of S^T for this lane's query column(s); p: raw scores in, probabilities out
 template <int NB>
-__device__ __forceinline__ void softmax_T(f32x16 (&p)[NB][NB], const MhsaArgs& a, unsigned long long live, int half) {
+__device__ __forceinline__ void softmax_T(f32x16 (&p)[NB][NB], const MhsaArgs& a, unsigned long long live, int half, int xmask = 0, int qcol = 0) {
 #pragma unroll
   for (int ib = 0; ib < NB; ++ib) {
     float m = -INFINITY;
@@ -195,6 +218,7 @@ __device__ __forceinline__ void softmax_T(f32x16 (&p)[NB][NB], const MhsaArgs& a
         const int j = jb * 32 + acc_row(reg, half);
         float sc = p[jb][ib][reg] * a.scale;
         if (j >= a.Lq) sc = -INFINITY;
+        else if ((qcol ^ j) & xmask) sc = -INFINITY;                    // (NB == 1) a key of ANOTHER title of the group: this lane's query is qcol
         else if (!((live >> j) & 1)) sc = -1e9f;
         p[jb][ib][reg] = sc;
         m = fmaxf(m, sc);
@@ -303,6 +327,8 @@ __global__ __launch_bounds__(256) void mhsa_fwd_kernel(MhsaArgs a_in, int coop) 
   float* Vs = Ks + LP * SD;
   const int pair0 = blockIdx.x * 4, smp0 = pair0 / a.heads, head0 = pair0 - smp0 * a.heads;    // coop: the workgroup's 4 heads
   const int* rmap = a.rowmap ? a.rowmap + (long)smp0 * a.Lq : nullptr;        // (packed rows: coop path only, checked by the entry point)
+  const MhsaPairing pg = mhsa_pairing(a);
+  if (a.pair_off && smp0 >= pg.nv) return;                                     // (paired: coop path only; the grid is sized for n samples)
   if (coop) {
     const float* base0 = a.qkv + (rmap ? 0 : (long)smp0 * a.Lq * ld) + head0 * dh;
     const float* const src[3] = {base0, base0 + HD, base0 + 2 * HD};
@@ -327,7 +353,7 @@ __global__ __launch_bounds__(256) void mhsa_fwd_kernel(MhsaArgs a_in, int coop) 
   }
   f32x16 p[NB][NB];                        // p[jb][ib] = S^T block: rows keys, cols queries
   rows_dot<NB, DH>(Ks, Qs, dh, SD, lane, p);
-  softmax_T<NB>(p, a, key_bits(a, smp, lane), half);
+  softmax_T<NB>(p, a, key_bits(a, smp, lane), half, mhsa_xmask(a, pg, smp), lane & 31);
   if (a.prob) {
     float* pp = a.prob + (long)pair * (NB * NB * 1024);
 #pragma unroll
@@ -558,7 +584,8 @@ __global__ __launch_bounds__(256, 2) void mhsa_bwd_persist_kernel(MhsaArgs a_in,
   float* Vs = Ks + LP * SD;
   float* Gs = Vs + LP * SD;                // dO
   float* T = Gs + LP * SD;                 // [LP][ST] transpose tile
-  const int ngroups = a.n * a.heads / 4;
+  const MhsaPairing pg = mhsa_pairing(a);
+  const int ngroups = pg.nv * a.heads / 4;                     // (paired short titles: nv virtual samples, the grid is sized for n)
   const int g_lo = blockIdx.x * gp, g_hi = min(ngroups, g_lo + gp);
   if (g_lo >= g_hi) return;
   float4 r[4][3];
@@ -587,7 +614,7 @@ __global__ __launch_bounds__(256, 2) void mhsa_bwd_persist_kernel(MhsaArgs a_in,
     __syncthreads();                                            // this group's tiles are in LDS
     f32x16 p[NB][NB], dp[NB][NB];
     rows_dot<NB, DH>(Ks, Qs, dh, SD, lane, p);
-    softmax_T<NB>(p, a, live, half);
+    softmax_T<NB>(p, a, live, half, mhsa_xmask(a, pg, smp0), l31);
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) T[acc_row(reg, half) * ST + l31] = p[0][0][reg];
     __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -650,15 +677,16 @@ __global__ __launch_bounds__(256, 2) void mhsa_bwd_persist_kernel(MhsaArgs a_in,
 }  // namespace
 
 static int mhsa_fwd_launch(const float* qkv, const uint8_t* mask, const int* rowmap, int n, int Lq, int heads, int dh, float scale, float* out,
-                           float* prob, float drop_p, uint32_t seed, hipStream_t stream) {
+                           float* prob, float drop_p, uint32_t seed, hipStream_t stream, const int* pair_off = nullptr) {
   if (!qkv || !out || n <= 0) return NNR_ERR_ARG;
   if (Lq > 64 || dh > 32 || (dh & 1)) return NNR_ERR_UNSUPPORTED;
+  if (pair_off && (!rowmap || Lq != 32)) return NNR_ERR_UNSUPPORTED;
   MhsaArgs a{qkv, mask, n, Lq, heads, dh, scale, out, prob, nullptr, nullptr, seed, nnr_drop_thresh(drop_p),
-             drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, rowmap};
+             drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, rowmap, pair_off};
   const int NB = Lq > 32 ? 2 : 1, LP = 32 * NB, SD = dh | 1;
   const int waves = 4;
   const int coop = (heads % 4 == 0 && dh % 4 == 0) ? 1 : 0;        // a workgroup's 4 waves then are 4 adjacent heads of one sample
-  if (rowmap && (!coop || prob)) return NNR_ERR_UNSUPPORTED;       // packed rows: the 4-head cooperative staging only
+  if (rowmap && (!coop || prob)) return NNR_ERR_UNSUPPORTED;       // packed rows (and paired titles): the 4-head cooperative staging only
   const size_t shm = ((size_t)waves * 3 * LP * SD + 16) * sizeof(float);      // + 16: operand reads of lanes >= dh run up to 11 floats past the last row
   const int blocks = (n * heads + waves - 1) / waves;
   if (NB == 1 && dh == 20 && Lq == 32) hipLaunchKernelGGL((mhsa_fwd_kernel<1, 20, true>), dim3(blocks), dim3(64 * waves), shm, stream, a, coop);
@@ -681,11 +709,12 @@ extern "C" int nnr_mhsa_fwd_packed(const float* qkv, const uint8_t* mask, const 
 }
 
 static int mhsa_bwd_launch(const float* qkv, const uint8_t* mask, const int* rowmap, const float* prob, const float* dout, int n, int Lq, int heads,
-                           int dh, float scale, float* dqkv, float drop_p, uint32_t seed, hipStream_t stream) {
+                           int dh, float scale, float* dqkv, float drop_p, uint32_t seed, hipStream_t stream, const int* pair_off = nullptr) {
   if (!qkv || !dout || !dqkv || n <= 0) return NNR_ERR_ARG;         // prob == NULL: P is recomputed from Q, K
   if (Lq > 64 || dh > 32 || (dh & 1)) return NNR_ERR_UNSUPPORTED;
+  if (pair_off && (!rowmap || Lq != 32)) return NNR_ERR_UNSUPPORTED;
   MhsaArgs a{qkv, mask, n, Lq, heads, dh, scale, nullptr, const_cast<float*>(prob), dout, dqkv, seed, nnr_drop_thresh(drop_p),
-             drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, rowmap};
+             drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f, rowmap, pair_off};
   const int NB = Lq > 32 ? 2 : 1, LP = 32 * NB, SD = dh | 1;
   const int waves = NB == 1 ? 4 : 1;
   const int coop = (waves == 4 && heads % 4 == 0 && dh % 4 == 0) ? 1 : 0;
@@ -693,7 +722,8 @@ static int mhsa_bwd_launch(const float* qkv, const uint8_t* mask, const int* row
   const size_t shm = ((size_t)waves * (4 * LP * SD + LP * (LP + 1)) + 16) * sizeof(float);
   const int blocks = (n * heads + waves - 1) / waves;
   static const int persist = [] { const char* e = getenv("NNR_MHSA_PERSIST"); return e ? atoi(e) : 1; }();      // A/B: 0 = one 4-head group per workgroup
-  if (persist && coop && !prob && 32 * dh <= 768) {
+  if (pair_off && !(coop && !prob && 32 * dh <= 768)) return NNR_ERR_UNSUPPORTED;      // paired titles: the persistent 4-head kernel only
+  if ((persist || pair_off) && coop && !prob && 32 * dh <= 768) {
     // one workgroup per sample's heads (heads / 4 groups), or fewer groups when that leaves the chip short of workgroups
     const int ngroups = n * heads / 4;
     int gp = heads / 4;
@@ -721,4 +751,16 @@ extern "C" int nnr_mhsa_bwd_packed(const float* qkv, const uint8_t* mask, const 
                                    float scale, float* dqkv, float drop_p, uint32_t seed, hipStream_t stream) {
   if (!rowmap) return NNR_ERR_ARG;
   return mhsa_bwd_launch(qkv, mask, rowmap, nullptr, dout, n, Lq, heads, dh, scale, dqkv, drop_p, seed, stream);
+}
+
+// Paired short titles (mhsa_pairing above): vmask / vrowmap [n, 32] from nnr_mhsa_pair_map (csrc/seq_plan.hip), off = the plan's offsets.
+extern "C" int nnr_mhsa_fwd_paired(const float* qkv, const uint8_t* vmask, const int* vrowmap, const int* off, int n, int heads, int dh, float scale,
+                                   float* out, float drop_p, uint32_t seed, hipStream_t stream) {
+  if (!vrowmap || !vmask || !off) return NNR_ERR_ARG;
+  return mhsa_fwd_launch(qkv, vmask, vrowmap, n, 32, heads, dh, scale, out, nullptr, drop_p, seed, stream, off);
+}
+extern "C" int nnr_mhsa_bwd_paired(const float* qkv, const uint8_t* vmask, const int* vrowmap, const int* off, const float* dout, int n, int heads,
+                                   int dh, float scale, float* dqkv, float drop_p, uint32_t seed, hipStream_t stream) {
+  if (!vrowmap || !vmask || !off) return NNR_ERR_ARG;
+  return mhsa_bwd_launch(qkv, vmask, vrowmap, nullptr, dout, n, 32, heads, dh, scale, dqkv, drop_p, seed, stream, off);
 }

@@ -235,6 +235,41 @@ __global__ void seq_rowmap_kernel(const int* __restrict__ off, const int* __rest
   const int i = (int)(idx / L), t = (int)(idx - (long)i * L);
   rowmap[idx] = t < len[i] ? off[t] + rank[i] : -1;
 }
+// Virtual samples of the GROUPED attention core (csrc/mhsa.hip: mhsa_pairing): in the plan's sorted order, the n16 = off[17] - off[16] titles that
+// cover more than 16 positions stay alone (virtual sample v = sorted position v); the n8 - n16 titles covering 9..16 positions go two to a sample
+// (positions 0..15 / 16..31), the n - n8 covering <= 8 four to a sample (0..7 / 8..15 / 16..23 / 24..31).  vrowmap[v, q] = packed row of that
+// position (off[t] + s) or -1, vmask[v, q] = the ORIGINAL key mask of that position; rows v >= n_virtual are filled with (-1, 0) and never read.
+__global__ void mhsa_pair_map_kernel(const int* __restrict__ off, const int* __restrict__ slen, const int* __restrict__ order,
+                                     const uint8_t* __restrict__ mask, int n, int* __restrict__ vrowmap, uint8_t* __restrict__ vmask) {
+  constexpr int L = 32;
+  const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (idx >= (long)n * L) return;
+  const int v = (int)(idx / L), q = (int)(idx - (long)v * L);
+  const int n16 = off[17] - off[16], n8 = off[9] - off[8];
+  const int np = (n8 - n16 + 1) / 2, nv = n16 + np + (n - n8 + 3) / 4;
+  int row = -1;
+  uint8_t mk = 0;
+  if (v < nv) {
+    int s, t, end;
+    if (v < n16) { s = v; t = q; end = n16; }
+    else if (v < n16 + np) { s = n16 + 2 * (v - n16) + (q >> 4); t = q & 15; end = n8; }
+    else { s = n8 + 4 * (v - n16 - np) + (q >> 3); t = q & 7; end = n; }
+    if (s < end) {
+      if (t < slen[s]) row = off[t] + s;
+      mk = mask[(long)order[s] * L + t];
+    }
+  }
+  vrowmap[idx] = row;
+  vmask[idx] = mk;
+}
+extern "C" int nnr_mhsa_pair_map(const int* off, const int* slen, const int* order, const uint8_t* mask, int n, int L, int* vrowmap, uint8_t* vmask,
+                                 hipStream_t stream) {
+  if (!off || !slen || !order || !mask || !vrowmap || !vmask || n <= 0) return NNR_ERR_ARG;
+  if (L != 32) return NNR_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(mhsa_pair_map_kernel, dim3((unsigned)(((long)n * L + 255) / 256)), dim3(256), 0, stream, off, slen, order, mask, n, vrowmap, vmask);
+  NNR_CHECK_LAUNCH();
+  return NNR_OK;
+}
 extern "C" int nnr_mask_cover(const uint8_t* mask, int n, int L, uint8_t* cover, hipStream_t stream) {
   if (!mask || !cover || n <= 0 || L <= 0) return NNR_ERR_ARG;
   hipLaunchKernelGGL(mask_cover_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, mask, n, L, cover);

@@ -46,7 +46,7 @@ const Entry REGISTRY[] = {
   R(nnr_dropout), R(nnr_relu_bwd), R(nnr_gcn_aggregate_fwd), R(nnr_gcn_aggregate_bwd), R(nnr_relu_drop_bwd), R(nnr_mhsa_fwd), R(nnr_mhsa_bwd),
   R(nnr_sue_x0_fwd), R(nnr_sue_x0_bwd), R(nnr_sue_slice_fwd), R(nnr_sue_slice_bwd), R(nnr_sue_intra_fwd), R(nnr_sue_intra_bwd),
   R(nnr_corpus_batch), R(nnr_history_graph), R(nnr_logits_loss_fwd), R(nnr_logits_fwd), R(nnr_nls_loss), R(nnr_logits_bwd),
-  R(nnr_layernorm_fwd), R(nnr_layernorm_bwd), R(nnr_sumsq), R(nnr_sumsq_part), R(nnr_clip_adam), R(nnr_dp_allreduce), R(nnr_dp_broadcast), R(nnr_dp_busy), R(nnr_split_bf16x3), R(nnr_mhsa_fwd_packed), R(nnr_mhsa_bwd_packed), R(nnr_mask_cover), R(nnr_seq_rowmap),
+  R(nnr_layernorm_fwd), R(nnr_layernorm_bwd), R(nnr_sumsq), R(nnr_sumsq_part), R(nnr_clip_adam), R(nnr_dp_allreduce), R(nnr_dp_broadcast), R(nnr_dp_busy), R(nnr_split_bf16x3), R(nnr_mhsa_fwd_packed), R(nnr_mhsa_bwd_packed), R(nnr_mhsa_pair_map), R(nnr_mhsa_fwd_paired), R(nnr_mhsa_bwd_paired), R(nnr_mask_cover), R(nnr_seq_rowmap),
   R(nnr_fill_zero), R(nnr_copy_bytes), R(nnr_fill_column_u8), R(nnr_fusion_rows_fwd), R(nnr_fusion_rows_bwd), R(nnr_click_loss), R(nnr_rank_metrics),
   R(nnr_token_sort), R(nnr_embed_scatter_sorted), R(nnr_fusion_rows_bwd_det),
   R(nnr_rows_touch), R(nnr_rows_compact), R(nnr_rows_pack), R(nnr_rows_unpack),

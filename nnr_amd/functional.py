@@ -40,6 +40,8 @@ class MhsaPack:
         self.plan = ops.SeqPlan(cover, ids.contiguous(), None)          # (its in-place mask[:, 0] = 1 acts on `cover`: a no-op there)
         self.rowmap = ops.seq_rowmap(self.plan)
         self.cover = cover
+        # round 6: two titles of <= 16 positions per 32 x 32 attention problem (the core's matrix work does not depend on a title's length)
+        self.pair = ops.mhsa_pair_map(self.plan, mask) if (ops.MHSA_PAIR and self.plan.L == 32) else None
 
 
 class PackedEmbedDropFn(torch.autograd.Function):
@@ -66,15 +68,22 @@ class PackedMhsaCoreFn(torch.autograd.Function):
     def forward(ctx, qkv, mask, pack, heads, dh, p=0.0, seed=0):
         qkv = qkv.contiguous()
         out = torch.empty((pack.plan.cap, heads * dh), device=qkv.device, dtype=torch.float32)
-        ops.mhsa_fwd_packed(qkv, mask, pack.rowmap, pack.plan, heads, dh, out, p, seed)
-        ctx.qkv, ctx.mask, ctx.pack, ctx.dims, ctx.drop = qkv, mask, pack, (heads, dh), (p, seed)
+        paired = pack.pair is not None and heads % 4 == 0 and dh % 4 == 0 and 32 * dh <= 768
+        if paired:
+            ops.mhsa_fwd_paired(qkv, pack.pair, pack.plan, heads, dh, out, p, seed)
+        else:
+            ops.mhsa_fwd_packed(qkv, mask, pack.rowmap, pack.plan, heads, dh, out, p, seed)
+        ctx.qkv, ctx.mask, ctx.pack, ctx.dims, ctx.drop, ctx.paired = qkv, mask, pack, (heads, dh), (p, seed), paired
         return out
 
     @staticmethod
     def backward(ctx, dout):
         heads, dh = ctx.dims
         dqkv = torch.empty_like(ctx.qkv)
-        ops.mhsa_bwd_packed(ctx.qkv, ctx.mask, ctx.pack.rowmap, ctx.pack.plan, dout.contiguous(), heads, dh, dqkv, *ctx.drop)
+        if ctx.paired:
+            ops.mhsa_bwd_paired(ctx.qkv, ctx.pack.pair, ctx.pack.plan, dout.contiguous(), heads, dh, dqkv, *ctx.drop)
+        else:
+            ops.mhsa_bwd_packed(ctx.qkv, ctx.mask, ctx.pack.rowmap, ctx.pack.plan, dout.contiguous(), heads, dh, dqkv, *ctx.drop)
         return dqkv, None, None, None, None, None, None
 
 

@@ -284,7 +284,7 @@ def wt(w):
         e.t = torch.empty((cols, rows), device=w.device, dtype=torch.float32)      # kept across refreshes: stable address
         _WT[id(w)] = e
         _WT_TABLE['ids'] = None
-        mark_weight(e.t)
+        mark_weight(e.t, prefetchable=True)
     tape_keep(e.t)
     transpose2d(w, e.t, rows, cols)
     e.event = torch.cuda.Event()
@@ -405,10 +405,53 @@ _B3 = {}
 BX3_SEEN = {}                                                  # diagnostics: (M, N, K, 'weight' | 'other') -> launches that met every other condition
 
 
-def mark_weight(*tensors):
-    """`tensors` are derived weights (a cached transpose, a packed layout): rewritten only when the parameters change (layers.PARAM_EPOCH)."""
+def mark_weight(*tensors, prefetchable=False):
+    """`tensors` are derived weights (a cached transpose, a packed layout): rewritten only when the parameters change (layers.PARAM_EPOCH).
+    prefetchable: the tensor is refreshed on the leaf stream at the START of a step (wt_prefetch's transposes), so bx3_prefetch may re-split
+    it there; the packed LSTM weights are re-packed inside the forward pass and are split by their first user instead."""
     for t in tensors:
         t._nnr_weight = True
+        if prefetchable:
+            t._nnr_prefetch = True
+
+
+BX3_PREFETCH = os.environ.get('NNR_BX3_PREFETCH', '1') != '0'
+
+
+def bx3_prefetch(dev):
+    """Re-split, on the leaf stream at the start of a training step (right behind wt_prefetch's transposes, same stream), the bf16 images of
+    every weight bx3_images() has served before and that changed since (i.e. after an optimizer step): parameters and their cached transposes.
+    Made lazily, each split is a 3-30 us launch on the stream of its first user -- five of them sat on the step's dependent chain in front of
+    their GEMMs (profiles/r06_ab.txt: split_bf16x3_kernel 21 / 11 / 34 / 28 / 14 us on the main streams)."""
+    if not (BX3[0] and BX3_PREFETCH) or not _B3 or torch.cuda.is_current_stream_capturing():
+        return
+    from .layers import PARAM_EPOCH
+    stale = []
+    for e in _B3.values():
+        B = e[3]()
+        if B is None or e[4][0] != B.data_ptr() or not (isinstance(B, torch.nn.Parameter) or getattr(B, '_nnr_prefetch', False)):
+            continue
+        if e[1] == PARAM_EPOCH[0] and e[2] == B._version:
+            continue
+        stale.append((e, B))
+    if not stale:
+        return
+    key = (dev.type, dev.index)
+    if key not in _LEAF:
+        _LEAF[key] = new_stream(dev)
+    leaf = _LEAF[key]
+    leaf.wait_stream(torch.cuda.current_stream(dev))       # behind the optimizer step that changed the parameters
+    with torch.cuda.stream(leaf):
+        for e, B in stale:
+            _, N, K, ldb = e[4]
+            ldo = e[0].shape[2]
+            tape_keep(e[0])
+            L.check(L.lib().nnr_split_bf16x3(_p(B), N, K, ldb, ldo, _p(e[0]), C.c_long(N * ldo), _s()), 'nnr_split_bf16x3')
+        ev = torch.cuda.Event()
+        ev.record()
+        cur = torch._C._cuda_getCurrentRawStream(_DEV_INDEX[0] if _DEV_INDEX else torch.cuda.current_device())
+    for e, B in stale:
+        e[1], e[2], e[5], e[6] = PARAM_EPOCH[0], B._version, ev, cur
 
 
 def bx3_images(B, N, K, ldb):
@@ -1183,6 +1226,34 @@ def mhsa_bwd_packed(qkv, mask, rowmap, plan, dout, heads, dh, dqkv, p=0.0, seed=
     with _mhsa_span_packed('mhsa_bwd', plan, heads, dh, 10.0, 7.0):
         L.check(L.lib().nnr_mhsa_bwd_packed(_p(qkv), _p(mask), _p(rowmap), _p(dout), plan.n, plan.L, heads, dh, C.c_float(1.0 / math.sqrt(dh)),
                                             _p(dqkv), C.c_float(p), C.c_uint32(seed & 0xFFFFFFFF), _s()), 'nnr_mhsa_bwd_packed')
+
+
+MHSA_PAIR = os.environ.get('NNR_MHSA_PAIR', '1') != '0'      # round 6: two titles of <= 16 positions per 32 x 32 attention problem (csrc/mhsa.hip: mhsa_pairing)
+
+
+def mhsa_pair_map(plan, mask):
+    """(vrowmap [n, 32] int32, vmask [n, 32] uint8) of the paired attention core over `plan` (a packed call with L = 32) and the ORIGINAL key mask."""
+    if mask.dtype == torch.bool:
+        mask = mask.view(torch.uint8)
+    vrow = torch.empty((plan.n, plan.L), device=plan.off.device, dtype=torch.int32)
+    vmask = torch.empty((plan.n, plan.L), device=plan.off.device, dtype=torch.uint8)
+    L.check(L.lib().nnr_mhsa_pair_map(_p(plan.off), _p(plan.slen), _p(plan.order), _p(mask.contiguous()), plan.n, plan.L, _p(vrow), _p(vmask), _s()),
+            'nnr_mhsa_pair_map')
+    return vrow, vmask
+
+
+def mhsa_fwd_paired(qkv, pair, plan, heads, dh, out, p=0.0, seed=0):
+    vrow, vmask = pair
+    with _mhsa_span_packed('mhsa_fwd', plan, heads, dh, 4.0, 4.0):
+        L.check(L.lib().nnr_mhsa_fwd_paired(_p(qkv), _p(vmask), _p(vrow), _p(plan.off), plan.n, heads, dh, C.c_float(1.0 / math.sqrt(dh)), _p(out),
+                                            C.c_float(p), C.c_uint32(seed & 0xFFFFFFFF), _s()), 'nnr_mhsa_fwd_paired')
+
+
+def mhsa_bwd_paired(qkv, pair, plan, dout, heads, dh, dqkv, p=0.0, seed=0):
+    vrow, vmask = pair
+    with _mhsa_span_packed('mhsa_bwd', plan, heads, dh, 10.0, 7.0):
+        L.check(L.lib().nnr_mhsa_bwd_paired(_p(qkv), _p(vmask), _p(vrow), _p(plan.off), _p(dout), plan.n, heads, dh, C.c_float(1.0 / math.sqrt(dh)),
+                                            _p(dqkv), C.c_float(p), C.c_uint32(seed & 0xFFFFFFFF), _s()), 'nnr_mhsa_bwd_paired')
 
 
 def mhsa_prob_size(n, Lq, heads):

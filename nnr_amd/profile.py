@@ -18,7 +18,7 @@ KERNEL_OF = {
     'gemm_nt_64x80k64': 'gemm_kernel<1, 5, false, false, 64>', 'gemm_nn_64x80k64': 'gemm_kernel<1, 5, false, true, 64>',
     'gemm_tn_64x80k64': 'gemm_kernel<1, 5, true, true, 64>',
     'gemm_nt_pipe128x80': 'gemm_nt_pipe_kernel<2, 5, 16, 3, 4, 0>', 'gemm_nt_pipe128x80s2': 'gemm_nt_pipe_kernel<2, 5, 16, 2, 5, 0>',
-    'gemm_nt_bx3_128x80': 'gemm_nt_bx3_kernel<2, 5>', 'gemm_nt_bx3_64x80': 'gemm_nt_bx3_kernel<1, 5>',
+    'gemm_nt_bx3_128x80': 'gemm_nt_bx3_kernel<2, 5, 2>', 'gemm_nt_bx3_64x80': 'gemm_nt_bx3_kernel<1, 5, 2>',
     'gemm_nt_pipe2_128x80': 'gemm_nt_pipe2_kernel<2, 5, 3, 2>', 'gemm_nt_pipe2_128x64': 'gemm_nt_pipe2_kernel<2, 4, 3, 2>',
     'gemm_tn_pipe2_128x80': 'gemm_tn_pipe2_kernel<2, 5, 3, 3>', 'gemm_tn_pipe2_128x208': 'gemm_tn_pipe2_kernel<2, 13, 3, 2>', 'gemm_tn_pipe2_128x160': 'gemm_tn_pipe2_kernel<2, 10, 3, 2>', 'gemm_tn_pipe2_64x208': 'gemm_tn_pipe2_kernel<1, 13, 3, 2>',
     'gemm_tn_pipe128x80': 'gemm_tn_pipe_kernel<2, 5, 3, 3, 0>', 'gemm_tn_pipe128x208': 'gemm_tn_pipe_kernel<2, 13, 3, 2, 0>',

@@ -1059,6 +1059,26 @@ def test_mhsa_core_over_packed_rows_equals_dense():
         wantb = dq.cpu()[live.reshape(-1)]
         assert bool(torch.isfinite(gotb).all())
         assert float((gotb - wantb).abs().max()) <= 2e-6 * max(1.0, float(wantb.abs().max())), 'packed backward (p = %g)' % p
+        # round 6: GROUPED short titles (two titles of <= 16 / four of <= 8 positions per 32 x 32 problem, -inf scores between them): same rows, same values up to the
+        # order of fp32 additions inside a softmax row; junk-free (NaN rows beyond the live count untouched)
+        if Lq == 32:
+            pair = ops.mhsa_pair_map(plan, md)
+            vrow, vmask = pair[0].cpu(), pair[1].cpu()
+            n16, n8 = int(plan.bs.cpu()[16]), int(plan.bs.cpu()[8])
+            nvirt = n16 + (n8 - n16 + 1) // 2 + (n - n8 + 3) // 4
+            assert n16 < n8 < n, 'the test batch must hold titles of 9..16 and of <= 8 positions'
+            lr = vrow[:nvirt][vrow[:nvirt] >= 0]
+            assert sorted(lr.tolist()) == list(range(int(plan.total.item()))) and bool((vrow[nvirt:] == -1).all())      # every packed row exactly once
+            outq = torch.full((cap, HD), float('nan'), device=d)
+            ops.mhsa_fwd_paired(qpd, pair, plan, heads, dh, outq, p, seed)
+            gotq = outq.cpu()[rm[live]]
+            assert bool(torch.isfinite(gotq).all()) and bool(torch.isnan(outq.cpu()[int(plan.total.item()):]).all())
+            assert float((gotq - got).abs().max()) <= 1e-6 * max(1.0, float(got.abs().max())), 'paired forward (p = %g)' % p
+            dqq = torch.full((cap, 3 * HD), float('nan'), device=d)
+            ops.mhsa_bwd_paired(qpd, pair, plan, dpd, heads, dh, dqq, p, seed)
+            gotqb = dqq.cpu()[rm[live]]
+            assert bool(torch.isfinite(gotqb).all()) and bool(torch.isnan(dqq.cpu()[int(plan.total.item()):]).all())
+            assert float((gotqb - gotb).abs().max()) <= 2e-6 * max(1.0, float(gotb.abs().max())), 'paired backward (p = %g)' % p
     with pytest.raises(Exception):                    # the packed form is the 4-head cooperative path only
         ops.mhsa_fwd_packed(qpd, md, rowmap, plan, 5, 20, outp)
 

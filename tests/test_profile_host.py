@@ -69,7 +69,7 @@ def test_executed_flops_beside_the_algorithmic_ones(records):
     total = 2 * records['tn_flops'] + 9.0e9 + 3.4e10 + 8.0e9
     assert r['step']['gflop_algorithmic'] == r['step']['gflop'] == round(total / 1e9, 1)
     assert r['step']['gflop_executed'] == round((total + 8.0e9 * (832.0 / 800.0 - 1.0)) / 1e9, 1)
-    assert profile.KERNEL_OF['gemm_nt_bx3_128x80'] == 'gemm_nt_bx3_kernel<2, 5>'
+    assert profile.KERNEL_OF['gemm_nt_bx3_128x80'] == 'gemm_nt_bx3_kernel<2, 5, 2>'
 
 
 def test_rocprof_block_reproduces_frac_from_the_committed_tables(records, monkeypatch, tmp_path):
