@@ -431,8 +431,9 @@ def bx3_prefetch(dev):
         B = e[3]()
         if B is None or e[4][0] != B.data_ptr() or not (isinstance(B, torch.nn.Parameter) or getattr(B, '_nnr_prefetch', False)):
             continue
-        if e[1] == PARAM_EPOCH[0] and e[2] == B._version:
-            continue
+        if not e[7] or (e[1] == PARAM_EPOCH[0] and e[2] == B._version):
+            continue                                  # (not served since the last prefetch -- another model's weight -- or still fresh)
+        e[7] = False
         stale.append((e, B))
     if not stale:
         return
@@ -445,7 +446,7 @@ def bx3_prefetch(dev):
         for e, B in stale:
             _, N, K, ldb = e[4]
             ldo = e[0].shape[2]
-            tape_keep(e[0])
+            tape_keep(e[0], B)                    # (B: a parameter -- inside the trainer's flat buffer -- or a long-lived cached transpose)
             L.check(L.lib().nnr_split_bf16x3(_p(B), N, K, ldb, ldo, _p(e[0]), C.c_long(N * ldo), _s()), 'nnr_split_bf16x3')
         ev = torch.cuda.Event()
         ev.record()
@@ -472,8 +473,9 @@ def bx3_images(B, N, K, ldb):
         if len(_B3) > 512:
             for k in [k for k, v in _B3.items() if v[3]() is None]:
                 del _B3[k]
-        e = _B3[id(B)] = [torch.empty((3, N, ldo), device=B.device, dtype=torch.int16), -1, None, weakref.ref(B), (B.data_ptr(), N, K, ldb), None, None]
+        e = _B3[id(B)] = [torch.empty((3, N, ldo), device=B.device, dtype=torch.int16), -1, None, weakref.ref(B), (B.data_ptr(), N, K, ldb), None, None, True]
     tape_keep(e[0])
+    e[7] = True                                   # served since the last bx3_prefetch: worth re-splitting ahead of the next step's first user
     if e[1] != PARAM_EPOCH[0] or e[2] != B._version:
         # (write-after-read: last step's readers on every stream joined the main stream before the optimizer step that changed the epoch)
         L.check(L.lib().nnr_split_bf16x3(_p(B), N, K, ldb, ldo, _p(e[0]), C.c_long(N * ldo), _s()), 'nnr_split_bf16x3')

@@ -179,7 +179,19 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bx3(const float* __restrict__ 
 // (item j of the 4 + 7 float4s a thread stages goes behind the MFMAs of column tile j), fragments of column tile n + 1 read under the MFMAs of tile n.
 // K must be a multiple of 32 per slice (micro-benchmark: no reduction tail); columns beyond M / N are clamped (they feed outputs that are never stored).
 // ABL (ablation, wrong results): 1 = no split / image stores in the loop, 2 = no global loads in the loop, 3 = neither, 4 = no MFMAs
-template <int TN, bool DUAL, bool SWZ, int ABL = 0, int SGB = 0>
+// round 6: TRUNC = the images by truncation (csrc/gemm.hip: split3_trunc8 -- high 16 bits of the word, exact remainders; 9 VALU instructions per
+// two values, no conversion) instead of three round-to-nearest conversions
+__device__ __forceinline__ unsigned hi16_pair(float odd, float even) {
+  return __builtin_amdgcn_perm(__float_as_uint(odd), __float_as_uint(even), 0x07060302u);
+}
+__device__ __forceinline__ void split3_trunc_pair(float xe, float xo, unsigned& p1, unsigned& p2, unsigned& p3) {
+  p1 = hi16_pair(xo, xe);
+  const float re = xe - __uint_as_float(p1 << 16), ro = xo - __uint_as_float(p1 & 0xffff0000u);
+  p2 = hi16_pair(ro, re);
+  const float se = re - __uint_as_float(p2 << 16), so = ro - __uint_as_float(p2 & 0xffff0000u);
+  p3 = hi16_pair(so, se);
+}
+template <int TN, bool DUAL, bool SWZ, int ABL = 0, int SGB = 0, bool TRUNC = false>
 __global__ __launch_bounds__(256, 1) void gemm_tn_bx3_db(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ slab, int M, int N,
                                                          int K, int kslice) {
   constexpr int TM = 2, BM = 128, BN = 16 * TN, BK = 32;
@@ -222,8 +234,13 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_bx3_db(const float* __restrict
     const int img = j < NA4 ? A_IMG : B_IMG;
     const f32x4 v = rg[j];
     unsigned a0, b0, c0, a1, b1, c1;
-    split3_pk(f32x2{v[0], v[1]}, a0, b0, c0);
-    split3_pk(f32x2{v[2], v[3]}, a1, b1, c1);
+    if constexpr (TRUNC) {
+      split3_trunc_pair(v[0], v[1], a0, b0, c0);
+      split3_trunc_pair(v[2], v[3], a1, b1, c1);
+    } else {
+      split3_pk(f32x2{v[0], v[1]}, a0, b0, c0);
+      split3_pk(f32x2{v[2], v[3]}, a1, b1, c1);
+    }
     const u32x2 h1 = {a0, a1}, h2 = {b0, b1}, h3 = {c0, c1};
     *reinterpret_cast<u32x2*>(base) = h1;
     *reinterpret_cast<u32x2*>(base + img) = h2;
@@ -680,6 +697,9 @@ int main(int argc, char** argv) {
     case 15: kern = gemm_tn_bx3_db<13, true, false, 0, 1>; vbm = 128; vname = "v3 + sched_group_barrier interleave (1 MFMA : 2 VALU)"; break;
     case 30: vbm = 128; vname = "v5: PRE-SPLIT operands (three bf16 images each, written by a producer), 128 x 208 double-buffered, two accumulators; the split pass is timed separately"; break;
     case 31: vbm = 128; vname = "v5: PRE-SPLIT operands, one accumulator"; break;
+    case 40: kern = gemm_tn_bx3_db<13, true, false, 0, 0, true>; vbm = 128; vname = "round 6: v3 with the TRUNCATION split, 128 x 208, two accumulators"; break;
+    case 41: kern = gemm_tn_bx3_db<10, true, false, 0, 0, true>; vbm = 128; vbn = 160; vname = "round 6: v3 with the TRUNCATION split, 128 x 160, two accumulators"; break;
+    case 42: kern = gemm_tn_bx3_db<10, true, false>; vbm = 128; vbn = 160; vname = "v3 (round-to-nearest split), 128 x 160, two accumulators"; break;
     case 13: kern = gemm_tn_bx3_w32<true>; vbm = 128; vbn = 224; vname = "v4: 128 x 224 on 32x32x16 MFMA, double-buffered, 1 workgroup / CU, two accumulators"; break;
     case 14: kern = gemm_tn_bx3_w32<false>; vbm = 128; vbn = 224; vname = "v4: 128 x 224 on 32x32x16 MFMA, double-buffered, 1 workgroup / CU, one accumulator"; break;
     default: break;
