@@ -538,7 +538,14 @@ def main():
     roof = prof.roofline(PEAK_F32_TFLOPS, sampled_steps=sampled, ms_per_step=1000 * dt / a.steps)
     if roof:
         roof['timed_window'] = 'un-instrumented; per-call HIP events from %d extra steps after the window (same resident batches)' % sampled
-        roof['rocprof'] = prof.rocprof_block(roof, PEAK_F32_TFLOPS)
+        # (the committed kernel tables are of the HEADLINE command: other batch sizes / encoder pairs launch the same kernels at other sizes)
+        roof['rocprof'] = prof.rocprof_block(roof, PEAK_F32_TFLOPS) if (a.news_encoder, a.user_encoder, per_gpu, a.dense, world) == ('CNE', 'SUE', 64, False, 1) else None
+        if str(roof.get('family', '')).startswith('gemm_nt_bx3'):
+            # fp32-EQUIVALENT FLOPs (2 M N K) against the fp32 MFMA peak, as for every other family -- the kernel itself issues six bf16 MFMA products per
+            # fp32 product, so ITS matrix-pipe bound is the dense bf16 rate / 6
+            roof['peak_note'] = ('achieved / frac are fp32-equivalent FLOPs (2 M N K) against the fp32 MFMA peak of %.1f TFLOP/s; the bf16x3 kernel runs six '
+                                 'v_mfma_f32_16x16x32_bf16 products per fp32 product: its own matrix-pipe bound is 2 500 / 6 = 416.7 TFLOP/s-equivalent' % PEAK_F32_TFLOPS)
+            roof['frac_of_bf16x3_bound'] = round(roof['achieved'] / (2500.0 / 6.0), 4)
     headline = (a.news_encoder, a.user_encoder, per_gpu, a.dense) == ('CNE', 'SUE', 64, False)
     if roof and not headline:
         roof['traffic'] = None            # the committed PMC passes (profiles/pmc_traffic.json) are of the headline command only

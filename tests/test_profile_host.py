@@ -148,7 +148,7 @@ def test_committed_counter_file_is_well_formed():
     for k in d['kernels']:
         assert k['launches'] > 0 and k['hbm_bytes_per_launch'] == pytest.approx(k['fetch_bytes_per_launch'] + k['write_bytes_per_launch'], abs=2)
     names = {k['kernel'] for k in d['kernels']}
-    assert {'gemm_tn_pipe2_kernel<1, 13, 3, 2>', 'gemm_nt_pipe2_kernel<2, 5, 3, 2>', 'lstm_bwd_pair_kernel<13, true>'} <= names
+    assert {'gemm_tn_pipe2_kernel<1, 13, 3, 2>', 'gemm_nt_bx3_kernel<2, 5, 2>', 'lstm_bwd_pair_kernel<13, true>'} <= names
 
 
 def test_hbm_families_get_their_own_roofline_and_stay_out_of_the_mfma_one(records, monkeypatch):
