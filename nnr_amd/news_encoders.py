@@ -235,13 +235,14 @@ def cne_forward_many(mod, calls):
             mod._packed_weights('content', mod.content_lstm)
             mod.__dict__['_packed_ev'] = torch.cuda.Event()
             mod.__dict__['_packed_ev'].record()
-    pre = _fork_join(len(calls), dev, lambda i, on_main: _cne_fwd_pre(mod, *calls[i], par=on_main))
-    items = [st for sv in pre for st in (sv['streams'][1],)] + [st for sv in pre for st in (sv['streams'][0],) if not st.get('lstm_done')]   # content streams first
     if mod.training:
         # the bf16 images of the parameters (and of their cached transposes) the gate / attention / user-encoder GEMMs will read: re-split on the LEAF
-        # stream HERE -- behind the weight packing and the token sorts the projection phase put there, under the forward recurrence, in front of
-        # their first users.  (At the step's head they delayed nnr_lstm_pack_weights, which the input projection waits for: +0.3 ms.)
+        # stream HERE -- behind the weight packing (which the input projection waits for: in front of it the splits cost +0.3 ms) and in FRONT of the
+        # token sorts (needed by the backward pass only), i.e. under the input projection.  (Under the forward recurrence, whose workgroups fill every
+        # CU, the 29 launches of ~5 us crawled at 70-160 us each and ended level with their first users: profiles/r06f_timeline_b64.txt, first collection.)
         ops.bx3_prefetch(dev)
+    pre = _fork_join(len(calls), dev, lambda i, on_main: _cne_fwd_pre(mod, *calls[i], par=on_main))
+    items = [st for sv in pre for st in (sv['streams'][1],)] + [st for sv in pre for st in (sv['streams'][0],) if not st.get('lstm_done')]   # content streams first
     for i in range(0, len(items), 4):
         ops.lstm_fwd(items[i:i + 4], H)
     return _fork_join(len(calls), dev, lambda i, on_main: _cne_fwd_post(mod, pre[i], on_main))
