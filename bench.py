@@ -255,7 +255,7 @@ def matrix_path(ops, seen=None):
 
 def scaling_ceiling(per_gpu, global_batch):
     """N > 1: the ceiling the per-GPU batch sweep of the SAME build puts on this run before any exchange cost -- a rank's step cannot be
-    shorter than the 1-GPU step at its per-GPU batch (profiles/batch_sweep.json, written by tools/r6/collect.sh; build-id stamped)."""
+    shorter than the 1-GPU step at its per-GPU batch (profiles/batch_sweep.json, written by tools/collect_round6.sh; build-id stamped)."""
     try:
         from nnr_amd import _lib
         d = json.load(open(os.path.join(ROOT, 'profiles', 'batch_sweep.json')))

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 6: the judged artefacts of the FINAL build in one gpurun call (from the repo root):  bash tools/r6/collect.sh r06f
+# Round 6: the judged artefacts of the FINAL build in one gpurun call (from the repo root):  bash tools/collect_round6.sh r06f
 #  1. default bench line (headline + secondary legs + CPU baseline); rocprofv3 --kernel-trace --stats of the headline command, in-step and with
 #     every stream collapsed into one (NNR_ONE_STREAM=1) -> profiles/kernel_stats.json (build-id stamped; bench.py `roofline.rocprof` quotes it);
 #     PMC FETCH_SIZE / WRITE_SIZE passes (NNR_REPLAY=0: the call-by-call native step -- same kernels, same order) -> profiles/pmc_traffic.json
