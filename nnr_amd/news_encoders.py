@@ -144,6 +144,7 @@ _POST_INLINE = os.environ.get('NNR_POST_INLINE', '0') == '1'      # A/B: the con
 _DX_SPLIT = os.environ.get('NNR_DX_SPLIT', '1') == '1'      # embedding-row gradient as plain GEMM + scatter kernel (11.46 vs 11.51 ms fused)
 _BWD_SPLIT = os.environ.get('NNR_LSTM_BWD_SPLIT', '1') == '1'      # batch 8: 4.68 (split) vs 4.93 ms; batch 64: no difference
 _PROJ_TILE = int(os.environ.get('NNR_PROJ_TILE', '0'))       # A/B (round 4): tile of the LSTM input projection (N = 1664 = 8 x 208), 0 = automatic (15)
+_DCN_TILE = int(os.environ.get('NNR_DCN_TILE', '0'))         # round 6: tile of the d c_n product in front of the backward recurrence (0 = automatic: 6)
 _GATE_TILE = int(os.environ.get('NNR_GATE_TILE', '0'))       # ... of the gate / attention / their data-gradient GEMMs over the token rows (N = 400 / 200)
 _GATE_FUSED = os.environ.get('NNR_GATE_FUSED', '1') != '0'      # A/B: the gate's backward inside the epilogue of the GEMM that completes dHt
 _CNE_UNION = os.environ.get('NNR_CNE_UNION', '1') != '0'      # A/B switch: candidate + history call as one packed token stream
@@ -566,10 +567,14 @@ def _cne_bwd_pre(mod, sv, drep, par=False, leaf=None):
         pm, opm = st['pm'], other['pm']                   # union of two calls: mproj[s] = M(cn_other[pm[s]])  (pm^-1 = other's pm)
         leaf(lambda: ops.linear_bwd_weight(dP, other['cn'], grad_of(st['Mlin'].weight), db=grad_of(st['Mlin'].bias),
                                            **({} if pm is None else {'b_idx': pm})), dP, alt=alt_leaf(st))
+        # (NNR_DCN_TILE: this [n, 400] x [400, 400] product runs beside the leaf stream's weight-gradient GEMMs, whose workgroups hold 120 KB of a
+        #  CU's LDS, and its 74 KB tile waits for them: 277 us in the step against 40 us alone.  The 19 KB register-staged tile (2) halves its
+        #  in-step time and leaves the step where it was -- the chain waits for the same leaf work one call later; profiles/r06_ab.txt call 24)
+        dcn_kw = {'tile': _DCN_TILE} if _DCN_TILE else {}
         if opm is not None and _CN_SPLIT:
-            other['dcn'] = ops.embed_gather(ops.linear_bwd_data(dP, st['Mlin'].weight), opm, 0.0, 0)            # [n, H2], rank-indexed
+            other['dcn'] = ops.embed_gather(ops.linear_bwd_data(dP, st['Mlin'].weight, **dcn_kw), opm, 0.0, 0)            # [n, H2], rank-indexed
         else:
-            other['dcn'] = ops.linear_bwd_data(dP, st['Mlin'].weight, **({} if opm is None else {'a_idx': opm}))   # [n, H2], rank-indexed
+            other['dcn'] = ops.linear_bwd_data(dP, st['Mlin'].weight, **dcn_kw, **({} if opm is None else {'a_idx': opm}))   # [n, H2], rank-indexed
         st['dHt'] = None
 
     _two_chains(dev, par, lambda: self_gate_bwd(t_, c_, 0), lambda: self_gate_bwd(c_, t_, H2))
