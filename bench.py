@@ -351,15 +351,19 @@ def timed_run(a, trainer, fresh, steps, warmup, prof, dp, torch, dev, world, pri
     if marks:
         marks[0].record()
     t0 = time.perf_counter()
+    host = []
     for i in range(steps):
         trainer.train_step(fresh(warmup + i))
         if marks:
             marks[i + 1].record()
+            host.append(time.perf_counter() - t0)
     dp.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if marks:         # diagnostic: where inside the window the time went (one event per step on the main stream; stderr only)
         print('step marks (ms): ' + ' '.join('%.2f' % marks[i].elapsed_time(marks[i + 1]) for i in range(steps)), file=sys.stderr)
+        # ... and when the HOST had finished enqueueing each step (ms since the window opened): far below the marks' running sum = the host runs ahead
+        print('host enqueue done (ms): ' + ' '.join('%.2f' % (1000 * h) for h in host), file=sys.stderr)
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
