@@ -236,14 +236,16 @@ def plumbing_check(a):
     return 0 if ok else 4
 
 
-def matrix_path(ops, seen=None):
+def matrix_path(ops, seen=None, classes=None):
     """`config.matrix_path`: which matrix instructions the step's products run on (`dtype` stays "f32": fp32 operands in, fp32 results out,
     fp32 accumulation; the split is exact and the error against fp64 a third of the fp32-MFMA kernel's -- DESIGN.md section 9.4)."""
-    if not ops.BX3[0]:
+    if classes is None:
+        classes = ops._BX3_CLASSES
+    if not ops.BX3[0] or not classes:
         return {'nt_weight_gemms': 'v_mfma_f32_16x16x4_f32', 'weight_gradient_gemms': 'v_mfma_f32_16x16x4_f32', 'recurrences': 'v_mfma_f32_16x16x4_f32 / 4x4x1',
                 'switch': 'NNR_BX3=0'}
     out = {'nt_weight_gemms': 'bf16x3: each fp32 operand as three exact bf16 images, six v_mfma_f32_16x16x32_bf16 products, two fp32 accumulators '
-                              '(csrc/gemm.hip: gemm_nt_bx3_kernel); shape classes %s, rows >= %d' % (','.join(sorted(ops._BX3_CLASSES)), ops._BX3_MIN_ROWS),
+                              '(csrc/gemm.hip: gemm_nt_bx3_kernel); shape classes %s, rows >= %d' % (','.join(sorted(classes)), ops._BX3_MIN_ROWS),
            'weight_gradient_gemms': 'v_mfma_f32_16x16x4_f32', 'recurrences': 'v_mfma_f32_16x16x4_f32 / 4x4x1', 'switch': 'NNR_BX3=1 (default)',
            'pure_f32_leg': 'secondary.f32_mfma_only_cne_sue_b64'}
     if seen:
@@ -418,7 +420,7 @@ def secondary_legs(a, prof, dp, torch, dev, rank_seed=0):
     from nnr_amd.synth import SynthSpec, SynthCorpus
     from nnr_amd.trainer import Trainer
     out = {}
-    from nnr_amd import ops as _ops
+    from nnr_amd import ops as _ops, step as native_step
     for name, ne, ue, dataset, gbatch, gworld, per_gpu, V in SECONDARY_LEGS + (() if a.no_experimental else F32_ONLY_LEGS):
         t_leg = time.perf_counter()
         f32_only = name.startswith('f32_mfma_only_')
@@ -450,7 +452,7 @@ def secondary_legs(a, prof, dp, torch, dev, rank_seed=0):
                    'per_gpu_batch': per_gpu, 'steps': steps, 'warmup': warm, 'ms_per_step': round(1000 * dt / steps, 3),
                    'value': round(steps * per_gpu / dt, 2), 'unit': 'impressions/s (this GPU\'s shard)',
                    'timed_window': 'un-instrumented replays; per-call events from %d extra steps after it' % sampled,
-                   'matrix_path': matrix_path(_ops)['nt_weight_gemms'],
+                   'matrix_path': matrix_path(_ops, classes=native_step.bx3_classes(model))['nt_weight_gemms'],
                    'step': roof.get('step'), 'abi_calls_per_step': round(calls, 1), 'launch_path': launch_path(trainer)['path'],
                    'dominant': {k: roof.get(k) for k in ('kernel', 'family', 'achieved', 'frac', 'avg_launch_us', 'launches', 'share_of_instrumented_time')} if roof else None}
             # the HBM-bound families of THIS leg against the 8 TB/s peak (configs[4] = the "large-vocab embedding table, HBM-bound gather
@@ -484,7 +486,7 @@ def main():
 
     import numpy as np
     import torch
-    from nnr_amd import dp, ops
+    from nnr_amd import dp, ops, step as native_step
     from nnr_amd.config import make_config
     from nnr_amd.model import Model
     from nnr_amd.synth import SynthSpec, SynthCorpus, to_torch
@@ -632,7 +634,7 @@ def main():
             'config': {'workload': '%s+%s train step, MIND-200k-shaped synthetic batches, dropout %.2f, gcn_layer_num %d%s' %
                                    (a.news_encoder, a.user_encoder, cfg.dropout_rate, cfg.gcn_layer_num, ', dense lengths' if a.dense else ''),
                        'global_batch': global_batch, 'per_gpu_batch': per_gpu, 'parallelism': 'dp%d' % world,
-                       'matrix_path': matrix_path(ops, bx3_seen_headline),
+                       'matrix_path': matrix_path(ops, bx3_seen_headline, classes=native_step.bx3_classes(trainer.model)),
                        'synth': {k: v for k, v in spec.describe().items() if k in ('vocabulary_size', 'title_len_mean', 'content_len_mean', 'news_pool', 'dense')},
                        'batches': ('device-resident corpus, id-only: a fresh batch is gathered / built in HBM inside every timed step (%d distinct id sets)' % nb)
                                   if device_corpus else 'pre-built, %d batches resident in HBM, re-used' % nb,

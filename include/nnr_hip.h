@@ -264,6 +264,10 @@ int nnr_transpose_batch(const nnr_transpose_desc* descs_dev, int count, hipStrea
 int nnr_add(float* y, const float* x, long n, float alpha, hipStream_t stream);
 int nnr_add_atomic(float* y, const float* x, long n, float alpha, hipStream_t stream);   /* y += alpha*x with f32 atomics */
 int nnr_add2d(float* y, int ldy, const float* x, int ldx, int rows, int cols, float alpha, int accumulate, hipStream_t stream);
+/* y[b, j, :] = x[b, :] for j < N -- the user vector repeated over the candidates (userEncoders.py:172 `.repeat`, :190 `.expand`) -- and its
+ * backward dx[b, :] = sum_j dy[b, j, :] (ascending j).  x / dx [B, D], y / dy [B, N, D], contiguous. */
+int nnr_expand_rows_fwd(const float* x, float* y, int B, int N, int D, hipStream_t stream);
+int nnr_expand_rows_bwd(const float* dy, float* dx, int B, int N, int D, hipStream_t stream);
 int nnr_dropout(const float* x, float* y, long n, float p, uint32_t seed, hipStream_t stream);
 int nnr_relu_bwd(const float* dy, const float* y, float* dx, long n, hipStream_t stream);
 /* SUE's per-user graph aggregate (layers.py:285-292: `graph @ feature` inside GCNLayer.forward, B users x [G, G] x [G, D]) with

@@ -56,7 +56,7 @@ class PoolArgs(C.Structure):
 SYMBOLS = [
     'nnr_version', 'nnr_gemm_f32', 'nnr_split_bf16x3', 'nnr_seq_plan', 'nnr_seq_plan_pair', 'nnr_cne_pair_map', 'nnr_lstm_dims', 'nnr_lstm_pack_weights', 'nnr_lstm_unpack_grads',
     'nnr_lstm_fwd', 'nnr_lstm_bwd', 'nnr_lstm_sync_bytes', 'nnr_lstm_sync_diag_offset', 'nnr_lstm_set_timeout_counter', 'nnr_attn_pool_fwd', 'nnr_attn_pool_bwd', 'nnr_gate_bwd', 'nnr_packed_seq_sum',
-    'nnr_tanh_score_bwd', 'nnr_slot_workspace_floats', 'nnr_colsum', 'nnr_rowdot', 'nnr_small_embed_fwd', 'nnr_small_embed_bwd', 'nnr_add', 'nnr_add_atomic', 'nnr_add2d', 'nnr_dropout',
+    'nnr_tanh_score_bwd', 'nnr_slot_workspace_floats', 'nnr_colsum', 'nnr_rowdot', 'nnr_small_embed_fwd', 'nnr_small_embed_bwd', 'nnr_add', 'nnr_add_atomic', 'nnr_add2d', 'nnr_expand_rows_fwd', 'nnr_expand_rows_bwd', 'nnr_dropout',
     'nnr_layernorm_fwd', 'nnr_layernorm_bwd', 'nnr_relu_bwd', 'nnr_relu_drop_bwd', 'nnr_gcn_aggregate_fwd', 'nnr_gcn_aggregate_bwd', 'nnr_sue_x0_fwd', 'nnr_sue_x0_bwd', 'nnr_sue_slice_fwd', 'nnr_sue_slice_bwd',
     'nnr_sue_intra_fwd', 'nnr_sue_intra_bwd', 'nnr_logits_loss_fwd', 'nnr_logits_fwd', 'nnr_nls_loss', 'nnr_logits_bwd', 'nnr_sumsq', 'nnr_sumsq_part', 'nnr_clip_adam',
     'nnr_mhsa_fwd', 'nnr_mhsa_bwd', 'nnr_mhsa_fwd_packed', 'nnr_mhsa_bwd_packed', 'nnr_mhsa_pair_map', 'nnr_mhsa_fwd_paired', 'nnr_mhsa_bwd_paired', 'nnr_mask_cover', 'nnr_seq_rowmap', 'nnr_embed_gather', 'nnr_embed_scatter', 'nnr_embed_scatter_dyn', 'nnr_transpose2d', 'nnr_transpose_batch', 'nnr_corpus_batch', 'nnr_history_graph', 'nnr_rank_metrics',

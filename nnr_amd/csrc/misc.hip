@@ -339,6 +339,27 @@ __global__ void add2d_kernel(float* __restrict__ y, int ldy, const float* __rest
     *p = accumulate ? *p + v : v;
   }
 }
+// ---- [B, D] -> [B, N, D] (the user vector repeated over the N candidates, userEncoders.py:172,190) and its backward, the sum over the N copies in
+//      ascending candidate order; one launch each (the add2d form took N launches per direction on the dependent chain of the MHSA step)
+__global__ void expand_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int N, int D) {
+  const long total = (long)B * N * D;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / D;
+    const int c = (int)(i - row * D);
+    y[i] = x[(row / N) * D + c];
+  }
+}
+__global__ void expand_rows_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int B, int N, int D) {
+  const long total = (long)B * D;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / D;
+    const int c = (int)(i - b * D);
+    const float* p = dy + b * N * D + c;
+    float acc = p[0];
+    for (int j = 1; j < N; ++j) acc += p[(long)j * D];
+    dx[i] = acc;
+  }
+}
 
 // ---- SUE graph input (userEncoders.py:80): X0[b, :Hn] = hist[b] ; X0[b, Hn + k] = dropout_(proxy[k])  (mask per sample)
 //      backward: dhist = dX0[:, :Hn] ; dproxy[k] += sum_b mask * dX0[b, Hn + k]
@@ -1041,6 +1062,15 @@ extern "C" int nnr_add_atomic(float* y, const float* x, long n, float alpha, hip
 extern "C" int nnr_add2d(float* y, int ldy, const float* x, int ldx, int rows, int cols, float alpha, int accumulate,
                          hipStream_t stream) {
   EW_LAUNCH(add2d_kernel, (long)rows * cols, y, ldy, x, ldx, rows, cols, alpha, accumulate);
+}
+
+extern "C" int nnr_expand_rows_fwd(const float* x, float* y, int B, int N, int D, hipStream_t stream) {
+  if (!x || !y || B <= 0 || N <= 0 || D <= 0) return NNR_ERR_ARG;
+  EW_LAUNCH(expand_rows_kernel, (long)B * N * D, x, y, B, N, D);
+}
+extern "C" int nnr_expand_rows_bwd(const float* dy, float* dx, int B, int N, int D, hipStream_t stream) {
+  if (!dy || !dx || B <= 0 || N <= 0 || D <= 0) return NNR_ERR_ARG;
+  EW_LAUNCH(expand_rows_bwd_kernel, (long)B * D, dy, dx, B, N, D);
 }
 
 extern "C" int nnr_sue_x0_fwd(const float* hist, const float* proxy, float* x0, int B, int Hn, int Kc, int D, float p, uint32_t seed,

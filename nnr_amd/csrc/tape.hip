@@ -42,7 +42,7 @@ const Entry REGISTRY[] = {
   R(nnr_gemm_f32), R(nnr_seq_plan), R(nnr_seq_plan_pair), R(nnr_cne_pair_map), R(nnr_lstm_pack_weights), R(nnr_lstm_unpack_grads),
   R(nnr_lstm_fwd), R(nnr_lstm_bwd), R(nnr_attn_pool_fwd), R(nnr_attn_pool_bwd), R(nnr_gate_bwd), R(nnr_packed_seq_sum),
   R(nnr_tanh_score_bwd), R(nnr_colsum), R(nnr_rowdot), R(nnr_small_embed_fwd), R(nnr_small_embed_bwd), R(nnr_embed_gather),
-  R(nnr_embed_scatter), R(nnr_embed_scatter_dyn), R(nnr_transpose2d), R(nnr_transpose_batch), R(nnr_add), R(nnr_add_atomic), R(nnr_add2d),
+  R(nnr_embed_scatter), R(nnr_embed_scatter_dyn), R(nnr_transpose2d), R(nnr_transpose_batch), R(nnr_add), R(nnr_add_atomic), R(nnr_add2d), R(nnr_expand_rows_fwd), R(nnr_expand_rows_bwd),
   R(nnr_dropout), R(nnr_relu_bwd), R(nnr_gcn_aggregate_fwd), R(nnr_gcn_aggregate_bwd), R(nnr_relu_drop_bwd), R(nnr_mhsa_fwd), R(nnr_mhsa_bwd),
   R(nnr_sue_x0_fwd), R(nnr_sue_x0_bwd), R(nnr_sue_slice_fwd), R(nnr_sue_slice_bwd), R(nnr_sue_intra_fwd), R(nnr_sue_intra_bwd),
   R(nnr_corpus_batch), R(nnr_history_graph), R(nnr_logits_loss_fwd), R(nnr_logits_fwd), R(nnr_nls_loss), R(nnr_logits_bwd),

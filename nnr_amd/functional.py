@@ -3,6 +3,7 @@ Parameter gradients are accumulated straight into `param.grad` (see layers.grad_
 only for activations."""
 import math
 
+import os
 import torch
 
 from . import ops
@@ -318,8 +319,8 @@ class FuseFn(torch.autograd.Function):
         ops.add2d(out, D, rep.contiguous(), F, n, F)
         cat = category.reshape(n).to(torch.int32).contiguous()
         sub = subCategory.reshape(n).to(torch.int32).contiguous()
-        ops.small_embed_fwd(enc.category_embedding.weight, cat, out[:, F:], D, p, seed + 3)
-        ops.small_embed_fwd(enc.subCategory_embedding.weight, sub, out[:, F + cd:], D, p, seed + 4)
+        # (both tables in one launch, the kernel of the CNE step; same per-element masks as two nnr_small_embed_fwd calls)
+        ops.fusion_rows_fwd(enc.category_embedding.weight, enc.subCategory_embedding.weight, cat, sub, None, None, out[:, F:], D, p, seed + 3, seed + 4)
         ctx.enc, ctx.cat, ctx.sub, ctx.dims, ctx.p, ctx.seed = enc, cat, sub, (n, F, cd, sd, D), p, seed
         return out
 
@@ -327,8 +328,8 @@ class FuseFn(torch.autograd.Function):
     def backward(ctx, dout):
         n, F, cd, sd, D = ctx.dims
         dout = dout.contiguous()
-        ops.small_embed_bwd(ctx.cat, cd, dout[:, F:], D, grad_of(ctx.enc.category_embedding.weight), ctx.p, ctx.seed + 3)
-        ops.small_embed_bwd(ctx.sub, sd, dout[:, F + cd:], D, grad_of(ctx.enc.subCategory_embedding.weight), ctx.p, ctx.seed + 4)
+        ops.fusion_rows_bwd(ctx.cat, ctx.sub, None, None, cd, sd, dout[:, F:], D, grad_of(ctx.enc.category_embedding.weight),
+                            grad_of(ctx.enc.subCategory_embedding.weight), ctx.p, ctx.seed + 3, ctx.seed + 4)
         drep = torch.empty((n, F), device=dout.device, dtype=torch.float32)
         ops.add2d(drep, F, dout, D, n, F)
         return drep, None, None, None, None, None
@@ -339,19 +340,9 @@ class ExpandFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, N):
-        B, D = x.shape
-        out = torch.empty((B, N, D), device=x.device, dtype=torch.float32)
-        x = x.contiguous()
-        for j in range(N):
-            ops.add2d(out[:, j], N * D, x, D, B, D)
         ctx.N = N
-        return out
+        return ops.expand_rows(x.contiguous(), N)
 
     @staticmethod
     def backward(ctx, dout):
-        B, N, D = dout.shape
-        dout = dout.contiguous()
-        dx = torch.empty((B, D), device=dout.device, dtype=torch.float32)
-        for j in range(N):
-            ops.add2d(dx, D, dout[:, j], N * D, B, D, accumulate=(j > 0))
-        return dx, None
+        return ops.expand_rows_bwd(dout.contiguous()), None

@@ -943,6 +943,22 @@ def add_atomic_(y, x, alpha=1.0):
     return y
 
 
+def expand_rows(x, N):
+    """[B, D] -> [B, N, D]: x repeated over N (userEncoders.py:172,190), one launch."""
+    B, D = x.shape
+    y = torch.empty((B, N, D), device=x.device, dtype=torch.float32)
+    L.check(L.lib().nnr_expand_rows_fwd(_p(x), _p(y), B, N, D, _s()), 'nnr_expand_rows_fwd')
+    return y
+
+
+def expand_rows_bwd(dy):
+    """[B, N, D] -> [B, D]: the sum over N in ascending order, one launch."""
+    B, N, D = dy.shape
+    dx = torch.empty((B, D), device=dy.device, dtype=torch.float32)
+    L.check(L.lib().nnr_expand_rows_bwd(_p(dy), _p(dx), B, N, D, _s()), 'nnr_expand_rows_bwd')
+    return dx
+
+
 def add2d(y, ldy, x, ldx, rows, cols, alpha=1.0, accumulate=False):
     L.check(L.lib().nnr_add2d(_p(y), ldy, _p(x), ldx, rows, cols, C.c_float(alpha), int(accumulate), _s()), 'nnr_add2d')
 

@@ -14,7 +14,8 @@ import torch
 from . import ops
 from .news_encoders import cne_forward_many, cne_backward_many, _CNE_UNION
 
-_BX3_MHSA = os.environ.get('NNR_BX3_MHSA', '0') == '1'
+_BX3_MHSA = os.environ.get('NNR_BX3_MHSA', '0') == '1'              # A/B: every class of ops._BX3_CLASSES in the MHSA step too
+_BX3_MHSA_CLASSES = set(c for c in os.environ.get('NNR_BX3_MHSA_CLASSES', 'dx').split(',') if c)
 _MHSA_NATIVE = os.environ.get('NNR_MHSA_NATIVE', '1') != '0'      # A/B: MHSA+MHSA through autograd (round 3) instead of the native step
 
 
@@ -31,19 +32,34 @@ def kind(model):
     return None
 
 
+def bx3_classes(model):
+    """The shape classes (ops.bx3_class) whose weight-operand NT GEMMs run on the bf16x3 kernel in a step of `model`; empty = the pure fp32-MFMA
+    path.  CNE + SUE: every class (ops._BX3_CLASSES).  MHSA news encoder (configs[1]): only the K >= 1024 data-gradient products ('dx': dQKV of
+    the user encoder, the word-embedding gradient's 3 h d -> E product) -- per-class same-box A/Bs, profiles/r06_ab.txt call 30: 'dx' -0.03..-0.07 ms
+    on three pairs, 'proj' neutral, 'gate' and all classes together unstable (the 63 KB tiles beside the attention core's workgroups)."""
+    from . import news_encoders as NE
+    if not ops.BX3[0]:
+        return set()
+    if type(getattr(model, 'news_encoder', None)) is NE.MHSA and not _BX3_MHSA:
+        return set(_BX3_MHSA_CLASSES)
+    return set(ops._BX3_CLASSES)
+
+
 @contextlib.contextmanager
 def matrix_path(model):
-    """The matrix path of one step of `model`: bf16x3 NT GEMMs (ops.BX3) unless its news encoder is the MHSA one (see forward_backward).
-    Used by the native step AND by the trainer's autograd path, so that both run the same kernels."""
-    from . import news_encoders as NE
-    off = bool(ops.BX3[0]) and not _BX3_MHSA and type(getattr(model, 'news_encoder', None)) is NE.MHSA
-    if off:
-        ops.BX3[0] = False
+    """The matrix path of one step of `model` (bx3_classes).  Used by the native step AND by the trainer's autograd path, so that both run
+    the same kernels."""
+    want = bx3_classes(model)
+    on, classes = ops.BX3[0], ops._BX3_CLASSES
+    if on:
+        if want:
+            ops._BX3_CLASSES = want
+        else:
+            ops.BX3[0] = False
     try:
         yield
     finally:
-        if off:
-            ops.BX3[0] = True
+        ops.BX3[0], ops._BX3_CLASSES = on, classes
 
 
 def supported(model):
@@ -137,6 +153,7 @@ def forward_backward_mhsa(trainer, batch):
     f32 = dict(device=dev, dtype=torch.float32)
     with torch.no_grad():
         ops.wt_prefetch(dev)
+        ops.bx3_prefetch(dev)                             # the bf16 images of the transposes above, same leaf stream (idle at the head of this step)
         ops.STEP_ROWS[0] = user_title_text.shape[0] * user_title_text.shape[1] * user_title_text.shape[2]
         ops._DEFER['manual'] = True                      # ops.leaf_deferred: no autograd end-of-pass callback here; joined below
         try:
@@ -201,9 +218,9 @@ def forward_backward(trainer, batch):
     Returns (logits [B, N], loss []) -- fresh tensors of this call."""
     model = trainer.model
     if kind(model) == 'mhsa':
-        # The MHSA + MHSA step keeps its GEMMs on the fp32-MFMA kernels: its products are small (~100 GFLOP per step, 40 k live title rows) and
-        # interleaved with the attention-core launches; with the bf16x3 tiles (63 KB of LDS, two workgroups per CU) the step measured SLOWER on three
-        # same-box pairs (2.18 vs 2.24 ms, profiles/r06_ab.txt).  NNR_BX3_MHSA=1 sends them there all the same.
+        # The MHSA + MHSA step keeps most of its GEMMs on the fp32-MFMA kernels: its products are small (~100 GFLOP per step, 40 k live title rows)
+        # and interleaved with the attention-core launches; with EVERY class on the bf16x3 tiles (63 KB of LDS, two workgroups per CU) the step measured
+        # slower on three same-box pairs (2.18 vs 2.24 ms, profiles/r06_ab.txt).  Only the K >= 1024 data-gradient products take them (bx3_classes).
         with matrix_path(model):
             return forward_backward_mhsa(trainer, batch)
     ne, ue = model.news_encoder, model.user_encoder

@@ -1228,6 +1228,17 @@ def test_embed_gather_scatter_and_transpose():
     o = torch.empty(5, 37, device=d)
     ops.transpose2d(a.to(d), o, 37, 5)
     close(o, a.t(), tol=0, what='transpose')
+    # the user vector repeated over the candidates (userEncoders.py:172,190) and its backward: the sum over the copies in ascending order
+    for B, N, D in ((64, 5, 400), (3, 1, 7), (17, 64, 33)):
+        u = rnd(B, D, seed=5)
+        rep = ops.expand_rows(u.to(d), N)
+        assert rep.shape == (B, N, D)
+        close(rep, u[:, None, :].expand(B, N, D), tol=0, what='expand_rows')
+        g = rnd(B, N, D, seed=6)
+        want = g[:, 0].clone()
+        for j in range(1, N):
+            want += g[:, j]
+        close(ops.expand_rows_bwd(g.to(d)), want, tol=0, what='expand_rows_bwd (ascending fp32 sum)')
 
 
 @pytest.mark.parametrize('M,N,K,live', [(3000, 400, 200, 2500), (70000, 400, 200, 70000), (130, 64, 36, 130)])

@@ -18,9 +18,11 @@ from nnr_amd.trainer import Trainer
 ap = argparse.ArgumentParser()
 ap.add_argument('--batch_size', type=int, default=64)
 ap.add_argument('--vocabulary_size', type=int, default=60000)
+ap.add_argument('--news_encoder', default='CNE')
+ap.add_argument('--user_encoder', default='SUE')
 a = ap.parse_args()
 T.TAG_ALL[0] = True
-cfg = make_config(['--news_encoder=CNE', '--user_encoder=SUE', '--dataset=200k', '--batch_size=%d' % a.batch_size], corpus_sizes=dict(vocabulary_size=a.vocabulary_size))
+cfg = make_config(['--news_encoder=' + a.news_encoder, '--user_encoder=' + a.user_encoder, '--dataset=200k', '--batch_size=%d' % a.batch_size], corpus_sizes=dict(vocabulary_size=a.vocabulary_size))
 torch.manual_seed(0)
 table = torch.randn(cfg.vocabulary_size, cfg.word_embedding_dim) * 0.3
 table[0] = 0
