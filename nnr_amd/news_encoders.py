@@ -240,7 +240,7 @@ def cne_forward_many(mod, calls):
         # the bf16 images of the parameters (and of their cached transposes) the gate / attention / user-encoder GEMMs will read: re-split on the LEAF
         # stream HERE -- behind the weight packing (which the input projection waits for: in front of it the splits cost +0.3 ms) and in FRONT of the
         # token sorts (needed by the backward pass only), i.e. under the input projection.  (Under the forward recurrence, whose workgroups fill every
-        # CU, the 29 launches of ~5 us crawled at 70-160 us each and ended level with their first users: profiles/r06f_timeline_b64.txt, first collection.)
+        # CU, the 29 launches of ~5 us crawled at 70-160 us each and ended level with their first users: profiles/r06_ab.txt, first collection of the round.)
         ops.bx3_prefetch(dev)
     pre = _fork_join(len(calls), dev, lambda i, on_main: _cne_fwd_pre(mod, *calls[i], par=on_main))
     items = [st for sv in pre for st in (sv['streams'][1],)] + [st for sv in pre for st in (sv['streams'][0],) if not st.get('lstm_done')]   # content streams first

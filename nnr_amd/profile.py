@@ -135,7 +135,8 @@ def summary(hbm=False):
 # HBM-bound families -> the kernels one call launches (names as tools/pmc_traffic.py shortens them; prefix match), kernels per call
 HBM_KERNELS = {
     'embed_gather': (('embed_gather_kernel',), 1), 'embed_scatter': (('embed_scatter_kernel', 'embed_scatter_sorted_kernel'), 1),
-    'pool_fwd': (('pool_kernel<false',), 1), 'pool_bwd': (('pool_kernel<true',), 1), 'gate_bwd': (('gate_bwd_kernel',), 1),
+    # (round 6: the packed token streams run pool_packed_kernel, only the user encoder's dense pools still run pool_kernel)
+    'pool_fwd': (('pool_kernel<false', 'pool_packed_kernel<false'), 1), 'pool_bwd': (('pool_kernel<true', 'pool_packed_kernel<true'), 1), 'gate_bwd': (('gate_bwd_kernel',), 1),
     'gcn_aggregate_fwd': (('gcn_aggregate_kernel<0',), 1), 'gcn_aggregate_bwd': (('gcn_aggregate_kernel<1',), 1),
     'sue_intra_fwd': (('sue_intra_fwd_kernel',), 1), 'sue_intra_bwd': (('sue_intra_bwd_ds_kernel', 'sue_intra_bwd_dg_kernel'), 2),
     'clip_adam': (('adam_kernel',), 1), 'sumsq': (('sumsq_kernel',), 1),

@@ -108,7 +108,7 @@ def test_secondary_legs_name_every_other_baseline_config():
         assert abs(cfg.dropout_rate - (0.1 if dataset == 'large' else 0.2)) < 1e-12 and cfg.gcn_layer_num == 4
     a = bench.parse([])
     assert not a.no_secondary and a.secondary_steps == 10 and a.secondary_warmup >= 5      # >= 5: the timed steps are all native replays
-    committed = os.path.join(ROOT, 'profiles', 'r06f_bench.json')
+    committed = os.path.join(ROOT, 'profiles', 'r06h_bench.json')
     if os.path.exists(committed):                      # the shape of a real GPU line (committed with the round's profiles)
         line = json.loads([l for l in open(committed) if l.startswith('{')][-1])
         sec = line['secondary']
