@@ -452,7 +452,7 @@ def secondary_legs(a, prof, dp, torch, dev, rank_seed=0):
                    'per_gpu_batch': per_gpu, 'steps': steps, 'warmup': warm, 'ms_per_step': round(1000 * dt / steps, 3),
                    'value': round(steps * per_gpu / dt, 2), 'unit': 'impressions/s (this GPU\'s shard)',
                    'timed_window': 'un-instrumented replays; per-call events from %d extra steps after it' % sampled,
-                   'matrix_path': matrix_path(_ops, classes=native_step.bx3_classes(model))['nt_weight_gemms'],
+                   'matrix_path': matrix_path(_ops, classes=native_step.bx3_classes(model, per_gpu * (cfg.negative_sample_num + 1 + cfg.max_history_num)))['nt_weight_gemms'],
                    'step': roof.get('step'), 'abi_calls_per_step': round(calls, 1), 'launch_path': launch_path(trainer)['path'],
                    'dominant': {k: roof.get(k) for k in ('kernel', 'family', 'achieved', 'frac', 'avg_launch_us', 'launches', 'share_of_instrumented_time')} if roof else None}
             # the HBM-bound families of THIS leg against the 8 TB/s peak (configs[4] = the "large-vocab embedding table, HBM-bound gather
@@ -634,7 +634,7 @@ def main():
             'config': {'workload': '%s+%s train step, MIND-200k-shaped synthetic batches, dropout %.2f, gcn_layer_num %d%s' %
                                    (a.news_encoder, a.user_encoder, cfg.dropout_rate, cfg.gcn_layer_num, ', dense lengths' if a.dense else ''),
                        'global_batch': global_batch, 'per_gpu_batch': per_gpu, 'parallelism': 'dp%d' % world,
-                       'matrix_path': matrix_path(ops, bx3_seen_headline, classes=native_step.bx3_classes(trainer.model)),
+                       'matrix_path': matrix_path(ops, bx3_seen_headline, classes=native_step.bx3_classes(trainer.model, per_gpu * (cfg.negative_sample_num + 1 + cfg.max_history_num))),
                        'synth': {k: v for k, v in spec.describe().items() if k in ('vocabulary_size', 'title_len_mean', 'content_len_mean', 'news_pool', 'dense')},
                        'batches': ('device-resident corpus, id-only: a fresh batch is gathered / built in HBM inside every timed step (%d distinct id sets)' % nb)
                                   if device_corpus else 'pre-built, %d batches resident in HBM, re-used' % nb,

@@ -15,6 +15,7 @@ from . import ops
 from .news_encoders import cne_forward_many, cne_backward_many, _CNE_UNION
 
 _BX3_MHSA = os.environ.get('NNR_BX3_MHSA', '0') == '1'              # A/B: every class of ops._BX3_CLASSES in the MHSA step too
+_BX3_MIN_SEQS = int(os.environ.get('NNR_BX3_MIN_SEQS', '1408'))         # CNE + SUE: bf16x3 from this many news-encoder sequences per step on (batch 32: 1 760)
 _BX3_MHSA_CLASSES = set(c for c in os.environ.get('NNR_BX3_MHSA_CLASSES', 'dx').split(',') if c)
 _MHSA_NATIVE = os.environ.get('NNR_MHSA_NATIVE', '1') != '0'      # A/B: MHSA+MHSA through autograd (round 3) instead of the native step
 
@@ -32,24 +33,35 @@ def kind(model):
     return None
 
 
-def bx3_classes(model):
+def step_sequences(batch):
+    """Sequences the news encoder runs in one step on `batch` (candidates + history: 3 520 at per-GPU batch 64)."""
+    return int(batch[15].shape[0]) * (int(batch[15].shape[1]) + int(batch[3].shape[1]))
+
+
+def bx3_classes(model, seqs=None):
     """The shape classes (ops.bx3_class) whose weight-operand NT GEMMs run on the bf16x3 kernel in a step of `model`; empty = the pure fp32-MFMA
-    path.  CNE + SUE: every class (ops._BX3_CLASSES).  MHSA news encoder (configs[1]): only the K >= 1024 data-gradient products ('dx': dQKV of
-    the user encoder, the word-embedding gradient's 3 h d -> E product) -- per-class same-box A/Bs, profiles/r06_ab.txt call 30: 'dx' -0.03..-0.07 ms
-    on three pairs, 'proj' neutral, 'gate' and all classes together unstable (the 63 KB tiles beside the attention core's workgroups)."""
+    path.  CNE + SUE: every class (ops._BX3_CLASSES) -- from `_BX3_MIN_SEQS` news-encoder sequences per step on (`seqs`: step_sequences(batch);
+    None = unknown, no size rule): at per-GPU batch 8 / 16 (440 / 880 sequences, the 8- and 4-GPU shards of a global batch of 64) the products are
+    too small to repay the step's ~33 image splits and the 63 KB tiles -- fp32 kernels 3.20 vs 3.37 ms and 4.31 vs 4.45 ms; batch 32 (1 760): bx3
+    5.70-5.80 vs 5.93-6.02, batch 64: 9.45 vs 10.1 (profiles/r06_ab.txt calls 34-36).  MHSA news encoder (configs[1]): only the K >= 1024
+    data-gradient products ('dx': dQKV of the user encoder, the word-embedding gradient's 3 h d -> E product) -- per-class same-box A/Bs, call 30:
+    'dx' -0.03..-0.07 ms on three pairs, 'proj' neutral, 'gate' and all classes together unstable (the 63 KB tiles beside the attention core's
+    workgroups)."""
     from . import news_encoders as NE
     if not ops.BX3[0]:
         return set()
-    if type(getattr(model, 'news_encoder', None)) is NE.MHSA and not _BX3_MHSA:
-        return set(_BX3_MHSA_CLASSES)
+    if type(getattr(model, 'news_encoder', None)) is NE.MHSA:
+        return set(ops._BX3_CLASSES) if _BX3_MHSA else set(_BX3_MHSA_CLASSES)
+    if seqs is not None and seqs < _BX3_MIN_SEQS:
+        return set()
     return set(ops._BX3_CLASSES)
 
 
 @contextlib.contextmanager
-def matrix_path(model):
-    """The matrix path of one step of `model` (bx3_classes).  Used by the native step AND by the trainer's autograd path, so that both run
-    the same kernels."""
-    want = bx3_classes(model)
+def matrix_path(model, batch=None):
+    """The matrix path of one step of `model` on `batch` (bx3_classes).  Used by the native step AND by the trainer's autograd path, so that
+    both run the same kernels."""
+    want = bx3_classes(model, None if batch is None else step_sequences(batch))
     on, classes = ops.BX3[0], ops._BX3_CLASSES
     if on:
         if want:
@@ -221,7 +233,7 @@ def forward_backward(trainer, batch):
         # The MHSA + MHSA step keeps most of its GEMMs on the fp32-MFMA kernels: its products are small (~100 GFLOP per step, 40 k live title rows)
         # and interleaved with the attention-core launches; with EVERY class on the bf16x3 tiles (63 KB of LDS, two workgroups per CU) the step measured
         # slower on three same-box pairs (2.18 vs 2.24 ms, profiles/r06_ab.txt).  Only the K >= 1024 data-gradient products take them (bx3_classes).
-        with matrix_path(model):
+        with matrix_path(model, batch):
             return forward_backward_mhsa(trainer, batch)
     ne, ue = model.news_encoder, model.user_encoder
     (user_ID, user_category, user_subCategory, user_title_text, user_title_mask, user_title_entity, user_content_text, user_content_mask,
@@ -231,7 +243,8 @@ def forward_backward(trainer, batch):
     f32 = dict(device=dev, dtype=torch.float32)
     ops._DEFER['step_joins'] = True                   # this function ends with join_extra_streams(): leaf work may stay un-joined until then
     try:
-        return _forward_backward_cne_sue(trainer, model, ne, ue, batch, dev, f32)
+        with matrix_path(model, batch):
+            return _forward_backward_cne_sue(trainer, model, ne, ue, batch, dev, f32)
     finally:
         ops._DEFER['step_joins'] = False
 

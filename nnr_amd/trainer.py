@@ -184,7 +184,7 @@ class Trainer:
         self.exchange.begin_step(int(batch[0].shape[0]))
         self.flat.zero_grad()
         from . import step as native_step
-        with native_step.matrix_path(model):             # (same kernels as the native step of this model would run)
+        with native_step.matrix_path(model, batch):      # (same kernels as the native step of this model would run)
             logits = model(*batch)
             loss = negative_log_softmax(logits)
             loss.backward()
