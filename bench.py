@@ -437,10 +437,12 @@ def secondary_legs(a, prof, dp, torch, dev, rank_seed=0):
             model = Model(cfg, table)
             model.initialize()
             trainer = Trainer(model.to(dev).train(), cfg)
-            rng = np.random.default_rng(200 + rank_seed)
+            # the SAME draws as a stand-alone run of this shard makes (`bench.py --batch_size <per_gpu> --steps <secondary_steps> --warmup <secondary_warmup>`:
+            # rng(100 + rank), 4 096 behaviours, steps + warmup id sets): the leg and that command time the same batches (round-5 verdict, item 4 i)
+            rng = np.random.default_rng(100 + rank_seed)
             steps, warm = a.secondary_steps, a.secondary_warmup
-            dc = from_synth(SynthCorpus(spec), 2048, rng, dev, graph='build')
-            order = [torch.from_numpy(rng.permutation(2048)[:per_gpu].astype(np.int32)).to(dev) for _ in range(steps + warm)]
+            dc = from_synth(SynthCorpus(spec), 4096, rng, dev, graph='build')
+            order = [torch.from_numpy(rng.permutation(4096)[:per_gpu].astype(np.int32)).to(dev) for _ in range(steps + warm)]
             src = lambda i: dc.train_batch(order[i % len(order)])
             dt, calls = timed_run(a, trainer, src, steps, warm, prof, dp, torch, dev, 1, True)
             sampled = instrumented_steps(trainer, src, max(1, a.roofline_steps), warm + steps, prof, torch)
@@ -452,6 +454,10 @@ def secondary_legs(a, prof, dp, torch, dev, rank_seed=0):
                    'per_gpu_batch': per_gpu, 'steps': steps, 'warmup': warm, 'ms_per_step': round(1000 * dt / steps, 3),
                    'value': round(steps * per_gpu / dt, 2), 'unit': 'impressions/s (this GPU\'s shard)',
                    'timed_window': 'un-instrumented replays; per-call events from %d extra steps after it' % sampled,
+                   'stand_alone': ('`bench.py %s--steps %d --warmup %d --no_secondary` times the SAME batches in a fresh process; the latency-bound small-batch shards run '
+                                   '~7 %% faster there (3.10 vs 3.37 ms at batch 8 on one box): which of the step\'s 5-6 HIP streams share one of HIP\'s 4 hardware queues '
+                                   'depends on the streams the process used before (profiles/r06_ab.txt calls 40-46)') % (
+                                       '--config mhsa ' if ne == 'MHSA' else '--batch_size %d%s ' % (per_gpu, '' if V == 60000 else ' --vocabulary_size %d' % V), steps, warm),
                    'matrix_path': matrix_path(_ops, classes=native_step.bx3_classes(model, per_gpu * (cfg.negative_sample_num + 1 + cfg.max_history_num)))['nt_weight_gemms'],
                    'step': roof.get('step'), 'abi_calls_per_step': round(calls, 1), 'launch_path': launch_path(trainer)['path'],
                    'dominant': {k: roof.get(k) for k in ('kernel', 'family', 'achieved', 'frac', 'avg_launch_us', 'launches', 'share_of_instrumented_time')} if roof else None}

@@ -103,12 +103,35 @@ def new_stream(dev, critical=False):
     # chain-carrying side streams get HIP's high priority.  Measured: no difference (11.20 / 10.80 vs 11.33 / 10.75 ms, 20 steps /
     # sustained).  Running the MAIN chain on a high-priority stream as well did not finish (the pair recurrence's partner workgroups
     # of lower-priority launches wait behind it): not offered.
+    # HIP binds a stream to one of its 4 hardware queues (GPU_MAX_HW_QUEUES; 5 and up fall off a cliff: 13 ms per batch-64 step, 6.5 per batch-8 step) and
+    # the step runs on 5-6 streams, so some share a queue; WHICH ones do depends on the order the process created and first used its streams, and it
+    # decides up to 7 % of the latency-bound batch-8 step: 3.10-3.20 ms in the natural order of a fresh process, 3.3-4.1 ms with 1-4 idle streams in front
+    # of the set or of one of its streams; at batch 64 every pattern tried is within 0.08 ms of the natural one (profiles/r06_ab.txt calls 42-46).
+    # NNR_STREAM_BURN=a,b,...: the A/B knob -- a, b, ... idle streams (used once) in front of the 1st, 2nd, ... stream of the set.
+    k = len(EXTRA_STREAMS)
+    if _STREAM_BURN:
+        from . import tape as _tape
+        assert _tape.ACTIVE[0] is None, 'NNR_STREAM_BURN: a stream was created while a launch tape records'
+        for _ in range(_STREAM_BURN[k] if k < len(_STREAM_BURN) else 0):
+            _bind(torch.cuda.Stream(device=dev), dev)
     st = torch.cuda.Stream(device=dev, priority=-1) if (critical and STREAM_PRIO >= 1) else torch.cuda.Stream(device=dev)
+    if _STREAM_BURN:
+        _bind(st, dev)                                # first use = creation
     EXTRA_STREAMS.append(st)
     return st
 
 
+_BURNT = []
+
+
+def _bind(st, dev):
+    with torch.cuda.stream(st):
+        torch.empty(64, device=dev).zero_()           # (a torch kernel, not a C-ABI call)
+    _BURNT.append(st)
+
+
 STREAM_PRIO = int(os.environ.get('NNR_PRIO', '0'))
+_STREAM_BURN = [int(x) for x in os.environ.get('NNR_STREAM_BURN', '').split(',') if x.strip()]
 
 
 STREAM_CACHES.append(_LEAF)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 6: the judged artefacts of the FINAL build in one gpurun call (from the repo root):  bash tools/collect_round6.sh r06h
+# Round 6: the judged artefacts of the FINAL build in one gpurun call (from the repo root):  bash tools/collect_round6.sh r06i
 #  1. default bench line (headline + secondary legs + CPU baseline); rocprofv3 --kernel-trace --stats of the headline command, in-step and with
 #     every stream collapsed into one (NNR_ONE_STREAM=1) -> profiles/kernel_stats.json (build-id stamped; bench.py `roofline.rocprof` quotes it);
 #     PMC FETCH_SIZE / WRITE_SIZE passes (NNR_REPLAY=0: the call-by-call native step -- same kernels, same order) -> profiles/pmc_traffic.json
@@ -7,7 +7,7 @@
 #  3. --prebuilt, per-GPU batch sweep -> profiles/batch_sweep.json, --config mhsa (+ its kernel table and matrix-pipe busy counter pass),
 #     kernel tables of the batch-8 shard and of the V = 130 000 shard (round-5 verdict item 4 v)
 #  4. per-call timelines of a replayed step (batch 64 / 8), phase table, kernel trace folded per step, 1 500-step soak
-TAG=${1:-r06h}
+TAG=${1:-r06i}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $ROOT
 export PYTHONWARNINGS=ignore
