@@ -15,6 +15,7 @@ from . import ops
 from .news_encoders import cne_forward_many, cne_backward_many, _CNE_UNION
 
 _BX3_MHSA = os.environ.get('NNR_BX3_MHSA', '0') == '1'              # A/B: every class of ops._BX3_CLASSES in the MHSA step too
+_CNE_STEP_ROWS = os.environ.get('NNR_CNE_STEP_ROWS', '0') == '1'      # A/B: post the history call's token rows (Model.forward's rule) instead of 0
 _BX3_MIN_SEQS = int(os.environ.get('NNR_BX3_MIN_SEQS', '1408'))         # CNE + SUE: bf16x3 from this many news-encoder sequences per step on (batch 32: 1 760)
 _BX3_MHSA_CLASSES = set(c for c in os.environ.get('NNR_BX3_MHSA_CLASSES', 'dx').split(',') if c)
 _MHSA_NATIVE = os.environ.get('NNR_MHSA_NATIVE', '1') != '0'      # A/B: MHSA+MHSA through autograd (round 3) instead of the native step
@@ -254,6 +255,11 @@ def _forward_backward_cne_sue(trainer, model, ne, ue, batch, dev, f32):
      user_content_entity, user_history_mask, user_history_graph, user_history_category_mask, user_history_category_indices, news_category,
      news_subCategory, news_title_text, news_title_mask, news_title_entity, news_content_text, news_content_mask, news_content_entity) = batch
     with torch.no_grad():
+        # ops.leaf_deferred's "is the step big enough to defer small reductions" input.  This step never posted it and ran on whatever the process's last
+        # OTHER step had left there (0 in a fresh process -- what every A/B of this step was tuned on --, 102 400 behind an MHSA step): posted now, so
+        # that the step does not depend on its predecessors.  (Measured neutral either way, call 49; it is NOT why bench.py's batch-8 leg runs 7 % behind
+        # its stand-alone command -- see ops.new_stream.)
+        ops.STEP_ROWS[0] = user_title_text.numel() if _CNE_STEP_ROWS else 0
         ops.wt_prefetch(dev)                          # W^T copies the backward pass multiplies by, on the leaf stream
         cand = (news_title_text, news_title_mask, news_content_text, news_content_mask, news_category, news_subCategory)
         hist = (user_title_text, user_title_mask, user_content_text, user_content_mask, user_category, user_subCategory)
