@@ -12,11 +12,15 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--batch_size', type=int, default=8)
 ap.add_argument('--exchange', type=int, default=1)
 ap.add_argument('--steps', type=int, default=40)
+ap.add_argument('--timeline', action='store_true', help='per-call timeline of one replayed step (every call tagged)')
 a = ap.parse_args()
 os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=os.environ.get('MASTER_PORT', '29547'))
 os.environ['NNR_DP_FORCE'] = '1' if a.exchange else '0'
 import numpy as np
 import torch
+from nnr_amd import tape as T
+if a.timeline:
+    T.TAG_ALL[0] = True
 import torch.distributed as dist
 from nnr_amd import dp
 from nnr_amd.config import make_config
@@ -50,5 +54,17 @@ for rep in range(3):
 print('batch %d exchange %d: %s ms/step; path %s; exchange %s; streams created by the package: %d' % (
     a.batch_size, a.exchange, ' '.join('%.3f' % x for x in best), tr.last_path, tr.exchange.describe() if tr.exchange.active() else 'inactive',
     len(__import__('nnr_amd.ops', fromlist=['x']).EXTRA_STREAMS)))
+if a.timeline and tr.tapes:
+    tr.timing = True
+    tr.train_step(batches[0])
+    tr.timing = False
+    torch.cuda.synchronize()
+    tape = next(iter(tr.tapes.values()))
+    print(tape.info())
+    prev = {}
+    for s_, d_, st, fam, tag in sorted(tape.timeline(0)):
+        gap = s_ - prev.get(st, 0.0)
+        prev[st] = s_ + d_
+        print('%9.1f %8.1f  s%d  gap %7.1f  %s %s' % (1000 * s_, 1000 * d_, st, 1000 * gap, fam, tag))
 if a.exchange:
     dist.destroy_process_group()
