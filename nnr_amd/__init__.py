@@ -13,3 +13,6 @@ elif _q.strip() != '4':
     _warnings.warn('nnr_amd: GPU_MAX_HW_QUEUES=%s -- the training step is tuned on HIP\'s default of 4 hardware queues; 5 and more measured 1.4-2.1x '
                    'SLOWER steps, 2-3 serialise its streams (profiles/r06_ab.txt calls 42-43)' % _q)
 del _q
+# Kernel arguments in device memory (HIP_FORCE_DEV_KERNARG=1, this ROCm's default): with 0 the step's ~230 dependent launches cost +0.15 ms at batch 64, +0.13 ms at batch 8,
+# +0.08 ms on the MHSA step (profiles/r06_ab.txt call 57).  Made explicit when the caller has not chosen.
+_os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')

@@ -14,8 +14,8 @@ def _run(code, **env):
 
 
 def test_hardware_queue_count_is_pinned_when_the_caller_has_not_chosen():
-    r = _run('import os, nnr_amd; print(os.environ["GPU_MAX_HW_QUEUES"])')
-    assert r.returncode == 0 and r.stdout.strip() == '4' and 'GPU_MAX_HW_QUEUES' not in r.stderr
+    r = _run('import os, nnr_amd; print(os.environ["GPU_MAX_HW_QUEUES"], os.environ["HIP_FORCE_DEV_KERNARG"])')
+    assert r.returncode == 0 and r.stdout.split() == ['4', '1'] and 'GPU_MAX_HW_QUEUES' not in r.stderr
 
 
 def test_another_hardware_queue_count_is_kept_and_warned_about():
